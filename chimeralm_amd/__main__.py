@@ -1,0 +1,81 @@
+"""`chimeralm predict` for the MI355X engine -- same options as /root/reference/chimeralm/__main__.py:248-259:
+
+    python -m chimeralm_amd predict DATA_PATH [-g GPUS] [-o OUTPUT] [-b BATCH] [-w WORKERS] [-c CKPT] [-r] [-v]
+
+plus engine-only options `--weights` (directory/file with the released `model.safetensors`; the reference downloads
+`yangliz5/chimeralm` from the Hub) and `--precision`.  `--gpus 0` (the reference's CPU mode) is refused: this engine
+has no CPU path.  Only `predict` is built; `filter` and `web` are outside the hot path.
+"""
+from __future__ import annotations
+
+import logging
+import os
+import subprocess
+import sys
+from pathlib import Path
+
+import torch
+import typer
+
+app = typer.Typer(context_settings={"help_option_names": ["-h", "--help"]},
+                  help="ChimeraLM predict on AMD MI355X: flag chimera artifacts from whole genome amplification.")
+log = logging.getLogger("chimeralm_amd")
+
+
+@app.callback()
+def main():
+    """ChimeraLM (MI355X engine)."""
+
+
+@app.command()
+def predict(
+    data_path: Path = typer.Argument(..., help="Path to the dataset (BAM)"),
+    gpus: int = typer.Option(1, "--gpus", "-g", help="Number of GPUs to use"),
+    output_path: Path | None = typer.Option(None, "--output", "-o", help="Output path for predictions"),
+    batch_size: int = typer.Option(12, "--batch-size", "-b", help="Batch size"),
+    num_workers: int = typer.Option(0, "--workers", "-w", help="Number of workers"),
+    ckpt_path: Path | None = typer.Option(None, "--ckpt", "-c", hidden=True, help="Path to the checkpoint file"),
+    weights: str = typer.Option("yangliz5/chimeralm", "--weights", help="Directory/file with model.safetensors"),
+    precision: str = typer.Option("fp32", "--precision", help="MFMA input type: fp32 | bf16 | fp16"),
+    random: bool = typer.Option(False, "--random", "-r", help="Make the prediction not deterministic"),
+    verbose: bool = typer.Option(False, "--verbose", "-v", help="Enable verbose output"),
+):
+    """Predict the given dataset using ChimeraLM."""
+    logging.basicConfig(level=logging.DEBUG if verbose else logging.INFO, format="%(message)s")
+    if gpus < 1:
+        raise typer.BadParameter("this engine runs on MI355X GPUs only; use --gpus >= 1 (no CPU path exists)")
+    if output_path is None:                       # README-documented default (the reference crashes here)
+        output_path = data_path.with_suffix(".predictions")
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if gpus > 1 and world == 1:                   # one process per GPU, launched before anything touches HIP
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", os.environ.get("MASTER_PORT", "29511"),
+               "-m", "chimeralm_amd", *sys.argv[1:]]
+        raise typer.Exit(subprocess.call(cmd))
+
+    from . import bam, callbacks, distributed, lm, predict as loop, tokenizer
+
+    rank, local_rank, world = distributed.init_process_group()
+    if not random:
+        torch.manual_seed(42)
+    device = torch.device("cuda", local_rank)
+    torch.cuda.set_device(device)
+    tok = tokenizer.load_tokenizer_from_hyena_model("hyenadna-small-32k-seqlen")
+    dm = bam.BamDataModule(tokenizer=tok, train_data_path=Path("dummy.bam"), predict_data_path=data_path,
+                           batch_size=batch_size, num_workers=num_workers)
+    if ckpt_path is not None:
+        log.info(f"Loading model from {ckpt_path}")
+        model = lm.ChimeraLM.new(precision=precision).load_reference_checkpoint(ckpt_path)
+    else:
+        log.info(f"Loading model weights {weights}")
+        model = lm.ChimeraLM.from_pretrained(weights, precision=precision)
+    output_path.mkdir(parents=True, exist_ok=True)
+    dm.setup("predict", world_size=world, rank=rank)
+    writer = callbacks.PredictionWriter(output_dir=output_path, write_interval="batch")
+    n = loop.run_predict(model, dm, writer, device, rank=rank)
+    distributed.barrier()
+    log.info(f"[rank {rank}] {n} reads; predictions saved to {output_path}")
+
+
+if __name__ == "__main__":
+    app()

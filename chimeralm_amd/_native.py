@@ -1,0 +1,76 @@
+"""ctypes binding of the C ABI declared in include/chimeralm_hip.h (csrc/libchimeralm_hip.so).
+
+There is no fallback: if the shared library is missing or does not export the full ABI, importing the
+engine fails loudly.  Build it with `python -m chimeralm_amd.build` (hipcc, gfx950).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from pathlib import Path
+
+LIB_PATH = Path(__file__).resolve().parent / "csrc" / "libchimeralm_hip.so"
+
+# error codes / enums (mirror include/chimeralm_hip.h)
+OK, E_INVALID, E_HIP, E_MISSING, E_UNSUPPORTED, E_STATE = 0, -1, -2, -3, -4, -5
+DT_F32, DT_F64, DT_BF16, DT_F16, DT_U8, DT_I32, DT_I64 = range(7)
+PREC_F32, PREC_BF16, PREC_F16 = 0, 1, 2
+PRECISIONS = {"fp32": PREC_F32, "f32": PREC_F32, "bf16": PREC_BF16, "fp16": PREC_F16, "f16": PREC_F16}
+STAGES = ["embed", "ln1_in_proj", "short_long_conv", "out_proj", "ln2_fc1_gelu", "fc2", "lnf_pool_score",
+          "softmax_pool", "head_mlp", "filter"]
+N_STAGES = len(STAGES)
+ABI_VERSION = 1
+
+
+class ClmConfig(C.Structure):
+    _fields_ = [
+        ("struct_size", C.c_int32), ("d_model", C.c_int32), ("n_layer", C.c_int32), ("d_inner", C.c_int32),
+        ("vocab_rows", C.c_int32), ("filter_order", C.c_int32), ("emb_dim", C.c_int32), ("max_seq_len", C.c_int32),
+        ("head_hidden", C.c_int32), ("n_classes", C.c_int32), ("ln_eps", C.c_float), ("precision", C.c_int32),
+        ("chunk_reads", C.c_int32),
+    ]
+
+
+# every symbol include/chimeralm_hip.h declares: name -> (restype, argtypes)
+_H = C.c_void_p
+SYMBOLS = {
+    "clm_abi_version": (C.c_int, []),
+    "clm_default_config": (C.c_int, [C.POINTER(ClmConfig)]),
+    "clm_create": (C.c_int, [C.POINTER(ClmConfig), C.c_int, C.POINTER(_H)]),
+    "clm_load_weight": (C.c_int, [_H, C.c_char_p, C.c_void_p, C.c_int, C.POINTER(C.c_int64), C.c_int]),
+    "clm_finalize": (C.c_int, [_H]),
+    "clm_reserve": (C.c_int, [_H, C.c_int, C.c_int]),
+    "clm_forward": (C.c_int, [_H, C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "clm_debug_fetch": (C.c_int, [_H, C.c_char_p, C.c_void_p, C.c_size_t]),
+    "clm_debug_stop_after": (C.c_int, [_H, C.c_int, C.c_int]),
+    "clm_profile_enable": (C.c_int, [_H, C.c_int]),
+    "clm_profile_read": (C.c_int, [_H, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.c_int]),
+    "clm_profile_stage_name": (C.c_char_p, [C.c_int]),
+    "clm_last_error": (C.c_char_p, [_H]),
+    "clm_destroy": (C.c_int, [_H]),
+}
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """Load the engine library and bind every ABI symbol; raises if anything is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not LIB_PATH.exists():
+        raise ImportError(
+            f"{LIB_PATH} not found: the ChimeraLM MI355X engine has no CPU or PyTorch fallback. "
+            "Build it with `python -m chimeralm_amd.build` (needs hipcc, targets gfx950)."
+        )
+    lib = C.CDLL(str(LIB_PATH))
+    for name, (res, args) in SYMBOLS.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise ImportError(f"{LIB_PATH} does not export {name}; rebuild with `python -m chimeralm_amd.build --force`") from e
+        fn.restype = res
+        fn.argtypes = args
+    if lib.clm_abi_version() != ABI_VERSION:
+        raise ImportError(f"{LIB_PATH}: ABI version {lib.clm_abi_version()} != {ABI_VERSION}; rebuild the library")
+    _lib = lib
+    return lib

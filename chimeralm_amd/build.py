@@ -1,0 +1,54 @@
+"""Build the C-ABI shared library `csrc/libchimeralm_hip.so` for gfx950 with hipcc (in-tree, no JIT cache).
+
+    python -m chimeralm_amd.build [--force] [--verbose]
+
+hipcc cross-compiles without a GPU, so this also runs in the CPU-only build container.
+"""
+from __future__ import annotations
+
+import subprocess
+import sys
+from pathlib import Path
+
+CSRC = Path(__file__).resolve().parent / "csrc"
+INCLUDE = Path(__file__).resolve().parent.parent / "include"
+LIB = CSRC / "libchimeralm_hip.so"
+SOURCES = ["clm_api.hip", "gemm.hip", "hyena_conv.hip", "head.hip"]
+HEADERS = ["clm_common.h", "fft_core.h", "fft_passes.h"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function"]
+
+
+def _stale() -> bool:
+    if not LIB.exists():
+        return True
+    t = LIB.stat().st_mtime
+    deps = [CSRC / s for s in SOURCES + HEADERS] + [INCLUDE / "chimeralm_hip.h"]
+    return any(d.stat().st_mtime > t for d in deps)
+
+
+def build(force: bool = False, verbose: bool = False) -> Path:
+    if not force and not _stale():
+        return LIB
+    objs = []
+    procs = []
+    for s in SOURCES:
+        obj = CSRC / (Path(s).stem + ".o")
+        cmd = ["hipcc", *FLAGS, f"-I{INCLUDE}", f"-I{CSRC}", "-c", str(CSRC / s), "-o", str(obj)]
+        if verbose:
+            cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
+        procs.append((s, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
+        objs.append(str(obj))
+    failed = False
+    for s, p in procs:
+        out, _ = p.communicate()
+        if p.returncode != 0 or verbose:
+            print(f"--- hipcc {s} (rc={p.returncode})\n{out}", file=sys.stderr)
+        failed |= p.returncode != 0
+    if failed:
+        raise RuntimeError("hipcc failed building the gfx950 engine")
+    subprocess.run(["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", str(LIB), *objs], check=True)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose="--verbose" in sys.argv))

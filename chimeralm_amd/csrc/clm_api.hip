@@ -1,0 +1,635 @@
+// clm_api.hip -- C ABI (include/chimeralm_hip.h) and host-side orchestration of the forward pass.
+// The call sequence mirrors the reference protocol HyenaDna.forward -> backbone -> head
+// (/root/reference/chimeralm/models/components/hyena.py:244-256); the operator order inside is the
+// HyenaDNA block order of SURVEY.md section 8(a) rows 5-13.
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "chimeralm_hip.h"
+#include "clm_common.h"
+
+using namespace clm;
+
+namespace {
+
+struct Tensor {
+    float* d = nullptr;
+    std::vector<int64_t> shape;
+    size_t numel = 0;
+    bool loaded = false;
+};
+
+struct FilterSet {
+    int L = 0, logn = 0;
+    float* ktime[NLAYER] = {};
+    float2* kf[NLAYER] = {};
+    float2* tw = nullptr;
+    uint64_t stamp = 0;
+};
+
+struct ProfRec {
+    int stage;
+    hipEvent_t e0, e1;
+};
+
+std::string g_create_error;
+
+}  // namespace
+
+struct clm_handle {
+    clm_config cfg{};
+    int device = 0;
+    std::string err;
+    std::map<std::string, Tensor> w;
+    bool finalized = false;
+    // packed / derived weights
+    void* packed[NLAYER][4] = {};
+    void* packed_score = nullptr;
+    float* head_t[5] = {};
+    LayerW lw[NLAYER]{};
+    HeadW hw{};
+    std::vector<FilterSet> filters;
+    uint64_t clock = 0;
+    // workspace (one chunk of reads)
+    int ws_B = 0, ws_L = 0;
+    float* h = nullptr;
+    void *z = nullptr, *y = nullptr, *u = nullptr;
+    float *scores = nullptr, *stats = nullptr, *partial = nullptr, *pooled = nullptr;
+    int last_B = 0, last_L = 0, last_Lp = 0;
+    // debug / profiling
+    int stop_layer = -1, stop_stage = -1;
+    bool prof = false;
+    std::vector<ProfRec> recs;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> free_events;
+    double prof_ms[CLM_N_STAGES] = {};
+    int64_t prof_n[CLM_N_STAGES] = {};
+};
+
+namespace {
+
+int fail(clm_handle* h, int code, const std::string& msg) {
+    if (h) h->err = msg;
+    else g_create_error = msg;
+    return code;
+}
+
+#define HIPCHK(h, expr)                                                                                   \
+    do {                                                                                                  \
+        hipError_t _e = (expr);                                                                           \
+        if (_e != hipSuccess)                                                                             \
+            return fail(h, CLM_E_HIP, std::string(#expr) + ": " + hipGetErrorString(_e));                 \
+    } while (0)
+
+size_t elem_size(int prec) { return prec == PREC_F32 ? 4 : 2; }
+int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+// ---- expected weights -------------------------------------------------------------------------------
+struct KeySpec {
+    std::string key;
+    std::vector<int64_t> shape;
+};
+
+std::vector<KeySpec> expected_keys(const clm_config& c) {
+    std::vector<KeySpec> k;
+    const int64_t d = c.d_model, di = c.d_inner, fo = c.filter_order, hh = c.head_hidden;
+    k.push_back({"bb.embeddings.word_embeddings.weight", {c.vocab_rows, d}});
+    for (int i = 0; i < c.n_layer; ++i) {
+        std::string p = "bb.layers." + std::to_string(i) + ".";
+        for (const char* n : {"norm1", "norm2"}) {
+            k.push_back({p + n + ".weight", {d}});
+            k.push_back({p + n + ".bias", {d}});
+        }
+        k.push_back({p + "mixer.in_proj.weight", {3 * d, d}});
+        k.push_back({p + "mixer.in_proj.bias", {3 * d}});
+        k.push_back({p + "mixer.out_proj.weight", {d, d}});
+        k.push_back({p + "mixer.out_proj.bias", {d}});
+        k.push_back({p + "mixer.short_filter.weight", {3 * d, 1, 3}});
+        k.push_back({p + "mixer.short_filter.bias", {3 * d}});
+        std::string f = p + "mixer.filter_fn.";
+        k.push_back({f + "bias", {d}});
+        k.push_back({f + "pos_emb.z", {1, c.max_seq_len, c.emb_dim}});
+        k.push_back({f + "pos_emb.t", {1, c.max_seq_len, 1}});
+        k.push_back({f + "implicit_filter.0.weight", {fo, c.emb_dim}});
+        k.push_back({f + "implicit_filter.0.bias", {fo}});
+        k.push_back({f + "implicit_filter.1.freq", {1, fo}});
+        k.push_back({f + "implicit_filter.2.weight", {fo, fo}});
+        k.push_back({f + "implicit_filter.2.bias", {fo}});
+        k.push_back({f + "implicit_filter.4.weight", {fo, fo}});
+        k.push_back({f + "implicit_filter.4.bias", {fo}});
+        k.push_back({f + "implicit_filter.6.weight", {d, fo}});
+        k.push_back({f + "modulation.deltas", {1, 1, d}});
+        k.push_back({p + "mlp.fc1.weight", {di, d}});
+        k.push_back({p + "mlp.fc1.bias", {di}});
+        k.push_back({p + "mlp.fc2.weight", {d, di}});
+        k.push_back({p + "mlp.fc2.bias", {d}});
+    }
+    k.push_back({"bb.ln_f.weight", {d}});
+    k.push_back({"bb.ln_f.bias", {d}});
+    k.push_back({"head.attention.0.weight", {hh / 2, d}});
+    k.push_back({"head.attention.0.bias", {hh / 2}});
+    k.push_back({"head.attention.2.weight", {1, hh / 2}});
+    k.push_back({"head.attention.2.bias", {1}});
+    k.push_back({"head.classifier.0.weight", {hh, d}});
+    k.push_back({"head.classifier.0.bias", {hh}});
+    k.push_back({"head.classifier.3.weight", {hh, hh}});
+    k.push_back({"head.classifier.3.bias", {hh}});
+    k.push_back({"head.classifier.6.layers.0.weight", {hh, hh}});
+    k.push_back({"head.classifier.6.layers.0.bias", {hh}});
+    k.push_back({"head.classifier.6.layers.3.weight", {hh, hh}});
+    k.push_back({"head.classifier.6.layers.3.bias", {hh}});
+    k.push_back({"head.output_layer.weight", {c.n_classes, hh}});
+    k.push_back({"head.output_layer.bias", {c.n_classes}});
+    return k;
+}
+
+// "net.backbone.backbone.X" | "backbone.backbone.X" | "backbone.X" -> "bb.X";  "net.head.Y" | "head.Y" -> "head.Y"
+bool canonical_key(const char* key, std::string& out) {
+    std::string s(key);
+    if (s.rfind("net.", 0) == 0) s = s.substr(4);
+    if (s.rfind("backbone.backbone.", 0) == 0) {
+        out = "bb." + s.substr(18);
+        return true;
+    }
+    if (s.rfind("backbone.", 0) == 0) {
+        out = "bb." + s.substr(9);
+        return true;
+    }
+    if (s.rfind("head.", 0) == 0) {
+        out = s;
+        return true;
+    }
+    return false;
+}
+
+__global__ void convert_to_f32_kernel(const void* in, float* out, size_t n, int dtype) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    if (dtype == CLM_DT_F64)
+        out[i] = (float)reinterpret_cast<const double*>(in)[i];
+    else if (dtype == CLM_DT_BF16)
+        out[i] = to_float(reinterpret_cast<const bf16_t*>(in)[i]);
+    else if (dtype == CLM_DT_F16)
+        out[i] = to_float(reinterpret_cast<const f16_t*>(in)[i]);
+}
+
+void free_filter_set(FilterSet& f) {
+    for (int i = 0; i < NLAYER; ++i) {
+        if (f.ktime[i]) (void)hipFree(f.ktime[i]);
+        if (f.kf[i]) (void)hipFree(f.kf[i]);
+        f.ktime[i] = nullptr;
+        f.kf[i] = nullptr;
+    }
+    if (f.tw) (void)hipFree(f.tw);
+    f.tw = nullptr;
+}
+
+void free_filters(clm_handle* h) {
+    for (auto& f : h->filters) free_filter_set(f);
+    h->filters.clear();
+}
+
+void free_workspace(clm_handle* h) {
+    for (void* p : {(void*)h->h, h->z, h->y, h->u, (void*)h->scores, (void*)h->stats, (void*)h->partial,
+                    (void*)h->pooled})
+        if (p) (void)hipFree(p);
+    h->h = nullptr; h->z = h->y = h->u = nullptr;
+    h->scores = h->stats = h->partial = h->pooled = nullptr;
+    h->ws_B = h->ws_L = 0;
+}
+
+void free_packed(clm_handle* h) {
+    for (int i = 0; i < NLAYER; ++i)
+        for (int j = 0; j < 4; ++j)
+            if (h->packed[i][j]) { (void)hipFree(h->packed[i][j]); h->packed[i][j] = nullptr; }
+    if (h->packed_score) { (void)hipFree(h->packed_score); h->packed_score = nullptr; }
+    for (int j = 0; j < 5; ++j)
+        if (h->head_t[j]) { (void)hipFree(h->head_t[j]); h->head_t[j] = nullptr; }
+}
+
+const float* W(clm_handle* h, const std::string& key) { return h->w[key].d; }
+
+int ensure_workspace(clm_handle* h, int Bc, int L, hipStream_t st) {
+    if (Bc <= h->ws_B && L <= h->ws_L) return CLM_OK;
+    HIPCHK(h, hipStreamSynchronize(st));
+    int nb = Bc > h->ws_B ? Bc : h->ws_B, nl = L > h->ws_L ? L : h->ws_L;
+    free_workspace(h);
+    const size_t es = elem_size(h->cfg.precision), Lp = (size_t)round_up(nl, 64);
+    const size_t n_h = (size_t)nb * nl * D * 4, n_z = (size_t)nb * D3 * Lp * es, n_y = (size_t)nb * D * Lp * es,
+                 n_u = (size_t)nb * nl * DI * es;
+    HIPCHK(h, hipMalloc((void**)&h->h, n_h));
+    HIPCHK(h, hipMalloc(&h->z, n_z));
+    HIPCHK(h, hipMalloc(&h->y, n_y));
+    HIPCHK(h, hipMalloc(&h->u, n_u));
+    HIPCHK(h, hipMalloc((void**)&h->scores, (size_t)nb * nl * 4));
+    HIPCHK(h, hipMalloc((void**)&h->stats, (size_t)nb * 2 * 4));
+    HIPCHK(h, hipMalloc((void**)&h->partial, (size_t)nb * POOL_SPLIT * 4 * D * 4));
+    HIPCHK(h, hipMalloc((void**)&h->pooled, (size_t)nb * D * 4));
+    HIPCHK(h, hipMemset(h->z, 0, n_z));   // padding columns [L, Lp) must never hold NaN garbage
+    HIPCHK(h, hipMemset(h->y, 0, n_y));
+    h->ws_B = nb;
+    h->ws_L = nl;
+    return CLM_OK;
+}
+
+int ensure_filters(clm_handle* h, int L, hipStream_t st, FilterSet** out) {
+    for (auto& f : h->filters)
+        if (f.L == L) {
+            f.stamp = ++h->clock;
+            *out = &f;
+            return CLM_OK;
+        }
+    const int logn = conv_logn_for(L);
+    if (logn < 0)
+        return fail(h, CLM_E_UNSUPPORTED,
+                    "sequence length " + std::to_string(L) + " tokens: long convolution supports L <= 8193");
+    HIPCHK(h, hipStreamSynchronize(st));
+    if (h->filters.size() >= 3) {  // drop the least recently used length
+        size_t lru = 0;
+        for (size_t i = 1; i < h->filters.size(); ++i)
+            if (h->filters[i].stamp < h->filters[lru].stamp) lru = i;
+        free_filter_set(h->filters[lru]);
+        h->filters.erase(h->filters.begin() + lru);
+    }
+    const int N = 1 << logn;
+    FilterSet f;
+    f.L = L;
+    f.logn = logn;
+    f.stamp = ++h->clock;
+    double2* scratch = nullptr;
+    HIPCHK(h, hipMalloc((void**)&scratch, (size_t)D * N * sizeof(double2)));
+    HIPCHK(h, hipMalloc((void**)&f.tw, (size_t)(N / 2) * sizeof(float2)));
+    launch_twiddles(f.tw, logn, st);
+    for (int i = 0; i < NLAYER; ++i) {
+        HIPCHK(h, hipMalloc((void**)&f.ktime[i], (size_t)L * D * 4));
+        HIPCHK(h, hipMalloc((void**)&f.kf[i], (size_t)D * N * sizeof(float2)));
+        std::string p = "bb.layers." + std::to_string(i) + ".mixer.filter_fn.";
+        launch_filter(W(h, p + "pos_emb.z"), W(h, p + "pos_emb.t"), W(h, p + "implicit_filter.0.weight"),
+                      W(h, p + "implicit_filter.0.bias"), W(h, p + "implicit_filter.1.freq"),
+                      W(h, p + "implicit_filter.2.weight"), W(h, p + "implicit_filter.2.bias"),
+                      W(h, p + "implicit_filter.4.weight"), W(h, p + "implicit_filter.4.bias"),
+                      W(h, p + "implicit_filter.6.weight"), W(h, p + "modulation.deltas"), f.ktime[i], L, st);
+        launch_filter_spectrum(f.ktime[i], f.kf[i], scratch, L, logn, st);
+    }
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipStreamSynchronize(st));
+    HIPCHK(h, hipFree(scratch));
+    h->filters.push_back(f);
+    *out = &h->filters.back();
+    return CLM_OK;
+}
+
+struct StageTimer {
+    clm_handle* h;
+    hipStream_t st;
+    int stage;
+    bool on;
+    hipEvent_t e0{}, e1{};
+    StageTimer(clm_handle* h_, hipStream_t st_, int stage_) : h(h_), st(st_), stage(stage_), on(h_->prof) {
+        if (!on) return;
+        if (h->recs.size() > 200000) { on = false; return; }
+        if (!h->free_events.empty()) {
+            e0 = h->free_events.back().first;
+            e1 = h->free_events.back().second;
+            h->free_events.pop_back();
+        } else if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) {
+            on = false;
+            return;
+        }
+        (void)hipEventRecord(e0, st);
+    }
+    ~StageTimer() {
+        if (!on) return;
+        (void)hipEventRecord(e1, st);
+        h->recs.push_back({stage, e0, e1});
+    }
+};
+
+bool stop_here(clm_handle* h, int layer, int stage) { return h->stop_layer == layer && h->stop_stage == stage; }
+
+int forward_chunk(clm_handle* h, const void* ids, int ids_dtype, int64_t row_stride, int Bc, int L, float* logits,
+                  hipStream_t st) {
+    const int prec = h->cfg.precision, Lp = round_up(L, 64);
+    const float eps = h->cfg.ln_eps;
+    FilterSet* fs = nullptr;
+    int rc = ensure_filters(h, L, st, &fs);
+    if (rc) return rc;
+    rc = ensure_workspace(h, Bc, L, st);
+    if (rc) return rc;
+    h->last_B = Bc; h->last_L = L; h->last_Lp = Lp;
+    {
+        StageTimer t(h, st, CLM_STAGE_EMBED);
+        launch_embed(ids, ids_dtype, row_stride, W(h, "bb.embeddings.word_embeddings.weight"), h->h, Bc, L, st);
+    }
+    if (stop_here(h, -1, CLM_STAGE_EMBED)) return CLM_OK;
+    for (int i = 0; i < NLAYER; ++i) {
+        const LayerW& lw = h->lw[i];
+        {
+            StageTimer t(h, st, CLM_STAGE_INPROJ);
+            launch_inproj(prec, h->h, lw.ln1_g, lw.ln1_b, lw.w_in, lw.b_in, h->z, Bc, L, Lp, eps, st);
+        }
+        if (stop_here(h, i, CLM_STAGE_INPROJ)) return CLM_OK;
+        {
+            StageTimer t(h, st, CLM_STAGE_CONV);
+            launch_hyena_conv(prec, h->z, h->y, fs->kf[i], fs->tw, fs->ktime[i], lw.short_w, lw.short_b, lw.filt_bias,
+                              Bc, L, Lp, fs->logn, st);
+        }
+        if (stop_here(h, i, CLM_STAGE_CONV)) return CLM_OK;
+        {
+            StageTimer t(h, st, CLM_STAGE_OUTPROJ);
+            launch_outproj(prec, h->y, lw.w_out, lw.b_out, h->h, Bc, L, Lp, st);
+        }
+        if (stop_here(h, i, CLM_STAGE_OUTPROJ)) return CLM_OK;
+        {
+            StageTimer t(h, st, CLM_STAGE_FC1);
+            launch_fc1(prec, h->h, lw.ln2_g, lw.ln2_b, lw.w_fc1, lw.b_fc1, h->u, Bc, L, eps, st);
+        }
+        if (stop_here(h, i, CLM_STAGE_FC1)) return CLM_OK;
+        {
+            StageTimer t(h, st, CLM_STAGE_FC2);
+            launch_fc2(prec, h->u, lw.w_fc2, lw.b_fc2, h->h, Bc, L, st);
+        }
+        if (stop_here(h, i, CLM_STAGE_FC2)) return CLM_OK;
+    }
+    {
+        StageTimer t(h, st, CLM_STAGE_SCORE);
+        launch_score(prec, h->h, W(h, "bb.ln_f.weight"), W(h, "bb.ln_f.bias"), h->packed_score,
+                     W(h, "head.attention.0.bias"), W(h, "head.attention.2.weight"), W(h, "head.attention.2.bias"),
+                     h->scores, Bc, L, eps, st);
+    }
+    {
+        StageTimer t(h, st, CLM_STAGE_POOL);
+        launch_softmax_stats(h->scores, h->stats, Bc, L, st);
+        launch_pool(h->h, W(h, "bb.ln_f.weight"), W(h, "bb.ln_f.bias"), h->scores, h->stats, h->partial, Bc, L, eps,
+                    st);
+    }
+    {
+        StageTimer t(h, st, CLM_STAGE_HEADMLP);
+        launch_head_mlp(h->partial, h->hw, h->pooled, logits, Bc, st);
+    }
+    HIPCHK(h, hipGetLastError());
+    return CLM_OK;
+}
+
+}  // namespace
+
+// ======================================================================================== C ABI
+extern "C" {
+
+int clm_abi_version(void) { return CLM_ABI_VERSION; }
+
+int clm_default_config(clm_config* c) {
+    if (!c) return CLM_E_INVALID;
+    std::memset(c, 0, sizeof(*c));
+    c->struct_size = (int32_t)sizeof(clm_config);
+    c->d_model = D; c->n_layer = NLAYER; c->d_inner = DI; c->vocab_rows = VOCAB; c->filter_order = FORDER;
+    c->emb_dim = EMB; c->max_seq_len = 32770; c->head_hidden = HH; c->n_classes = NCLS;
+    c->ln_eps = 1e-5f;
+    c->precision = CLM_PREC_F32;
+    c->chunk_reads = 32;
+    return CLM_OK;
+}
+
+int clm_create(const clm_config* cfg, int device, clm_handle** out) {
+    if (!cfg || !out) return fail(nullptr, CLM_E_INVALID, "clm_create: null argument");
+    if (cfg->struct_size != (int32_t)sizeof(clm_config)) return fail(nullptr, CLM_E_INVALID, "clm_config size mismatch");
+    if (cfg->d_model != D || cfg->n_layer != NLAYER || cfg->d_inner != DI || cfg->vocab_rows != VOCAB ||
+        cfg->filter_order != FORDER || cfg->emb_dim != EMB || cfg->head_hidden != HH || cfg->n_classes != NCLS)
+        return fail(nullptr, CLM_E_UNSUPPORTED,
+                    "only the HyenaDNA-small-32k + 512-wide attention-pooling head of chimeralm/models/lm.py is built");
+    if (cfg->precision < CLM_PREC_F32 || cfg->precision > CLM_PREC_F16 || cfg->chunk_reads < 1 ||
+        cfg->max_seq_len < 2)
+        return fail(nullptr, CLM_E_INVALID, "clm_create: bad precision / chunk_reads / max_seq_len");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev)
+        return fail(nullptr, CLM_E_HIP, "clm_create: no such HIP device " + std::to_string(device));
+    if (hipSetDevice(device) != hipSuccess) return fail(nullptr, CLM_E_HIP, "hipSetDevice failed");
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) return fail(nullptr, CLM_E_HIP, "hipGetDeviceProperties failed");
+    if (std::string(prop.gcnArchName).rfind("gfx950", 0) != 0)
+        return fail(nullptr, CLM_E_UNSUPPORTED, std::string("this engine is built for gfx950 (MI355X) only, found ") + prop.gcnArchName);
+    clm_handle* h = new clm_handle();
+    h->cfg = *cfg;
+    h->device = device;
+    *out = h;
+    return CLM_OK;
+}
+
+int clm_load_weight(clm_handle* h, const char* key, const void* data, int dtype, const int64_t* shape, int ndim) {
+    if (!h || !key || !data || !shape || ndim < 1 || ndim > 4) return fail(h, CLM_E_INVALID, "clm_load_weight: bad argument");
+    std::string ck;
+    if (!canonical_key(key, ck)) return fail(h, CLM_E_INVALID, std::string("unknown weight key: ") + key);
+    if (ck.find("implicit_filter.3.freq") != std::string::npos || ck.find("implicit_filter.5.freq") != std::string::npos)
+        return CLM_OK;  // aliases of the shared sine module's parameter (implicit_filter.1.freq)
+    const KeySpec* spec = nullptr;
+    static thread_local std::vector<KeySpec> specs;
+    specs = expected_keys(h->cfg);
+    for (auto& s : specs)
+        if (s.key == ck) spec = &s;
+    if (!spec) return fail(h, CLM_E_INVALID, std::string("unknown weight key: ") + key);
+    std::vector<int64_t> shp(shape, shape + ndim);
+    if (shp != spec->shape) {
+        std::string got, want;
+        for (auto v : shp) got += std::to_string(v) + ",";
+        for (auto v : spec->shape) want += std::to_string(v) + ",";
+        return fail(h, CLM_E_INVALID, std::string(key) + ": shape [" + got + "] does not match [" + want + "]");
+    }
+    size_t n = 1;
+    for (auto v : shp) n *= (size_t)v;
+    HIPCHK(h, hipSetDevice(h->device));
+    Tensor& t = h->w[ck];
+    if (!t.d) HIPCHK(h, hipMalloc((void**)&t.d, n * 4));
+    t.shape = shp;
+    t.numel = n;
+    if (dtype == CLM_DT_F32) {
+        HIPCHK(h, hipMemcpy(t.d, data, n * 4, hipMemcpyDefault));
+    } else if (dtype == CLM_DT_F64 || dtype == CLM_DT_BF16 || dtype == CLM_DT_F16) {
+        size_t es = dtype == CLM_DT_F64 ? 8 : 2;
+        void* stage = nullptr;
+        HIPCHK(h, hipMalloc(&stage, n * es));
+        HIPCHK(h, hipMemcpy(stage, data, n * es, hipMemcpyDefault));
+        hipLaunchKernelGGL(convert_to_f32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, stage, t.d, n, dtype);
+        HIPCHK(h, hipDeviceSynchronize());
+        HIPCHK(h, hipFree(stage));
+    } else {
+        return fail(h, CLM_E_INVALID, "clm_load_weight: dtype must be f32/f64/bf16/f16");
+    }
+    t.loaded = true;
+    h->finalized = false;
+    return CLM_OK;
+}
+
+int clm_finalize(clm_handle* h) {
+    if (!h) return CLM_E_INVALID;
+    HIPCHK(h, hipSetDevice(h->device));
+    for (auto& s : expected_keys(h->cfg)) {
+        auto it = h->w.find(s.key);
+        if (it == h->w.end() || !it->second.loaded) return fail(h, CLM_E_MISSING, "missing weight: " + s.key);
+    }
+    HIPCHK(h, hipDeviceSynchronize());
+    free_packed(h);
+    free_filters(h);
+    const int prec = h->cfg.precision;
+    hipStream_t st = 0;
+    auto pack = [&](const std::string& key, int n, int k, void** out) -> int {
+        HIPCHK(h, hipMalloc(out, packed_weight_bytes(prec, n, k)));
+        launch_pack_weight(prec, W(h, key), *out, n, k, st);
+        return CLM_OK;
+    };
+    for (int i = 0; i < NLAYER; ++i) {
+        std::string p = "bb.layers." + std::to_string(i) + ".";
+        int rc;
+        if ((rc = pack(p + "mixer.in_proj.weight", D3, D, &h->packed[i][0]))) return rc;
+        if ((rc = pack(p + "mixer.out_proj.weight", D, D, &h->packed[i][1]))) return rc;
+        if ((rc = pack(p + "mlp.fc1.weight", DI, D, &h->packed[i][2]))) return rc;
+        if ((rc = pack(p + "mlp.fc2.weight", D, DI, &h->packed[i][3]))) return rc;
+        LayerW& lw = h->lw[i];
+        lw.ln1_g = W(h, p + "norm1.weight"); lw.ln1_b = W(h, p + "norm1.bias");
+        lw.ln2_g = W(h, p + "norm2.weight"); lw.ln2_b = W(h, p + "norm2.bias");
+        lw.w_in = h->packed[i][0]; lw.w_out = h->packed[i][1]; lw.w_fc1 = h->packed[i][2]; lw.w_fc2 = h->packed[i][3];
+        lw.b_in = W(h, p + "mixer.in_proj.bias"); lw.b_out = W(h, p + "mixer.out_proj.bias");
+        lw.b_fc1 = W(h, p + "mlp.fc1.bias"); lw.b_fc2 = W(h, p + "mlp.fc2.bias");
+        lw.short_w = W(h, p + "mixer.short_filter.weight"); lw.short_b = W(h, p + "mixer.short_filter.bias");
+        lw.filt_bias = W(h, p + "mixer.filter_fn.bias");
+    }
+    {
+        int rc;
+        if ((rc = pack("head.attention.0.weight", D, D, &h->packed_score))) return rc;
+    }
+    struct { const char* key; int rows, cols; } tr[5] = {
+        {"head.classifier.0.weight", HH, D}, {"head.classifier.3.weight", HH, HH},
+        {"head.classifier.6.layers.0.weight", HH, HH}, {"head.classifier.6.layers.3.weight", HH, HH},
+        {"head.output_layer.weight", NCLS, HH}};
+    for (int j = 0; j < 5; ++j) {
+        HIPCHK(h, hipMalloc((void**)&h->head_t[j], (size_t)tr[j].rows * tr[j].cols * 4));
+        launch_transpose(W(h, tr[j].key), h->head_t[j], tr[j].rows, tr[j].cols, st);
+    }
+    h->hw.w0t = h->head_t[0]; h->hw.b0 = W(h, "head.classifier.0.bias");
+    h->hw.w3t = h->head_t[1]; h->hw.b3 = W(h, "head.classifier.3.bias");
+    h->hw.w60t = h->head_t[2]; h->hw.b60 = W(h, "head.classifier.6.layers.0.bias");
+    h->hw.w63t = h->head_t[3]; h->hw.b63 = W(h, "head.classifier.6.layers.3.bias");
+    h->hw.wot = h->head_t[4]; h->hw.bo = W(h, "head.output_layer.bias");
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipDeviceSynchronize());
+    h->finalized = true;
+    return CLM_OK;
+}
+
+int clm_reserve(clm_handle* h, int B, int L) {
+    if (!h || B < 1 || L < 1) return fail(h, CLM_E_INVALID, "clm_reserve: bad argument");
+    if (!h->finalized) return fail(h, CLM_E_STATE, "clm_reserve before clm_finalize");
+    HIPCHK(h, hipSetDevice(h->device));
+    FilterSet* fs = nullptr;
+    int rc = ensure_filters(h, L, 0, &fs);
+    if (rc) return rc;
+    int Bc = B < h->cfg.chunk_reads ? B : h->cfg.chunk_reads;
+    return ensure_workspace(h, Bc, L, 0);
+}
+
+int clm_forward(clm_handle* h, const void* ids, int ids_dtype, int64_t ids_row_stride, int B, int L,
+                float* logits_out, void* stream) {
+    if (!h) return CLM_E_INVALID;
+    if (!h->finalized) return fail(h, CLM_E_STATE, "clm_forward before clm_finalize");
+    if (!ids || !logits_out || B < 1 || L < 1 || ids_row_stride < L)
+        return fail(h, CLM_E_INVALID, "clm_forward: bad argument");
+    if (ids_dtype != CLM_DT_I64 && ids_dtype != CLM_DT_I32 && ids_dtype != CLM_DT_U8)
+        return fail(h, CLM_E_INVALID, "clm_forward: ids dtype must be i64, i32 or u8");
+    HIPCHK(h, hipSetDevice(h->device));
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const size_t ies = ids_dtype == CLM_DT_I64 ? 8 : (ids_dtype == CLM_DT_I32 ? 4 : 1);
+    const int chunk = h->cfg.chunk_reads;
+    for (int b0 = 0; b0 < B; b0 += chunk) {
+        int Bc = B - b0 < chunk ? B - b0 : chunk;
+        const char* p = reinterpret_cast<const char*>(ids) + (size_t)b0 * ids_row_stride * ies;
+        int rc = forward_chunk(h, p, ids_dtype, ids_row_stride, Bc, L, logits_out + (size_t)b0 * NCLS, st);
+        if (rc) return rc;
+    }
+    return CLM_OK;
+}
+
+int clm_debug_stop_after(clm_handle* h, int layer, int stage) {
+    if (!h) return CLM_E_INVALID;
+    h->stop_layer = layer;
+    h->stop_stage = stage;
+    return CLM_OK;
+}
+
+int clm_debug_fetch(clm_handle* h, const char* name, void* host_out, size_t bytes) {
+    if (!h || !name || !host_out) return fail(h, CLM_E_INVALID, "clm_debug_fetch: bad argument");
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipDeviceSynchronize());
+    const size_t es = elem_size(h->cfg.precision);
+    const size_t B = h->last_B, L = h->last_L, Lp = h->last_Lp;
+    const void* src = nullptr;
+    size_t have = 0;
+    std::string n(name);
+    if (n == "hidden" || n == "h") { src = h->h; have = B * L * D * 4; }
+    else if (n == "z") { src = h->z; have = B * D3 * Lp * es; }
+    else if (n == "y") { src = h->y; have = B * D * Lp * es; }
+    else if (n == "u") { src = h->u; have = B * L * DI * es; }
+    else if (n == "scores") { src = h->scores; have = B * L * 4; }
+    else if (n == "pooled") { src = h->pooled; have = B * D * 4; }
+    else if (n.rfind("filter.", 0) == 0) {
+        int i = std::atoi(n.c_str() + 7);
+        for (auto& f : h->filters)
+            if (f.L == (int)L && i >= 0 && i < NLAYER) { src = f.ktime[i]; have = L * D * 4; }
+    }
+    if (!src) return fail(h, CLM_E_INVALID, "clm_debug_fetch: unknown or empty buffer " + n);
+    if (bytes > have) return fail(h, CLM_E_INVALID, "clm_debug_fetch: " + n + " holds only " + std::to_string(have) + " bytes");
+    HIPCHK(h, hipMemcpy(host_out, src, bytes, hipMemcpyDeviceToHost));
+    return CLM_OK;
+}
+
+int clm_profile_enable(clm_handle* h, int on) {
+    if (!h) return CLM_E_INVALID;
+    h->prof = on != 0;
+    return CLM_OK;
+}
+
+int clm_profile_read(clm_handle* h, double* ms_out, int64_t* launches_out, int reset) {
+    if (!h) return CLM_E_INVALID;
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipDeviceSynchronize());
+    for (auto& r : h->recs) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, r.e0, r.e1) == hipSuccess) {
+            h->prof_ms[r.stage] += ms;
+            h->prof_n[r.stage] += 1;
+        }
+        h->free_events.push_back({r.e0, r.e1});
+    }
+    h->recs.clear();
+    for (int i = 0; i < CLM_N_STAGES; ++i) {
+        if (ms_out) ms_out[i] = h->prof_ms[i];
+        if (launches_out) launches_out[i] = h->prof_n[i];
+        if (reset) { h->prof_ms[i] = 0; h->prof_n[i] = 0; }
+    }
+    return CLM_OK;
+}
+
+const char* clm_profile_stage_name(int stage) {
+    static const char* names[CLM_N_STAGES] = {"embed", "ln1_in_proj", "short_long_conv", "out_proj", "ln2_fc1_gelu",
+                                              "fc2", "lnf_pool_score", "softmax_pool", "head_mlp", "filter"};
+    return (stage >= 0 && stage < CLM_N_STAGES) ? names[stage] : "?";
+}
+
+const char* clm_last_error(const clm_handle* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+int clm_destroy(clm_handle* h) {
+    if (!h) return CLM_OK;
+    (void)hipSetDevice(h->device);
+    (void)hipDeviceSynchronize();
+    for (auto& r : h->recs) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
+    for (auto& e : h->free_events) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+    free_workspace(h);
+    free_filters(h);
+    free_packed(h);
+    for (auto& kv : h->w)
+        if (kv.second.d) (void)hipFree(kv.second.d);
+    delete h;
+    return CLM_OK;
+}
+
+}  // extern "C"

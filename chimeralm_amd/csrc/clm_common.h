@@ -1,0 +1,139 @@
+// clm_common.h -- shared device helpers and the kernel launch prototypes of the ChimeraLM MI355X engine.
+// gfx950 only: wave64, MFMA 32x32, 160 KiB LDS.  No CUDA compatibility layer.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace clm {
+
+// model constants fixed by the reference (chimeralm/models/lm.py:19-31)
+constexpr int D = 256;          // d_model
+constexpr int D3 = 768;         // in_proj width (x0 | x1 | v)
+constexpr int DI = 1024;        // MLP inner width
+constexpr int NLAYER = 4;
+constexpr int VOCAB = 16;
+constexpr int FORDER = 64;      // implicit filter MLP width
+constexpr int EMB = 5;          // positional embedding width
+constexpr int HH = 512;         // head hidden
+constexpr int NCLS = 2;
+
+using f32x16 = float __attribute__((ext_vector_type(16)));
+using bf16x8 = __bf16 __attribute__((ext_vector_type(8)));
+using f16x8 = _Float16 __attribute__((ext_vector_type(8)));
+using u16x8 = unsigned short __attribute__((ext_vector_type(8)));
+using u16x4 = unsigned short __attribute__((ext_vector_type(4)));
+
+// ---- storage element types of the 16-bit activations -------------------------------------------------
+struct bf16_t {
+    unsigned short bits;
+};
+struct f16_t {
+    unsigned short bits;
+};
+
+__device__ __forceinline__ float to_float(float v) { return v; }
+__device__ __forceinline__ float to_float(bf16_t v) { return __uint_as_float(uint32_t(v.bits) << 16); }
+__device__ __forceinline__ float to_float(f16_t v) {
+    _Float16 h;
+    __builtin_memcpy(&h, &v.bits, 2);
+    return float(h);
+}
+template <typename T>
+__device__ __forceinline__ T from_float(float v);
+template <>
+__device__ __forceinline__ float from_float<float>(float v) { return v; }
+template <>
+__device__ __forceinline__ bf16_t from_float<bf16_t>(float v) {
+    __bf16 b = __bf16(v);  // round to nearest even, NaN-preserving (v_cvt_pk_bf16_f32)
+    bf16_t r;
+    __builtin_memcpy(&r.bits, &b, 2);
+    return r;
+}
+template <>
+__device__ __forceinline__ f16_t from_float<f16_t>(float v) {
+    _Float16 h = _Float16(v);
+    f16_t r;
+    __builtin_memcpy(&r.bits, &h, 2);
+    return r;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// gelu(x, approximate="tanh") = x * sigmoid(2*sqrt(2/pi)*(x + 0.044715 x^3))      (HyenaMlp activation)
+__device__ __forceinline__ float gelu_tanh(float x) {
+    float u = 0.7978845608028654f * (x + 0.044715f * x * x * x);
+    return x / (1.0f + __expf(-2.0f * u));
+}
+// exact gelu (erf form): nn.GELU() of the head (hyena.py:38,47,162)
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.7071067811865476f)); }
+
+// ---- kernel launchers (definitions in the .hip files); all are asynchronous on `st` --------------------
+enum Prec { PREC_F32 = 0, PREC_BF16 = 1, PREC_F16 = 2 };
+
+struct LayerW {            // device pointers, fp32 unless noted
+    const float *ln1_g, *ln1_b, *ln2_g, *ln2_b;
+    const void *w_in, *w_out, *w_fc1, *w_fc2;   // packed MFMA-fragment order, compute dtype
+    const float *b_in, *b_out, *b_fc1, *b_fc2;
+    const float *short_w, *short_b;             // [768][3], [768]
+    const float *filt_bias;                     // [256]  (D skip term)
+};
+
+// embedding gather: ids [B, L] (dtype code CLM_DT_*) -> h fp32 [B, L, 256]
+void launch_embed(const void* ids, int ids_dtype, int64_t row_stride, const float* table, float* h, int B, int L,
+                  hipStream_t st);
+
+// GEMM family (gemm.hip).  `prec` selects compute dtype; T16 activations are bf16/f16 (or fp32 for PREC_F32).
+// z  = in_proj(LN1(h))      -> channel-major [B, 768, Lp]
+void launch_inproj(int prec, const float* h, const float* g, const float* b, const void* w, const float* bias, void* z,
+                   int B, int L, int Lp, float eps, hipStream_t st);
+// h += out_proj(y^T)        y channel-major [B, 256, Lp]
+void launch_outproj(int prec, const void* y, const void* w, const float* bias, float* h, int B, int L, int Lp,
+                    hipStream_t st);
+// u  = gelu_tanh(fc1(LN2(h)))  token-major [B, L, 1024]
+void launch_fc1(int prec, const float* h, const float* g, const float* b, const void* w, const float* bias, void* u,
+                int B, int L, float eps, hipStream_t st);
+// h += fc2(u)
+void launch_fc2(int prec, const void* u, const void* w, const float* bias, float* h, int B, int L, hipStream_t st);
+// scores[b,t] = w2 . gelu_erf(W1 LNf(h) + b1) + b2
+void launch_score(int prec, const float* h, const float* g, const float* b, const void* w1, const float* b1,
+                  const float* w2, const float* b2, float* scores, int B, int L, float eps, hipStream_t st);
+size_t packed_weight_bytes(int prec, int n, int k);
+// pack W [n][k] fp32 (device) into MFMA fragment order of the compute dtype
+void launch_pack_weight(int prec, const float* w, void* out, int n, int k, hipStream_t st);
+
+// long convolution (hyena_conv.hip)
+int conv_logn_for(int L);                         // log2 of the FFT size used for L tokens; <0 if unsupported
+void launch_filter(const float* z /*[maxlen][5]*/, const float* t /*[maxlen]*/, const float* w0, const float* b0,
+                   const float* freq, const float* w2, const float* b2, const float* w4, const float* b4,
+                   const float* w6, const float* deltas, float* k_out /*[L][256]*/, int L, hipStream_t st);
+// spectrum of one layer's filter: kf [256][N] float2 = FFT_N(k[:, c]) / N (double precision inside);
+// scratch: 256*N double2
+void launch_filter_spectrum(const float* k /*[L][256]*/, float2* kf, double2* scratch, int L, int logn,
+                            hipStream_t st);
+void launch_twiddles(float2* tw, int logn, hipStream_t st);   // tw[m] = exp(-2 pi i m / N), m < N/2
+// y = ((causal_conv(v*x1, k) + D*(v*x1)) * x0)   with (x0,x1,v) = short_filter(z)    [B,256,Lp]
+void launch_hyena_conv(int prec, const void* z, void* y, const float2* kf, const float2* tw, const float* ktime,
+                       const float* short_w, const float* short_b, const float* dbias, int B, int L, int Lp, int logn,
+                       hipStream_t st);
+
+// head (head.hip)
+void launch_softmax_stats(const float* scores, float* stats /*[B][2] = max, sum*/, int B, int L, hipStream_t st);
+constexpr int POOL_SPLIT = 16;
+void launch_pool(const float* h, const float* g, const float* b, const float* scores, const float* stats,
+                 float* partial /*[B][POOL_SPLIT][4][256]*/, int B, int L, float eps, hipStream_t st);
+struct HeadW {  // transposed [in][out] fp32
+    const float *w0t, *b0, *w3t, *b3, *w60t, *b60, *w63t, *b63, *wot, *bo;
+};
+void launch_head_mlp(const float* partial, const HeadW& hw, float* pooled_out, float* logits, int B, hipStream_t st);
+void launch_transpose(const float* in, float* out, int rows, int cols, hipStream_t st);
+
+}  // namespace clm

@@ -1,0 +1,119 @@
+// Host emulation of the LDS Stockham convolution used by hyena_conv.hip (built with g++ by
+// tests/test_fft_core.py).  Every "thread" of the kernel is run in turn, barriers become loop boundaries,
+// and the result is checked against a direct double-precision causal convolution, including the
+// single-alias correction used when L == N/2 + 1 ("long convolution").
+#include <complex>
+#include <cstdio>
+#include <cstdlib>
+#include <random>
+#include <vector>
+
+#include "fft_passes.h"
+
+using namespace clmfft;
+using cd = std::complex<double>;
+
+static void fft_ref(std::vector<cd>& a, bool inv) {  // plain recursive radix-2, double
+    size_t n = a.size();
+    if (n == 1) return;
+    std::vector<cd> e(n / 2), o(n / 2);
+    for (size_t i = 0; i < n / 2; ++i) e[i] = a[2 * i], o[i] = a[2 * i + 1];
+    fft_ref(e, inv);
+    fft_ref(o, inv);
+    for (size_t k = 0; k < n / 2; ++k) {
+        cd w = std::polar(1.0, (inv ? 2.0 : -2.0) * M_PI * double(k) / double(n)) * o[k];
+        a[k] = e[k] + w;
+        a[k + n / 2] = e[k] - w;
+    }
+}
+
+template <int LOGN, int R, bool INV>
+static void run_pass(std::vector<float2>& buf, int Ns, const std::vector<float2>& tw) {
+    constexpr int NT = Plan<LOGN>::NT;
+    std::vector<float2> regs(size_t(NT) * 16);
+    for (int tid = 0; tid < NT; ++tid) pass_load<LOGN, R>(buf.data(), &regs[size_t(tid) * 16], tid);
+    for (int tid = 0; tid < NT; ++tid) pass_compute<LOGN, R, INV>(&regs[size_t(tid) * 16], tid, Ns, tw.data());
+    for (int tid = 0; tid < NT; ++tid) pass_store<LOGN, R>(buf.data(), &regs[size_t(tid) * 16], tid, Ns);
+}
+
+template <int LOGN>
+static double test_conv(int L, unsigned seed) {
+    using P = Plan<LOGN>;
+    constexpr int N = P::N, NT = P::NT, LAST = P::LAST;
+    if (!(2 * L - 2 <= N && L >= 1)) {
+        std::printf("bad L\n");
+        std::exit(2);
+    }
+    std::mt19937 rng(seed);
+    std::normal_distribution<double> nd;
+    std::vector<double> g0(L), g1(L), k(L);
+    for (int t = 0; t < L; ++t) g0[t] = nd(rng), g1[t] = nd(rng), k[t] = nd(rng) * std::exp(-3.0 * t / L);
+    // filter spectrum / N  (what the engine precomputes in double, stored as float2)
+    std::vector<cd> kf(N);
+    for (int t = 0; t < L; ++t) kf[t] = k[t];
+    fft_ref(kf, false);
+    std::vector<float2> kff(N), tw(N / 2);
+    for (int m = 0; m < N; ++m) kff[m] = make_float2(float(kf[m].real() / N), float(kf[m].imag() / N));
+    for (int m = 0; m < N / 2; ++m) tw[m] = make_float2(float(std::cos(2 * M_PI * m / N)), float(-std::sin(2 * M_PI * m / N)));
+    // signal in padded "LDS"
+    std::vector<float2> buf(padded_size(N), make_float2(0.f, 0.f));
+    for (int t = 0; t < L; ++t) buf[pad_index(t)] = make_float2(float(g0[t]), float(g1[t]));
+    // forward passes
+    int Ns = 1;
+    for (int p = 0; p < P::NPASS - 1; ++p) {
+        run_pass<LOGN, 16, false>(buf, Ns, tw);
+        Ns *= 16;
+    }
+    {
+        std::vector<float2> regs(size_t(NT) * 16);
+        for (int tid = 0; tid < NT; ++tid) pass_load<LOGN, LAST>(buf.data(), &regs[size_t(tid) * 16], tid);
+        for (int tid = 0; tid < NT; ++tid) pass_compute<LOGN, LAST, false>(&regs[size_t(tid) * 16], tid, Ns, tw.data());
+        for (int tid = 0; tid < NT; ++tid) spectrum_multiply_and_first_inverse<LOGN, LAST>(&regs[size_t(tid) * 16], tid, kff.data());
+        for (int tid = 0; tid < NT; ++tid) pass_store<LOGN, LAST>(buf.data(), &regs[size_t(tid) * 16], tid, 1);
+    }
+    Ns = LAST;
+    for (int p = 0; p < P::NPASS - 1; ++p) {
+        run_pass<LOGN, 16, true>(buf, Ns, tw);
+        Ns *= 16;
+    }
+    // reference: direct causal convolution in double
+    double max_err = 0, max_ref = 0;
+    for (int t = 0; t < L; ++t) {
+        double r0 = 0, r1 = 0;
+        for (int s = 0; s <= t; ++s) r0 += k[s] * g0[t - s], r1 += k[s] * g1[t - s];
+        double y0 = buf[pad_index(t)].x, y1 = buf[pad_index(t)].y;
+        if (t == 0 && 2 * L - 2 == N) {  // the one aliased term k[L-1]*g[L-1] wraps onto output 0
+            y0 -= double(float(k[L - 1])) * double(float(g0[L - 1]));
+            y1 -= double(float(k[L - 1])) * double(float(g1[L - 1]));
+        }
+        max_err = std::fmax(max_err, std::fmax(std::fabs(y0 - r0), std::fabs(y1 - r1)));
+        max_ref = std::fmax(max_ref, std::fmax(std::fabs(r0), std::fabs(r1)));
+    }
+    return max_err / max_ref;
+}
+
+template <int LOGN>
+static int run(unsigned seed) {
+    constexpr int N = 1 << LOGN;
+    int fails = 0;
+    for (int L : {N / 2 + 1, N / 2, N / 2 - 3, N / 4 + 7, 5}) {
+        if (2 * L - 2 > N || L < 1) continue;
+        double e = test_conv<LOGN>(L, seed + L);
+        std::printf("LOGN=%d L=%d rel_err=%.3e\n", LOGN, L, e);
+        if (!(e < 2e-5)) ++fails;
+    }
+    return fails;
+}
+
+int main() {
+    int fails = 0;
+    fails += run<8>(1);
+    fails += run<9>(2);
+    fails += run<10>(3);
+    fails += run<11>(4);
+    fails += run<12>(5);
+    fails += run<13>(6);
+    fails += run<14>(7);
+    std::printf(fails ? "FAIL %d\n" : "ALL OK\n", fails);
+    return fails ? 1 : 0;
+}

@@ -1,0 +1,374 @@
+// hyena_conv.hip -- the Hyena mixer's non-GEMM half on gfx950:
+//   implicit filter MLP, filter spectrum, short (3-tap) depthwise filter, gates and the causal long convolution.
+//
+// Reference arithmetic (HyenaDNA remote code):
+//   uc = Conv1d(768,768,3,padding=2,groups=768)(z)[..., :L];  x0, x1, v = split(uc, 256)
+//   g  = v * x1
+//   yc = irfft(rfft(g, 2L) * rfft(k, 2L) / 2L, n=2L, norm="forward")[..., :L] + g * D        (fftconv)
+//   y  = yc * x0
+// with k[t, c] = MLP_sin(z_pos[t]) * (exp(-t_norm |delta_c|) + 0.05).
+//
+// Engine formulation: a causal linear convolution is the same operator for any transform size that avoids
+// wrap-around, so the FFT-hostile 2L (2L = 16386 for 8 kbp reads) is replaced by a power-of-two COMPLEX FFT of
+// N >= 2L-2 points held entirely in LDS, with TWO reads of the same channel packed as real and imaginary part
+// (the filter is real, so it acts on both parts independently: no untangling pass, and the filter spectrum
+// is fetched once per pair).  N == 2L-2 (the 8193-token case) aliases exactly one product, k[L-1]*g[L-1],
+// onto output 0; it is subtracted explicitly.  One workgroup = one (channel, read pair).
+#include "clm_common.h"
+#include "fft_passes.h"
+
+namespace clm {
+using namespace clmfft;
+
+// ---------------------------------------------------------------------------------------- implicit filter
+// One workgroup of 64 threads per position t; double precision inside (evaluated once per distinct L and
+// cached by the handle, so its cost is irrelevant and its rounding error is below the reference's own).
+__global__ __launch_bounds__(64) void filter_kernel(const float* __restrict__ z, const float* __restrict__ tn,
+                                                    const float* __restrict__ w0, const float* __restrict__ b0,
+                                                    const float* __restrict__ freq, const float* __restrict__ w2,
+                                                    const float* __restrict__ b2, const float* __restrict__ w4,
+                                                    const float* __restrict__ b4, const float* __restrict__ w6,
+                                                    const float* __restrict__ deltas, float* __restrict__ k_out,
+                                                    int L) {
+    __shared__ double hbuf[2][FORDER];
+    const int t = blockIdx.x, j = threadIdx.x;
+    const double f = (double)freq[j];
+    double acc = (double)b0[j];
+#pragma unroll
+    for (int e = 0; e < EMB; ++e) acc += (double)w0[j * EMB + e] * (double)z[(size_t)t * EMB + e];
+    hbuf[0][j] = sin(f * acc);
+    __syncthreads();
+    acc = (double)b2[j];
+    for (int i = 0; i < FORDER; ++i) acc += (double)w2[j * FORDER + i] * hbuf[0][i];
+    hbuf[1][j] = sin(f * acc);
+    __syncthreads();
+    acc = (double)b4[j];
+    for (int i = 0; i < FORDER; ++i) acc += (double)w4[j * FORDER + i] * hbuf[1][i];
+    __syncthreads();
+    hbuf[0][j] = sin(f * acc);
+    __syncthreads();
+    const double tt = (double)tn[t];
+    for (int c = j; c < D; c += 64) {
+        double o = 0.0;
+        for (int i = 0; i < FORDER; ++i) o += (double)w6[c * FORDER + i] * hbuf[0][i];
+        double decay = exp(-tt * fabs((double)deltas[c]));
+        k_out[(size_t)t * D + c] = (float)(o * (decay + 0.05));
+    }
+}
+
+void launch_filter(const float* z, const float* t, const float* w0, const float* b0, const float* freq,
+                   const float* w2, const float* b2, const float* w4, const float* b4, const float* w6,
+                   const float* deltas, float* k_out, int L, hipStream_t st) {
+    hipLaunchKernelGGL(filter_kernel, dim3(L), dim3(64), 0, st, z, t, w0, b0, freq, w2, b2, w4, b4, w6, deltas,
+                       k_out, L);
+}
+
+// ---------------------------------------------------------------------------------------- filter spectrum
+// kf[c][m] = (1/N) sum_t k[t][c] exp(-2 pi i m t / N), double precision radix-2 in global scratch, one
+// workgroup per channel (runs once per distinct L).
+__global__ __launch_bounds__(256) void spectrum_kernel(const float* __restrict__ k, float2* __restrict__ kf,
+                                                       double2* __restrict__ scratch, int L, int logn) {
+    const int N = 1 << logn, c = blockIdx.x;
+    double2* a = scratch + (size_t)c * N;
+    for (int i = threadIdx.x; i < N; i += blockDim.x) {  // bit-reversed load
+        int rv = __brev((unsigned)i) >> (32 - logn);
+        a[rv] = make_double2(i < L ? (double)k[(size_t)i * D + c] : 0.0, 0.0);
+    }
+    __syncthreads();
+    for (int s = 1; s <= logn; ++s) {
+        const int half = 1 << (s - 1);
+        for (int i = threadIdx.x; i < N / 2; i += blockDim.x) {
+            int grp = i >> (s - 1), pos = i & (half - 1);
+            int i0 = (grp << s) + pos, i1 = i0 + half;
+            double sn, cs;
+            sincospi(-(double)pos / (double)half, &sn, &cs);  // exp(-2 pi i pos / 2^s)
+            double2 u = a[i0], v = a[i1];
+            double2 w = make_double2(v.x * cs - v.y * sn, v.x * sn + v.y * cs);
+            a[i0] = make_double2(u.x + w.x, u.y + w.y);
+            a[i1] = make_double2(u.x - w.x, u.y - w.y);
+        }
+        __syncthreads();
+    }
+    const double inv = 1.0 / (double)N;
+    for (int i = threadIdx.x; i < N; i += blockDim.x)
+        kf[(size_t)c * N + i] = make_float2((float)(a[i].x * inv), (float)(a[i].y * inv));
+}
+
+void launch_filter_spectrum(const float* k, float2* kf, double2* scratch, int L, int logn, hipStream_t st) {
+    hipLaunchKernelGGL(spectrum_kernel, dim3(D), dim3(256), 0, st, k, kf, scratch, L, logn);
+}
+
+__global__ void twiddle_kernel(float2* tw, int logn) {
+    int m = blockIdx.x * blockDim.x + threadIdx.x, N = 1 << logn;
+    if (m < N / 2) {
+        double sn, cs;
+        sincospi(-2.0 * (double)m / (double)N, &sn, &cs);
+        tw[m] = make_float2((float)cs, (float)sn);
+    }
+}
+void launch_twiddles(float2* tw, int logn, hipStream_t st) {
+    int n = (1 << logn) / 2;
+    hipLaunchKernelGGL(twiddle_kernel, dim3((n + 255) / 256), dim3(256), 0, st, tw, logn);
+}
+
+// ---------------------------------------------------------------------------------------- the convolution
+int conv_logn_for(int L) {
+    if (L < 1) return -1;
+    for (int logn = 8; logn <= 14; ++logn)
+        if (2 * L - 2 <= (1 << logn)) return logn;
+    return -1;  // L > 8193: needs the segmented overlap-add variant (not built yet)
+}
+
+// 8 consecutive activations (one 16-byte vector for the 16-bit types, two for fp32) as floats
+template <typename T>
+__device__ __forceinline__ void load8(const T* p, float* o);
+template <>
+__device__ __forceinline__ void load8<float>(const float* p, float* o) {
+    float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
+    o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = a.w; o[4] = b.x; o[5] = b.y; o[6] = b.z; o[7] = b.w;
+}
+template <>
+__device__ __forceinline__ void load8<bf16_t>(const bf16_t* p, float* o) {
+    uint4 a = *reinterpret_cast<const uint4*>(p);
+    unsigned w[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        o[2 * i] = __uint_as_float(w[i] << 16);
+        o[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
+    }
+}
+template <>
+__device__ __forceinline__ void load8<f16_t>(const f16_t* p, float* o) {
+    uint4 a = *reinterpret_cast<const uint4*>(p);
+    _Float16 h[8];
+    __builtin_memcpy(h, &a, 16);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) o[i] = (float)h[i];
+}
+template <typename T>
+__device__ __forceinline__ void store8(T* p, const float* v);
+template <>
+__device__ __forceinline__ void store8<float>(float* p, const float* v) {
+    *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+    *reinterpret_cast<float4*>(p + 4) = make_float4(v[4], v[5], v[6], v[7]);
+}
+template <>
+__device__ __forceinline__ void store8<bf16_t>(bf16_t* p, const float* v) {
+    u16x8 o;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) o[i] = from_float<bf16_t>(v[i]).bits;
+    *reinterpret_cast<u16x8*>(p) = o;
+}
+template <>
+__device__ __forceinline__ void store8<f16_t>(f16_t* p, const float* v) {
+    u16x8 o;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) o[i] = from_float<f16_t>(v[i]).bits;
+    *reinterpret_cast<u16x8*>(p) = o;
+}
+
+// short filter on 8 consecutive samples of one channel row: out[e] = b + w0*x[t-2] + w1*x[t-1] + w2*x[t]
+template <typename T>
+__device__ __forceinline__ void short_filter8(const T* row, int t0, float w0, float w1, float w2, float bias,
+                                              float* out) {
+    float x[10];
+    load8<T>(row + t0, x + 2);
+    if (t0 > 0) {
+        x[0] = to_float(row[t0 - 2]);
+        x[1] = to_float(row[t0 - 1]);
+    } else {
+        x[0] = 0.f;
+        x[1] = 0.f;
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) out[e] = bias + w0 * x[e] + w1 * x[e + 1] + w2 * x[e + 2];
+}
+template <typename T>
+__device__ __forceinline__ float short_filter1(const T* row, int t, float w0, float w1, float w2, float bias) {
+    float xm2 = t >= 2 ? to_float(row[t - 2]) : 0.f, xm1 = t >= 1 ? to_float(row[t - 1]) : 0.f;
+    return bias + w0 * xm2 + w1 * xm1 + w2 * to_float(row[t]);
+}
+
+template <int LOGN, typename T>
+__global__ __launch_bounds__(Plan<LOGN>::NT) void hyena_conv_kernel(
+    const T* __restrict__ z, T* __restrict__ y, const float2* __restrict__ kf, const float2* __restrict__ tw,
+    const float* __restrict__ ktime, const float* __restrict__ short_w, const float* __restrict__ short_b,
+    const float* __restrict__ dbias, int B, int L, int Lp) {
+    using P = Plan<LOGN>;
+    constexpr int N = P::N, NT = P::NT, LAST = P::LAST, HALF = N / 2;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float2* buf = reinterpret_cast<float2*>(smem);
+
+    const int tid = threadIdx.x;
+    const int c = blockIdx.y, pair = blockIdx.x;
+    const int bA = 2 * pair, bB = 2 * pair + 1;
+    const bool hasB = bB < B;
+    const T* zA = z + (size_t)bA * D3 * Lp;
+    const T* zB = z + (size_t)(hasB ? bB : bA) * D3 * Lp;
+
+    // per-channel constants: short filter taps of channels c (x0), 256+c (x1), 512+c (v)
+    float sw[3][3], sb[3];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+#pragma unroll
+        for (int e = 0; e < 3; ++e) sw[q][e] = short_w[(q * D + c) * 3 + e];
+        sb[q] = short_b[q * D + c];
+    }
+    const float dskip = dbias[c];
+
+    // ---------------------------------------------------------------- phase A: load, short filter, gate
+    // chunk of 8 tokens t0 = 8*tid (lower half of the transform); x0 and g stay in registers for phase C.
+    const int t0 = 8 * tid;
+    float x0A[8], gA[8], x0B[8], gB[8];
+    if (t0 < HALF) {
+        if (t0 < L) {
+            float x1[8], v[8];
+            short_filter8<T>(zA + (size_t)(0 * D + c) * Lp, t0, sw[0][0], sw[0][1], sw[0][2], sb[0], x0A);
+            short_filter8<T>(zA + (size_t)(1 * D + c) * Lp, t0, sw[1][0], sw[1][1], sw[1][2], sb[1], x1);
+            short_filter8<T>(zA + (size_t)(2 * D + c) * Lp, t0, sw[2][0], sw[2][1], sw[2][2], sb[2], v);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) gA[e] = (t0 + e < L) ? v[e] * x1[e] : 0.f;
+            if (hasB) {
+                short_filter8<T>(zB + (size_t)(0 * D + c) * Lp, t0, sw[0][0], sw[0][1], sw[0][2], sb[0], x0B);
+                short_filter8<T>(zB + (size_t)(1 * D + c) * Lp, t0, sw[1][0], sw[1][1], sw[1][2], sb[1], x1);
+                short_filter8<T>(zB + (size_t)(2 * D + c) * Lp, t0, sw[2][0], sw[2][1], sw[2][2], sb[2], v);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) gB[e] = (t0 + e < L) ? v[e] * x1[e] : 0.f;
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) gB[e] = 0.f, x0B[e] = 0.f;
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) gA[e] = 0.f, gB[e] = 0.f, x0A[e] = 0.f, x0B[e] = 0.f;
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) buf[pad_index(t0 + e)] = make_float2(gA[e], gB[e]);
+        // upper half is zero padding ...
+#pragma unroll
+        for (int e = 0; e < 8; ++e) buf[pad_index(HALF + t0 + e)] = make_float2(0.f, 0.f);
+    }
+    // ... except the single token t = N/2 when L == N/2 + 1 (8193 tokens in a 16384-point transform)
+    const bool tail = (L == HALF + 1);
+    float x0At = 0.f, gAt = 0.f, x0Bt = 0.f, gBt = 0.f;
+    if (tail && tid == 0) {
+        const int t = HALF;
+        x0At = short_filter1<T>(zA + (size_t)(0 * D + c) * Lp, t, sw[0][0], sw[0][1], sw[0][2], sb[0]);
+        gAt = short_filter1<T>(zA + (size_t)(1 * D + c) * Lp, t, sw[1][0], sw[1][1], sw[1][2], sb[1]) *
+              short_filter1<T>(zA + (size_t)(2 * D + c) * Lp, t, sw[2][0], sw[2][1], sw[2][2], sb[2]);
+        if (hasB) {
+            x0Bt = short_filter1<T>(zB + (size_t)(0 * D + c) * Lp, t, sw[0][0], sw[0][1], sw[0][2], sb[0]);
+            gBt = short_filter1<T>(zB + (size_t)(1 * D + c) * Lp, t, sw[1][0], sw[1][1], sw[1][2], sb[1]) *
+                  short_filter1<T>(zB + (size_t)(2 * D + c) * Lp, t, sw[2][0], sw[2][1], sw[2][2], sb[2]);
+        }
+    }
+    __syncthreads();
+    if (tail && tid == 0) buf[pad_index(HALF)] = make_float2(gAt, gBt);
+    __syncthreads();
+
+    // ---------------------------------------------------------------- phase B: FFT, spectrum product, inverse FFT
+    const float2* kfc = kf + (size_t)c * N;
+    float2 v[16];
+    int Ns = 1;
+#pragma unroll
+    for (int p = 0; p < P::NPASS - 1; ++p) {
+        pass_load<LOGN, 16>(buf, v, tid);
+        pass_compute<LOGN, 16, false>(v, tid, Ns, tw);
+        __syncthreads();
+        pass_store<LOGN, 16>(buf, v, tid, Ns);
+        __syncthreads();
+        Ns *= 16;
+    }
+    pass_load<LOGN, LAST>(buf, v, tid);
+    pass_compute<LOGN, LAST, false>(v, tid, Ns, tw);
+    spectrum_multiply_and_first_inverse<LOGN, LAST>(v, tid, kfc);
+    __syncthreads();
+    pass_store<LOGN, LAST>(buf, v, tid, 1);
+    __syncthreads();
+    Ns = LAST;
+#pragma unroll
+    for (int p = 0; p < P::NPASS - 1; ++p) {
+        pass_load<LOGN, 16>(buf, v, tid);
+        pass_compute<LOGN, 16, true>(v, tid, Ns, tw);
+        __syncthreads();
+        pass_store<LOGN, 16>(buf, v, tid, Ns);
+        __syncthreads();
+        Ns *= 16;
+    }
+
+    // ---------------------------------------------------------------- phase C: skip term, gate, store
+    T* yA = y + ((size_t)bA * D + c) * Lp;
+    T* yB = y + ((size_t)(hasB ? bB : bA) * D + c) * Lp;
+    if (t0 < HALF && t0 < Lp) {
+        float oA[8], oB[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float2 pc = buf[pad_index(t0 + e)];
+            if (tail && t0 + e == 0) {  // remove the one wrapped product k[L-1]*g[L-1]
+                float kl = ktime[(size_t)(L - 1) * D + c];
+                pc.x -= kl * gAt;
+                pc.y -= kl * gBt;
+            }
+            bool ok = t0 + e < L;
+            oA[e] = ok ? (pc.x + dskip * gA[e]) * x0A[e] : 0.f;
+            oB[e] = ok ? (pc.y + dskip * gB[e]) * x0B[e] : 0.f;
+        }
+        store8<T>(yA + t0, oA);
+        if (hasB) store8<T>(yB + t0, oB);
+    }
+    if (tail && tid == 0) {
+        float2 pc = buf[pad_index(HALF)];
+        yA[HALF] = from_float<T>((pc.x + dskip * gAt) * x0At);
+        if (hasB) yB[HALF] = from_float<T>((pc.y + dskip * gBt) * x0Bt);
+    }
+}
+
+template <int LOGN, typename T>
+static void launch_conv_t(const void* z, void* y, const float2* kf, const float2* tw, const float* ktime,
+                          const float* short_w, const float* short_b, const float* dbias, int B, int L, int Lp,
+                          hipStream_t st) {
+    using P = Plan<LOGN>;
+    constexpr size_t lds = (size_t)padded_size(P::N) * sizeof(float2);
+    auto kern = hyena_conv_kernel<LOGN, T>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)lds);
+        attr_done = true;
+    }
+    dim3 grid((B + 1) / 2, D), block(P::NT);
+    hipLaunchKernelGGL(kern, grid, block, lds, st, reinterpret_cast<const T*>(z), reinterpret_cast<T*>(y), kf, tw,
+                       ktime, short_w, short_b, dbias, B, L, Lp);
+}
+
+template <int LOGN>
+static void launch_conv_p(int prec, const void* z, void* y, const float2* kf, const float2* tw, const float* ktime,
+                          const float* short_w, const float* short_b, const float* dbias, int B, int L, int Lp,
+                          hipStream_t st) {
+    if (prec == PREC_F32)
+        launch_conv_t<LOGN, float>(z, y, kf, tw, ktime, short_w, short_b, dbias, B, L, Lp, st);
+    else if (prec == PREC_BF16)
+        launch_conv_t<LOGN, bf16_t>(z, y, kf, tw, ktime, short_w, short_b, dbias, B, L, Lp, st);
+    else
+        launch_conv_t<LOGN, f16_t>(z, y, kf, tw, ktime, short_w, short_b, dbias, B, L, Lp, st);
+}
+
+void launch_hyena_conv(int prec, const void* z, void* y, const float2* kf, const float2* tw, const float* ktime,
+                       const float* short_w, const float* short_b, const float* dbias, int B, int L, int Lp, int logn,
+                       hipStream_t st) {
+#define CLM_CONV_CASE(n) \
+    case n: launch_conv_p<n>(prec, z, y, kf, tw, ktime, short_w, short_b, dbias, B, L, Lp, st); break;
+    switch (logn) {
+        CLM_CONV_CASE(8)
+        CLM_CONV_CASE(9)
+        CLM_CONV_CASE(10)
+        CLM_CONV_CASE(11)
+        CLM_CONV_CASE(12)
+        CLM_CONV_CASE(13)
+        CLM_CONV_CASE(14)
+        default: break;
+    }
+#undef CLM_CONV_CASE
+}
+
+}  // namespace clm

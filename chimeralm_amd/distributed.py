@@ -1,0 +1,56 @@
+"""Read-parallel multi-GPU support: one process per GPU, weights replicated, reads sharded, and ONE small collective
+per batch -- an all-gather of the per-read logits (RCCL over xGMI when the backend is "nccl" on ROCm).
+
+The reference has no collective on the predict path (Lightning DDP; each rank writes `{rank}_{batch}.txt`,
+/root/reference/chimeralm/models/callbacks.py:134; batch_size // world_size per device, data/bam.py:142-146).
+The gather exists so rank 0 can own the whole batch's logits (single writer / aggregated `predictions.txt`,
+SURVEY.md section 8(e)); it moves B*2 floats, so it is latency- not bandwidth-bound.
+"""
+from __future__ import annotations
+
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def env_world() -> tuple[int, int, int]:
+    """(rank, local_rank, world_size) from the torchrun environment (1-process defaults)."""
+    return int(os.environ.get("RANK", 0)), int(os.environ.get("LOCAL_RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
+
+
+def init_process_group(backend: str | None = None) -> tuple[int, int, int]:
+    rank, local_rank, world = env_world()
+    if world > 1 and not dist.is_initialized():
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, local_rank, world
+
+
+def shard_bounds(n_reads: int, rank: int, world: int) -> tuple[int, int]:
+    """Contiguous shard [lo, hi) of a global batch; the reference requires divisibility (bam.py:143-145)."""
+    if n_reads % world != 0:
+        raise RuntimeError(f"Batch size ({n_reads}) is not divisible by the number of devices ({world}).")
+    per = n_reads // world
+    return rank * per, (rank + 1) * per
+
+
+def gather_logits(local_logits: torch.Tensor, world: int | None = None) -> torch.Tensor:
+    """All-gather [B/G, C] -> [B, C] in rank order (contiguous shards, so this restores the global read order)."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return local_logits
+    world = dist.get_world_size() if world is None else world
+    out = torch.empty((world * local_logits.shape[0], local_logits.shape[1]), dtype=local_logits.dtype,
+                      device=local_logits.device)
+    dist.all_gather_into_tensor(out, local_logits.contiguous())
+    return out
+
+
+def barrier():
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        dist.barrier()

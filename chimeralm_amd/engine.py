@@ -1,0 +1,127 @@
+"""`Engine`: thin Python owner of one `clm_handle` (one per GPU).  Torch is used only for device memory
+and the current HIP stream; all arithmetic happens behind the C ABI (include/chimeralm_hip.h)."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _native as N
+
+_TORCH_DT = {torch.float32: N.DT_F32, torch.float64: N.DT_F64, torch.bfloat16: N.DT_BF16, torch.float16: N.DT_F16}
+_IDS_DT = {torch.int64: N.DT_I64, torch.int32: N.DT_I32, torch.uint8: N.DT_U8}
+
+
+class EngineError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"chimeralm_hip error {code}: {msg}")
+        self.code = code
+
+
+class Engine:
+    """One MI355X inference engine instance bound to `device` (e.g. "cuda:0")."""
+
+    def __init__(self, device: torch.device | str | int = "cuda:0", precision: str = "fp32", chunk_reads: int = 32):
+        self._lib = N.load()
+        self._h = N._H()
+        device = torch.device(device if not isinstance(device, int) else f"cuda:{device}")
+        if device.type != "cuda":
+            raise EngineError(N.E_UNSUPPORTED, "the engine runs on an MI355X (torch device type 'cuda' on ROCm) only; "
+                                               "there is no CPU path")
+        if precision not in N.PRECISIONS:
+            raise ValueError(f"precision must be one of {sorted(N.PRECISIONS)}")
+        self.device = torch.device("cuda", device.index if device.index is not None else torch.cuda.current_device())
+        self.precision = precision
+        cfg = N.ClmConfig()
+        self._lib.clm_default_config(C.byref(cfg))
+        cfg.precision = N.PRECISIONS[precision]
+        cfg.chunk_reads = int(chunk_reads)
+        self.cfg = cfg
+        rc = self._lib.clm_create(C.byref(cfg), self.device.index, C.byref(self._h))
+        if rc:
+            raise EngineError(rc, (self._lib.clm_last_error(None) or b"").decode())
+        self.finalized = False
+
+    # ------------------------------------------------------------------ helpers
+    def _check(self, rc: int):
+        if rc:
+            raise EngineError(rc, (self._lib.clm_last_error(self._h) or b"").decode())
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            self._lib.clm_destroy(self._h)
+            self._h = N._H()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001 - interpreter shutdown
+            pass
+
+    # ------------------------------------------------------------------ weights
+    def load_weight(self, key: str, tensor: torch.Tensor):
+        t = tensor.detach()
+        if t.dtype not in _TORCH_DT:
+            t = t.float()
+        t = t.contiguous()
+        shape = (C.c_int64 * t.dim())(*t.shape)
+        self._check(self._lib.clm_load_weight(self._h, key.encode(), C.c_void_p(t.data_ptr()), _TORCH_DT[t.dtype],
+                                              shape, t.dim()))
+        self.finalized = False
+
+    def load_state_dict(self, state_dict: dict[str, torch.Tensor]):
+        """Load every `net.backbone.*` / `net.head.*` entry of a reference checkpoint and finalize."""
+        for k, v in state_dict.items():
+            kk = k[4:] if k.startswith("net.") else k
+            if kk.startswith("backbone.") or kk.startswith("head."):
+                self.load_weight(k, v)
+        self.finalize()
+
+    def finalize(self):
+        self._check(self._lib.clm_finalize(self._h))
+        self.finalized = True
+
+    def reserve(self, batch: int, length: int):
+        self._check(self._lib.clm_reserve(self._h, int(batch), int(length)))
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, input_ids: torch.Tensor, out: torch.Tensor | None = None) -> torch.Tensor:
+        """input_ids [B, L] (int64 / int32 / uint8) on this engine's device -> logits fp32 [B, 2].
+        Asynchronous on torch's current stream."""
+        if input_ids.dim() != 2:
+            raise ValueError("input_ids must be [batch, length]")
+        if input_ids.device != self.device:
+            raise EngineError(N.E_INVALID, f"input_ids is on {input_ids.device}, engine on {self.device}; "
+                                           "no CPU execution path exists")
+        if input_ids.dtype not in _IDS_DT:
+            raise ValueError("input_ids dtype must be int64, int32 or uint8")
+        if input_ids.stride(1) != 1:
+            input_ids = input_ids.contiguous()
+        B, L = input_ids.shape
+        if out is None:
+            out = torch.empty((B, self.cfg.n_classes), dtype=torch.float32, device=self.device)
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        self._check(self._lib.clm_forward(self._h, C.c_void_p(input_ids.data_ptr()), _IDS_DT[input_ids.dtype],
+                                          input_ids.stride(0), B, L, C.c_void_p(out.data_ptr()), C.c_void_p(stream)))
+        return out
+
+    __call__ = forward
+
+    # ------------------------------------------------------------------ taps
+    def debug_stop_after(self, layer: int = -1, stage: int = -1):
+        self._check(self._lib.clm_debug_stop_after(self._h, layer, stage))
+
+    def debug_fetch(self, name: str, shape, dtype=np.float32) -> np.ndarray:
+        arr = np.empty(shape, dtype=dtype)
+        self._check(self._lib.clm_debug_fetch(self._h, name.encode(), arr.ctypes.data_as(C.c_void_p), arr.nbytes))
+        return arr
+
+    def profile_enable(self, on: bool = True):
+        self._check(self._lib.clm_profile_enable(self._h, int(on)))
+
+    def profile_read(self, reset: bool = True) -> dict[str, tuple[float, int]]:
+        ms = (C.c_double * N.N_STAGES)()
+        n = (C.c_int64 * N.N_STAGES)()
+        self._check(self._lib.clm_profile_read(self._h, ms, n, int(reset)))
+        return {N.STAGES[i]: (ms[i], n[i]) for i in range(N.N_STAGES)}

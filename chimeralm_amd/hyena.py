@@ -1,0 +1,231 @@
+"""Host-side mirror of the reference's `net` for the predict path.
+
+Mirrors /root/reference/chimeralm/models/components/hyena.py:
+  `HyenaDna(number_of_classes, head, backbone_name, *, freeze_backbone)`  (:218-242)
+  `HyenaDna.forward(input_ids, input_quals=None) -> logits[B, 2]`         (:244-256)
+  `BinarySequenceClassifier`, `ResidualBlock`                             (:6-180)
+with the same constructor arguments, attribute names and `state_dict()` keys, so checkpoints written
+by the reference load unchanged (`net.backbone.backbone.layers.0.mixer.in_proj.weight`, ...).
+
+The modules here only OWN parameters.  All arithmetic runs in the MI355X engine behind the C ABI
+(`chimeralm_amd.engine.Engine`); there is no PyTorch or CPU forward -- calling `forward` without the
+HIP library or with CPU tensors raises.
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+from torch import nn
+
+from .engine import Engine
+
+_SMALL_32K = dict(d_model=256, n_layer=4, d_inner=1024, vocab_rows=16, filter_order=64, emb_dim=5, max_seq_len=32770)
+
+
+class _Holder(nn.Module):
+    """Parameter container; never executed."""
+
+    def forward(self, *a, **k):  # pragma: no cover
+        raise RuntimeError("parameter container of the MI355X engine: use HyenaDna.forward")
+
+
+def _linear(out_f: int, in_f: int, bias: bool = True) -> nn.Linear:
+    return nn.Linear(in_f, out_f, bias=bias)  # default init; used as a container only
+
+
+class _Sin(_Holder):
+    def __init__(self, width: int, freq: float = 10.0):
+        super().__init__()
+        self.freq = nn.Parameter(freq * torch.ones(1, width))
+
+
+class _PosEmb(_Holder):
+    def __init__(self, emb_dim: int, seq_len: int):
+        super().__init__()
+        t = torch.linspace(0, 1, seq_len, dtype=torch.float64)[None, :, None]
+        bands = (emb_dim - 1) // 2
+        w = 2 * math.pi * torch.linspace(0, seq_len - 1, seq_len, dtype=torch.float64)[None, :, None] / seq_len
+        f = torch.linspace(1e-4, bands - 1, bands, dtype=torch.float64)[None, None]
+        z = torch.exp(-1j * f * w)
+        self.z = nn.Parameter(torch.cat([t, z.real, z.imag], dim=-1).float())
+        self.register_buffer("t", t.float())
+
+
+class _Modulation(_Holder):
+    def __init__(self, d_model: int, fast=0.3, slow=1.5, target=1e-2):
+        super().__init__()
+        deltas = torch.linspace(math.log(target) / slow, math.log(target) / fast, d_model, dtype=torch.float64)
+        self.register_buffer("deltas", deltas[None, None].float())
+
+
+class _Filter(_Holder):
+    def __init__(self, c):
+        super().__init__()
+        self.bias = nn.Parameter(torch.randn(c["d_model"]))
+        self.pos_emb = _PosEmb(c["emb_dim"], c["max_seq_len"])
+        act = _Sin(c["filter_order"])          # ONE module registered three times (keys .1/.3/.5 .freq)
+        self.implicit_filter = nn.Sequential(
+            _linear(c["filter_order"], c["emb_dim"]), act,
+            _linear(c["filter_order"], c["filter_order"]), act,
+            _linear(c["filter_order"], c["filter_order"]), act,
+            _linear(c["d_model"], c["filter_order"], bias=False),
+        )
+        self.modulation = _Modulation(c["d_model"])
+
+
+class _Mixer(_Holder):
+    def __init__(self, c):
+        super().__init__()
+        d = c["d_model"]
+        self.in_proj = _linear(3 * d, d)
+        self.out_proj = _linear(d, d)
+        self.short_filter = nn.Conv1d(3 * d, 3 * d, 3, padding=2, groups=3 * d)
+        self.filter_fn = _Filter(c)
+
+
+class _Mlp(_Holder):
+    def __init__(self, c):
+        super().__init__()
+        self.fc1 = _linear(c["d_inner"], c["d_model"])
+        self.fc2 = _linear(c["d_model"], c["d_inner"])
+
+
+class _Block(_Holder):
+    def __init__(self, c):
+        super().__init__()
+        self.mixer = _Mixer(c)
+        self.norm1 = nn.LayerNorm(c["d_model"], eps=1e-5)
+        self.mlp = _Mlp(c)
+        self.norm2 = nn.LayerNorm(c["d_model"], eps=1e-5)
+
+
+class _Embeddings(_Holder):
+    def __init__(self, c):
+        super().__init__()
+        self.word_embeddings = nn.Embedding(c["vocab_rows"], c["d_model"])
+
+
+class _LMBackbone(_Holder):
+    def __init__(self, c):
+        super().__init__()
+        self.embeddings = _Embeddings(c)
+        self.layers = nn.ModuleList([_Block(c) for _ in range(c["n_layer"])])
+        self.ln_f = nn.LayerNorm(c["d_model"], eps=1e-5)
+
+
+class HyenaDNAParams(_Holder):
+    """Parameter tree with the key layout of the HF model `LongSafari/hyenadna-small-32k-seqlen-hf`
+    (`HyenaDNAModel.backbone.*`), which the reference builds at hyena.py:237."""
+
+    def __init__(self, backbone_name: str = "hyenadna-small-32k-seqlen"):
+        super().__init__()
+        if backbone_name != "hyenadna-small-32k-seqlen":
+            raise NotImplementedError(
+                f"backbone {backbone_name!r}: the MI355X engine is built for hyenadna-small-32k-seqlen, the only "
+                "backbone `chimeralm predict` uses (chimeralm/models/lm.py:21)")
+        self.backbone = _LMBackbone(_SMALL_32K)
+
+
+# ------------------------------------------------------------------------------------------------ head
+class ResidualBlock(_Holder):
+    """Parameters of the reference's ResidualBlock (hyena.py:149-180)."""
+
+    def __init__(self, hidden_dim: int, dropout: float = 0.1):
+        super().__init__()
+        self.layers = nn.Sequential(nn.Linear(hidden_dim, hidden_dim), nn.GELU(), nn.Dropout(dropout),
+                                    nn.Linear(hidden_dim, hidden_dim))
+        self.dropout = nn.Dropout(dropout)
+
+
+class BinarySequenceClassifier(_Holder):
+    """Parameters and hyper-parameters of the reference head (hyena.py:16-77); same constructor."""
+
+    def __init__(self, input_dim: int, hidden_dim: int = 512, num_layers: int = 2, dropout: float = 0.1,
+                 pooling_type: str = "attention", activation: str = "gelu", *, use_residual: bool = True,
+                 save_attention: bool = False):
+        super().__init__()
+        if (input_dim, hidden_dim, num_layers, pooling_type, activation, use_residual) != (256, 512, 2, "attention",
+                                                                                           "gelu", True):
+            raise NotImplementedError(
+                "the MI355X engine implements the production head only: input_dim=256, hidden_dim=512, num_layers=2, "
+                "pooling_type='attention', activation='gelu', use_residual=True (chimeralm/models/lm.py:22-31)")
+        self.input_dim, self.hidden_dim, self.pooling_type = input_dim, hidden_dim, pooling_type
+        self.use_residual, self.save_attention = use_residual, save_attention
+        self.activation = nn.GELU()
+        self.attention = nn.Sequential(nn.Linear(input_dim, hidden_dim // 2), self.activation,
+                                       nn.Linear(hidden_dim // 2, 1), nn.Softmax(dim=1))
+        self.classifier = nn.Sequential(
+            nn.Linear(input_dim, hidden_dim), self.activation, nn.Dropout(dropout),
+            nn.Linear(hidden_dim, hidden_dim), self.activation, nn.Dropout(dropout),
+            ResidualBlock(hidden_dim, dropout),
+        )
+        self.output_layer = nn.Linear(hidden_dim, 2)
+        if save_attention:
+            self.attention_weights = None
+
+
+_HEAD_KEYS = ("attention.0.weight", "attention.0.bias", "attention.2.weight", "attention.2.bias",
+              "classifier.0.weight", "classifier.0.bias", "classifier.3.weight", "classifier.3.bias",
+              "classifier.6.layers.0.weight", "classifier.6.layers.0.bias", "classifier.6.layers.3.weight",
+              "classifier.6.layers.3.bias", "output_layer.weight", "output_layer.bias")
+
+
+class HyenaDna(nn.Module):
+    """Drop-in for the reference's `HyenaDna` net: same signature, same state_dict keys, MI355X forward.
+
+    Extra keyword-only arguments (engine knobs, absent in the reference): `precision` in
+    {"fp32", "bf16", "fp16"} selects the MFMA input type of the dense projections, `chunk_reads` the number
+    of reads pushed through all layers together.
+    """
+
+    def __init__(self, number_of_classes: int, head: nn.Module, backbone_name: str = "hyenadna-small-32k-seqlen", *,
+                 freeze_backbone: bool = False, precision: str = "fp32", chunk_reads: int = 32):
+        super().__init__()
+        if number_of_classes != 2:
+            raise NotImplementedError("the engine implements the binary (2-class) head only")
+        missing = [k for k in _HEAD_KEYS if k not in head.state_dict()]
+        if missing or getattr(head, "pooling_type", "attention") != "attention":
+            raise NotImplementedError(f"head is not the production attention-pooling classifier (missing {missing})")
+        self.number_of_classes = number_of_classes
+        self.backbone_name = backbone_name
+        self.backbone = HyenaDNAParams(backbone_name)
+        self.head = head
+        self.precision = precision
+        self.chunk_reads = chunk_reads
+        if freeze_backbone:
+            for p in self.backbone.parameters():
+                p.requires_grad = False
+        self._engine: Engine | None = None
+        self._engine_sig = None
+
+    # -------------------------------------------------------------------------------- engine plumbing
+    def _signature(self):
+        return tuple((p.data_ptr(), p._version) for p in list(self.parameters()) + list(self.buffers()))
+
+    def engine(self, device: torch.device) -> Engine:
+        """Engine for `device`, (re)loaded whenever a parameter tensor was replaced or modified in place."""
+        if self._engine is None or self._engine.device != device:
+            if self._engine is not None:
+                self._engine.close()
+            self._engine = Engine(device, precision=self.precision, chunk_reads=self.chunk_reads)
+            self._engine_sig = None
+        sig = self._signature()
+        if sig != self._engine_sig:
+            self._engine.load_state_dict(self.state_dict())
+            self._engine_sig = sig
+        return self._engine
+
+    def forward(self, input_ids: torch.Tensor, input_quals: torch.Tensor | None = None) -> torch.Tensor:
+        """`input_quals` is accepted and ignored, exactly as the reference does (hyena.py:244-256)."""
+        if input_ids.device.type != "cuda":
+            raise RuntimeError("chimeralm_amd.HyenaDna runs on an MI355X only (move the batch to 'cuda'); "
+                               "there is no CPU forward")
+        eng = self.engine(input_ids.device)
+        logits = eng.forward(input_ids)
+        if getattr(self.head, "save_attention", False):
+            B, L = input_ids.shape
+            torch.cuda.current_stream(input_ids.device).synchronize()
+            scores = torch.from_numpy(eng.debug_fetch("scores", (B, L)))
+            self.head.attention_weights = torch.softmax(scores, dim=1).unsqueeze(-1)
+        return logits

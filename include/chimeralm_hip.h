@@ -1,0 +1,143 @@
+/*
+ * chimeralm_hip.h -- C ABI of the MI355X (gfx950) inference engine for ChimeraLM's `predict` hot path.
+ *
+ * The drop-in boundary of the reference is the `net` module of `ClassificationLit`
+ *   /root/reference/chimeralm/models/basic_module.py:14-22,38,67-77   (ClassificationLit.forward -> self.net)
+ *   /root/reference/chimeralm/models/components/hyena.py:218-256      (HyenaDna.__init__ / forward)
+ * i.e. `forward(input_ids int64[B,L], input_quals=None) -> logits fp32[B,2]`.  The reference is pure Python
+ * on torch and has no FFI of its own; these entry points are what a ctypes binding behind
+ * `HyenaDna.forward` binds (INTEGRATION.md shows the stub).  Plain pointers and sizes only -- no torch types.
+ *
+ * Conventions
+ *   - every function returns 0 on success or a negative CLM_E_* code; `clm_last_error` gives the text.
+ *     No exception crosses this boundary.
+ *   - one handle per GPU; a handle is not re-entrant; different handles are independent.
+ *   - `clm_forward` is asynchronous on the caller's HIP stream and performs no host synchronisation,
+ *     PROVIDED the workspace is already large enough (`clm_reserve`); growing it synchronises the stream first.
+ *   - weight memory is copied at `clm_load_weight`; the caller keeps ownership of `data`.
+ */
+#ifndef CHIMERALM_HIP_H
+#define CHIMERALM_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CLM_ABI_VERSION 1
+
+/* error codes */
+#define CLM_OK 0
+#define CLM_E_INVALID (-1)     /* bad argument / shape / unknown key            */
+#define CLM_E_HIP (-2)         /* a HIP runtime call failed                      */
+#define CLM_E_MISSING (-3)     /* clm_finalize: a required weight was not loaded */
+#define CLM_E_UNSUPPORTED (-4) /* shape or mode outside what the kernels cover   */
+#define CLM_E_STATE (-5)       /* call order (e.g. forward before finalize)      */
+
+/* element types for clm_load_weight / token ids */
+#define CLM_DT_F32 0
+#define CLM_DT_F64 1
+#define CLM_DT_BF16 2
+#define CLM_DT_F16 3
+#define CLM_DT_U8 4
+#define CLM_DT_I32 5
+#define CLM_DT_I64 6
+
+/* arithmetic type of the dense projections (in_proj / out_proj / fc1 / fc2 / pooling score GEMM).
+ * Accumulation, LayerNorm statistics, the residual stream, the long convolution (FFT) and the softmax are
+ * fp32 in every mode.  F32 uses v_mfma_f32_32x32x2_f32 (exact fp32); BF16/F16 use v_mfma_f32_32x32x16_*. */
+#define CLM_PREC_F32 0
+#define CLM_PREC_BF16 1
+#define CLM_PREC_F16 2
+
+typedef struct clm_handle clm_handle;
+
+/* Mirrors the hyper-parameters fixed by the reference at
+ *   chimeralm/models/lm.py:19-31 (head: 256 -> 512, 2 layers, attention pooling, gelu, residual) and by the
+ *   HyenaDNA-small-32k config.  Only these values are accepted (checked in clm_create). */
+typedef struct clm_config {
+    int32_t struct_size;   /* = sizeof(clm_config), ABI guard                               */
+    int32_t d_model;       /* 256                                                           */
+    int32_t n_layer;       /* 4                                                             */
+    int32_t d_inner;       /* 1024                                                          */
+    int32_t vocab_rows;    /* 16  (vocab 12 padded to a multiple of 8)                      */
+    int32_t filter_order;  /* 64                                                            */
+    int32_t emb_dim;       /* 5                                                             */
+    int32_t max_seq_len;   /* 32770 rows of pos_emb.z / pos_emb.t                           */
+    int32_t head_hidden;   /* 512                                                           */
+    int32_t n_classes;     /* 2                                                             */
+    float ln_eps;          /* 1e-5                                                          */
+    int32_t precision;     /* CLM_PREC_*                                                    */
+    int32_t chunk_reads;   /* reads pushed through all layers together (workspace ~ chunk)  */
+} clm_config;
+
+int clm_abi_version(void);
+int clm_default_config(clm_config* cfg);
+
+/* Replaces HyenaDna.__init__ (hyena.py:218-242): allocate an engine on HIP device `device`. */
+int clm_create(const clm_config* cfg, int device, clm_handle** out);
+
+/* Replaces the state_dict load of PyTorchModelHubMixin.from_pretrained / Lightning ckpt_path
+ * (lm.py:17, __main__.py:317).  `key` is the reference checkpoint key with or without the `net.` prefix, e.g.
+ * `net.backbone.backbone.layers.0.mixer.in_proj.weight`, `net.head.attention.0.weight`.
+ * `data` may be host or device memory (hipMemcpyDefault); `shape[ndim]` is checked against the model.
+ * Unknown keys return CLM_E_INVALID; the aliases `implicit_filter.{3,5}.freq` of the shared sine module are
+ * accepted and ignored in favour of `.1.freq`. */
+int clm_load_weight(clm_handle* h, const char* key, const void* data, int dtype, const int64_t* shape, int ndim);
+
+/* Packs weights for the kernels (MFMA fragment order, compute dtype) and checks completeness.
+ * May be called again after further clm_load_weight calls; cached per-length filters are dropped. */
+int clm_finalize(clm_handle* h);
+
+/* Grow the workspace for batches up to B reads of L tokens (optional; clm_forward does it on demand). */
+int clm_reserve(clm_handle* h, int B, int L);
+
+/* Replaces HyenaDna.forward(input_ids, input_quals=None) (hyena.py:244-256).
+ *   ids        device pointer, [B, L] row-major with `ids_row_stride` elements between rows,
+ *              dtype CLM_DT_I64 (what the reference's collator produces), CLM_DT_I32 or CLM_DT_U8.
+ *   logits_out device pointer, fp32 [B, n_classes].
+ *   stream     hipStream_t (NULL = default stream). */
+int clm_forward(clm_handle* h, const void* ids, int ids_dtype, int64_t ids_row_stride, int B, int L,
+                float* logits_out, void* stream);
+
+/* ---- test / measurement taps (not on the product path) -------------------------------------------- */
+
+/* Copy a named intermediate of the LAST clm_forward to host memory (synchronises the device).  Names:
+ *   "hidden"        fp32 [B, L, 256]  residual stream after the final block (before ln_f)
+ *   "scores"        fp32 [B, L]       pooling scores before the softmax
+ *   "pooled"        fp32 [B, 256]
+ *   "filter.<i>"    fp32 [L, 256]     implicit long filter of layer i for the last L
+ * Only data of the last processed chunk is meaningful for "hidden"/"scores" when B > chunk_reads. */
+int clm_debug_fetch(clm_handle* h, const char* name, void* host_out, size_t bytes);
+/* Make clm_forward return right after stage `stage` (CLM_STAGE_*) of block `layer` (-1 with CLM_STAGE_EMBED:
+ * after the embedding); the raw buffers "h", "z" [B,768,Lp], "y" [B,256,Lp], "u" [B,L,1024] can then be
+ * fetched (z/y/u in the activation storage type of the precision mode).  layer = -1, stage = -1 disables. */
+int clm_debug_stop_after(clm_handle* h, int layer, int stage);
+
+/* Per-stage device timing with HIP events on the forward stream.  Stage names: clm_profile_stage_name. */
+#define CLM_STAGE_EMBED 0
+#define CLM_STAGE_INPROJ 1
+#define CLM_STAGE_CONV 2
+#define CLM_STAGE_OUTPROJ 3
+#define CLM_STAGE_FC1 4
+#define CLM_STAGE_FC2 5
+#define CLM_STAGE_SCORE 6
+#define CLM_STAGE_POOL 7
+#define CLM_STAGE_HEADMLP 8
+#define CLM_STAGE_FILTER 9
+#define CLM_N_STAGES 10
+int clm_profile_enable(clm_handle* h, int on);
+/* Synchronises, then returns accumulated milliseconds and launch counts per stage since the last reset. */
+int clm_profile_read(clm_handle* h, double* ms_out /*[CLM_N_STAGES]*/, int64_t* launches_out /*[CLM_N_STAGES]*/,
+                     int reset);
+const char* clm_profile_stage_name(int stage);
+
+const char* clm_last_error(const clm_handle* h); /* h may be NULL: error of the last failed clm_create */
+int clm_destroy(clm_handle* h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CHIMERALM_HIP_H */
