@@ -1,0 +1,170 @@
+"""Headline benchmark of the ChimeraLM `predict` hot path on MI355X (contract: see the task description).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch 256] [--bases 8192] [--precision P]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+           bench.py --gpus N --steps K --warmup W
+
+A step = one forward of the whole path (embedding -> 4 Hyena blocks -> ln_f -> attention pooling -> classifier) over
+one global batch of synthetic reads (A/C/G/T uniform, N with p=0.001, [SEP] appended), token ids
+already resident in HBM.  With N > 1 the batch is read-sharded (B/N contiguous reads per rank, weights replicated)
+and the per-read logits are all-gathered over RCCL inside the step; the global batch stays fixed (strong scaling),
+as BASELINE.json's configs[2]/[3] state (8k-bp reads, batch = 256 at 1/2/4/8 GPUs).
+
+Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel (longest accumulated device time over the timed
+region, measured with HIP events on the launch stream by the engine's own taps); `cpu_baseline` is the CPU oracle
+(oracle/hyena_oracle.py, a port of the reference path) timed on the host cores of this box on a bounded sample.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+import torch
+
+sys.path.insert(0, str(Path(__file__).resolve().parent))
+
+D, DI, NLAYER = 256, 1024, 4
+PEAK_TFLOPS = {"fp32": 157.3, "bf16": 2500.0, "fp16": 2500.0}      # dense MFMA peaks, MI355X_MICROARCH.md
+PEAK_HBM_GBS = 8000.0
+# algorithmic FLOPs per token of each GEMM stage
+STAGE_FLOPS_PER_TOKEN = {"ln1_in_proj": 2 * D * 3 * D, "out_proj": 2 * D * D, "ln2_fc1_gelu": 2 * D * DI,
+                         "fc2": 2 * D * DI, "lnf_pool_score": 2 * D * D + 2 * D}
+
+
+def stage_bytes_per_token(stage: str, es: int) -> float:
+    """Algorithmic HBM bytes per token and launch of the bandwidth-bound stages (es = activation element size)."""
+    return {"short_long_conv": 3 * D * es + D * es,      # read z (x0|x1|v), write y
+            "embed": 1 + D * 4, "softmax_pool": D * 4 + 8}.get(stage, 0.0)
+
+
+def synthetic_ids(batch_index: int, batch: int, bases: int) -> np.ndarray:
+    rng = np.random.default_rng(1234 + batch_index)
+    ids = rng.integers(7, 11, size=(batch, bases), dtype=np.uint8)
+    ids[rng.random((batch, bases)) < 0.001] = 11
+    return np.concatenate([ids, np.ones((batch, 1), np.uint8)], axis=1)
+
+
+def cpu_baseline(bases: int, budget_s: float = 20.0) -> dict:
+    from oracle import hyena_oracle as ho
+
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    sd = ho.make_state_dict(0)
+    b = 4
+    ids = torch.from_numpy(synthetic_ids(10_000, b, bases).astype(np.int64))
+    ho.forward(ids[:1], sd)                       # warm-up (thread pool, FFT plans)
+    t0, n = time.perf_counter(), 0
+    while True:
+        ho.forward(ids, sd)
+        n += b
+        if time.perf_counter() - t0 > budget_s or n >= 64:
+            break
+    dt = time.perf_counter() - t0
+    return {"value": n / dt, "unit": "reads/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{n} synthetic {bases}-bp reads in batches of {b}, fp32 torch-CPU oracle (oracle/hyena_oracle.py)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=256, help="global batch (reads per step)")
+    ap.add_argument("--bases", type=int, default=8192)
+    ap.add_argument("--precision", default=os.environ.get("CLM_PRECISION", "fp16"))
+    ap.add_argument("--chunk-reads", type=int, default=32)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+
+    from chimeralm_amd import distributed as cdist
+    from chimeralm_amd.engine import Engine
+    from oracle import hyena_oracle as ho       # weights generator + CPU baseline only
+
+    rank, local_rank, world = cdist.init_process_group("nccl")
+    if world != a.gpus:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus}")
+    device = torch.device("cuda", local_rank)
+    torch.cuda.set_device(device)
+    lo, hi = cdist.shard_bounds(a.batch, rank, world)
+    L = a.bases + 1
+
+    eng = Engine(device, precision=a.precision, chunk_reads=a.chunk_reads)
+    eng.load_state_dict(ho.make_state_dict(0))
+    eng.reserve(hi - lo, L)
+    n_data = max(1, min(4, a.steps))                 # a few distinct resident batches, cycled
+    batches = [torch.from_numpy(synthetic_ids(i, a.batch, a.bases)[lo:hi]).to(device) for i in range(n_data)]
+    logits = torch.empty((hi - lo, 2), dtype=torch.float32, device=device)
+
+    def step(i):
+        eng.forward(batches[i % n_data], out=logits)
+        return cdist.gather_logits(logits) if world > 1 else logits
+
+    for i in range(a.warmup):
+        step(i)
+    torch.cuda.synchronize(device)
+    eng.profile_read(reset=True)
+    eng.profile_enable(True)
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]
+    cdist.barrier()
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    for i in range(a.steps):
+        ev[i][0].record()
+        out = step(i)
+        ev[i][1].record()
+    torch.cuda.synchronize(device)
+    cdist.barrier()
+    elapsed = time.perf_counter() - t0
+    eng.profile_enable(False)
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t.item())
+    prof = eng.profile_read(reset=True)
+    lat = sorted(e0.elapsed_time(e1) for e0, e1 in ev)
+    assert out.shape[0] == a.batch and bool(torch.isfinite(out).all())
+
+    if rank == 0:
+        es = 4 if a.precision == "fp32" else 2
+        total_ms = sum(ms for ms, _ in prof.values()) or 1.0
+        dom = max(prof, key=lambda k: prof[k][0])
+        ms, launches = prof[dom]
+        tokens_per_launch = (hi - lo) * L * a.steps * (NLAYER if dom not in ("embed", "lnf_pool_score", "softmax_pool", "head_mlp") else 1) / max(1, launches)
+        if dom in STAGE_FLOPS_PER_TOKEN:
+            achieved = STAGE_FLOPS_PER_TOKEN[dom] * tokens_per_launch / (ms / launches * 1e-3) / 1e12
+            roof = {"bound": "mfma", "kernel": dom, "achieved": achieved, "peak": PEAK_TFLOPS[a.precision],
+                    "unit": "TFLOP/s", "frac": achieved / PEAK_TFLOPS[a.precision], "traffic": None}
+        else:
+            achieved = stage_bytes_per_token(dom, es) * tokens_per_launch / (ms / launches * 1e-3) / 1e9
+            roof = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                    "frac": achieved / PEAK_HBM_GBS, "traffic": None}
+        roof["avg_launch_ms"] = ms / max(1, launches)
+        roof["launches"] = launches
+        res = {
+            "metric": "reads/sec (whole node), 8k-bp reads batch=256", "value": a.batch * a.steps / elapsed,
+            "unit": "reads/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": elapsed / a.steps * 1e3, "p50_batch_latency_ms": lat[len(lat) // 2],
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": a.precision,
+            "data": "synthetic reads (seeded), seeded random-init weights of the production architecture",
+            "config": {"workload": f"synthetic {a.bases}-bp reads, global batch {a.batch}, 1 forward per step",
+                       "global_batch": a.batch, "tokens_per_read": L, "reads_per_gpu": hi - lo,
+                       "parallelism": f"read-sharded x{world}, logits all-gather" if world > 1 else "single GPU"},
+            "dense_tflops_per_gpu": 6_423_040 * L * (hi - lo) * a.steps / elapsed / 1e12,
+            "stage_ms_share": {k: round(v[0] / total_ms, 4) for k, v in prof.items() if v[1]},
+            "roofline": roof,
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(a.bases)
+        print(json.dumps(res), flush=True)
+    cdist.barrier()
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -271,7 +271,7 @@ int ensure_filters(clm_handle* h, int L, hipStream_t st, FilterSet** out) {
                       W(h, p + "implicit_filter.2.weight"), W(h, p + "implicit_filter.2.bias"),
                       W(h, p + "implicit_filter.4.weight"), W(h, p + "implicit_filter.4.bias"),
                       W(h, p + "implicit_filter.6.weight"), W(h, p + "modulation.deltas"), f.ktime[i], L, st);
-        launch_filter_spectrum(f.ktime[i], f.kf[i], scratch, L, logn, st);
+        launch_filter_spectrum(f.ktime[i], W(h, p + "bias"), f.kf[i], scratch, L, logn, st);
     }
     HIPCHK(h, hipGetLastError());
     HIPCHK(h, hipStreamSynchronize(st));
@@ -333,8 +333,8 @@ int forward_chunk(clm_handle* h, const void* ids, int ids_dtype, int64_t row_str
         if (stop_here(h, i, CLM_STAGE_INPROJ)) return CLM_OK;
         {
             StageTimer t(h, st, CLM_STAGE_CONV);
-            launch_hyena_conv(prec, h->z, h->y, fs->kf[i], fs->tw, fs->ktime[i], lw.short_w, lw.short_b, lw.filt_bias,
-                              Bc, L, Lp, fs->logn, st);
+            launch_hyena_conv(prec, h->z, h->y, fs->kf[i], fs->tw, fs->ktime[i], lw.short_w, lw.short_b, Bc, L, Lp,
+                              fs->logn, st);
         }
         if (stop_here(h, i, CLM_STAGE_CONV)) return CLM_OK;
         {

@@ -117,13 +117,12 @@ void launch_filter(const float* z /*[maxlen][5]*/, const float* t /*[maxlen]*/, 
                    const float* w6, const float* deltas, float* k_out /*[L][256]*/, int L, hipStream_t st);
 // spectrum of one layer's filter: kf [256][N] float2 = FFT_N(k[:, c]) / N (double precision inside);
 // scratch: 256*N double2
-void launch_filter_spectrum(const float* k /*[L][256]*/, float2* kf, double2* scratch, int L, int logn,
-                            hipStream_t st);
+void launch_filter_spectrum(const float* k /*[L][256]*/, const float* dskip /*[256], folded into tap 0*/, float2* kf,
+                            double2* scratch, int L, int logn, hipStream_t st);
 void launch_twiddles(float2* tw, int logn, hipStream_t st);   // tw[m] = exp(-2 pi i m / N), m < N/2
-// y = ((causal_conv(v*x1, k) + D*(v*x1)) * x0)   with (x0,x1,v) = short_filter(z)    [B,256,Lp]
+// y = ((causal_conv(v*x1, k) + D*(v*x1)) * x0)   with (x0,x1,v) = short_filter(z)    [B,256,Lp]; D lives in kf
 void launch_hyena_conv(int prec, const void* z, void* y, const float2* kf, const float2* tw, const float* ktime,
-                       const float* short_w, const float* short_b, const float* dbias, int B, int L, int Lp, int logn,
-                       hipStream_t st);
+                       const float* short_w, const float* short_b, int B, int L, int Lp, int logn, hipStream_t st);
 
 // head (head.hip)
 void launch_softmax_stats(const float* scores, float* stats /*[B][2] = max, sum*/, int B, int L, hipStream_t st);

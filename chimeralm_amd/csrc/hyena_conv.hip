@@ -66,13 +66,18 @@ void launch_filter(const float* z, const float* t, const float* w0, const float*
 // ---------------------------------------------------------------------------------------- filter spectrum
 // kf[c][m] = (1/N) sum_t k[t][c] exp(-2 pi i m t / N), double precision radix-2 in global scratch, one
 // workgroup per channel (runs once per distinct L).
-__global__ __launch_bounds__(256) void spectrum_kernel(const float* __restrict__ k, float2* __restrict__ kf,
-                                                       double2* __restrict__ scratch, int L, int logn) {
+// The skip term of fftconv, y += g * D[c], is a convolution with D[c]*delta: it is folded into tap 0 here, so the
+// convolution kernel needs neither D nor g after the transform.
+__global__ __launch_bounds__(256) void spectrum_kernel(const float* __restrict__ k, const float* __restrict__ dskip,
+                                                       float2* __restrict__ kf, double2* __restrict__ scratch, int L,
+                                                       int logn) {
     const int N = 1 << logn, c = blockIdx.x;
     double2* a = scratch + (size_t)c * N;
     for (int i = threadIdx.x; i < N; i += blockDim.x) {  // bit-reversed load
         int rv = __brev((unsigned)i) >> (32 - logn);
-        a[rv] = make_double2(i < L ? (double)k[(size_t)i * D + c] : 0.0, 0.0);
+        double v = i < L ? (double)k[(size_t)i * D + c] : 0.0;
+        if (i == 0) v += (double)dskip[c];
+        a[rv] = make_double2(v, 0.0);
     }
     __syncthreads();
     for (int s = 1; s <= logn; ++s) {
@@ -94,8 +99,9 @@ __global__ __launch_bounds__(256) void spectrum_kernel(const float* __restrict__
         kf[(size_t)c * N + i] = make_float2((float)(a[i].x * inv), (float)(a[i].y * inv));
 }
 
-void launch_filter_spectrum(const float* k, float2* kf, double2* scratch, int L, int logn, hipStream_t st) {
-    hipLaunchKernelGGL(spectrum_kernel, dim3(D), dim3(256), 0, st, k, kf, scratch, L, logn);
+void launch_filter_spectrum(const float* k, const float* dskip, float2* kf, double2* scratch, int L, int logn,
+                            hipStream_t st) {
+    hipLaunchKernelGGL(spectrum_kernel, dim3(D), dim3(256), 0, st, k, dskip, kf, scratch, L, logn);
 }
 
 __global__ void twiddle_kernel(float2* tw, int logn) {
@@ -167,6 +173,27 @@ __device__ __forceinline__ void store8<f16_t>(f16_t* p, const float* v) {
     *reinterpret_cast<u16x8*>(p) = o;
 }
 
+template <typename T>
+__device__ __forceinline__ void load2(const T* p, float* o);
+template <>
+__device__ __forceinline__ void load2<float>(const float* p, float* o) {
+    float2 a = *reinterpret_cast<const float2*>(p);
+    o[0] = a.x; o[1] = a.y;
+}
+template <>
+__device__ __forceinline__ void load2<bf16_t>(const bf16_t* p, float* o) {
+    unsigned w = *reinterpret_cast<const unsigned*>(p);
+    o[0] = __uint_as_float(w << 16);
+    o[1] = __uint_as_float(w & 0xffff0000u);
+}
+template <>
+__device__ __forceinline__ void load2<f16_t>(const f16_t* p, float* o) {
+    unsigned w = *reinterpret_cast<const unsigned*>(p);
+    _Float16 h[2];
+    __builtin_memcpy(h, &w, 4);
+    o[0] = (float)h[0]; o[1] = (float)h[1];
+}
+
 // short filter on 8 consecutive samples of one channel row: out[e] = b + w0*x[t-2] + w1*x[t-1] + w2*x[t]
 template <typename T>
 __device__ __forceinline__ void short_filter8(const T* row, int t0, float w0, float w1, float w2, float bias,
@@ -174,8 +201,7 @@ __device__ __forceinline__ void short_filter8(const T* row, int t0, float w0, fl
     float x[10];
     load8<T>(row + t0, x + 2);
     if (t0 > 0) {
-        x[0] = to_float(row[t0 - 2]);
-        x[1] = to_float(row[t0 - 1]);
+        load2<T>(row + t0 - 2, x);   // t0 is a multiple of 8: the pair is naturally aligned
     } else {
         x[0] = 0.f;
         x[1] = 0.f;
@@ -192,8 +218,8 @@ __device__ __forceinline__ float short_filter1(const T* row, int t, float w0, fl
 template <int LOGN, typename T>
 __global__ __launch_bounds__(Plan<LOGN>::NT) void hyena_conv_kernel(
     const T* __restrict__ z, T* __restrict__ y, const float2* __restrict__ kf, const float2* __restrict__ tw,
-    const float* __restrict__ ktime, const float* __restrict__ short_w, const float* __restrict__ short_b,
-    const float* __restrict__ dbias, int B, int L, int Lp) {
+    const float* __restrict__ ktime, const float* __restrict__ short_w, const float* __restrict__ short_b, int B, int L,
+    int Lp) {
     using P = Plan<LOGN>;
     constexpr int N = P::N, NT = P::NT, LAST = P::LAST, HALF = N / 2;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -214,13 +240,13 @@ __global__ __launch_bounds__(Plan<LOGN>::NT) void hyena_conv_kernel(
         for (int e = 0; e < 3; ++e) sw[q][e] = short_w[(q * D + c) * 3 + e];
         sb[q] = short_b[q * D + c];
     }
-    const float dskip = dbias[c];
 
     // ---------------------------------------------------------------- phase A: load, short filter, gate
-    // chunk of 8 tokens t0 = 8*tid (lower half of the transform); x0 and g stay in registers for phase C.
+    // chunk of 8 tokens t0 = 8*tid (lower half of the transform); only x0 stays in registers for phase C.
     const int t0 = 8 * tid;
-    float x0A[8], gA[8], x0B[8], gB[8];
+    float x0A[8], x0B[8];
     if (t0 < HALF) {
+        float gA[8], gB[8];
         if (t0 < L) {
             float x1[8], v[8];
             short_filter8<T>(zA + (size_t)(0 * D + c) * Lp, t0, sw[0][0], sw[0][1], sw[0][2], sb[0], x0A);
@@ -310,22 +336,22 @@ __global__ __launch_bounds__(Plan<LOGN>::NT) void hyena_conv_kernel(
                 pc.y -= kl * gBt;
             }
             bool ok = t0 + e < L;
-            oA[e] = ok ? (pc.x + dskip * gA[e]) * x0A[e] : 0.f;
-            oB[e] = ok ? (pc.y + dskip * gB[e]) * x0B[e] : 0.f;
+            oA[e] = ok ? pc.x * x0A[e] : 0.f;
+            oB[e] = ok ? pc.y * x0B[e] : 0.f;
         }
         store8<T>(yA + t0, oA);
         if (hasB) store8<T>(yB + t0, oB);
     }
     if (tail && tid == 0) {
         float2 pc = buf[pad_index(HALF)];
-        yA[HALF] = from_float<T>((pc.x + dskip * gAt) * x0At);
-        if (hasB) yB[HALF] = from_float<T>((pc.y + dskip * gBt) * x0Bt);
+        yA[HALF] = from_float<T>(pc.x * x0At);
+        if (hasB) yB[HALF] = from_float<T>(pc.y * x0Bt);
     }
 }
 
 template <int LOGN, typename T>
 static void launch_conv_t(const void* z, void* y, const float2* kf, const float2* tw, const float* ktime,
-                          const float* short_w, const float* short_b, const float* dbias, int B, int L, int Lp,
+                          const float* short_w, const float* short_b, int B, int L, int Lp,
                           hipStream_t st) {
     using P = Plan<LOGN>;
     constexpr size_t lds = (size_t)padded_size(P::N) * sizeof(float2);
@@ -338,26 +364,26 @@ static void launch_conv_t(const void* z, void* y, const float2* kf, const float2
     }
     dim3 grid((B + 1) / 2, D), block(P::NT);
     hipLaunchKernelGGL(kern, grid, block, lds, st, reinterpret_cast<const T*>(z), reinterpret_cast<T*>(y), kf, tw,
-                       ktime, short_w, short_b, dbias, B, L, Lp);
+                       ktime, short_w, short_b, B, L, Lp);
 }
 
 template <int LOGN>
 static void launch_conv_p(int prec, const void* z, void* y, const float2* kf, const float2* tw, const float* ktime,
-                          const float* short_w, const float* short_b, const float* dbias, int B, int L, int Lp,
+                          const float* short_w, const float* short_b, int B, int L, int Lp,
                           hipStream_t st) {
     if (prec == PREC_F32)
-        launch_conv_t<LOGN, float>(z, y, kf, tw, ktime, short_w, short_b, dbias, B, L, Lp, st);
+        launch_conv_t<LOGN, float>(z, y, kf, tw, ktime, short_w, short_b, B, L, Lp, st);
     else if (prec == PREC_BF16)
-        launch_conv_t<LOGN, bf16_t>(z, y, kf, tw, ktime, short_w, short_b, dbias, B, L, Lp, st);
+        launch_conv_t<LOGN, bf16_t>(z, y, kf, tw, ktime, short_w, short_b, B, L, Lp, st);
     else
-        launch_conv_t<LOGN, f16_t>(z, y, kf, tw, ktime, short_w, short_b, dbias, B, L, Lp, st);
+        launch_conv_t<LOGN, f16_t>(z, y, kf, tw, ktime, short_w, short_b, B, L, Lp, st);
 }
 
 void launch_hyena_conv(int prec, const void* z, void* y, const float2* kf, const float2* tw, const float* ktime,
-                       const float* short_w, const float* short_b, const float* dbias, int B, int L, int Lp, int logn,
+                       const float* short_w, const float* short_b, int B, int L, int Lp, int logn,
                        hipStream_t st) {
 #define CLM_CONV_CASE(n) \
-    case n: launch_conv_p<n>(prec, z, y, kf, tw, ktime, short_w, short_b, dbias, B, L, Lp, st); break;
+    case n: launch_conv_p<n>(prec, z, y, kf, tw, ktime, short_w, short_b, B, L, Lp, st); break;
     switch (logn) {
         CLM_CONV_CASE(8)
         CLM_CONV_CASE(9)

@@ -1,0 +1,180 @@
+"""GPU (MI355X): parity of the HIP engine, called through the C ABI, with the CPU oracle on the same seeded inputs.
+
+Tolerances (north_star: identical labels, logits within 1e-3 in fp32):
+  fp32 mode  |logit - oracle| <= 1e-3  (observed ~1e-5)        -- the parity gate
+  fp16 mode  |logit - oracle| <= 5e-3  (observed 0.5-1.5e-3), labels identical wherever the oracle margin > 2e-2
+  bf16 mode  |logit - oracle| <= 6e-2  (observed ~2e-2),       labels identical wherever the oracle margin > 2e-1
+"""
+from __future__ import annotations
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import data_oracle as do
+from oracle import hyena_oracle as ho
+
+pytestmark = pytest.mark.gpu
+
+TOL = {"fp32": 1e-3, "fp16": 5e-3, "bf16": 6e-2}
+MARGIN = {"fp32": 2e-3, "fp16": 2e-2, "bf16": 2e-1}
+
+
+@pytest.fixture(scope="module")
+def sd():
+    return ho.make_state_dict(0, head_scale=3.0)
+
+
+@pytest.fixture(scope="module")
+def engines(sd, built_lib):
+    from chimeralm_amd.engine import Engine
+
+    out = {}
+    for prec in ("fp32", "fp16", "bf16"):
+        e = Engine("cuda:0", precision=prec, chunk_reads=4)
+        e.load_state_dict(sd)
+        out[prec] = e
+    yield out
+    for e in out.values():
+        e.close()
+
+
+def _ids(B, L, seed=5, pads=0):
+    ids, _ = ho.synthetic_batch(seed, B, L - 1, seed=99)
+    if pads:
+        ids[:, :pads] = 4
+    return ids
+
+
+def _check(engine, prec, ids_np, sd, dtype=torch.int64):
+    ref = ho.forward(torch.from_numpy(ids_np.astype(np.int64)), sd).numpy()
+    got = engine.forward(torch.from_numpy(ids_np).to(dtype).cuda()).cpu().numpy()
+    assert np.isfinite(got).all()
+    err = np.abs(got - ref).max()
+    assert err <= TOL[prec], f"{prec}: max |logit error| {err:.3e} > {TOL[prec]}"
+    decided = np.abs(ref[:, 0] - ref[:, 1]) > MARGIN[prec]
+    assert (got.argmax(1)[decided] == ref.argmax(1)[decided]).all()
+    return err
+
+
+@pytest.mark.parametrize("B,L", [(1, 2), (1, 5), (3, 129), (2, 128), (5, 300), (4, 513), (3, 1000), (7, 2049)])
+def test_fp32_parity_shapes(engines, sd, B, L):
+    """Odd batches (half-empty read pair), every FFT size class incl. the aliased L = N/2 + 1 cases."""
+    _check(engines["fp32"], "fp32", _ids(B, L, pads=min(3, L - 1)), sd)
+
+
+@pytest.mark.parametrize("prec", ["fp16", "bf16"])
+@pytest.mark.parametrize("B,L", [(3, 129), (5, 300), (6, 1000)])
+def test_16bit_modes(engines, sd, prec, B, L):
+    _check(engines[prec], prec, _ids(B, L, pads=2), sd)
+
+
+def test_intermediates_fp32(engines, sd):
+    B, L = 3, 257
+    ids = _ids(B, L, pads=4)
+    trace = {}
+    ho.forward(torch.from_numpy(ids.astype(np.int64)), sd, trace=trace)
+    e = engines["fp32"]
+    e.forward(torch.from_numpy(ids).cuda())
+    torch.cuda.synchronize()
+    for name, shape, ref in (("hidden", (B, L, 256), trace["l3.out"]), ("scores", (B, L), trace["scores"]),
+                             ("pooled", (B, 256), trace["pooled"])):
+        got = e.debug_fetch(name, shape)
+        scale = float(ref.abs().max())
+        assert np.abs(got - ref.numpy()).max() <= 2e-5 * scale + 1e-6, name
+    for i in range(4):
+        k = e.debug_fetch(f"filter.{i}", (L, 256))
+        assert np.abs(k - trace[f"l{i}.filter"].T.numpy()).max() <= 5e-5
+
+
+def test_ids_dtypes_and_strides(engines, sd):
+    ids = _ids(4, 200)
+    e = engines["fp32"]
+    a = e.forward(torch.from_numpy(ids).to(torch.int64).cuda()).cpu()
+    b = e.forward(torch.from_numpy(ids).to(torch.int32).cuda()).cpu()
+    c = e.forward(torch.from_numpy(ids).cuda()).cpu()                                   # uint8
+    wide = torch.zeros(4, 333, dtype=torch.uint8).cuda()
+    wide[:, :200] = torch.from_numpy(ids).cuda()
+    d = e.forward(wide[:, :200]).cpu()                                                   # row stride 333
+    assert torch.equal(a, b) and torch.equal(a, c) and torch.equal(a, d)
+
+
+def test_determinism_and_chunk_invariance(sd, built_lib):
+    from chimeralm_amd.engine import Engine
+
+    ids = torch.from_numpy(_ids(6, 700)).cuda()
+    e1 = Engine("cuda:0", precision="fp16", chunk_reads=32)
+    e2 = Engine("cuda:0", precision="fp16", chunk_reads=2)
+    e1.load_state_dict(sd), e2.load_state_dict(sd)
+    a, b, c = e1.forward(ids).cpu(), e1.forward(ids).cpu(), e2.forward(ids).cpu()
+    assert torch.equal(a, b)                    # bit-identical run to run (no atomics, fixed reduction orders)
+    assert torch.equal(a, c)                    # same read pairs in both chunkings -> identical bits
+    solo = e1.forward(ids[1:2]).cpu()           # a read alone vs inside a batch (different pair partner)
+    assert (solo - a[1:2]).abs().max() < 2e-3
+    e1.close(), e2.close()
+
+
+@pytest.mark.parametrize("prec", ["fp32", "fp16"])
+def test_full_size_8k_reads(engines, sd, prec):
+    """BASELINE config size (8192 bases + [SEP] = 8193 tokens, FFT size 16384 with the aliased tail)."""
+    ids = _ids(3, 8193, seed=11)
+    _check(engines[prec], prec, ids, sd)
+
+
+def test_collated_bam_batch_against_oracle(engines, sd, golden_dir):
+    """configs[0] plumbing: real reads -> tokenizer -> collator (left pad) -> engine == oracle on the same batch."""
+    from chimeralm_amd import bam, tokenizer as T
+
+    tok = T.CharTokenizer(model_max_length=3000, padding_side="left")
+    dm = bam.BamDataModule(tokenizer=tok, predict_data_path=golden_dir / "test_chimric_reads.bam", batch_size=6,
+                           max_predict_samples=12)
+    dm.setup("predict")
+    for batch in dm.predict_dataloader():
+        ids = batch["input_ids"]
+        assert ids.shape[1] <= 2999 and (ids == 4).any()                                 # ragged -> padded
+        ref = ho.forward(ids, sd).numpy()
+        got = engines["fp32"].forward(ids.cuda()).cpu().numpy()
+        assert np.abs(got - ref).max() <= 1e-3
+        assert do.prediction_lines(got, batch["id"].numpy()) == do.prediction_lines(ref, batch["id"].numpy())
+
+
+def test_module_boundary_and_writer(sd, tmp_path, built_lib):
+    """The drop-in boundary: ClassificationLit(net=HyenaDna(...)).predict_step + PredictionWriter files."""
+    from types import SimpleNamespace
+
+    from chimeralm_amd import lm
+    from chimeralm_amd.callbacks import PredictionWriter
+    from chimeralm_amd.tokenizer import pack_read_name
+
+    model = lm.ChimeraLM.new(precision="fp32")
+    model.load_state_dict(sd, strict=True)
+    ids_np = _ids(4, 150)
+    batch = {"input_ids": torch.from_numpy(ids_np.astype(np.int64)).cuda(),
+             "labels": torch.full((4,), -1), "id": torch.tensor([pack_read_name(f"r{i}") for i in range(4)]).to(torch.int8)}
+    logits, labels = model.predict_step(batch, 0)
+    ref = ho.forward(torch.from_numpy(ids_np.astype(np.int64)), sd)
+    assert (logits.cpu() - ref).abs().max() < 1e-3 and (labels == -1).all()
+    PredictionWriter(tmp_path, "batch").write_on_batch_end(SimpleNamespace(global_rank=0), model, (logits, labels), None,
+                                                           batch, 0, 0)
+    assert (tmp_path / "0_0.txt").read_text() == "".join(do.prediction_lines(ref.numpy(), batch["id"].numpy()))
+    # weights changed in place -> engine reloads them
+    with torch.no_grad():
+        model.net.head.output_layer.bias.add_(1.0)
+    logits2, _ = model.predict_step(batch, 1)
+    assert ((logits2 - logits).cpu() - 1.0).abs().max() < 1e-5
+
+
+def test_error_behaviour(engines):
+    from chimeralm_amd.engine import EngineError
+
+    e = engines["fp32"]
+    with pytest.raises(EngineError, match="8193"):
+        e.forward(torch.zeros(1, 9000, dtype=torch.uint8).cuda())                        # beyond the built FFT sizes
+    with pytest.raises(EngineError):
+        e.forward(torch.zeros(1, 9, dtype=torch.uint8))                                  # CPU tensor: no CPU path
+    with pytest.raises(ValueError):
+        e.forward(torch.zeros(1, 9, dtype=torch.float32).cuda())
+    with pytest.raises(EngineError, match="shape"):
+        e.load_weight("net.head.output_layer.bias", torch.zeros(3))
+    with pytest.raises(EngineError, match="unknown"):
+        e.load_weight("net.nope", torch.zeros(3))

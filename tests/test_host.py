@@ -1,0 +1,166 @@
+"""CPU: the C-ABI library loads and exports every symbol of include/chimeralm_hip.h (no compute without a GPU), and the
+host-side mirror of the reference interface (tokenizer, collator, BAM module, writer, CLI, model containers)."""
+from __future__ import annotations
+
+import ctypes
+import json
+import re
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+
+REPO = Path(__file__).resolve().parent.parent
+
+
+def test_abi_exports_every_header_symbol(built_lib):
+    header = (REPO / "include" / "chimeralm_hip.h").read_text()
+    declared = set(re.findall(r"\b(clm_[a-z_]+)\s*\(", header))
+    lib = ctypes.CDLL(str(built_lib))
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"{name} declared in the header but not exported"
+    from chimeralm_amd import _native
+
+    assert declared == set(_native.SYMBOLS), "python binding and header disagree"
+    lib2 = _native.load()
+    assert lib2.clm_abi_version() == _native.ABI_VERSION
+    cfg = _native.ClmConfig()
+    assert lib2.clm_default_config(ctypes.byref(cfg)) == 0
+    assert (cfg.d_model, cfg.n_layer, cfg.d_inner, cfg.head_hidden, cfg.n_classes) == (256, 4, 1024, 512, 2)
+    assert cfg.struct_size == ctypes.sizeof(_native.ClmConfig)
+    assert lib2.clm_profile_stage_name(2) == b"short_long_conv"
+
+
+def test_no_cpu_path_and_loud_failure(built_lib):
+    from chimeralm_amd import lm
+    from chimeralm_amd.engine import Engine, EngineError
+
+    model = lm.ChimeraLM.new()
+    with pytest.raises(RuntimeError, match="MI355X"):
+        model(torch.zeros(1, 8, dtype=torch.long))
+    with pytest.raises(EngineError):
+        Engine("cpu")
+    if not torch.cuda.is_available():            # clm_create must fail cleanly, not crash, without a device
+        with pytest.raises(EngineError):
+            Engine("cuda:0")
+
+
+def test_product_package_never_imports_oracle():
+    for f in (REPO / "chimeralm_amd").rglob("*.py"):
+        assert "oracle" not in f.read_text(), f"{f} mentions the oracle: the product path must not use it"
+
+
+def test_state_dict_keys_match_reference_checkpoint_layout():
+    from chimeralm_amd import lm
+    from oracle import hyena_oracle as ho
+
+    model = lm.ChimeraLM.new()
+    sd = ho.make_state_dict(3)
+    assert set(model.state_dict()) == set(sd)
+    model.load_state_dict(sd, strict=True)
+    for k in ("net.backbone.backbone.layers.0.mixer.in_proj.weight", "net.head.classifier.6.layers.3.bias",
+              "net.backbone.backbone.layers.3.mixer.filter_fn.implicit_filter.5.freq"):
+        assert k in model.state_dict()
+    assert model.net.number_of_classes == 2
+
+
+def test_head_must_be_production_configuration():
+    from chimeralm_amd.hyena import BinarySequenceClassifier
+
+    with pytest.raises(NotImplementedError):
+        BinarySequenceClassifier(256, 512, 2, 0.1, "mean")
+
+
+def test_tokenizer_and_collator_match_reference_goldens(golden_dir):
+    from chimeralm_amd import tokenizer as T
+
+    assert T.CharTokenizer(add_cls=True).encode("ATCG") == [0, 7, 10, 8, 9, 1]        # tests/test_tokenzier.py:11
+    prod = T.load_tokenizer_from_hyena_model("hyenadna-small-32k-seqlen")
+    assert prod.encode("ATCG") == [7, 10, 8, 9, 1] and prod.padding_side == "left"
+    assert prod.max_len_single_sentence == 32769                                       # <= 32768 bases + [SEP]
+    assert len(prod("A" * 40000, truncation=True, max_length=prod.max_len_single_sentence)["input_ids"]) == 32769
+    with pytest.raises(ValueError):
+        T.load_tokenizer_from_hyena_model("nope")
+    gold = json.loads((golden_dir / "collate_golden.json").read_text())
+    for case in gold["cases"]:
+        tok = T.CharTokenizer(model_max_length=case["model_max_length"], padding_side=case["padding_side"], add_cls=True)
+        assert tok.max_len_single_sentence == case["max_length"]
+        feats = [T.tokenize_and_align_labels_and_quals_ids({"id": n, "seq": s}, tok, case["max_length"])
+                 for n, s in gold["reads"]]
+        assert [f["input_ids"] for f in feats] == case["per_read_input_ids"]
+        assert [f["id"] for f in feats] == case["per_read_id"]
+        batch = T.DataCollator(tok).torch_call(feats)
+        assert batch["input_ids"].dtype == torch.int64 and batch["input_ids"].tolist() == case["input_ids"]
+        assert batch["id"].dtype == torch.int8 and batch["id"].tolist() == case["id_int8"]
+        assert batch["labels"].tolist() == case["labels"]
+    # superset behaviour: names of 128..255 characters survive (the reference collator raises on them)
+    tok = T.CharTokenizer()
+    long_name = "n" * 200
+    b = T.DataCollator(tok).torch_call([T.tokenize_and_align_labels_and_quals_ids({"id": long_name, "seq": "ACGT"}, tok, 100)])
+    from chimeralm_amd.callbacks import resume_read_name
+
+    assert resume_read_name(b["id"][0]) == long_name
+
+
+def test_resume_read_name_matches_reference_where_it_accepts(golden_dir):
+    from chimeralm_amd.callbacks import resume_read_name
+
+    for row in json.loads((golden_dir / "readname_golden.json").read_text()):
+        if not isinstance(row["resumed"], dict):
+            assert resume_read_name(torch.tensor(row["row_int8"], dtype=torch.int8)) == row["resumed"]
+    with pytest.raises(ValueError):
+        resume_read_name(torch.zeros(256, dtype=torch.int8))
+    assert resume_read_name(torch.zeros(0)) == ""
+
+
+def test_bam_module_batches_like_the_reference(golden_dir):
+    from chimeralm_amd import bam, tokenizer as T
+    from oracle import data_oracle as do
+
+    path = golden_dir / "test_chimric_reads.bam"
+    assert list(bam.parse_bam_file(path)) == list(do.chimeric_reads(path))
+    tok = T.load_tokenizer_from_hyena_model("hyenadna-small-32k-seqlen")
+    dm = bam.BamDataModule(tokenizer=tok, train_data_path="dummy.bam", predict_data_path=path, batch_size=12)
+    dm.setup("predict")
+    batches = list(dm.predict_dataloader())
+    assert len(batches) == 9 and [len(b["labels"]) for b in batches] == [12] * 8 + [4]
+    assert all((b["labels"] == -1).all() for b in batches)
+    reads = list(do.chimeric_reads(path))
+    b0 = batches[0]
+    want = do.collate([{"input_ids": do.tokenize(r["seq"], 32769), "id": do.pack_read_name(r["id"]), "labels": -1}
+                       for r in reads[:12]], padding_side="left")
+    assert (b0["input_ids"].numpy() == want["input_ids"]).all() and (b0["id"].numpy() == want["id"]).all()
+    assert max(b["input_ids"].shape[1] for b in batches) == 32769            # truncation is exercised
+    with pytest.raises(RuntimeError, match="not divisible"):
+        dm.setup("predict", world_size=5)
+    dm.setup("predict", world_size=2, rank=1)                                # rank r sees reads r, r+G, ...
+    first = next(iter(dm.predict_dataloader()))
+    assert first["input_ids"].shape[0] == 6
+
+
+def test_prediction_writer_file_format(tmp_path):
+    from types import SimpleNamespace
+
+    from chimeralm_amd.callbacks import PredictionWriter
+    from chimeralm_amd.tokenizer import pack_read_name
+
+    ids = torch.tensor([pack_read_name("read/1"), pack_read_name("read;2"), [0] * 256], dtype=torch.int64).to(torch.int8)
+    logits = torch.tensor([[1.0, -1.0], [-2.0, 3.0], [0.5, 0.4]])
+    w = PredictionWriter(tmp_path / "out", "batch")
+    w.write_on_batch_end(SimpleNamespace(global_rank=3), None, (logits, torch.full((3,), -1)), None, {"id": ids}, 7, 0)
+    assert (tmp_path / "out" / "3_7.txt").read_text() == "read/1\t0\nread;2\t1\nerror_read_2\t0\n"
+
+
+def test_cli_surface():
+    from typer.testing import CliRunner
+
+    from chimeralm_amd.__main__ import app
+
+    r = CliRunner().invoke(app, ["predict", "--help"])
+    assert r.exit_code == 0
+    for opt in ("--gpus", "-g", "--output", "-o", "--batch-size", "-b", "--workers", "-w", "--random", "-r",
+                "--verbose", "-v"):
+        assert opt in r.output
+    r = CliRunner().invoke(app, ["predict", "x.bam", "--gpus", "0"])
+    assert r.exit_code != 0 and "CPU" in " ".join(r.output.split())
