@@ -3,6 +3,7 @@
 // (/root/reference/chimeralm/models/components/hyena.py:244-256); the operator order inside is the
 // HyenaDNA block order of SURVEY.md section 8(a) rows 5-13.
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -61,6 +62,7 @@ struct clm_handle {
     int last_B = 0, last_L = 0, last_Lp = 0;
     // debug / profiling
     int stop_layer = -1, stop_stage = -1;
+    bool force_generic = false;   // CLM_GENERIC_GEMM=1: route 16-bit modes through the generic kernels (A/B runs)
     bool prof = false;
     std::vector<ProfRec> recs;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> free_events;
@@ -326,9 +328,11 @@ int forward_chunk(clm_handle* h, const void* ids, int ids_dtype, int64_t row_str
     if (stop_here(h, -1, CLM_STAGE_EMBED)) return CLM_OK;
     for (int i = 0; i < NLAYER; ++i) {
         const LayerW& lw = h->lw[i];
+        const bool tuned16 = prec != PREC_F32 && !h->force_generic;
         {
             StageTimer t(h, st, CLM_STAGE_INPROJ);
-            launch_inproj(prec, h->h, lw.ln1_g, lw.ln1_b, lw.w_in, lw.b_in, h->z, Bc, L, Lp, eps, st);
+            if (tuned16) launch_inproj16(prec, h->h, lw.ln1_g, lw.ln1_b, lw.w_in, lw.b_in, h->z, Bc, L, Lp, eps, st);
+            else launch_inproj(prec, h->h, lw.ln1_g, lw.ln1_b, lw.w_in, lw.b_in, h->z, Bc, L, Lp, eps, st);
         }
         if (stop_here(h, i, CLM_STAGE_INPROJ)) return CLM_OK;
         {
@@ -339,19 +343,23 @@ int forward_chunk(clm_handle* h, const void* ids, int ids_dtype, int64_t row_str
         if (stop_here(h, i, CLM_STAGE_CONV)) return CLM_OK;
         {
             StageTimer t(h, st, CLM_STAGE_OUTPROJ);
-            launch_outproj(prec, h->y, lw.w_out, lw.b_out, h->h, Bc, L, Lp, st);
+            if (tuned16) launch_outproj16(prec, h->y, lw.w_out, lw.b_out, h->h, Bc, L, Lp, st);
+            else launch_outproj(prec, h->y, lw.w_out, lw.b_out, h->h, Bc, L, Lp, st);
         }
         if (stop_here(h, i, CLM_STAGE_OUTPROJ)) return CLM_OK;
-        {
+        if (tuned16) {   // fc1 + GELU + fc2 + residual fused; reported under the fc1 stage
             StageTimer t(h, st, CLM_STAGE_FC1);
-            launch_fc1(prec, h->h, lw.ln2_g, lw.ln2_b, lw.w_fc1, lw.b_fc1, h->u, Bc, L, eps, st);
-        }
-        if (stop_here(h, i, CLM_STAGE_FC1)) return CLM_OK;
-        {
+            launch_mlp16(prec, h->h, lw.ln2_g, lw.ln2_b, lw.w_fc1, lw.b_fc1, lw.w_fc2, lw.b_fc2, Bc, L, eps, st);
+        } else {
+            {
+                StageTimer t(h, st, CLM_STAGE_FC1);
+                launch_fc1(prec, h->h, lw.ln2_g, lw.ln2_b, lw.w_fc1, lw.b_fc1, h->u, Bc, L, eps, st);
+            }
+            if (stop_here(h, i, CLM_STAGE_FC1)) return CLM_OK;
             StageTimer t(h, st, CLM_STAGE_FC2);
             launch_fc2(prec, h->u, lw.w_fc2, lw.b_fc2, h->h, Bc, L, st);
         }
-        if (stop_here(h, i, CLM_STAGE_FC2)) return CLM_OK;
+        if (stop_here(h, i, CLM_STAGE_FC2) || (tuned16 && stop_here(h, i, CLM_STAGE_FC1))) return CLM_OK;
     }
     {
         StageTimer t(h, st, CLM_STAGE_SCORE);
@@ -411,6 +419,7 @@ int clm_create(const clm_config* cfg, int device, clm_handle** out) {
     if (std::string(prop.gcnArchName).rfind("gfx950", 0) != 0)
         return fail(nullptr, CLM_E_UNSUPPORTED, std::string("this engine is built for gfx950 (MI355X) only, found ") + prop.gcnArchName);
     clm_handle* h = new clm_handle();
+    h->force_generic = std::getenv("CLM_GENERIC_GEMM") && std::getenv("CLM_GENERIC_GEMM")[0] == '1';
     h->cfg = *cfg;
     h->device = device;
     *out = h;

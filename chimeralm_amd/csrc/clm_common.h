@@ -106,6 +106,14 @@ void launch_fc2(int prec, const void* u, const void* w, const float* bias, float
 // scores[b,t] = w2 . gelu_erf(W1 LNf(h) + b1) + b2
 void launch_score(int prec, const float* h, const float* g, const float* b, const void* w1, const float* b1,
                   const float* w2, const float* b2, float* scores, int B, int L, float eps, hipStream_t st);
+// tuned 16-bit kernels (gemm16.hip); prec must be PREC_BF16 or PREC_F16
+void launch_inproj16(int prec, const float* h, const float* g, const float* b, const void* w, const float* bias,
+                     void* z, int B, int L, int Lp, float eps, hipStream_t st);
+void launch_outproj16(int prec, const void* y, const void* w, const float* bias, float* h, int B, int L, int Lp,
+                      hipStream_t st);
+// h += fc2(gelu_tanh(fc1(LN2(h)))) in one kernel (hidden activations stay on chip)
+void launch_mlp16(int prec, float* h, const float* g, const float* b, const void* w1, const float* b1, const void* w2,
+                  const float* b2, int B, int L, float eps, hipStream_t st);
 size_t packed_weight_bytes(int prec, int n, int k);
 // pack W [n][k] fp32 (device) into MFMA fragment order of the compute dtype
 void launch_pack_weight(int prec, const float* w, void* out, int n, int k, hipStream_t st);

@@ -17,49 +17,9 @@
 //   A/B operand, 16-bit: lane l holds row/col (l&31), k = 8*(l>>5) + j, j = 0..7
 //   A/B operand, f32   : lane l holds row/col (l&31), k = (l>>5)
 //   C/D                : col = l&31, row = (reg&3) + 8*(reg>>2) + 4*(l>>5)
-#include <type_traits>
-
-#include "clm_common.h"
+#include "gemm_common.h"
 
 namespace clm {
-
-template <int PREC>
-struct CT;
-template <>
-struct CT<PREC_F32> {
-    using elem = float;
-    using frag = float;
-    static constexpr int MFMA_K = 2, BM = 64, RS = 257;
-};
-template <>
-struct CT<PREC_BF16> {
-    using elem = bf16_t;
-    using frag = u16x8;
-    static constexpr int MFMA_K = 16, BM = 128, RS = 264;
-};
-template <>
-struct CT<PREC_F16> {
-    using elem = f16_t;
-    using frag = u16x8;
-    static constexpr int MFMA_K = 16, BM = 128, RS = 264;
-};
-
-template <int PREC>
-__device__ __forceinline__ f32x16 mfma(typename CT<PREC>::frag a, typename CT<PREC>::frag b, f32x16 c);
-template <>
-__device__ __forceinline__ f32x16 mfma<PREC_F32>(float a, float b, f32x16 c) {
-    return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
-}
-template <>
-__device__ __forceinline__ f32x16 mfma<PREC_BF16>(u16x8 a, u16x8 b, f32x16 c) {
-    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0,
-                                                   0, 0);
-}
-template <>
-__device__ __forceinline__ f32x16 mfma<PREC_F16>(u16x8 a, u16x8 b, f32x16 c) {
-    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0,
-                                                  0);
-}
 
 // ---------------------------------------------------------------------------------------- weight packing
 // 16-bit: out[((nt*(K/16) + ks)*64 + lane)*8 + j] = W[nt*32 + (lane&31)][ks*16 + 8*(lane>>5) + j]
@@ -94,253 +54,6 @@ void launch_pack_weight(int prec, const float* w, void* out, int n, int k, hipSt
         hipLaunchKernelGGL(pack_weight_kernel<PREC_BF16>, grid, block, 0, st, w, (bf16_t*)out, n, k);
     else
         hipLaunchKernelGGL(pack_weight_kernel<PREC_F16>, grid, block, 0, st, w, (f16_t*)out, n, k);
-}
-
-// compile-time loop: f(std::integral_constant<int, I>) for I in [0, N) -- guarantees static register indexing
-template <int I, int N, typename F>
-__device__ __forceinline__ void static_for(F&& f) {
-    if constexpr (I < N) {
-        f(std::integral_constant<int, I>{});
-        static_for<I + 1, N>(f);
-    }
-}
-
-// ---------------------------------------------------------------------------------------- the kernel
-enum { A_LN = 0, A_TM = 1, A_CM = 2 };
-enum { E_CM = 0, E_GELU_TM = 1, E_RESID = 2, E_SCORE = 3 };
-
-struct GemmArgs {
-    const float* h_in;    // A_LN source [B, L, 256] fp32
-    const void* a_in;     // A_TM: [B, L, K] ; A_CM: [B, 256, Lp]   (compute dtype)
-    const float* ln_g;
-    const float* ln_b;
-    const void* w;        // packed
-    const float* bias;    // [N]
-    void* out;            // E_CM: z [B, N, Lp] ; E_GELU_TM: u [B, L, N]
-    float* h_out;         // E_RESID: residual stream [B, L, 256], updated in place
-    const float* w2;      // E_SCORE: attention.2.weight [256]
-    const float* b2;      // E_SCORE: attention.2.bias [1]
-    float* scores;        // E_SCORE: [B, L]
-    int B, L, Lp;
-    float eps;
-};
-
-template <typename E>
-__device__ __forceinline__ void store4(E* dst, float a, float b, float c, float d);
-template <>
-__device__ __forceinline__ void store4<float>(float* dst, float a, float b, float c, float d) {
-    dst[0] = a; dst[1] = b; dst[2] = c; dst[3] = d;
-}
-template <>
-__device__ __forceinline__ void store4<bf16_t>(bf16_t* dst, float a, float b, float c, float d) {
-    u16x4 p = {from_float<bf16_t>(a).bits, from_float<bf16_t>(b).bits, from_float<bf16_t>(c).bits,
-               from_float<bf16_t>(d).bits};
-    *reinterpret_cast<u16x4*>(dst) = p;
-}
-template <>
-__device__ __forceinline__ void store4<f16_t>(f16_t* dst, float a, float b, float c, float d) {
-    u16x4 p = {from_float<f16_t>(a).bits, from_float<f16_t>(b).bits, from_float<f16_t>(c).bits,
-               from_float<f16_t>(d).bits};
-    *reinterpret_cast<u16x4*>(dst) = p;
-}
-
-// ---- A-tile staging: BM tokens x 256 reduction columns of chunk kc into LDS, in the compute dtype ----------
-template <int PREC, int ASRC, int K>
-__device__ __forceinline__ void stage_a_tile(const GemmArgs& a, typename CT<PREC>::elem* As, int b, int t0, int kc) {
-    using C = CT<PREC>;
-    using elem = typename C::elem;
-    constexpr int BM = C::BM, RS = C::RS, KC = 256;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, L = a.L, Lp = a.Lp;
-    if (ASRC == A_LN) {
-        const float4 g4 = *reinterpret_cast<const float4*>(a.ln_g + lane * 4);
-        const float4 b4 = *reinterpret_cast<const float4*>(a.ln_b + lane * 4);
-#pragma unroll 4
-        for (int r = wave; r < BM; r += 4) {
-            int t = t0 + r;
-            float y0 = 0.f, y1 = 0.f, y2 = 0.f, y3 = 0.f;
-            if (t < L) {  // wave-uniform
-                float4 x = *reinterpret_cast<const float4*>(a.h_in + ((size_t)b * L + t) * D + lane * 4);
-                float mean = wave_sum((x.x + x.y) + (x.z + x.w)) * (1.0f / D);
-                float d0 = x.x - mean, d1 = x.y - mean, d2 = x.z - mean, d3 = x.w - mean;
-                float var = wave_sum((d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3)) * (1.0f / D);
-                float rstd = 1.0f / sqrtf(var + a.eps);
-                y0 = d0 * rstd * g4.x + b4.x;
-                y1 = d1 * rstd * g4.y + b4.y;
-                y2 = d2 * rstd * g4.z + b4.z;
-                y3 = d3 * rstd * g4.w + b4.w;
-            }
-            store4<elem>(As + r * RS + lane * 4, y0, y1, y2, y3);
-        }
-    } else if (ASRC == A_TM) {
-        const elem* src = reinterpret_cast<const elem*>(a.a_in);
-        if (PREC == PREC_F32) {
-            for (int r = wave; r < BM; r += 4) {
-                int t = t0 + r;
-                float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (t < L)
-                    x = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(src) +
-                                                         ((size_t)b * L + t) * K + kc * KC + lane * 4);
-                float* d = reinterpret_cast<float*>(As) + r * RS + lane * 4;
-                d[0] = x.x; d[1] = x.y; d[2] = x.z; d[3] = x.w;
-            }
-        } else {
-#pragma unroll 4
-            for (int r = tid >> 5; r < BM; r += 8) {
-                int t = t0 + r, c8 = (tid & 31) * 8;
-                uint4 x = make_uint4(0, 0, 0, 0);
-                if (t < L) x = *reinterpret_cast<const uint4*>(src + ((size_t)b * L + t) * K + kc * KC + c8);
-                *reinterpret_cast<uint4*>(As + r * RS + c8) = x;
-            }
-        }
-    } else {  // A_CM: y [B, 256, Lp] channel-major -> LDS [token][channel]   (scalar LDS scatter)
-        const elem* src = reinterpret_cast<const elem*>(a.a_in);
-        constexpr int TPV = (PREC == PREC_F32) ? 4 : 8;   // tokens per 16-byte vector
-        static_assert(BM / TPV == 16, "tile is 256 B per channel");
-#pragma unroll 2
-        for (int c = tid >> 4; c < KC; c += 16) {
-            int tk = (tid & 15) * TPV;
-            elem v[TPV];
-            if (t0 + tk < Lp) {
-                uint4 x = *reinterpret_cast<const uint4*>(src + ((size_t)b * D + c) * Lp + t0 + tk);
-                __builtin_memcpy(v, &x, 16);
-            } else {
-#pragma unroll
-                for (int e = 0; e < TPV; ++e) v[e] = from_float<elem>(0.f);
-            }
-#pragma unroll
-            for (int e = 0; e < TPV; ++e) As[(tk + e) * RS + c] = v[e];
-        }
-    }
-}
-
-// ---- epilogue of one 256-wide output block --------------------------------------------------------------
-template <int PREC, int EPI, int N, bool MASK>
-__device__ __forceinline__ void epilogue(const GemmArgs& a, f32x16 (&acc)[CT<PREC>::BM / 32][2], int b, int t0,
-                                         int nb, unsigned char* smem) {
-    using C = CT<PREC>;
-    using elem = typename C::elem;
-    constexpr int BM = C::BM, MT = BM / 32;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, L = a.L, Lp = a.Lp;
-    const int lrow = lane & 31, lhalf = lane >> 5;
-    const int nbase = nb * 256 + wave * 64;
-    // Addresses are ONE per-lane base pointer plus compile-time offsets: anything fancier gets hoisted out of the
-    // block loop by LICM and its 64-bit address registers then live (and spill) across the MFMA phases.
-    if (EPI == E_CM) {
-        // acc rows = output channel (nbase + nt*32 + rowoff(r) + 4*lhalf), cols = token (t0 + mt*32 + lrow)
-        elem* zb = reinterpret_cast<elem*>(a.out) + ((size_t)b * N + nbase + 4 * lhalf) * Lp + t0 + lrow;
-        const float* bb = a.bias + nbase + 4 * lhalf;
-        const int tl = t0 + lrow;
-#pragma unroll
-        for (int nt = 0; nt < 2; ++nt) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int nrow = nt * 32 + (r & 3) + 8 * (r >> 2);
-                const float bias = bb[nrow];
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt)
-                    if (!MASK || tl + mt * 32 < L)
-                        zb[(size_t)nrow * Lp + mt * 32] = from_float<elem>(acc[mt][nt][r] + bias);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    } else if (EPI == E_GELU_TM) {
-        // acc rows = token (t0 + mt*32 + rowoff(r) + 4*lhalf), cols = hidden unit (nbase + nt*32 + lrow)
-        elem* ub = reinterpret_cast<elem*>(a.out) + ((size_t)b * L + t0 + 4 * lhalf) * N + nbase + lrow;
-        const int tl = t0 + 4 * lhalf;
-#pragma unroll
-        for (int nt = 0; nt < 2; ++nt) {
-            const float bias = a.bias[nbase + nt * 32 + lrow];
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int trow = mt * 32 + (r & 3) + 8 * (r >> 2);
-                    if (!MASK || tl + trow < L)
-                        ub[(size_t)trow * N + nt * 32] = from_float<elem>(gelu_tanh(acc[mt][nt][r] + bias));
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-    } else if (EPI == E_RESID) {
-        float* hb = a.h_out + ((size_t)b * L + t0 + 4 * lhalf) * D + nbase + lrow;
-        const int tl = t0 + 4 * lhalf;
-#pragma unroll
-        for (int nt = 0; nt < 2; ++nt) {
-            const float bias = a.bias[nbase + nt * 32 + lrow];
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int trow = mt * 32 + (r & 3) + 8 * (r >> 2);
-                    if (!MASK || tl + trow < L) {
-                        float* p = hb + (size_t)trow * D + nt * 32;
-                        *p = *p + (acc[mt][nt][r] + bias);
-                    }
-                }
-                __builtin_amdgcn_sched_barrier(0);   // at most 16 residual loads in flight per group
-            }
-        }
-    } else {  // E_SCORE: s[t] = sum_n w2[n] * gelu_erf(acc[t][n] + b1[n]) + b2, deterministic reduction
-        __syncthreads();  // every wave is done reading the A tile; reuse LDS for the partials
-        float* part = reinterpret_cast<float*>(smem);  // [4][BM]
-        float w2v[2], b1v[2];
-#pragma unroll
-        for (int nt = 0; nt < 2; ++nt) {
-            int n = nbase + nt * 32 + lrow;
-            w2v[nt] = a.w2[n];
-            b1v[nt] = a.bias[n];
-        }
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                float s = gelu_erf(acc[mt][0][r] + b1v[0]) * w2v[0] + gelu_erf(acc[mt][1][r] + b1v[1]) * w2v[1];
-#pragma unroll
-                for (int o = 16; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
-                if (lrow == 0) part[wave * BM + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhalf] = s;
-            }
-        __syncthreads();
-        if (tid < BM && t0 + tid < L)
-            a.scores[(size_t)b * L + t0 + tid] =
-                ((part[tid] + part[BM + tid]) + (part[2 * BM + tid] + part[3 * BM + tid])) + a.b2[0];
-    }
-}
-
-// one "set" of weight fragments: both column tiles of a wave x SETK k-steps (16 bytes per lane each)
-constexpr int SETK = 8;
-template <int PREC, int K>
-__device__ __forceinline__ void load_set(const typename CT<PREC>::frag* wp, int nb, int kc, int part, int wave, int lane,
-                                         typename CT<PREC>::frag (&dst)[2][SETK]) {
-    constexpr int KSTEPS = 256 / CT<PREC>::MFMA_K, KSTEPS_ALL = K / CT<PREC>::MFMA_K;
-#pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
-        const typename CT<PREC>::frag* p =
-            wp + ((size_t)(nb * 8 + wave * 2 + nt) * KSTEPS_ALL + kc * KSTEPS + part * SETK) * 64 + lane;
-#pragma unroll
-        for (int ks = 0; ks < SETK; ++ks) dst[nt][ks] = p[(size_t)ks * 64];
-    }
-}
-template <int PREC, int EPI>
-__device__ __forceinline__ void compute_set(const typename CT<PREC>::elem* As, int part, int lrow, int lhalf,
-                                            const typename CT<PREC>::frag (&src)[2][SETK],
-                                            f32x16 (&acc)[CT<PREC>::BM / 32][2]) {
-    using C = CT<PREC>;
-    using frag = typename C::frag;
-    constexpr int MT = C::BM / 32, RS = C::RS;
-#pragma unroll
-    for (int ks = 0; ks < SETK; ++ks) {
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-            frag af = *reinterpret_cast<const frag*>(As + (mt * 32 + lrow) * RS + (part * SETK + ks) * 16 + lhalf * 8);
-            if (EPI == E_CM) {
-                acc[mt][0] = mfma<PREC>(src[0][ks], af, acc[mt][0]);
-                acc[mt][1] = mfma<PREC>(src[1][ks], af, acc[mt][1]);
-            } else {
-                acc[mt][0] = mfma<PREC>(af, src[0][ks], acc[mt][0]);
-                acc[mt][1] = mfma<PREC>(af, src[1][ks], acc[mt][1]);
-            }
-        }
-    }
 }
 
 // A "set" = the weight fragments one wave needs for one (256-wide output block, 256-deep reduction chunk):

@@ -1,0 +1,336 @@
+// gemm16.hip -- the tuned bf16/f16 projection kernels (fp32 accumulate) of the Hyena block on gfx950.
+//
+//   in_proj16   z = in_proj(LN1(h))                      reference: HyenaOperator.in_proj after HyenaBlock.norm1
+//   out_proj16  h += out_proj(y^T)                                   HyenaOperator.out_proj + residual
+//   mlp16       h += fc2(gelu_tanh(fc1(LN2(h))))                     HyenaBlock.norm2 + HyenaMlp + residual
+//   
+//
+// What the first version got wrong (rocprofv3, profiles/r01_*): its epilogues issued one 2- or 4-byte global store
+// per accumulator register (128 store instructions per wave and output block, ~100 cycles each under load) and
+// out_proj transposed its channel-major input with 2-byte LDS scatters.  Here
+//   * 16-bit outputs are transposed through a wave-private LDS tile and leave as 16-byte stores of whole rows;
+//   * fp32 residual updates use the MFMA orientation whose accumulator quad is 4 consecutive features of one token:
+//     one float4 read-modify-write per quad;
+//   * out_proj keeps y in LDS exactly as it lies in HBM ([channel][token]) and forms MFMA operands with
+//     ds_read_b64_tr_b16, the CDNA4 transposing LDS read (no transposition pass at all);
+//   * fc1 -> GELU -> fc2 is ONE kernel: the 1024-wide hidden activations never leave the CU (they go from
+//     accumulators through GELU into an LDS tile that is the next MFMA's A operand), which removes 4 KiB/token of
+//     HBM traffic per layer and the whole fc1 store epilogue.
+// Weight fragments stream from L2 through the same two-set register ping-pong as in gemm.hip.
+//
+// Geometry: 512-thread workgroups = 8 waves = 2 per SIMD, 128 tokens x 256 features per pass, ONE 32-column tile
+// per wave (64 accumulator registers per GEMM), so a wave needs < 256 registers and the second wave on each SIMD
+// runs MFMAs while the first sits in a wait, a GELU or a store phase.  (rocprofv3 --pmc on the 4-wave version:
+// SQ_WAIT_ANY 47 % of wave cycles, MFMA busy 15 %.)
+#include "gemm_common.h"
+
+namespace clm {
+
+using v4i16 = short __attribute__((ext_vector_type(4)));
+typedef v4i16 __attribute__((address_space(3))) * lds_v4i16_ptr;
+
+constexpr int RS16 = 264;     // row stride (elements) of token-major LDS tiles: 528 B, conflict-free ds_read_b128
+constexpr int RSKM = 160;     // row stride of the k-major (channel-major) tile: 320 B = 256 B + 64 B, so the four
+                              // rows of a transposing read land on four different 64-byte bank groups
+constexpr int RSOUT = 136;    // row stride of the wave-private output staging tile: 272 B (16-byte aligned rows)
+
+template <int PREC>
+__device__ __forceinline__ unsigned short to_bits(float v) {
+    return from_float<typename CT<PREC>::elem>(v).bits;
+}
+
+// acc[mt][nt] += A-tile(token-major LDS) x weight set.  ROWS_N: accumulator rows are output features (lane = token).
+template <int PREC, bool ROWS_N>
+__device__ __forceinline__ void compute_tm(const typename CT<PREC>::elem* As, int part, int lrow, int lhalf,
+                                           const u16x8 (&src)[1][SETK], f32x16 (&acc)[4]) {
+#pragma unroll
+    for (int ks = 0; ks < SETK; ++ks) {
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            u16x8 af = *reinterpret_cast<const u16x8*>(As + (mt * 32 + lrow) * RS16 + (part * SETK + ks) * 16 + lhalf * 8);
+            if (ROWS_N) acc[mt] = mfma<PREC>(src[0][ks], af, acc[mt]);
+            else acc[mt] = mfma<PREC>(af, src[0][ks], acc[mt]);
+        }
+    }
+}
+
+// Same, A operand taken from the k-major tile Ys[k][token] with the transposing read: a 16-lane group reads a
+// 4(k) x 16(token) block and lane i receives token i's four k values (cdna_hip_programming.md T10).
+template <int PREC>
+__device__ __forceinline__ void compute_km(const typename CT<PREC>::elem* Ys, int part, int lane,
+                                           const u16x8 (&src)[1][SETK], f32x16 (&acc)[4]) {
+    const int li = lane & 15, g1 = (lane >> 4) & 1, h = lane >> 5, q = li >> 2, p = li & 3;
+    const typename CT<PREC>::elem* base = Ys + (8 * h + q) * RSKM + 16 * g1 + 4 * p;
+#pragma unroll
+    for (int ks = 0; ks < SETK; ++ks) {
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            const typename CT<PREC>::elem* p0 = base + ((part * SETK + ks) * 16) * RSKM + mt * 32;
+            v4i16 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4i16_ptr)(p0));
+            v4i16 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4i16_ptr)(p0 + 4 * RSKM));
+            u16x8 af = {(unsigned short)lo[0], (unsigned short)lo[1], (unsigned short)lo[2], (unsigned short)lo[3],
+                        (unsigned short)hi[0], (unsigned short)hi[1], (unsigned short)hi[2], (unsigned short)hi[3]};
+            acc[mt] = mfma<PREC>(src[0][ks], af, acc[mt]);     // rows = output feature, cols = token
+        }
+    }
+}
+
+__device__ __forceinline__ void zero_acc(f32x16 (&acc)[4]) {
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[mt][r] = 0.f;
+}
+
+// h[b, t, n0..n0+3] += acc quad + bias, accumulator rows = output features (ROWS_N orientation), 32 features/wave
+__device__ __forceinline__ void resid_epilogue(float* h_out, const float* bias, f32x16 (&acc)[4], int b, int t0,
+                                               int L, int wave, int lrow, int lhalf) {
+    const float* brow = bias + wave * 32 + 4 * lhalf;
+    float4 bb[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) bb[q] = *reinterpret_cast<const float4*>(brow + 8 * q);
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+        const int t = t0 + mt * 32 + lrow;
+        if (t < L) {
+            float* row = h_out + ((size_t)b * L + t) * D + wave * 32 + 4 * lhalf;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float4* p = reinterpret_cast<float4*>(row + 8 * q);
+                float4 v = *p;
+                v.x += acc[mt][4 * q + 0] + bb[q].x;
+                v.y += acc[mt][4 * q + 1] + bb[q].y;
+                v.z += acc[mt][4 * q + 2] + bb[q].z;
+                v.w += acc[mt][4 * q + 3] + bb[q].w;
+                *p = v;
+            }
+        }
+    }
+}
+
+// ================================================================================================ in_proj
+template <int PREC>
+__global__ __launch_bounds__(512) void in_proj16_kernel(GemmArgs a) {
+    using elem = typename CT<PREC>::elem;
+    using frag = u16x8;
+    constexpr int BM = 128, K = D, NBLOCKS = D3 / 256;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    elem* As = reinterpret_cast<elem*>(smem);
+    elem* Zs = As + BM * RS16;                              // 8 wave-private tiles [32 features][RSOUT]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lrow = lane & 31, lhalf = lane >> 5;
+    const int b = blockIdx.y, t0 = blockIdx.x * BM, Lp = a.Lp;
+    const frag* wp = reinterpret_cast<const frag*>(a.w);
+    elem* zs = Zs + wave * 32 * RSOUT;
+    f32x16 acc[4];
+    frag bs[2][1][SETK];
+
+    load_set<PREC, K, 1>(wp, 0, 0, 0, wave, lane, bs[0]);
+    __builtin_amdgcn_sched_barrier(0);
+    stage_a_tile<PREC, A_LN, K, 8>(a, As, b, t0, 0);
+    __syncthreads();
+#pragma unroll 1
+    for (int nb = 0; nb < NBLOCKS; ++nb) {
+        zero_acc(acc);
+        load_set<PREC, K, 1>(wp, nb, 0, 1, wave, lane, bs[1]);
+        __builtin_amdgcn_sched_barrier(0);
+        compute_tm<PREC, false>(As, 0, lrow, lhalf, bs[0], acc);
+        __builtin_amdgcn_sched_barrier(0);
+        load_set<PREC, K, 1>(wp, nb + 1 < NBLOCKS ? nb + 1 : 0, 0, 0, wave, lane, bs[0]);
+        __builtin_amdgcn_sched_barrier(0);
+        compute_tm<PREC, false>(As, 1, lrow, lhalf, bs[1], acc);
+        __builtin_amdgcn_sched_barrier(0);
+        // epilogue: rows = tokens (register quads = 4 consecutive tokens), cols = feature (lane) -> zs[feature][token]
+        const int nbase = nb * 256 + wave * 32;
+        const float bias = a.bias[nbase + lrow];
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                u16x4 pk = {to_bits<PREC>(acc[mt][4 * q + 0] + bias), to_bits<PREC>(acc[mt][4 * q + 1] + bias),
+                            to_bits<PREC>(acc[mt][4 * q + 2] + bias), to_bits<PREC>(acc[mt][4 * q + 3] + bias)};
+                *reinterpret_cast<u16x4*>(zs + lrow * RSOUT + mt * 32 + 8 * q + 4 * lhalf) = pk;
+            }
+        __builtin_amdgcn_sched_barrier(0);
+        elem* zg = reinterpret_cast<elem*>(a.out) + ((size_t)b * D3 + nbase) * Lp + t0;
+        const int col8 = (lane & 15) * 8;
+        const bool in_row = t0 + col8 < Lp;                    // Lp is a multiple of 64: whole vectors in or out
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int row = i * 4 + (lane >> 4);
+            const uint4 v = *reinterpret_cast<const uint4*>(zs + row * RSOUT + col8);
+            if (in_row) *reinterpret_cast<uint4*>(zg + (size_t)row * Lp + col8) = v;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// ================================================================================================ out_proj
+template <int PREC>
+__global__ __launch_bounds__(512) void out_proj16_kernel(GemmArgs a) {
+    using elem = typename CT<PREC>::elem;
+    using frag = u16x8;
+    constexpr int BM = 128, K = D;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    elem* Ys = reinterpret_cast<elem*>(smem);              // [256 channels][RSKM], as y lies in HBM
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lrow = lane & 31, lhalf = lane >> 5;
+    const int b = blockIdx.y, t0 = blockIdx.x * BM, L = a.L, Lp = a.Lp;
+    const frag* wp = reinterpret_cast<const frag*>(a.w);
+    f32x16 acc[4];
+    frag bs[2][1][SETK];
+
+    load_set<PREC, K, 1>(wp, 0, 0, 0, wave, lane, bs[0]);
+    load_set<PREC, K, 1>(wp, 0, 0, 1, wave, lane, bs[1]);
+    __builtin_amdgcn_sched_barrier(0);
+    {
+        const elem* src = reinterpret_cast<const elem*>(a.a_in) + (size_t)b * D * Lp + t0;
+        const int tk = (tid & 15) * 8;
+        const bool in_row = t0 + tk < Lp;
+#pragma unroll 4
+        for (int c = tid >> 4; c < D; c += 32) {
+            uint4 x = make_uint4(0, 0, 0, 0);
+            if (in_row) x = *reinterpret_cast<const uint4*>(src + (size_t)c * Lp + tk);
+            *reinterpret_cast<uint4*>(Ys + c * RSKM + tk) = x;
+        }
+    }
+    __syncthreads();
+    zero_acc(acc);
+    compute_km<PREC>(Ys, 0, lane, bs[0], acc);
+    compute_km<PREC>(Ys, 1, lane, bs[1], acc);
+    __builtin_amdgcn_sched_barrier(0);
+    resid_epilogue(a.h_out, a.bias, acc, b, t0, L, wave, lrow, lhalf);
+}
+
+// ================================================================================================ fused MLP
+struct MlpArgs {
+    float* h;                 // residual stream [B, L, 256], read (LN2) and updated in place
+    const float *ln_g, *ln_b;
+    const void *w1, *w2;      // packed fc1 [1024 x 256], fc2 [256 x 1024]
+    const float *b1, *b2;
+    int B, L;
+    float eps;
+};
+
+template <int PREC>
+__global__ __launch_bounds__(512) void mlp16_kernel(MlpArgs m) {
+    using elem = typename CT<PREC>::elem;
+    using frag = u16x8;
+    constexpr int BM = 128, NCH = DI / 256;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    elem* As = reinterpret_cast<elem*>(smem);              // LN2(h) tile   [128][RS16]
+    elem* Hs = As + BM * RS16;                              // gelu(fc1) chunk [128][RS16] (256 hidden units)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lrow = lane & 31, lhalf = lane >> 5;
+    const int b = blockIdx.y, t0 = blockIdx.x * BM, L = m.L;
+    const frag* w1 = reinterpret_cast<const frag*>(m.w1);
+    const frag* w2 = reinterpret_cast<const frag*>(m.w2);
+    f32x16 acc1[4], acc2[4];
+    frag bs[2][1][SETK];
+
+    load_set<PREC, D, 1>(w1, 0, 0, 0, wave, lane, bs[0]);
+    __builtin_amdgcn_sched_barrier(0);
+    {
+        GemmArgs a{};
+        a.h_in = m.h; a.ln_g = m.ln_g; a.ln_b = m.ln_b; a.L = L; a.eps = m.eps;
+        stage_a_tile<PREC, A_LN, D, 8>(a, As, b, t0, 0);
+    }
+    __syncthreads();
+    zero_acc(acc2);
+#pragma unroll 1
+    for (int j = 0; j < NCH; ++j) {
+        // ---- fc1, hidden units [256 j, 256 j + 256): rows = hidden unit, cols = token
+        zero_acc(acc1);
+        load_set<PREC, D, 1>(w1, j, 0, 1, wave, lane, bs[1]);
+        __builtin_amdgcn_sched_barrier(0);
+        compute_tm<PREC, true>(As, 0, lrow, lhalf, bs[0], acc1);
+        __builtin_amdgcn_sched_barrier(0);
+        load_set<PREC, DI, 1>(w2, 0, j, 0, wave, lane, bs[0]);
+        __builtin_amdgcn_sched_barrier(0);
+        compute_tm<PREC, true>(As, 1, lrow, lhalf, bs[1], acc1);
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- GELU -> Hs[token][hidden]: every wave must be done reading the previous chunk
+        __syncthreads();
+        {
+            const float* b1 = m.b1 + j * 256 + wave * 32 + 4 * lhalf;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 bb = *reinterpret_cast<const float4*>(b1 + 8 * q);
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) {
+                    u16x4 pk = {to_bits<PREC>(gelu_tanh(acc1[mt][4 * q + 0] + bb.x)),
+                                to_bits<PREC>(gelu_tanh(acc1[mt][4 * q + 1] + bb.y)),
+                                to_bits<PREC>(gelu_tanh(acc1[mt][4 * q + 2] + bb.z)),
+                                to_bits<PREC>(gelu_tanh(acc1[mt][4 * q + 3] + bb.w))};
+                    *reinterpret_cast<u16x4*>(Hs + (mt * 32 + lrow) * RS16 + wave * 32 + 8 * q + 4 * lhalf) = pk;
+                }
+            }
+        }
+        __syncthreads();
+        // ---- fc2, reduction chunk j: rows = output feature, cols = token
+        load_set<PREC, DI, 1>(w2, 0, j, 1, wave, lane, bs[1]);
+        __builtin_amdgcn_sched_barrier(0);
+        compute_tm<PREC, true>(Hs, 0, lrow, lhalf, bs[0], acc2);
+        __builtin_amdgcn_sched_barrier(0);
+        load_set<PREC, D, 1>(w1, j + 1 < NCH ? j + 1 : 0, 0, 0, wave, lane, bs[0]);
+        __builtin_amdgcn_sched_barrier(0);
+        compute_tm<PREC, true>(Hs, 1, lrow, lhalf, bs[1], acc2);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    resid_epilogue(m.h, m.b2, acc2, b, t0, L, wave, lrow, lhalf);
+}
+
+// ================================================================================================ launchers
+template <typename Kern>
+static void set_lds(Kern kern, size_t lds) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+}
+
+void launch_inproj16(int prec, const float* h, const float* g, const float* bta, const void* w, const float* bias,
+                     void* z, int B, int L, int Lp, float eps, hipStream_t st) {
+    GemmArgs a{};
+    a.h_in = h; a.ln_g = g; a.ln_b = bta; a.w = w; a.bias = bias; a.out = z; a.B = B; a.L = L; a.Lp = Lp; a.eps = eps;
+    constexpr size_t lds = (size_t)(128 * RS16 + 8 * 32 * RSOUT) * 2;
+    dim3 grid((L + 127) / 128, B), block(512);
+    if (prec == PREC_BF16) {
+        static bool once = (set_lds(in_proj16_kernel<PREC_BF16>, lds), true);
+        (void)once;
+        hipLaunchKernelGGL(in_proj16_kernel<PREC_BF16>, grid, block, lds, st, a);
+    } else {
+        static bool once = (set_lds(in_proj16_kernel<PREC_F16>, lds), true);
+        (void)once;
+        hipLaunchKernelGGL(in_proj16_kernel<PREC_F16>, grid, block, lds, st, a);
+    }
+}
+
+void launch_outproj16(int prec, const void* y, const void* w, const float* bias, float* h, int B, int L, int Lp,
+                      hipStream_t st) {
+    GemmArgs a{};
+    a.a_in = y; a.w = w; a.bias = bias; a.h_out = h; a.B = B; a.L = L; a.Lp = Lp;
+    constexpr size_t lds = (size_t)D * RSKM * 2;
+    dim3 grid((L + 127) / 128, B), block(512);
+    if (prec == PREC_BF16) {
+        static bool once = (set_lds(out_proj16_kernel<PREC_BF16>, lds), true);
+        (void)once;
+        hipLaunchKernelGGL(out_proj16_kernel<PREC_BF16>, grid, block, lds, st, a);
+    } else {
+        static bool once = (set_lds(out_proj16_kernel<PREC_F16>, lds), true);
+        (void)once;
+        hipLaunchKernelGGL(out_proj16_kernel<PREC_F16>, grid, block, lds, st, a);
+    }
+}
+
+void launch_mlp16(int prec, float* h, const float* g, const float* bta, const void* w1, const float* b1, const void* w2,
+                  const float* b2, int B, int L, float eps, hipStream_t st) {
+    MlpArgs m{h, g, bta, w1, w2, b1, b2, B, L, eps};
+    constexpr size_t lds = (size_t)2 * 128 * RS16 * 2;
+    dim3 grid((L + 127) / 128, B), block(512);
+    if (prec == PREC_BF16) {
+        static bool once = (set_lds(mlp16_kernel<PREC_BF16>, lds), true);
+        (void)once;
+        hipLaunchKernelGGL(mlp16_kernel<PREC_BF16>, grid, block, lds, st, m);
+    } else {
+        static bool once = (set_lds(mlp16_kernel<PREC_F16>, lds), true);
+        (void)once;
+        hipLaunchKernelGGL(mlp16_kernel<PREC_F16>, grid, block, lds, st, m);
+    }
+}
+
+}  // namespace clm
