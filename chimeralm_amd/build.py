@@ -15,7 +15,8 @@ INCLUDE = Path(__file__).resolve().parent.parent / "include"
 LIB = CSRC / "libchimeralm_hip.so"
 SOURCES = ["clm_api.hip", "gemm.hip", "gemm16.hip", "hyena_conv.hip", "head.hip"]
 HEADERS = ["clm_common.h", "gemm_common.h", "fft_core.h", "fft_passes.h"]
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast", "-Wall", "-Wno-unused-function",
+         "-Wno-pass-failed"]
 
 
 def _stale() -> bool:

@@ -24,7 +24,7 @@ struct Tensor {
 };
 
 struct FilterSet {
-    int L = 0, logn = 0;
+    int L = 0, logn = 0, S = 1;   // S > 1: segmented (overlap-add) long convolution, kf holds S spectra per channel
     float* ktime[NLAYER] = {};
     float2* kf[NLAYER] = {};
     float2* tw = nullptr;
@@ -59,6 +59,8 @@ struct clm_handle {
     float* h = nullptr;
     void *z = nullptr, *y = nullptr, *u = nullptr;
     float *scores = nullptr, *stats = nullptr, *partial = nullptr, *pooled = nullptr;
+    float2 *gscratch = nullptr, *carry = nullptr;   // overlap-add scratch of the long-read convolution
+    size_t gscratch_elems = 0;
     int last_B = 0, last_L = 0, last_Lp = 0;
     // debug / profiling
     int stop_layer = -1, stop_stage = -1;
@@ -195,8 +197,10 @@ void free_filters(clm_handle* h) {
 
 void free_workspace(clm_handle* h) {
     for (void* p : {(void*)h->h, h->z, h->y, h->u, (void*)h->scores, (void*)h->stats, (void*)h->partial,
-                    (void*)h->pooled})
+                    (void*)h->pooled, (void*)h->gscratch, (void*)h->carry})
         if (p) (void)hipFree(p);
+    h->gscratch = h->carry = nullptr;
+    h->gscratch_elems = 0;
     h->h = nullptr; h->z = h->y = h->u = nullptr;
     h->scores = h->stats = h->partial = h->pooled = nullptr;
     h->ws_B = h->ws_L = 0;
@@ -229,6 +233,12 @@ int ensure_workspace(clm_handle* h, int Bc, int L, hipStream_t st) {
     HIPCHK(h, hipMalloc((void**)&h->stats, (size_t)nb * 2 * 4));
     HIPCHK(h, hipMalloc((void**)&h->partial, (size_t)nb * POOL_SPLIT * 4 * D * 4));
     HIPCHK(h, hipMalloc((void**)&h->pooled, (size_t)nb * D * 4));
+    if (conv_segments_for(nl) > 1) {
+        const size_t pairs = (size_t)(nb + 1) / 2, S = (size_t)conv_segments_for(nl);
+        h->gscratch_elems = pairs * D * S * 16384;
+        HIPCHK(h, hipMalloc((void**)&h->gscratch, h->gscratch_elems * sizeof(float2)));
+        HIPCHK(h, hipMalloc((void**)&h->carry, pairs * D * SEG_LEN * sizeof(float2)));
+    }
     HIPCHK(h, hipMemset(h->z, 0, n_z));   // padding columns [L, Lp) must never hold NaN garbage
     HIPCHK(h, hipMemset(h->y, 0, n_y));
     h->ws_B = nb;
@@ -243,10 +253,11 @@ int ensure_filters(clm_handle* h, int L, hipStream_t st, FilterSet** out) {
             *out = &f;
             return CLM_OK;
         }
-    const int logn = conv_logn_for(L);
-    if (logn < 0)
-        return fail(h, CLM_E_UNSUPPORTED,
-                    "sequence length " + std::to_string(L) + " tokens: long convolution supports L <= 8193");
+    const int S = conv_segments_for(L);
+    const int logn = S > 1 ? 14 : conv_logn_for(L);
+    if (logn < 0 || L > h->cfg.max_seq_len)
+        return fail(h, CLM_E_UNSUPPORTED, "sequence length " + std::to_string(L) + " tokens exceeds max_seq_len " +
+                                              std::to_string(h->cfg.max_seq_len));
     HIPCHK(h, hipStreamSynchronize(st));
     if (h->filters.size() >= 3) {  // drop the least recently used length
         size_t lru = 0;
@@ -259,6 +270,7 @@ int ensure_filters(clm_handle* h, int L, hipStream_t st, FilterSet** out) {
     FilterSet f;
     f.L = L;
     f.logn = logn;
+    f.S = S;
     f.stamp = ++h->clock;
     double2* scratch = nullptr;
     HIPCHK(h, hipMalloc((void**)&scratch, (size_t)D * N * sizeof(double2)));
@@ -266,14 +278,27 @@ int ensure_filters(clm_handle* h, int L, hipStream_t st, FilterSet** out) {
     launch_twiddles(f.tw, logn, st);
     for (int i = 0; i < NLAYER; ++i) {
         HIPCHK(h, hipMalloc((void**)&f.ktime[i], (size_t)L * D * 4));
-        HIPCHK(h, hipMalloc((void**)&f.kf[i], (size_t)D * N * sizeof(float2)));
+        HIPCHK(h, hipMalloc((void**)&f.kf[i], (size_t)D * S * N * sizeof(float2)));
         std::string p = "bb.layers." + std::to_string(i) + ".mixer.filter_fn.";
         launch_filter(W(h, p + "pos_emb.z"), W(h, p + "pos_emb.t"), W(h, p + "implicit_filter.0.weight"),
                       W(h, p + "implicit_filter.0.bias"), W(h, p + "implicit_filter.1.freq"),
                       W(h, p + "implicit_filter.2.weight"), W(h, p + "implicit_filter.2.bias"),
                       W(h, p + "implicit_filter.4.weight"), W(h, p + "implicit_filter.4.bias"),
                       W(h, p + "implicit_filter.6.weight"), W(h, p + "modulation.deltas"), f.ktime[i], L, st);
-        launch_filter_spectrum(f.ktime[i], W(h, p + "bias"), f.kf[i], scratch, L, logn, st);
+        if (S == 1) {
+            launch_filter_spectrum(f.ktime[i], W(h, p + "bias"), f.kf[i], scratch, L, logn, 0, L, st);
+        } else {   // kf [256][S][N]: one launch per segment writes the strided slice through a temporary
+            float2* tmp = nullptr;
+            HIPCHK(h, hipMalloc((void**)&tmp, (size_t)D * N * sizeof(float2)));
+            for (int j = 0; j < S; ++j) {
+                launch_filter_spectrum(f.ktime[i], W(h, p + "bias"), tmp, scratch, L, logn, j * SEG_LEN, SEG_LEN, st);
+                HIPCHK(h, hipMemcpy2DAsync(f.kf[i] + (size_t)j * N, (size_t)S * N * sizeof(float2), tmp,
+                                           (size_t)N * sizeof(float2), (size_t)N * sizeof(float2), D,
+                                           hipMemcpyDeviceToDevice, st));
+            }
+            HIPCHK(h, hipStreamSynchronize(st));
+            HIPCHK(h, hipFree(tmp));
+        }
     }
     HIPCHK(h, hipGetLastError());
     HIPCHK(h, hipStreamSynchronize(st));
@@ -337,8 +362,12 @@ int forward_chunk(clm_handle* h, const void* ids, int ids_dtype, int64_t row_str
         if (stop_here(h, i, CLM_STAGE_INPROJ)) return CLM_OK;
         {
             StageTimer t(h, st, CLM_STAGE_CONV);
-            launch_hyena_conv(prec, h->z, h->y, fs->kf[i], fs->tw, fs->ktime[i], lw.short_w, lw.short_b, Bc, L, Lp,
-                              fs->logn, st);
+            if (fs->S == 1)
+                launch_hyena_conv(prec, h->z, h->y, fs->kf[i], fs->tw, fs->ktime[i], lw.short_w, lw.short_b, Bc, L, Lp,
+                                  fs->logn, st);
+            else
+                launch_hyena_conv_seg(prec, h->z, h->y, fs->kf[i], fs->tw, lw.short_w, lw.short_b, h->gscratch,
+                                      h->carry, Bc, L, Lp, fs->S, st);
         }
         if (stop_here(h, i, CLM_STAGE_CONV)) return CLM_OK;
         {

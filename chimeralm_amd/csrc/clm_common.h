@@ -69,9 +69,20 @@ __device__ __forceinline__ float wave_max(float v) {
 }
 
 // gelu(x, approximate="tanh") = x * sigmoid(2*sqrt(2/pi)*(x + 0.044715 x^3))      (HyenaMlp activation)
+//                              = x / (1 + 2^(x * (A + B x^2))),  A = -2 sqrt(2/pi) log2(e),  B = 0.044715 A
+// Saturates correctly for |x| -> inf (2^-inf = 0 -> x ; 2^+inf = inf -> rcp = 0 -> -0); v_exp_f32 / v_rcp_f32 are 1 ulp.
+constexpr float GELU_A = -2.3022081985f, GELU_B = -0.10294324f;
 __device__ __forceinline__ float gelu_tanh(float x) {
-    float u = 0.7978845608028654f * (x + 0.044715f * x * x * x);
-    return x / (1.0f + __expf(-2.0f * u));
+    float e = __builtin_amdgcn_exp2f(x * (GELU_A + GELU_B * (x * x)));
+    return x * __builtin_amdgcn_rcpf(1.0f + e);
+}
+// two at a time: the element-wise part maps onto v_pk_mul_f32 / v_pk_fma_f32 / v_pk_add_f32
+using f32x2 = float __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 gelu_tanh2(f32x2 x) {
+    f32x2 p = x * (GELU_A + GELU_B * (x * x));
+    f32x2 d = {1.0f + __builtin_amdgcn_exp2f(p.x), 1.0f + __builtin_amdgcn_exp2f(p.y)};
+    f32x2 r = {__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
+    return x * r;
 }
 // exact gelu (erf form): nn.GELU() of the head (hyena.py:38,47,162)
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.7071067811865476f)); }
@@ -119,18 +130,25 @@ size_t packed_weight_bytes(int prec, int n, int k);
 void launch_pack_weight(int prec, const float* w, void* out, int n, int k, hipStream_t st);
 
 // long convolution (hyena_conv.hip)
-int conv_logn_for(int L);                         // log2 of the FFT size used for L tokens; <0 if unsupported
+constexpr int SEG_LEN = 8192;                     // tokens per segment of the overlap-add path (half a 16384 transform)
+int conv_logn_for(int L);                         // log2 of the single-shot FFT size for L tokens; <0 if L > 8193
+int conv_segments_for(int L);                     // 1 = single shot; >1 = number of 8192-token segments
 void launch_filter(const float* z /*[maxlen][5]*/, const float* t /*[maxlen]*/, const float* w0, const float* b0,
                    const float* freq, const float* w2, const float* b2, const float* w4, const float* b4,
                    const float* w6, const float* deltas, float* k_out /*[L][256]*/, int L, hipStream_t st);
 // spectrum of one layer's filter: kf [256][N] float2 = FFT_N(k[:, c]) / N (double precision inside);
 // scratch: 256*N double2
 void launch_filter_spectrum(const float* k /*[L][256]*/, const float* dskip /*[256], folded into tap 0*/, float2* kf,
-                            double2* scratch, int L, int logn, hipStream_t st);
+                            double2* scratch, int L, int logn, int seg_off, int seg_len, hipStream_t st);
 void launch_twiddles(float2* tw, int logn, hipStream_t st);   // tw[m] = exp(-2 pi i m / N), m < N/2
 // y = ((causal_conv(v*x1, k) + D*(v*x1)) * x0)   with (x0,x1,v) = short_filter(z)    [B,256,Lp]; D lives in kf
 void launch_hyena_conv(int prec, const void* z, void* y, const float2* kf, const float2* tw, const float* ktime,
                        const float* short_w, const float* short_b, int B, int L, int Lp, int logn, hipStream_t st);
+
+// long reads (L > 8193): overlap-add over S segments; kf [256][S][N], gscratch [pairs][256][S][N], carry [pairs][256][8192]
+void launch_hyena_conv_seg(int prec, const void* z, void* y, const float2* kf, const float2* tw, const float* short_w,
+                           const float* short_b, float2* gscratch, float2* carry, int B, int L, int Lp, int S,
+                           hipStream_t st);
 
 // head (head.hip)
 void launch_softmax_stats(const float* scores, float* stats /*[B][2] = max, sum*/, int B, int L, hipStream_t st);

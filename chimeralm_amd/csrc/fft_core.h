@@ -35,10 +35,11 @@ CLM_HD float2 mul_mi(float2 a) {
     return INV ? make_float2(-a.y, a.x) : make_float2(a.y, -a.x);
 }
 
-// LDS index padding: one float2 of padding per 16 elements keeps the stride-R Stockham stores and the
-// unit-stride loads of ds_read_b64 / ds_write_b64 conflict-free ("long convolution").
-CLM_HDC int pad_index(int i) { return i + (i >> 4); }
-CLM_HDC int padded_size(int n) { return n + (n >> 4); }
+// LDS index padding: one float2 of padding per 32 elements.  Unit-stride ds_read_b64 (32-lane groups, 64 banks)
+// stays conflict-free -- padding per 16 made every such read 2-way -- while the stride-R stores of the first
+// (Ns = 1) pass drop from 16-way to 2-way ("long convolution").
+CLM_HDC int pad_index(int i) { return i + (i >> 5); }
+CLM_HDC int padded_size(int n) { return n + (n >> 5); }
 
 // ---- small DFTs, in place, natural order in and out ------------------------------------------------------
 template <bool INV>
@@ -167,7 +168,7 @@ struct Plan {
     static constexpr int N = 1 << LOGN;
     static constexpr int NPASS = (LOGN + 3) / 4;
     static constexpr int LAST = (LOGN % 4 == 0) ? 16 : (1 << (LOGN % 4));  // radix of the last forward pass
-    static constexpr int NT = (N / 16 < 64) ? 64 : N / 16;                 // threads per transform
+    static constexpr int NT = (N / 32 < 64) ? 64 : N / 32;                 // threads per transform (32 points each)
     static constexpr int radix(int pass) { return pass < NPASS - 1 ? 16 : LAST; }
 };
 
@@ -183,6 +184,20 @@ CLM_HD void butterfly(float2* v, int jb, int Ns, const float2* tw) {
         apply_twiddle_powers<R>(v, w1);
     }
     Dft<R, INV>::run(v);
+}
+
+// same with the twiddle already in a register (prefetched at kernel start)
+template <int R, bool INV>
+CLM_HD void butterfly_w(float2* v, bool has_tw, float2 w1) {
+    if (has_tw) apply_twiddle_powers<R>(v, w1);
+    Dft<R, INV>::run(v);
+}
+template <int LOGN, int R, bool INV>
+CLM_HD float2 twiddle_for(int jb, int Ns, const float2* tw) {
+    constexpr int N = 1 << LOGN;
+    if (Ns <= 1) return make_float2(1.f, 0.f);
+    float2 w1 = tw[(jb & (Ns - 1)) * (N / (Ns * R))];
+    return INV ? cconj(w1) : w1;
 }
 
 // element index read by butterfly jb for input r, and written for output q

@@ -30,10 +30,10 @@ static void fft_ref(std::vector<cd>& a, bool inv) {  // plain recursive radix-2,
 template <int LOGN, int R, bool INV>
 static void run_pass(std::vector<float2>& buf, int Ns, const std::vector<float2>& tw) {
     constexpr int NT = Plan<LOGN>::NT;
-    std::vector<float2> regs(size_t(NT) * 16);
-    for (int tid = 0; tid < NT; ++tid) pass_load<LOGN, R>(buf.data(), &regs[size_t(tid) * 16], tid);
-    for (int tid = 0; tid < NT; ++tid) pass_compute<LOGN, R, INV>(&regs[size_t(tid) * 16], tid, Ns, tw.data());
-    for (int tid = 0; tid < NT; ++tid) pass_store<LOGN, R>(buf.data(), &regs[size_t(tid) * 16], tid, Ns);
+    std::vector<float2> regs(size_t(NT) * 32);
+    for (int tid = 0; tid < NT; ++tid) pass_load<LOGN, R>(buf.data(), &regs[size_t(tid) * 32], tid);
+    for (int tid = 0; tid < NT; ++tid) pass_compute<LOGN, R, INV>(&regs[size_t(tid) * 32], tid, Ns, tw.data());
+    for (int tid = 0; tid < NT; ++tid) pass_store<LOGN, R>(buf.data(), &regs[size_t(tid) * 32], tid, Ns);
 }
 
 template <int LOGN>
@@ -58,22 +58,38 @@ static double test_conv(int L, unsigned seed) {
     // signal in padded "LDS"
     std::vector<float2> buf(padded_size(N), make_float2(0.f, 0.f));
     for (int t = 0; t < L; ++t) buf[pad_index(t)] = make_float2(float(g0[t]), float(g1[t]));
+    // all twiddles are fetched up front, exactly like the kernel does
+    using TL = TwLayout<LOGN>;
+    std::vector<float2> wall(size_t(NT) * TL::TOTAL);
+    for (int tid = 0; tid < NT; ++tid) {
+        float2* w = &wall[size_t(tid) * TL::TOTAL];
+        int ns = 16;
+        for (int p = 1; p <= P::NPASS - 2; ++p, ns *= 16) pass_twiddles<LOGN, 16, false>(w + TL::fwd(p), tid, ns, tw.data());
+        pass_twiddles<LOGN, LAST, false>(w + TL::fwd_last(), tid, ns, tw.data());
+        ns = LAST;
+        for (int p = 1; p <= P::NPASS - 1; ++p, ns *= 16) pass_twiddles<LOGN, 16, true>(w + TL::inv(p), tid, ns, tw.data());
+    }
+    std::vector<float2> regs(size_t(NT) * 32), kv(size_t(NT) * 32);
+    auto R = [&](int tid) { return &regs[size_t(tid) * 32]; };
+    auto W = [&](int tid) { return &wall[size_t(tid) * TL::TOTAL]; };
     // forward passes
     int Ns = 1;
     for (int p = 0; p < P::NPASS - 1; ++p) {
-        run_pass<LOGN, 16, false>(buf, Ns, tw);
+        for (int tid = 0; tid < NT; ++tid) pass_load<LOGN, 16>(buf.data(), R(tid), tid);
+        for (int tid = 0; tid < NT; ++tid) pass_compute_w<LOGN, 16, false>(R(tid), tid, p > 0, W(tid) + (p > 0 ? TL::fwd(p) : 0));
+        for (int tid = 0; tid < NT; ++tid) pass_store<LOGN, 16>(buf.data(), R(tid), tid, Ns);
         Ns *= 16;
     }
-    {
-        std::vector<float2> regs(size_t(NT) * 16);
-        for (int tid = 0; tid < NT; ++tid) pass_load<LOGN, LAST>(buf.data(), &regs[size_t(tid) * 16], tid);
-        for (int tid = 0; tid < NT; ++tid) pass_compute<LOGN, LAST, false>(&regs[size_t(tid) * 16], tid, Ns, tw.data());
-        for (int tid = 0; tid < NT; ++tid) spectrum_multiply_and_first_inverse<LOGN, LAST>(&regs[size_t(tid) * 16], tid, kff.data());
-        for (int tid = 0; tid < NT; ++tid) pass_store<LOGN, LAST>(buf.data(), &regs[size_t(tid) * 16], tid, 1);
-    }
+    for (int tid = 0; tid < NT; ++tid) spectrum_fetch<LOGN, LAST>(&kv[size_t(tid) * 32], tid, kff.data());
+    for (int tid = 0; tid < NT; ++tid) pass_load<LOGN, LAST>(buf.data(), R(tid), tid);
+    for (int tid = 0; tid < NT; ++tid) pass_compute_w<LOGN, LAST, false>(R(tid), tid, true, W(tid) + TL::fwd_last());
+    for (int tid = 0; tid < NT; ++tid) spectrum_multiply_and_first_inverse_v<LOGN, LAST>(R(tid), tid, &kv[size_t(tid) * 32]);
+    for (int tid = 0; tid < NT; ++tid) pass_store<LOGN, LAST>(buf.data(), R(tid), tid, 1);
     Ns = LAST;
-    for (int p = 0; p < P::NPASS - 1; ++p) {
-        run_pass<LOGN, 16, true>(buf, Ns, tw);
+    for (int p = 1; p <= P::NPASS - 1; ++p) {
+        for (int tid = 0; tid < NT; ++tid) pass_load<LOGN, 16>(buf.data(), R(tid), tid);
+        for (int tid = 0; tid < NT; ++tid) pass_compute_w<LOGN, 16, true>(R(tid), tid, true, W(tid) + TL::inv(p));
+        for (int tid = 0; tid < NT; ++tid) pass_store<LOGN, 16>(buf.data(), R(tid), tid, Ns);
         Ns *= 16;
     }
     // reference: direct causal convolution in double

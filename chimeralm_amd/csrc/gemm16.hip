@@ -89,6 +89,15 @@ __device__ __forceinline__ void resid_epilogue(float* h_out, const float* bias, 
     float4 bb[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) bb[q] = *reinterpret_cast<const float4*>(brow + 8 * q);
+    // all 16 residual vectors of the lane are requested before the first add (latency-bound phase)
+    float4 v[4][4];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+        const int t = t0 + mt * 32 + lrow;
+        const float* row = h_out + ((size_t)b * L + (t < L ? t : 0)) * D + wave * 32 + 4 * lhalf;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[mt][q] = *reinterpret_cast<const float4*>(row + 8 * q);
+    }
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) {
         const int t = t0 + mt * 32 + lrow;
@@ -96,13 +105,12 @@ __device__ __forceinline__ void resid_epilogue(float* h_out, const float* bias, 
             float* row = h_out + ((size_t)b * L + t) * D + wave * 32 + 4 * lhalf;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                float4* p = reinterpret_cast<float4*>(row + 8 * q);
-                float4 v = *p;
-                v.x += acc[mt][4 * q + 0] + bb[q].x;
-                v.y += acc[mt][4 * q + 1] + bb[q].y;
-                v.z += acc[mt][4 * q + 2] + bb[q].z;
-                v.w += acc[mt][4 * q + 3] + bb[q].w;
-                *p = v;
+                float4 o = v[mt][q];
+                o.x += acc[mt][4 * q + 0] + bb[q].x;
+                o.y += acc[mt][4 * q + 1] + bb[q].y;
+                o.z += acc[mt][4 * q + 2] + bb[q].z;
+                o.w += acc[mt][4 * q + 3] + bb[q].w;
+                *reinterpret_cast<float4*>(row + 8 * q) = o;
             }
         }
     }
@@ -185,12 +193,14 @@ __global__ __launch_bounds__(512) void out_proj16_kernel(GemmArgs a) {
         const elem* src = reinterpret_cast<const elem*>(a.a_in) + (size_t)b * D * Lp + t0;
         const int tk = (tid & 15) * 8;
         const bool in_row = t0 + tk < Lp;
-#pragma unroll 4
-        for (int c = tid >> 4; c < D; c += 32) {
-            uint4 x = make_uint4(0, 0, 0, 0);
-            if (in_row) x = *reinterpret_cast<const uint4*>(src + (size_t)c * Lp + tk);
-            *reinterpret_cast<uint4*>(Ys + c * RSKM + tk) = x;
+        uint4 x[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            x[i] = make_uint4(0, 0, 0, 0);
+            if (in_row) x[i] = *reinterpret_cast<const uint4*>(src + (size_t)((tid >> 4) + 32 * i) * Lp + tk);
         }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) *reinterpret_cast<uint4*>(Ys + ((tid >> 4) + 32 * i) * RSKM + tk) = x[i];
     }
     __syncthreads();
     zero_acc(acc);
@@ -255,10 +265,9 @@ __global__ __launch_bounds__(512) void mlp16_kernel(MlpArgs m) {
                 const float4 bb = *reinterpret_cast<const float4*>(b1 + 8 * q);
 #pragma unroll
                 for (int mt = 0; mt < 4; ++mt) {
-                    u16x4 pk = {to_bits<PREC>(gelu_tanh(acc1[mt][4 * q + 0] + bb.x)),
-                                to_bits<PREC>(gelu_tanh(acc1[mt][4 * q + 1] + bb.y)),
-                                to_bits<PREC>(gelu_tanh(acc1[mt][4 * q + 2] + bb.z)),
-                                to_bits<PREC>(gelu_tanh(acc1[mt][4 * q + 3] + bb.w))};
+                    const f32x2 g0 = gelu_tanh2(f32x2{acc1[mt][4 * q + 0] + bb.x, acc1[mt][4 * q + 1] + bb.y});
+                    const f32x2 g1 = gelu_tanh2(f32x2{acc1[mt][4 * q + 2] + bb.z, acc1[mt][4 * q + 3] + bb.w});
+                    u16x4 pk = {to_bits<PREC>(g0.x), to_bits<PREC>(g0.y), to_bits<PREC>(g1.x), to_bits<PREC>(g1.y)};
                     *reinterpret_cast<u16x4*>(Hs + (mt * 32 + lrow) * RS16 + wave * 32 + 8 * q + 4 * lhalf) = pk;
                 }
             }

@@ -101,24 +101,37 @@ __device__ __forceinline__ void stage_a_tile(const GemmArgs& a, typename CT<PREC
     constexpr int BM = C::BM, RS = C::RS, KC = 256;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, L = a.L, Lp = a.Lp;
     if (ASRC == A_LN) {
+        // All row loads of a batch are issued before the first reduction: the staging phase is HBM-latency bound
+        // (every wave of the workgroup is in it at once), so 16 rows in flight per wave instead of 4 cut it ~4x.
         const float4 g4 = *reinterpret_cast<const float4*>(a.ln_g + lane * 4);
         const float4 b4 = *reinterpret_cast<const float4*>(a.ln_b + lane * 4);
-#pragma unroll 4
-        for (int r = wave; r < BM; r += NW) {
-            int t = t0 + r;
-            float y0 = 0.f, y1 = 0.f, y2 = 0.f, y3 = 0.f;
-            if (t < L) {  // wave-uniform
-                float4 x = *reinterpret_cast<const float4*>(a.h_in + ((size_t)b * L + t) * D + lane * 4);
-                float mean = wave_sum((x.x + x.y) + (x.z + x.w)) * (1.0f / D);
-                float d0 = x.x - mean, d1 = x.y - mean, d2 = x.z - mean, d3 = x.w - mean;
-                float var = wave_sum((d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3)) * (1.0f / D);
-                float rstd = 1.0f / sqrtf(var + a.eps);
-                y0 = d0 * rstd * g4.x + b4.x;
-                y1 = d1 * rstd * g4.y + b4.y;
-                y2 = d2 * rstd * g4.z + b4.z;
-                y3 = d3 * rstd * g4.w + b4.w;
+        constexpr int ROWS = BM / NW, BATCH = ROWS < 16 ? ROWS : 16;
+        static_assert(ROWS % BATCH == 0, "rows per wave must be a multiple of the batch");
+#pragma unroll 1
+        for (int r0 = 0; r0 < ROWS; r0 += BATCH) {
+            float4 x[BATCH];
+#pragma unroll
+            for (int i = 0; i < BATCH; ++i) {
+                const int t = t0 + wave + (r0 + i) * NW;
+                x[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (t < L) x[i] = *reinterpret_cast<const float4*>(a.h_in + ((size_t)b * L + t) * D + lane * 4);
             }
-            store4<elem>(As + r * RS + lane * 4, y0, y1, y2, y3);
+#pragma unroll
+            for (int i = 0; i < BATCH; ++i) {
+                const int r = wave + (r0 + i) * NW, t = t0 + r;
+                float y0 = 0.f, y1 = 0.f, y2 = 0.f, y3 = 0.f;
+                if (t < L) {  // wave-uniform
+                    float mean = wave_sum((x[i].x + x[i].y) + (x[i].z + x[i].w)) * (1.0f / D);
+                    float d0 = x[i].x - mean, d1 = x[i].y - mean, d2 = x[i].z - mean, d3 = x[i].w - mean;
+                    float var = wave_sum((d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3)) * (1.0f / D);
+                    float rstd = 1.0f / sqrtf(var + a.eps);
+                    y0 = d0 * rstd * g4.x + b4.x;
+                    y1 = d1 * rstd * g4.y + b4.y;
+                    y2 = d2 * rstd * g4.z + b4.z;
+                    y3 = d3 * rstd * g4.w + b4.w;
+                }
+                store4<elem>(As + r * RS + lane * 4, y0, y1, y2, y3);
+            }
         }
     } else if (ASRC == A_TM) {
         const elem* src = reinterpret_cast<const elem*>(a.a_in);

@@ -68,15 +68,17 @@ void launch_filter(const float* z, const float* t, const float* w0, const float*
 // workgroup per channel (runs once per distinct L).
 // The skip term of fftconv, y += g * D[c], is a convolution with D[c]*delta: it is folded into tap 0 here, so the
 // convolution kernel needs neither D nor g after the transform.
+// Segment form (long reads): taps [seg_off, seg_off + seg_len) of the filter, zero-padded to N.
 __global__ __launch_bounds__(256) void spectrum_kernel(const float* __restrict__ k, const float* __restrict__ dskip,
                                                        float2* __restrict__ kf, double2* __restrict__ scratch, int L,
-                                                       int logn) {
+                                                       int logn, int seg_off, int seg_len) {
     const int N = 1 << logn, c = blockIdx.x;
     double2* a = scratch + (size_t)c * N;
     for (int i = threadIdx.x; i < N; i += blockDim.x) {  // bit-reversed load
         int rv = __brev((unsigned)i) >> (32 - logn);
-        double v = i < L ? (double)k[(size_t)i * D + c] : 0.0;
-        if (i == 0) v += (double)dskip[c];
+        const int t = seg_off + i;
+        double v = (i < seg_len && t < L) ? (double)k[(size_t)t * D + c] : 0.0;
+        if (t == 0) v += (double)dskip[c];
         a[rv] = make_double2(v, 0.0);
     }
     __syncthreads();
@@ -100,8 +102,8 @@ __global__ __launch_bounds__(256) void spectrum_kernel(const float* __restrict__
 }
 
 void launch_filter_spectrum(const float* k, const float* dskip, float2* kf, double2* scratch, int L, int logn,
-                            hipStream_t st) {
-    hipLaunchKernelGGL(spectrum_kernel, dim3(D), dim3(256), 0, st, k, dskip, kf, scratch, L, logn);
+                            int seg_off, int seg_len, hipStream_t st) {
+    hipLaunchKernelGGL(spectrum_kernel, dim3(D), dim3(256), 0, st, k, dskip, kf, scratch, L, logn, seg_off, seg_len);
 }
 
 __global__ void twiddle_kernel(float2* tw, int logn) {
@@ -122,8 +124,11 @@ int conv_logn_for(int L) {
     if (L < 1) return -1;
     for (int logn = 8; logn <= 14; ++logn)
         if (2 * L - 2 <= (1 << logn)) return logn;
-    return -1;  // L > 8193: needs the segmented overlap-add variant (not built yet)
+    return -1;  // L > 8193: segmented overlap-add path (conv_segments_for)
 }
+
+// Long reads: S segments of SEG_LEN tokens, each convolved through the 16384-point transform (overlap-add).
+int conv_segments_for(int L) { return L <= SEG_LEN + 1 ? 1 : (L + SEG_LEN - 1) / SEG_LEN; }
 
 // 8 consecutive activations (one 16-byte vector for the 16-bit types, two for fp32) as floats
 template <typename T>
@@ -215,13 +220,21 @@ __device__ __forceinline__ float short_filter1(const T* row, int t, float w0, fl
     return bias + w0 * xm2 + w1 * xm1 + w2 * to_float(row[t]);
 }
 
+// One workgroup = one (channel, pair of reads); NT = N/32 threads, each owning 32 complex points per pass.
+//   phase 0  issue every long-latency read that does not depend on data: all pass twiddles (registers)
+//   phase A  z -> short filter -> gate -> LDS (natural order, two reads packed as re/im); x0 stays in registers
+//   phase B  forward passes; last forward pass fused with the spectrum product and the first inverse pass;
+//            inverse passes (the filter spectrum bins are fetched one pass ahead)
+//   phase C  LDS -> * x0 -> y
 template <int LOGN, typename T>
 __global__ __launch_bounds__(Plan<LOGN>::NT) void hyena_conv_kernel(
     const T* __restrict__ z, T* __restrict__ y, const float2* __restrict__ kf, const float2* __restrict__ tw,
     const float* __restrict__ ktime, const float* __restrict__ short_w, const float* __restrict__ short_b, int B, int L,
     int Lp) {
     using P = Plan<LOGN>;
+    using TL = TwLayout<LOGN>;
     constexpr int N = P::N, NT = P::NT, LAST = P::LAST, HALF = N / 2;
+    constexpr int CH = (HALF / 8 + NT - 1) / NT;        // 8-token chunks of the lower half per thread (2, or 1)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float2* buf = reinterpret_cast<float2*>(smem);
 
@@ -231,6 +244,25 @@ __global__ __launch_bounds__(Plan<LOGN>::NT) void hyena_conv_kernel(
     const bool hasB = bB < B;
     const T* zA = z + (size_t)bA * D3 * Lp;
     const T* zB = z + (size_t)(hasB ? bB : bA) * D3 * Lp;
+    const float2* kfc = kf + (size_t)c * N;
+
+    // ---------------------------------------------------------------- phase 0: twiddles of every pass
+    float2 wall[TL::TOTAL];
+    {
+        int ns = 16;
+#pragma unroll
+        for (int p = 1; p <= P::NPASS - 2; ++p) {
+            pass_twiddles<LOGN, 16, false>(wall + TL::fwd(p), tid, ns, tw);
+            ns *= 16;
+        }
+        pass_twiddles<LOGN, LAST, false>(wall + TL::fwd_last(), tid, ns, tw);
+        ns = LAST;
+#pragma unroll
+        for (int p = 1; p <= P::NPASS - 1; ++p) {
+            pass_twiddles<LOGN, 16, true>(wall + TL::inv(p), tid, ns, tw);
+            ns *= 16;
+        }
+    }
 
     // per-channel constants: short filter taps of channels c (x0), 256+c (x1), 512+c (v)
     float sw[3][3], sb[3];
@@ -242,38 +274,40 @@ __global__ __launch_bounds__(Plan<LOGN>::NT) void hyena_conv_kernel(
     }
 
     // ---------------------------------------------------------------- phase A: load, short filter, gate
-    // chunk of 8 tokens t0 = 8*tid (lower half of the transform); only x0 stays in registers for phase C.
-    const int t0 = 8 * tid;
-    float x0A[8], x0B[8];
-    if (t0 < HALF) {
-        float gA[8], gB[8];
-        if (t0 < L) {
-            float x1[8], v[8];
-            short_filter8<T>(zA + (size_t)(0 * D + c) * Lp, t0, sw[0][0], sw[0][1], sw[0][2], sb[0], x0A);
-            short_filter8<T>(zA + (size_t)(1 * D + c) * Lp, t0, sw[1][0], sw[1][1], sw[1][2], sb[1], x1);
-            short_filter8<T>(zA + (size_t)(2 * D + c) * Lp, t0, sw[2][0], sw[2][1], sw[2][2], sb[2], v);
+    float x0A[CH][8], x0B[CH][8];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) gA[e] = (t0 + e < L) ? v[e] * x1[e] : 0.f;
-            if (hasB) {
-                short_filter8<T>(zB + (size_t)(0 * D + c) * Lp, t0, sw[0][0], sw[0][1], sw[0][2], sb[0], x0B);
-                short_filter8<T>(zB + (size_t)(1 * D + c) * Lp, t0, sw[1][0], sw[1][1], sw[1][2], sb[1], x1);
-                short_filter8<T>(zB + (size_t)(2 * D + c) * Lp, t0, sw[2][0], sw[2][1], sw[2][2], sb[2], v);
+    for (int ch = 0; ch < CH; ++ch) {
+        const int t0 = 8 * (tid + ch * NT);
+        if (t0 < HALF) {
+            float gA[8], gB[8];
+            if (t0 < L) {
+                float x1[8], v[8];
+                short_filter8<T>(zA + (size_t)(0 * D + c) * Lp, t0, sw[0][0], sw[0][1], sw[0][2], sb[0], x0A[ch]);
+                short_filter8<T>(zA + (size_t)(1 * D + c) * Lp, t0, sw[1][0], sw[1][1], sw[1][2], sb[1], x1);
+                short_filter8<T>(zA + (size_t)(2 * D + c) * Lp, t0, sw[2][0], sw[2][1], sw[2][2], sb[2], v);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) gB[e] = (t0 + e < L) ? v[e] * x1[e] : 0.f;
+                for (int e = 0; e < 8; ++e) gA[e] = (t0 + e < L) ? v[e] * x1[e] : 0.f;
+                if (hasB) {
+                    short_filter8<T>(zB + (size_t)(0 * D + c) * Lp, t0, sw[0][0], sw[0][1], sw[0][2], sb[0], x0B[ch]);
+                    short_filter8<T>(zB + (size_t)(1 * D + c) * Lp, t0, sw[1][0], sw[1][1], sw[1][2], sb[1], x1);
+                    short_filter8<T>(zB + (size_t)(2 * D + c) * Lp, t0, sw[2][0], sw[2][1], sw[2][2], sb[2], v);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) gB[e] = (t0 + e < L) ? v[e] * x1[e] : 0.f;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) gB[e] = 0.f, x0B[ch][e] = 0.f;
+                }
             } else {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) gB[e] = 0.f, x0B[e] = 0.f;
+                for (int e = 0; e < 8; ++e) gA[e] = 0.f, gB[e] = 0.f, x0A[ch][e] = 0.f, x0B[ch][e] = 0.f;
             }
-        } else {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) gA[e] = 0.f, gB[e] = 0.f, x0A[e] = 0.f, x0B[e] = 0.f;
+            for (int e = 0; e < 8; ++e) buf[pad_index(t0 + e)] = make_float2(gA[e], gB[e]);
         }
-#pragma unroll
-        for (int e = 0; e < 8; ++e) buf[pad_index(t0 + e)] = make_float2(gA[e], gB[e]);
-        // upper half is zero padding ...
-#pragma unroll
-        for (int e = 0; e < 8; ++e) buf[pad_index(HALF + t0 + e)] = make_float2(0.f, 0.f);
     }
+    // upper half = zero padding, written with unit stride across lanes (conflict-free)
+#pragma unroll
+    for (int i = 0; i < HALF / NT; ++i) buf[pad_index(HALF + tid + i * NT)] = make_float2(0.f, 0.f);
     // ... except the single token t = N/2 when L == N/2 + 1 (8193 tokens in a 16384-point transform)
     const bool tail = (L == HALF + 1);
     float x0At = 0.f, gAt = 0.f, x0Bt = 0.f, gBt = 0.f;
@@ -293,60 +327,290 @@ __global__ __launch_bounds__(Plan<LOGN>::NT) void hyena_conv_kernel(
     __syncthreads();
 
     // ---------------------------------------------------------------- phase B: FFT, spectrum product, inverse FFT
-    const float2* kfc = kf + (size_t)c * N;
-    float2 v[16];
-    int Ns = 1;
+    float2 v[32];
+    {
+        int Ns = 1;
 #pragma unroll
-    for (int p = 0; p < P::NPASS - 1; ++p) {
-        pass_load<LOGN, 16>(buf, v, tid);
-        pass_compute<LOGN, 16, false>(v, tid, Ns, tw);
-        __syncthreads();
-        pass_store<LOGN, 16>(buf, v, tid, Ns);
-        __syncthreads();
-        Ns *= 16;
+        for (int p = 0; p < P::NPASS - 1; ++p) {
+            pass_load<LOGN, 16>(buf, v, tid);
+            pass_compute_w<LOGN, 16, false>(v, tid, p > 0, wall + (p > 0 ? TL::fwd(p) : 0));
+            __syncthreads();
+            pass_store<LOGN, 16>(buf, v, tid, Ns);
+            __syncthreads();
+            Ns *= 16;
+        }
     }
-    pass_load<LOGN, LAST>(buf, v, tid);
-    pass_compute<LOGN, LAST, false>(v, tid, Ns, tw);
-    spectrum_multiply_and_first_inverse<LOGN, LAST>(v, tid, kfc);
+    {
+        float2 kv[32];
+        spectrum_fetch<LOGN, LAST>(kv, tid, kfc);          // L2 latency overlaps the LDS loads and the butterfly
+        pass_load<LOGN, LAST>(buf, v, tid);
+        pass_compute_w<LOGN, LAST, false>(v, tid, true, wall + TL::fwd_last());
+        spectrum_multiply_and_first_inverse_v<LOGN, LAST>(v, tid, kv);
+    }
     __syncthreads();
     pass_store<LOGN, LAST>(buf, v, tid, 1);
     __syncthreads();
-    Ns = LAST;
+    {
+        int Ns = LAST;
 #pragma unroll
-    for (int p = 0; p < P::NPASS - 1; ++p) {
-        pass_load<LOGN, 16>(buf, v, tid);
-        pass_compute<LOGN, 16, true>(v, tid, Ns, tw);
-        __syncthreads();
-        pass_store<LOGN, 16>(buf, v, tid, Ns);
-        __syncthreads();
-        Ns *= 16;
+        for (int p = 1; p <= P::NPASS - 1; ++p) {
+            pass_load<LOGN, 16>(buf, v, tid);
+            pass_compute_w<LOGN, 16, true>(v, tid, true, wall + TL::inv(p));
+            __syncthreads();
+            pass_store<LOGN, 16>(buf, v, tid, Ns);
+            __syncthreads();
+            Ns *= 16;
+        }
     }
 
-    // ---------------------------------------------------------------- phase C: skip term, gate, store
+    // ---------------------------------------------------------------- phase C: gate with x0, store
     T* yA = y + ((size_t)bA * D + c) * Lp;
     T* yB = y + ((size_t)(hasB ? bB : bA) * D + c) * Lp;
-    if (t0 < HALF && t0 < Lp) {
-        float oA[8], oB[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            float2 pc = buf[pad_index(t0 + e)];
-            if (tail && t0 + e == 0) {  // remove the one wrapped product k[L-1]*g[L-1]
-                float kl = ktime[(size_t)(L - 1) * D + c];
-                pc.x -= kl * gAt;
-                pc.y -= kl * gBt;
+    for (int ch = 0; ch < CH; ++ch) {
+        const int t0 = 8 * (tid + ch * NT);
+        if (t0 < HALF && t0 < Lp) {
+            float oA[8], oB[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float2 pc = buf[pad_index(t0 + e)];
+                if (tail && t0 + e == 0) {  // remove the one wrapped product k[L-1]*g[L-1]
+                    float kl = ktime[(size_t)(L - 1) * D + c];
+                    pc.x -= kl * gAt;
+                    pc.y -= kl * gBt;
+                }
+                bool ok = t0 + e < L;
+                oA[e] = ok ? pc.x * x0A[ch][e] : 0.f;
+                oB[e] = ok ? pc.y * x0B[ch][e] : 0.f;
             }
-            bool ok = t0 + e < L;
-            oA[e] = ok ? pc.x * x0A[e] : 0.f;
-            oB[e] = ok ? pc.y * x0B[e] : 0.f;
+            store8<T>(yA + t0, oA);
+            if (hasB) store8<T>(yB + t0, oB);
         }
-        store8<T>(yA + t0, oA);
-        if (hasB) store8<T>(yB + t0, oB);
     }
     if (tail && tid == 0) {
         float2 pc = buf[pad_index(HALF)];
         yA[HALF] = from_float<T>(pc.x * x0At);
         if (hasB) yB[HALF] = from_float<T>(pc.y * x0Bt);
     }
+}
+
+
+// ================================================================================================ long reads
+// L > 8193 tokens does not fit one LDS-resident transform.  Overlap-add over S = ceil(L / 8192) segments:
+//     y[m*Ls + t] = p_m[t] + p_{m-1}[Ls + t],   p_m = IFFT( sum_{i+j=m} FFT(g_i) . FFT(k_j) ),   0 <= t < Ls
+// with g_i / k_j the i-th / j-th 8192-token segment of the gated signal / the filter (each product is a linear
+// convolution of two 8192-long pieces, 16383 <= N outputs: no wrap-around).  One workgroup walks the segments of
+// its (channel, read pair) in order; segment spectra G_i and the carried upper half p_{m-1}[Ls:] live in a global
+// scratch that each thread only ever re-reads where it wrote itself (no fences needed).
+template <typename T>
+__global__ __launch_bounds__(Plan<14>::NT) void hyena_conv_seg_kernel(
+    const T* __restrict__ z, T* __restrict__ y, const float2* __restrict__ kf /*[256][S][N]*/,
+    const float2* __restrict__ tw, const float* __restrict__ short_w, const float* __restrict__ short_b,
+    float2* __restrict__ gscratch /*[pairs][256][S][N]*/, float2* __restrict__ carry /*[pairs][256][SEG_LEN]*/, int B,
+    int L, int Lp, int S) {
+    constexpr int LOGN = 14;
+    using P = Plan<LOGN>;
+    using TL = TwLayout<LOGN>;
+    constexpr int N = P::N, NT = P::NT, LAST = P::LAST, HALF = N / 2, CH = HALF / 8 / NT;
+    static_assert(HALF == SEG_LEN && CH == 2, "segment = half transform");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float2* buf = reinterpret_cast<float2*>(smem);
+
+    const int tid = threadIdx.x;
+    const int c = blockIdx.y, pair = blockIdx.x;
+    const int bA = 2 * pair, bB = 2 * pair + 1;
+    const bool hasB = bB < B;
+    const T* zA = z + (size_t)bA * D3 * Lp;
+    const T* zB = z + (size_t)(hasB ? bB : bA) * D3 * Lp;
+    T* yA = y + ((size_t)bA * D + c) * Lp;
+    T* yB = y + ((size_t)(hasB ? bB : bA) * D + c) * Lp;
+    const float2* kfc = kf + (size_t)c * S * N;
+    float2* gs = gscratch + ((size_t)pair * D + c) * S * N;
+    float2* cr = carry + ((size_t)pair * D + c) * SEG_LEN;
+
+    float2 wall[TL::TOTAL];
+    {
+        int ns = 16;
+#pragma unroll
+        for (int p = 1; p <= P::NPASS - 2; ++p) {
+            pass_twiddles<LOGN, 16, false>(wall + TL::fwd(p), tid, ns, tw);
+            ns *= 16;
+        }
+        pass_twiddles<LOGN, LAST, false>(wall + TL::fwd_last(), tid, ns, tw);
+        ns = LAST;
+#pragma unroll
+        for (int p = 1; p <= P::NPASS - 1; ++p) {
+            pass_twiddles<LOGN, 16, true>(wall + TL::inv(p), tid, ns, tw);
+            ns *= 16;
+        }
+    }
+    float sw[3][3], sb[3];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+#pragma unroll
+        for (int e = 0; e < 3; ++e) sw[q][e] = short_w[(q * D + c) * 3 + e];
+        sb[q] = short_b[q * D + c];
+    }
+
+#pragma unroll 1
+    for (int m = 0; m < S; ++m) {
+        const int seg0 = m * SEG_LEN;
+        // Launder the thread index once per segment: otherwise LICM hoists every LDS/global address of all seven
+        // passes out of this loop and ~1000 VGPRs spill.
+        int ltid = tid;
+        asm volatile("" : "+v"(ltid));
+#pragma unroll
+        for (int i = 0; i < TL::TOTAL; ++i) asm volatile("" : "+v"(wall[i].x), "+v"(wall[i].y));   // same for w^r trees
+        // ---- phase A: segment m of the gated signal into the lower half, zeros above
+        float x0A[CH][8], x0B[CH][8];
+#pragma unroll
+        for (int ch = 0; ch < CH; ++ch) {
+            const int tl = 8 * (ltid + ch * NT), t0 = seg0 + tl;
+            float gA[8], gB[8];
+            if (t0 < L) {
+                float x1[8], v[8];
+                short_filter8<T>(zA + (size_t)(0 * D + c) * Lp, t0, sw[0][0], sw[0][1], sw[0][2], sb[0], x0A[ch]);
+                short_filter8<T>(zA + (size_t)(1 * D + c) * Lp, t0, sw[1][0], sw[1][1], sw[1][2], sb[1], x1);
+                short_filter8<T>(zA + (size_t)(2 * D + c) * Lp, t0, sw[2][0], sw[2][1], sw[2][2], sb[2], v);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) gA[e] = (t0 + e < L) ? v[e] * x1[e] : 0.f;
+                if (hasB) {
+                    short_filter8<T>(zB + (size_t)(0 * D + c) * Lp, t0, sw[0][0], sw[0][1], sw[0][2], sb[0], x0B[ch]);
+                    short_filter8<T>(zB + (size_t)(1 * D + c) * Lp, t0, sw[1][0], sw[1][1], sw[1][2], sb[1], x1);
+                    short_filter8<T>(zB + (size_t)(2 * D + c) * Lp, t0, sw[2][0], sw[2][1], sw[2][2], sb[2], v);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) gB[e] = (t0 + e < L) ? v[e] * x1[e] : 0.f;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) gB[e] = 0.f, x0B[ch][e] = 0.f;
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) gA[e] = 0.f, gB[e] = 0.f, x0A[ch][e] = 0.f, x0B[ch][e] = 0.f;
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) buf[pad_index(tl + e)] = make_float2(gA[e], gB[e]);
+        }
+#pragma unroll
+        for (int i = 0; i < HALF / NT; ++i) buf[pad_index(HALF + ltid + i * NT)] = make_float2(0.f, 0.f);
+        __syncthreads();
+
+        // ---- forward transform
+        float2 v[32];
+        {
+            int Ns = 1;
+#pragma unroll
+            for (int p = 0; p < P::NPASS - 1; ++p) {
+                pass_load<LOGN, 16>(buf, v, ltid);
+                pass_compute_w<LOGN, 16, false>(v, ltid, p > 0, wall + (p > 0 ? TL::fwd(p) : 0));
+                __syncthreads();
+                pass_store<LOGN, 16>(buf, v, ltid, Ns);
+                __syncthreads();
+                Ns *= 16;
+            }
+        }
+        pass_load<LOGN, LAST>(buf, v, ltid);
+        pass_compute_w<LOGN, LAST, false>(v, ltid, true, wall + TL::fwd_last());
+        // ---- spectrum bookkeeping: keep G_m, form P_m = sum_i G_i K_{m-i}, first inverse butterfly
+        using G = PassGeom<LOGN, LAST>;
+        static_assert(G::IT * LAST == 32, "32 bins per thread");
+#pragma unroll
+        for (int e = 0; e < 32; ++e) {            // keep G_m, start P_m = G_m K_0
+            const int bin = stockham_in<LOGN, LAST>(ltid + (e / LAST) * G::NT, e % LAST);
+            gs[(size_t)m * N + bin] = v[e];
+            v[e] = cmul(v[e], kfc[bin]);
+        }
+#pragma unroll 1
+        for (int i = 0; i < m; ++i) {             // P_m += G_i K_{m-i}; each thread re-reads only bins it wrote
+            const float2* gi = gs + (size_t)i * N;
+            const float2* kj = kfc + (size_t)(m - i) * N;
+#pragma unroll
+            for (int e0 = 0; e0 < 32; e0 += 8) {
+                float2 a[8], b[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int bin = stockham_in<LOGN, LAST>(ltid + ((e0 + e) / LAST) * G::NT, (e0 + e) % LAST);
+                    a[e] = gi[bin];
+                    b[e] = kj[bin];
+                }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e0 + e] = cadd(v[e0 + e], cmul(a[e], b[e]));
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < G::IT; ++it) Dft<LAST, true>::run(v + it * LAST);
+        __syncthreads();
+        pass_store<LOGN, LAST>(buf, v, ltid, 1);
+        __syncthreads();
+        {
+            int Ns = LAST;
+#pragma unroll
+            for (int p = 1; p <= P::NPASS - 1; ++p) {
+                pass_load<LOGN, 16>(buf, v, ltid);
+                pass_compute_w<LOGN, 16, true>(v, ltid, true, wall + TL::inv(p));
+                __syncthreads();
+                pass_store<LOGN, 16>(buf, v, ltid, Ns);
+                __syncthreads();
+                Ns *= 16;
+            }
+        }
+        // ---- phase C: lower half + carried upper half of the previous segment -> y; keep this segment's upper half
+#pragma unroll
+        for (int ch = 0; ch < CH; ++ch) {
+            const int tl = 8 * (ltid + ch * NT), t0 = seg0 + tl;
+            float oA[8], oB[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float2 pc = buf[pad_index(tl + e)];
+                if (m > 0) {
+                    const float2 cv = cr[tl + e];
+                    pc.x += cv.x;
+                    pc.y += cv.y;
+                }
+                const bool ok = t0 + e < L;
+                oA[e] = ok ? pc.x * x0A[ch][e] : 0.f;
+                oB[e] = ok ? pc.y * x0B[ch][e] : 0.f;
+            }
+            if (t0 < Lp) {
+                store8<T>(yA + t0, oA);
+                if (hasB) store8<T>(yB + t0, oB);
+            }
+            if (m + 1 < S) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) cr[tl + e] = buf[pad_index(HALF + tl + e)];
+            }
+        }
+        __syncthreads();   // the LDS buffer is refilled by the next segment
+    }
+}
+
+template <typename T>
+static void launch_conv_seg_t(const void* z, void* y, const float2* kf, const float2* tw, const float* short_w,
+                              const float* short_b, float2* gscratch, float2* carry, int B, int L, int Lp, int S,
+                              hipStream_t st) {
+    using P = Plan<14>;
+    constexpr size_t lds = (size_t)padded_size(P::N) * sizeof(float2);
+    auto kern = hyena_conv_seg_kernel<T>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)lds);
+        attr_done = true;
+    }
+    dim3 grid((B + 1) / 2, D), block(P::NT);
+    hipLaunchKernelGGL(kern, grid, block, lds, st, reinterpret_cast<const T*>(z), reinterpret_cast<T*>(y), kf, tw,
+                       short_w, short_b, gscratch, carry, B, L, Lp, S);
+}
+
+void launch_hyena_conv_seg(int prec, const void* z, void* y, const float2* kf, const float2* tw, const float* short_w,
+                           const float* short_b, float2* gscratch, float2* carry, int B, int L, int Lp, int S,
+                           hipStream_t st) {
+    if (prec == PREC_F32)
+        launch_conv_seg_t<float>(z, y, kf, tw, short_w, short_b, gscratch, carry, B, L, Lp, S, st);
+    else if (prec == PREC_BF16)
+        launch_conv_seg_t<bf16_t>(z, y, kf, tw, short_w, short_b, gscratch, carry, B, L, Lp, S, st);
+    else
+        launch_conv_seg_t<f16_t>(z, y, kf, tw, short_w, short_b, gscratch, carry, B, L, Lp, S, st);
 }
 
 template <int LOGN, typename T>

@@ -121,6 +121,12 @@ def test_full_size_8k_reads(engines, sd, prec):
     _check(engines[prec], prec, ids, sd)
 
 
+@pytest.mark.parametrize("prec,B,L", [("fp32", 3, 8194), ("fp32", 2, 16385), ("fp16", 3, 20000)])
+def test_long_reads_segmented_convolution(engines, sd, prec, B, L):
+    """L > 8193: overlap-add over 8192-token segments (2 and 3 segments, odd batch, segment with a single token)."""
+    _check(engines[prec], prec, _ids(B, L, seed=21, pads=5), sd)
+
+
 def test_collated_bam_batch_against_oracle(engines, sd, golden_dir):
     """configs[0] plumbing: real reads -> tokenizer -> collator (left pad) -> engine == oracle on the same batch."""
     from chimeralm_amd import bam, tokenizer as T
@@ -168,8 +174,8 @@ def test_error_behaviour(engines):
     from chimeralm_amd.engine import EngineError
 
     e = engines["fp32"]
-    with pytest.raises(EngineError, match="8193"):
-        e.forward(torch.zeros(1, 9000, dtype=torch.uint8).cuda())                        # beyond the built FFT sizes
+    with pytest.raises(EngineError, match="max_seq_len"):
+        e.forward(torch.zeros(1, 32771, dtype=torch.uint8).cuda())                       # beyond pos_emb rows (32770)
     with pytest.raises(EngineError):
         e.forward(torch.zeros(1, 9, dtype=torch.uint8))                                  # CPU tensor: no CPU path
     with pytest.raises(ValueError):
