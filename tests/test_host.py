@@ -164,3 +164,30 @@ def test_cli_surface():
         assert opt in r.output
     r = CliRunner().invoke(app, ["predict", "x.bam", "--gpus", "0"])
     assert r.exit_code != 0 and "CPU" in " ".join(r.output.split())
+
+
+def test_hydra_style_configs_instantiate():
+    """configs/model/hyena.yaml keeps the reference's shape; resolve `_target_`s by hand (hydra is not installed)."""
+    import importlib
+
+    import yaml
+
+    def build(node):
+        if isinstance(node, dict) and "_target_" in node:
+            mod, _, name = node["_target_"].rpartition(".")
+            fn = getattr(importlib.import_module(mod), name)
+            kwargs = {k: build(v) for k, v in node.items() if k not in ("_target_", "_partial_")}
+            if node.get("_partial_"):
+                from functools import partial
+
+                return partial(fn, **kwargs)
+            return fn(**kwargs)
+        return node
+
+    cfg = yaml.safe_load((REPO / "configs" / "model" / "hyena.yaml").read_text())
+    model = build(cfg)
+    assert type(model).__name__ == "ClassificationLit" and model.net.number_of_classes == 2
+    assert model.net.precision == "fp16"
+    data = yaml.safe_load((REPO / "configs" / "data" / "bam.yaml").read_text())
+    dm = build({**data, "predict_data_path": str(REPO / "tests/golden/test_chimric_reads.bam"), "batch_size": 4})
+    assert dm.tokenizer.padding_side == "left"
