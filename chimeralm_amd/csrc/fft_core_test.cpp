@@ -27,15 +27,6 @@ static void fft_ref(std::vector<cd>& a, bool inv) {  // plain recursive radix-2,
     }
 }
 
-template <int LOGN, int R, bool INV>
-static void run_pass(std::vector<float2>& buf, int Ns, const std::vector<float2>& tw) {
-    constexpr int NT = Plan<LOGN>::NT;
-    std::vector<float2> regs(size_t(NT) * 32);
-    for (int tid = 0; tid < NT; ++tid) pass_load<LOGN, R>(buf.data(), &regs[size_t(tid) * 32], tid);
-    for (int tid = 0; tid < NT; ++tid) pass_compute<LOGN, R, INV>(&regs[size_t(tid) * 32], tid, Ns, tw.data());
-    for (int tid = 0; tid < NT; ++tid) pass_store<LOGN, R>(buf.data(), &regs[size_t(tid) * 32], tid, Ns);
-}
-
 template <int LOGN>
 static double test_conv(int L, unsigned seed) {
     using P = Plan<LOGN>;
@@ -56,40 +47,40 @@ static double test_conv(int L, unsigned seed) {
     for (int m = 0; m < N; ++m) kff[m] = make_float2(float(kf[m].real() / N), float(kf[m].imag() / N));
     for (int m = 0; m < N / 2; ++m) tw[m] = make_float2(float(std::cos(2 * M_PI * m / N)), float(-std::sin(2 * M_PI * m / N)));
     // signal in padded "LDS"
-    std::vector<float2> buf(padded_size(N), make_float2(0.f, 0.f));
-    for (int t = 0; t < L; ++t) buf[pad_index(t)] = make_float2(float(g0[t]), float(g1[t]));
+    std::vector<float> bre(padded_size(N), 0.f), bim(padded_size(N), 0.f);
+    for (int t = 0; t < L; ++t) bre[pad_index(t)] = float(g0[t]), bim[pad_index(t)] = float(g1[t]);
     // all twiddles are fetched up front, exactly like the kernel does
     using TL = TwLayout<LOGN>;
-    std::vector<float2> wall(size_t(NT) * TL::TOTAL);
+    std::vector<Cx2> wall(size_t(NT) * TL::TOTAL);
     for (int tid = 0; tid < NT; ++tid) {
-        float2* w = &wall[size_t(tid) * TL::TOTAL];
+        Cx2* w = &wall[size_t(tid) * TL::TOTAL];
         int ns = 16;
         for (int p = 1; p <= P::NPASS - 2; ++p, ns *= 16) pass_twiddles<LOGN, 16, false>(w + TL::fwd(p), tid, ns, tw.data());
         pass_twiddles<LOGN, LAST, false>(w + TL::fwd_last(), tid, ns, tw.data());
         ns = LAST;
         for (int p = 1; p <= P::NPASS - 1; ++p, ns *= 16) pass_twiddles<LOGN, 16, true>(w + TL::inv(p), tid, ns, tw.data());
     }
-    std::vector<float2> regs(size_t(NT) * 32), kv(size_t(NT) * 32);
-    auto R = [&](int tid) { return &regs[size_t(tid) * 32]; };
+    std::vector<Cx2> regs(size_t(NT) * 16), kv(size_t(NT) * 16);
+    auto R = [&](int tid) { return &regs[size_t(tid) * 16]; };
     auto W = [&](int tid) { return &wall[size_t(tid) * TL::TOTAL]; };
     // forward passes
     int Ns = 1;
     for (int p = 0; p < P::NPASS - 1; ++p) {
-        for (int tid = 0; tid < NT; ++tid) pass_load<LOGN, 16>(buf.data(), R(tid), tid);
+        for (int tid = 0; tid < NT; ++tid) pass_load<LOGN, 16>(bre.data(), bim.data(), R(tid), tid);
         for (int tid = 0; tid < NT; ++tid) pass_compute_w<LOGN, 16, false>(R(tid), tid, p > 0, W(tid) + (p > 0 ? TL::fwd(p) : 0));
-        for (int tid = 0; tid < NT; ++tid) pass_store<LOGN, 16>(buf.data(), R(tid), tid, Ns);
+        for (int tid = 0; tid < NT; ++tid) pass_store<LOGN, 16>(bre.data(), bim.data(), R(tid), tid, Ns);
         Ns *= 16;
     }
-    for (int tid = 0; tid < NT; ++tid) spectrum_fetch<LOGN, LAST>(&kv[size_t(tid) * 32], tid, kff.data());
-    for (int tid = 0; tid < NT; ++tid) pass_load<LOGN, LAST>(buf.data(), R(tid), tid);
+    for (int tid = 0; tid < NT; ++tid) spectrum_fetch<LOGN, LAST>(&kv[size_t(tid) * 16], tid, kff.data());
+    for (int tid = 0; tid < NT; ++tid) pass_load<LOGN, LAST>(bre.data(), bim.data(), R(tid), tid);
     for (int tid = 0; tid < NT; ++tid) pass_compute_w<LOGN, LAST, false>(R(tid), tid, true, W(tid) + TL::fwd_last());
-    for (int tid = 0; tid < NT; ++tid) spectrum_multiply_and_first_inverse_v<LOGN, LAST>(R(tid), tid, &kv[size_t(tid) * 32]);
-    for (int tid = 0; tid < NT; ++tid) pass_store<LOGN, LAST>(buf.data(), R(tid), tid, 1);
+    for (int tid = 0; tid < NT; ++tid) spectrum_multiply_and_first_inverse_v<LOGN, LAST>(R(tid), tid, &kv[size_t(tid) * 16]);
+    for (int tid = 0; tid < NT; ++tid) pass_store<LOGN, LAST>(bre.data(), bim.data(), R(tid), tid, 1);
     Ns = LAST;
     for (int p = 1; p <= P::NPASS - 1; ++p) {
-        for (int tid = 0; tid < NT; ++tid) pass_load<LOGN, 16>(buf.data(), R(tid), tid);
+        for (int tid = 0; tid < NT; ++tid) pass_load<LOGN, 16>(bre.data(), bim.data(), R(tid), tid);
         for (int tid = 0; tid < NT; ++tid) pass_compute_w<LOGN, 16, true>(R(tid), tid, true, W(tid) + TL::inv(p));
-        for (int tid = 0; tid < NT; ++tid) pass_store<LOGN, 16>(buf.data(), R(tid), tid, Ns);
+        for (int tid = 0; tid < NT; ++tid) pass_store<LOGN, 16>(bre.data(), bim.data(), R(tid), tid, Ns);
         Ns *= 16;
     }
     // reference: direct causal convolution in double
@@ -97,7 +88,7 @@ static double test_conv(int L, unsigned seed) {
     for (int t = 0; t < L; ++t) {
         double r0 = 0, r1 = 0;
         for (int s = 0; s <= t; ++s) r0 += k[s] * g0[t - s], r1 += k[s] * g1[t - s];
-        double y0 = buf[pad_index(t)].x, y1 = buf[pad_index(t)].y;
+        double y0 = bre[pad_index(t)], y1 = bim[pad_index(t)];
         if (t == 0 && 2 * L - 2 == N) {  // the one aliased term k[L-1]*g[L-1] wraps onto output 0
             y0 -= double(float(k[L - 1])) * double(float(g0[L - 1]));
             y1 -= double(float(k[L - 1])) * double(float(g1[L - 1]));

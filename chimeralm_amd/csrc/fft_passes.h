@@ -2,13 +2,14 @@
 // Shared by the device kernel (hyena_conv.hip) and the host emulation (fft_core_test.cpp): the host test
 // runs the phases for every tid in turn with the barriers replaced by loop boundaries.
 //
-// A thread owns 32 complex values per pass: IT = (N/R)/NT butterflies of radix R (NT = N/32 threads, at
-// least one wave).  Pass structure (in place, single buffer):
-//     load  : v[it*R + r] = buf[pad(jb + r*N/R)],  jb = tid + it*NT          (unit stride across lanes)
-//     -- no barrier needed between load and compute --
-//     compute: twiddle + DFT_R in registers
+// A thread owns 32 complex values per pass: IT = (N/R)/NT butterflies of radix R (NT = N/32 threads, at least one
+// wave), processed as NP = ceil(IT/2) PAIRS in the two lanes of a Cx2 (fft_core.h).  Pair p holds butterflies
+// jb_a = tid + 2p*NT and jb_b = jb_a + NT; a missing partner (odd IT, tiny transforms) computes on zeros.
+// Pass structure (in place, single buffer):
+//     load  : v[p*R + r].re = (re[pad(jb_a + r*N/R)], re[pad(jb_b + r*N/R)]), same for im   (unit stride across lanes)
+//     compute: twiddle + DFT_R in registers (no barrier needed between load and compute)
 //     barrier (all loads of the pass done)
-//     store : buf[pad((jb-k)*R + k + q*Ns)] = v[it*R + q]
+//     store : re/im[pad((jb-k)*R + k + q*Ns)] = v[p*R + q] lane a / b
 //     barrier
 #pragma once
 #include "fft_core.h"
@@ -21,118 +22,109 @@ struct PassGeom {
     static constexpr int NB = N / R;  // butterflies in the pass
     static constexpr int NT = Plan<LOGN>::NT;
     static constexpr int IT = (NB + NT - 1) / NT;
-    static_assert(IT * R <= 32, "a thread holds at most 32 complex values");
+    static constexpr int NP = (IT + 1) / 2;
+    static_assert(NP * R <= 16, "a thread holds at most 16 complex pairs");
+    static CLM_HD int jba(int tid, int p) { return tid + (2 * p) * NT; }
+    static CLM_HD int jbb(int tid, int p) { return tid + (2 * p + 1) * NT; }
+    static constexpr bool FULL = (NB % NT == 0);   // every thread owns exactly IT butterflies: no bounds checks at all
+    static CLM_HD bool has_a(int tid, int p) { return FULL || jba(tid, p) < NB; }
+    static CLM_HD bool has_b(int tid, int p) { return 2 * p + 1 < IT && (FULL || jbb(tid, p) < NB); }
 };
 
 template <int LOGN, int R>
-CLM_HD void pass_load(const float2* buf, float2* v, int tid) {
+CLM_HD void pass_load(const float* re, const float* im, Cx2* v, int tid) {
     using G = PassGeom<LOGN, R>;
 #pragma unroll
-    for (int it = 0; it < G::IT; ++it) {
-        int jb = tid + it * G::NT;
-        if (jb < G::NB) {
+    for (int p = 0; p < G::NP; ++p) {
+        const bool ha = G::has_a(tid, p), hb = G::has_b(tid, p);
+        const int pa = pad_index(G::jba(tid, p)), pb = pad_index(G::jbb(tid, p));   // bases; r*NB is the immediate
 #pragma unroll
-            for (int r = 0; r < R; ++r) v[it * R + r] = buf[pad_index(stockham_in<LOGN, R>(jb, r))];
+        for (int r = 0; r < R; ++r) {
+            const int off = pad_offset(r * G::NB);
+            v[p * R + r].re = make_v2(ha ? re[pa + off] : 0.f, hb ? re[pb + off] : 0.f);
+            v[p * R + r].im = make_v2(ha ? im[pa + off] : 0.f, hb ? im[pb + off] : 0.f);
         }
-    }
-}
-
-template <int LOGN, int R, bool INV>
-CLM_HD void pass_compute(float2* v, int tid, int Ns, const float2* tw) {
-    using G = PassGeom<LOGN, R>;
-#pragma unroll
-    for (int it = 0; it < G::IT; ++it) {
-        int jb = tid + it * G::NT;
-        if (jb < G::NB) butterfly<LOGN, R, INV>(v + it * R, jb, Ns, tw);
     }
 }
 
 template <int LOGN, int R>
-CLM_HD void pass_store(float2* buf, const float2* v, int tid, int Ns) {
+CLM_HD void pass_store(float* re, float* im, const Cx2* v, int tid, int Ns) {
     using G = PassGeom<LOGN, R>;
 #pragma unroll
-    for (int it = 0; it < G::IT; ++it) {
-        int jb = tid + it * G::NT;
-        if (jb < G::NB) {
+    for (int p = 0; p < G::NP; ++p) {
+        const bool ha = G::has_a(tid, p), hb = G::has_b(tid, p);
+        const int pa = pad_index(stockham_out<R>(G::jba(tid, p), 0, Ns));            // bases; q*Ns is the immediate
+        // partner butterfly jb + NT: a constant distance away in the two common cases, so both lanes of a component
+        // can leave in one ds_write2st64_b32
+        const int pb = (Ns <= G::NT && G::NT % Ns == 0) ? pa + pad_offset(G::NT * R)
+                       : (Ns >= G::NB)                 ? pa + pad_offset(G::NT)
+                                                       : pad_index(stockham_out<R>(G::jbb(tid, p), 0, Ns));
 #pragma unroll
-            for (int q = 0; q < R; ++q) buf[pad_index(stockham_out<R>(jb, q, Ns))] = v[it * R + q];
+        for (int q = 0; q < R; ++q) {
+            const int off = pad_offset(q * Ns);
+            if (ha) re[pa + off] = v[p * R + q].re.x, im[pa + off] = v[p * R + q].im.x;
+            if (hb) re[pb + off] = v[p * R + q].re.y, im[pb + off] = v[p * R + q].im.y;
         }
     }
 }
 
-// Twiddle prefetch: w[it] for the butterflies of one pass (issued at kernel start, consumed passes later).
+// Twiddle prefetch: w[p] for the butterfly pairs of one pass (issued at kernel start, consumed passes later).
 template <int LOGN, int R, bool INV>
-CLM_HD void pass_twiddles(float2* w, int tid, int Ns, const float2* tw) {
+CLM_HD void pass_twiddles(Cx2* w, int tid, int Ns, const float2* tw) {
     using G = PassGeom<LOGN, R>;
+    const float2 one = make_float2(1.f, 0.f);
 #pragma unroll
-    for (int it = 0; it < G::IT; ++it) {
-        int jb = tid + it * G::NT;
-        w[it] = (jb < G::NB) ? twiddle_for<LOGN, R, INV>(jb, Ns, tw) : make_float2(1.f, 0.f);
-    }
+    for (int p = 0; p < G::NP; ++p)
+        w[p] = pack2(G::has_a(tid, p) ? twiddle_for<LOGN, R, INV>(G::jba(tid, p), Ns, tw) : one,
+                     G::has_b(tid, p) ? twiddle_for<LOGN, R, INV>(G::jbb(tid, p), Ns, tw) : one);
 }
+
 template <int LOGN, int R, bool INV>
-CLM_HD void pass_compute_w(float2* v, int tid, bool has_tw, const float2* w) {
+CLM_HD void pass_compute_w(Cx2* v, int tid, bool has_tw, const Cx2* w) {
     using G = PassGeom<LOGN, R>;
 #pragma unroll
-    for (int it = 0; it < G::IT; ++it) {
-        int jb = tid + it * G::NT;
-        if (jb < G::NB) butterfly_w<R, INV>(v + it * R, has_tw, w[it]);
-    }
+    for (int p = 0; p < G::NP; ++p) butterfly_w<R, INV>(v + p * R, has_tw, w[p]);
 }
-// filter spectrum bins of the last forward pass, fetched ahead of the pass: kv[it*R + q] = kf[jb + q*N/R]
+
+// filter spectrum bins of the last forward pass, fetched ahead of the pass: kv[p*R + q] = kf[jb + q*N/R]
 template <int LOGN, int R>
-CLM_HD void spectrum_fetch(float2* kv, int tid, const float2* kf) {
+CLM_HD void spectrum_fetch(Cx2* kv, int tid, const float2* kf) {
     using G = PassGeom<LOGN, R>;
+    const float2 zero = make_float2(0.f, 0.f);
 #pragma unroll
-    for (int it = 0; it < G::IT; ++it) {
-        int jb = tid + it * G::NT;
-        if (jb < G::NB) {
+    for (int p = 0; p < G::NP; ++p) {
+        const bool ha = G::has_a(tid, p), hb = G::has_b(tid, p);
 #pragma unroll
-            for (int q = 0; q < R; ++q) kv[it * R + q] = kf[stockham_in<LOGN, R>(jb, q)];
-        }
-    }
-}
-template <int LOGN, int R>
-CLM_HD void spectrum_multiply_and_first_inverse_v(float2* v, int tid, const float2* kv) {
-    using G = PassGeom<LOGN, R>;
-#pragma unroll
-    for (int it = 0; it < G::IT; ++it) {
-        int jb = tid + it * G::NT;
-        if (jb < G::NB) {
-#pragma unroll
-            for (int q = 0; q < R; ++q) v[it * R + q] = cmul(v[it * R + q], kv[it * R + q]);
-            Dft<R, true>::run(v + it * R);
-        }
+        for (int q = 0; q < R; ++q)
+            kv[p * R + q] = pack2(ha ? kf[stockham_in<LOGN, R>(G::jba(tid, p), q)] : zero,
+                                  hb ? kf[stockham_in<LOGN, R>(G::jbb(tid, p), q)] : zero);
     }
 }
 
-// Twiddle register layout of a whole convolution (forward passes 1..NPASS-1, inverse passes 1..NPASS-1):
+// Fused middle of the convolution: after the LAST forward pass a thread holds, for each of its butterflies jb, the
+// spectrum bins m = jb + q*N/R (q = 0..R-1) -- exactly the inputs of the FIRST inverse pass (Ns = 1) of the same
+// radix.  Multiply by the filter spectrum and run that inverse butterfly (no twiddles at Ns = 1).
+template <int LOGN, int R>
+CLM_HD void spectrum_multiply_and_first_inverse_v(Cx2* v, int tid, const Cx2* kv) {
+    using G = PassGeom<LOGN, R>;
+#pragma unroll
+    for (int p = 0; p < G::NP; ++p) {
+#pragma unroll
+        for (int q = 0; q < R; ++q) v[p * R + q] = Cx2::mul(v[p * R + q], kv[p * R + q]);
+        Dft<R, true>::run(v + p * R);
+    }
+}
+
+// Twiddle register layout of a whole convolution (forward passes 1..NPASS-1, inverse passes 1..NPASS-1), in pairs:
 template <int LOGN>
 struct TwLayout {
     using P = Plan<LOGN>;
-    static constexpr int IT16 = PassGeom<LOGN, 16>::IT;
-    static constexpr int ITL = PassGeom<LOGN, P::LAST>::IT;
-    static constexpr int fwd(int p) { return (p - 1) * IT16; }              // R = 16 passes p = 1 .. NPASS-2
-    static constexpr int fwd_last() { return (P::NPASS - 2) * IT16; }
-    static constexpr int inv(int p) { return (P::NPASS - 2) * IT16 + ITL + (p - 1) * IT16; }   // p = 1 .. NPASS-1
-    static constexpr int TOTAL = (2 * P::NPASS - 3) * IT16 + ITL;
+    static constexpr int NP16 = PassGeom<LOGN, 16>::NP;
+    static constexpr int NPL = PassGeom<LOGN, P::LAST>::NP;
+    static constexpr int fwd(int p) { return (p - 1) * NP16; }              // R = 16 passes p = 1 .. NPASS-2
+    static constexpr int fwd_last() { return (P::NPASS - 2) * NP16; }
+    static constexpr int inv(int p) { return (P::NPASS - 2) * NP16 + NPL + (p - 1) * NP16; }   // p = 1 .. NPASS-1
+    static constexpr int TOTAL = (2 * P::NPASS - 3) * NP16 + NPL;
 };
-
-// Fused middle of the convolution: after the LAST forward pass thread `tid` holds, for each of its
-// butterflies jb, the spectrum bins m = jb + q*N/R (q = 0..R-1) -- exactly the inputs of the FIRST inverse
-// pass (Ns = 1) of the same radix.  Multiply by the filter spectrum and run that inverse butterfly.
-template <int LOGN, int R>
-CLM_HD void spectrum_multiply_and_first_inverse(float2* v, int tid, const float2* kf) {
-    using G = PassGeom<LOGN, R>;
-#pragma unroll
-    for (int it = 0; it < G::IT; ++it) {
-        int jb = tid + it * G::NT;
-        if (jb < G::NB) {
-#pragma unroll
-            for (int q = 0; q < R; ++q) v[it * R + q] = cmul(v[it * R + q], kf[stockham_in<LOGN, R>(jb, q)]);
-            butterfly<LOGN, R, true>(v + it * R, jb, 1, nullptr);
-        }
-    }
-}
 
 }  // namespace clmfft

@@ -220,6 +220,16 @@ __device__ __forceinline__ float short_filter1(const T* row, int t, float w0, fl
     return bias + w0 * xm2 + w1 * xm1 + w2 * to_float(row[t]);
 }
 
+// 8 consecutive floats to / from an LDS array whose padding never splits an aligned group of 8
+__device__ __forceinline__ void lds_store8(float* dst, const float* v) {
+    *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+    *reinterpret_cast<float4*>(dst + 4) = make_float4(v[4], v[5], v[6], v[7]);
+}
+__device__ __forceinline__ void lds_load8(const float* src, float* v) {
+    const float4 a = *reinterpret_cast<const float4*>(src), b = *reinterpret_cast<const float4*>(src + 4);
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+}
+
 // One workgroup = one (channel, pair of reads); NT = N/32 threads, each owning 32 complex points per pass.
 //   phase 0  issue every long-latency read that does not depend on data: all pass twiddles (registers)
 //   phase A  z -> short filter -> gate -> LDS (natural order, two reads packed as re/im); x0 stays in registers
@@ -236,7 +246,8 @@ __global__ __launch_bounds__(Plan<LOGN>::NT) void hyena_conv_kernel(
     constexpr int N = P::N, NT = P::NT, LAST = P::LAST, HALF = N / 2;
     constexpr int CH = (HALF / 8 + NT - 1) / NT;        // 8-token chunks of the lower half per thread (2, or 1)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    float2* buf = reinterpret_cast<float2*>(smem);
+    float* bre = reinterpret_cast<float*>(smem);             // read A of the pair = real parts
+    float* bim = bre + padded_size(N);                       // read B            = imaginary parts
 
     const int tid = threadIdx.x;
     const int c = blockIdx.y, pair = blockIdx.x;
@@ -247,7 +258,7 @@ __global__ __launch_bounds__(Plan<LOGN>::NT) void hyena_conv_kernel(
     const float2* kfc = kf + (size_t)c * N;
 
     // ---------------------------------------------------------------- phase 0: twiddles of every pass
-    float2 wall[TL::TOTAL];
+    Cx2 wall[TL::TOTAL];
     {
         int ns = 16;
 #pragma unroll
@@ -301,13 +312,13 @@ __global__ __launch_bounds__(Plan<LOGN>::NT) void hyena_conv_kernel(
 #pragma unroll
                 for (int e = 0; e < 8; ++e) gA[e] = 0.f, gB[e] = 0.f, x0A[ch][e] = 0.f, x0B[ch][e] = 0.f;
             }
-#pragma unroll
-            for (int e = 0; e < 8; ++e) buf[pad_index(t0 + e)] = make_float2(gA[e], gB[e]);
+            lds_store8(bre + pad_index(t0), gA);
+            lds_store8(bim + pad_index(t0), gB);
         }
     }
     // upper half = zero padding, written with unit stride across lanes (conflict-free)
 #pragma unroll
-    for (int i = 0; i < HALF / NT; ++i) buf[pad_index(HALF + tid + i * NT)] = make_float2(0.f, 0.f);
+    for (int i = 0; i < HALF / NT; ++i) bre[pad_index(HALF + tid + i * NT)] = 0.f, bim[pad_index(HALF + tid + i * NT)] = 0.f;
     // ... except the single token t = N/2 when L == N/2 + 1 (8193 tokens in a 16384-point transform)
     const bool tail = (L == HALF + 1);
     float x0At = 0.f, gAt = 0.f, x0Bt = 0.f, gBt = 0.f;
@@ -323,41 +334,41 @@ __global__ __launch_bounds__(Plan<LOGN>::NT) void hyena_conv_kernel(
         }
     }
     __syncthreads();
-    if (tail && tid == 0) buf[pad_index(HALF)] = make_float2(gAt, gBt);
+    if (tail && tid == 0) bre[pad_index(HALF)] = gAt, bim[pad_index(HALF)] = gBt;
     __syncthreads();
 
     // ---------------------------------------------------------------- phase B: FFT, spectrum product, inverse FFT
-    float2 v[32];
+    Cx2 v[16];   // 32 points per thread as 16 SoA pairs
     {
         int Ns = 1;
 #pragma unroll
         for (int p = 0; p < P::NPASS - 1; ++p) {
-            pass_load<LOGN, 16>(buf, v, tid);
+            pass_load<LOGN, 16>(bre, bim, v, tid);
             pass_compute_w<LOGN, 16, false>(v, tid, p > 0, wall + (p > 0 ? TL::fwd(p) : 0));
             __syncthreads();
-            pass_store<LOGN, 16>(buf, v, tid, Ns);
+            pass_store<LOGN, 16>(bre, bim, v, tid, Ns);
             __syncthreads();
             Ns *= 16;
         }
     }
     {
-        float2 kv[32];
+        Cx2 kv[16];
         spectrum_fetch<LOGN, LAST>(kv, tid, kfc);          // L2 latency overlaps the LDS loads and the butterfly
-        pass_load<LOGN, LAST>(buf, v, tid);
+        pass_load<LOGN, LAST>(bre, bim, v, tid);
         pass_compute_w<LOGN, LAST, false>(v, tid, true, wall + TL::fwd_last());
         spectrum_multiply_and_first_inverse_v<LOGN, LAST>(v, tid, kv);
     }
     __syncthreads();
-    pass_store<LOGN, LAST>(buf, v, tid, 1);
+    pass_store<LOGN, LAST>(bre, bim, v, tid, 1);
     __syncthreads();
     {
         int Ns = LAST;
 #pragma unroll
         for (int p = 1; p <= P::NPASS - 1; ++p) {
-            pass_load<LOGN, 16>(buf, v, tid);
+            pass_load<LOGN, 16>(bre, bim, v, tid);
             pass_compute_w<LOGN, 16, true>(v, tid, true, wall + TL::inv(p));
             __syncthreads();
-            pass_store<LOGN, 16>(buf, v, tid, Ns);
+            pass_store<LOGN, 16>(bre, bim, v, tid, Ns);
             __syncthreads();
             Ns *= 16;
         }
@@ -371,26 +382,26 @@ __global__ __launch_bounds__(Plan<LOGN>::NT) void hyena_conv_kernel(
         const int t0 = 8 * (tid + ch * NT);
         if (t0 < HALF && t0 < Lp) {
             float oA[8], oB[8];
+            lds_load8(bre + pad_index(t0), oA);
+            lds_load8(bim + pad_index(t0), oB);
+            if (tail && t0 == 0) {  // remove the one wrapped product k[L-1]*g[L-1] from output 0
+                const float kl = ktime[(size_t)(L - 1) * D + c];
+                oA[0] -= kl * gAt;
+                oB[0] -= kl * gBt;
+            }
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                float2 pc = buf[pad_index(t0 + e)];
-                if (tail && t0 + e == 0) {  // remove the one wrapped product k[L-1]*g[L-1]
-                    float kl = ktime[(size_t)(L - 1) * D + c];
-                    pc.x -= kl * gAt;
-                    pc.y -= kl * gBt;
-                }
-                bool ok = t0 + e < L;
-                oA[e] = ok ? pc.x * x0A[ch][e] : 0.f;
-                oB[e] = ok ? pc.y * x0B[ch][e] : 0.f;
+                const bool ok = t0 + e < L;
+                oA[e] = ok ? oA[e] * x0A[ch][e] : 0.f;
+                oB[e] = ok ? oB[e] * x0B[ch][e] : 0.f;
             }
             store8<T>(yA + t0, oA);
             if (hasB) store8<T>(yB + t0, oB);
         }
     }
     if (tail && tid == 0) {
-        float2 pc = buf[pad_index(HALF)];
-        yA[HALF] = from_float<T>(pc.x * x0At);
-        if (hasB) yB[HALF] = from_float<T>(pc.y * x0Bt);
+        yA[HALF] = from_float<T>(bre[pad_index(HALF)] * x0At);
+        if (hasB) yB[HALF] = from_float<T>(bim[pad_index(HALF)] * x0Bt);
     }
 }
 
@@ -414,7 +425,8 @@ __global__ __launch_bounds__(Plan<14>::NT) void hyena_conv_seg_kernel(
     constexpr int N = P::N, NT = P::NT, LAST = P::LAST, HALF = N / 2, CH = HALF / 8 / NT;
     static_assert(HALF == SEG_LEN && CH == 2, "segment = half transform");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    float2* buf = reinterpret_cast<float2*>(smem);
+    float* bre = reinterpret_cast<float*>(smem);             // read A of the pair = real parts
+    float* bim = bre + padded_size(N);                       // read B            = imaginary parts
 
     const int tid = threadIdx.x;
     const int c = blockIdx.y, pair = blockIdx.x;
@@ -428,7 +440,7 @@ __global__ __launch_bounds__(Plan<14>::NT) void hyena_conv_seg_kernel(
     float2* gs = gscratch + ((size_t)pair * D + c) * S * N;
     float2* cr = carry + ((size_t)pair * D + c) * SEG_LEN;
 
-    float2 wall[TL::TOTAL];
+    Cx2 wall[TL::TOTAL];
     {
         int ns = 16;
 #pragma unroll
@@ -460,7 +472,8 @@ __global__ __launch_bounds__(Plan<14>::NT) void hyena_conv_seg_kernel(
         int ltid = tid;
         asm volatile("" : "+v"(ltid));
 #pragma unroll
-        for (int i = 0; i < TL::TOTAL; ++i) asm volatile("" : "+v"(wall[i].x), "+v"(wall[i].y));   // same for w^r trees
+        for (int i = 0; i < TL::TOTAL; ++i)                                                  // same for w^r trees
+            asm volatile("" : "+v"(wall[i].re.x), "+v"(wall[i].re.y), "+v"(wall[i].im.x), "+v"(wall[i].im.y));
         // ---- phase A: segment m of the gated signal into the lower half, zeros above
         float x0A[CH][8], x0B[CH][8];
 #pragma unroll
@@ -488,68 +501,71 @@ __global__ __launch_bounds__(Plan<14>::NT) void hyena_conv_seg_kernel(
 #pragma unroll
                 for (int e = 0; e < 8; ++e) gA[e] = 0.f, gB[e] = 0.f, x0A[ch][e] = 0.f, x0B[ch][e] = 0.f;
             }
-#pragma unroll
-            for (int e = 0; e < 8; ++e) buf[pad_index(tl + e)] = make_float2(gA[e], gB[e]);
+            lds_store8(bre + pad_index(tl), gA);
+            lds_store8(bim + pad_index(tl), gB);
         }
 #pragma unroll
-        for (int i = 0; i < HALF / NT; ++i) buf[pad_index(HALF + ltid + i * NT)] = make_float2(0.f, 0.f);
+        for (int i = 0; i < HALF / NT; ++i) bre[pad_index(HALF + ltid + i * NT)] = 0.f, bim[pad_index(HALF + ltid + i * NT)] = 0.f;
         __syncthreads();
 
         // ---- forward transform
-        float2 v[32];
+        Cx2 v[16];
         {
             int Ns = 1;
 #pragma unroll
             for (int p = 0; p < P::NPASS - 1; ++p) {
-                pass_load<LOGN, 16>(buf, v, ltid);
+                pass_load<LOGN, 16>(bre, bim, v, ltid);
                 pass_compute_w<LOGN, 16, false>(v, ltid, p > 0, wall + (p > 0 ? TL::fwd(p) : 0));
                 __syncthreads();
-                pass_store<LOGN, 16>(buf, v, ltid, Ns);
+                pass_store<LOGN, 16>(bre, bim, v, ltid, Ns);
                 __syncthreads();
                 Ns *= 16;
             }
         }
-        pass_load<LOGN, LAST>(buf, v, ltid);
+        pass_load<LOGN, LAST>(bre, bim, v, ltid);
         pass_compute_w<LOGN, LAST, false>(v, ltid, true, wall + TL::fwd_last());
         // ---- spectrum bookkeeping: keep G_m, form P_m = sum_i G_i K_{m-i}, first inverse butterfly
         using G = PassGeom<LOGN, LAST>;
-        static_assert(G::IT * LAST == 32, "32 bins per thread");
+        static_assert(G::NP * LAST == 16 && G::IT == 2 * G::NP, "16 full pairs per thread");
 #pragma unroll
-        for (int e = 0; e < 32; ++e) {            // keep G_m, start P_m = G_m K_0
-            const int bin = stockham_in<LOGN, LAST>(ltid + (e / LAST) * G::NT, e % LAST);
-            gs[(size_t)m * N + bin] = v[e];
-            v[e] = cmul(v[e], kfc[bin]);
+        for (int e = 0; e < 16; ++e) {            // keep G_m, start P_m = G_m K_0
+            const int ba = stockham_in<LOGN, LAST>(G::jba(ltid, e / LAST), e % LAST);
+            const int bb = stockham_in<LOGN, LAST>(G::jbb(ltid, e / LAST), e % LAST);
+            gs[(size_t)m * N + ba] = lane_a(v[e]);
+            gs[(size_t)m * N + bb] = lane_b(v[e]);
+            v[e] = Cx2::mul(v[e], pack2(kfc[ba], kfc[bb]));
         }
 #pragma unroll 1
         for (int i = 0; i < m; ++i) {             // P_m += G_i K_{m-i}; each thread re-reads only bins it wrote
             const float2* gi = gs + (size_t)i * N;
             const float2* kj = kfc + (size_t)(m - i) * N;
 #pragma unroll
-            for (int e0 = 0; e0 < 32; e0 += 8) {
-                float2 a[8], b[8];
+            for (int e0 = 0; e0 < 16; e0 += 4) {
+                Cx2 a[4], b[4];
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const int bin = stockham_in<LOGN, LAST>(ltid + ((e0 + e) / LAST) * G::NT, (e0 + e) % LAST);
-                    a[e] = gi[bin];
-                    b[e] = kj[bin];
+                for (int e = 0; e < 4; ++e) {
+                    const int ba = stockham_in<LOGN, LAST>(G::jba(ltid, (e0 + e) / LAST), (e0 + e) % LAST);
+                    const int bb = stockham_in<LOGN, LAST>(G::jbb(ltid, (e0 + e) / LAST), (e0 + e) % LAST);
+                    a[e] = pack2(gi[ba], gi[bb]);
+                    b[e] = pack2(kj[ba], kj[bb]);
                 }
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[e0 + e] = cadd(v[e0 + e], cmul(a[e], b[e]));
+                for (int e = 0; e < 4; ++e) v[e0 + e] = Cx2::add(v[e0 + e], Cx2::mul(a[e], b[e]));
             }
         }
 #pragma unroll
-        for (int it = 0; it < G::IT; ++it) Dft<LAST, true>::run(v + it * LAST);
+        for (int p = 0; p < G::NP; ++p) Dft<LAST, true>::run(v + p * LAST);
         __syncthreads();
-        pass_store<LOGN, LAST>(buf, v, ltid, 1);
+        pass_store<LOGN, LAST>(bre, bim, v, ltid, 1);
         __syncthreads();
         {
             int Ns = LAST;
 #pragma unroll
             for (int p = 1; p <= P::NPASS - 1; ++p) {
-                pass_load<LOGN, 16>(buf, v, ltid);
+                pass_load<LOGN, 16>(bre, bim, v, ltid);
                 pass_compute_w<LOGN, 16, true>(v, ltid, true, wall + TL::inv(p));
                 __syncthreads();
-                pass_store<LOGN, 16>(buf, v, ltid, Ns);
+                pass_store<LOGN, 16>(bre, bim, v, ltid, Ns);
                 __syncthreads();
                 Ns *= 16;
             }
@@ -559,17 +575,18 @@ __global__ __launch_bounds__(Plan<14>::NT) void hyena_conv_seg_kernel(
         for (int ch = 0; ch < CH; ++ch) {
             const int tl = 8 * (ltid + ch * NT), t0 = seg0 + tl;
             float oA[8], oB[8];
+            lds_load8(bre + pad_index(tl), oA);
+            lds_load8(bim + pad_index(tl), oB);
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                float2 pc = buf[pad_index(tl + e)];
                 if (m > 0) {
                     const float2 cv = cr[tl + e];
-                    pc.x += cv.x;
-                    pc.y += cv.y;
+                    oA[e] += cv.x;
+                    oB[e] += cv.y;
                 }
                 const bool ok = t0 + e < L;
-                oA[e] = ok ? pc.x * x0A[ch][e] : 0.f;
-                oB[e] = ok ? pc.y * x0B[ch][e] : 0.f;
+                oA[e] = ok ? oA[e] * x0A[ch][e] : 0.f;
+                oB[e] = ok ? oB[e] * x0B[ch][e] : 0.f;
             }
             if (t0 < Lp) {
                 store8<T>(yA + t0, oA);
@@ -577,7 +594,8 @@ __global__ __launch_bounds__(Plan<14>::NT) void hyena_conv_seg_kernel(
             }
             if (m + 1 < S) {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) cr[tl + e] = buf[pad_index(HALF + tl + e)];
+                for (int e = 0; e < 8; ++e)
+                    cr[tl + e] = make_float2(bre[pad_index(HALF + tl + e)], bim[pad_index(HALF + tl + e)]);
             }
         }
         __syncthreads();   // the LDS buffer is refilled by the next segment
@@ -589,7 +607,7 @@ static void launch_conv_seg_t(const void* z, void* y, const float2* kf, const fl
                               const float* short_b, float2* gscratch, float2* carry, int B, int L, int Lp, int S,
                               hipStream_t st) {
     using P = Plan<14>;
-    constexpr size_t lds = (size_t)padded_size(P::N) * sizeof(float2);
+    constexpr size_t lds = (size_t)2 * padded_size(P::N) * sizeof(float);
     auto kern = hyena_conv_seg_kernel<T>;
     static bool attr_done = false;
     if (!attr_done) {
@@ -618,7 +636,7 @@ static void launch_conv_t(const void* z, void* y, const float2* kf, const float2
                           const float* short_w, const float* short_b, int B, int L, int Lp,
                           hipStream_t st) {
     using P = Plan<LOGN>;
-    constexpr size_t lds = (size_t)padded_size(P::N) * sizeof(float2);
+    constexpr size_t lds = (size_t)2 * padded_size(P::N) * sizeof(float);
     auto kern = hyena_conv_kernel<LOGN, T>;
     static bool attr_done = false;
     if (!attr_done) {
