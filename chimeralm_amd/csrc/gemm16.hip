@@ -22,6 +22,8 @@
 // per wave (64 accumulator registers per GEMM), so a wave needs < 256 registers and the second wave on each SIMD
 // runs MFMAs while the first sits in a wait, a GELU or a store phase.  (rocprofv3 --pmc on the 4-wave version:
 // SQ_WAIT_ANY 47 % of wave cycles, MFMA busy 15 %.)
+#include <cstdlib>
+
 #include "gemm_common.h"
 
 namespace clm {
@@ -82,37 +84,42 @@ __device__ __forceinline__ void zero_acc(f32x16 (&acc)[4]) {
         for (int r = 0; r < 16; ++r) acc[mt][r] = 0.f;
 }
 
-// h[b, t, n0..n0+3] += acc quad + bias, accumulator rows = output features (ROWS_N orientation), 32 features/wave
-__device__ __forceinline__ void resid_epilogue(float* h_out, const float* bias, f32x16 (&acc)[4], int b, int t0,
-                                               int L, int wave, int lrow, int lhalf) {
-    const float* brow = bias + wave * 32 + 4 * lhalf;
-    float4 bb[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) bb[q] = *reinterpret_cast<const float4*>(brow + 8 * q);
-    // all 16 residual vectors of the lane are requested before the first add (latency-bound phase)
-    float4 v[4][4];
+// h[b, t, 32 features of this wave] += acc + bias.  Accumulator rows = output features (lane = token, register quad =
+// 4 consecutive features).  Storing straight from that layout makes every wave instruction touch 64 different cache
+// lines (one 16-byte piece per token row); measured 28 % of the fused MLP kernel.  Instead the wave transposes its
+// 128 x 32 fp32 tile through LDS (16 KiB, XOR-swizzled 16-byte chunks) so that each read-modify-write instruction
+// covers 8 token rows x one whole 128-byte line.  `scratch` must be free (all waves past their last LDS read).
+__device__ __forceinline__ void resid_epilogue(float* h_out, const float* bias, f32x16 (&acc)[4], int b, int t0, int L,
+                                               int wave, int lane, float* scratch) {
+    const int lrow = lane & 31, lhalf = lane >> 5;
+    float* rs = scratch + wave * (128 * 32);
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) {
-        const int t = t0 + mt * 32 + lrow;
-        const float* row = h_out + ((size_t)b * L + (t < L ? t : 0)) * D + wave * 32 + 4 * lhalf;
+        const int tok = mt * 32 + lrow;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) v[mt][q] = *reinterpret_cast<const float4*>(row + 8 * q);
+        for (int q = 0; q < 4; ++q) {
+            const int chunk = (2 * q + lhalf) ^ (tok & 7);
+            *reinterpret_cast<float4*>(rs + tok * 32 + 4 * chunk) =
+                make_float4(acc[mt][4 * q + 0], acc[mt][4 * q + 1], acc[mt][4 * q + 2], acc[mt][4 * q + 3]);
+        }
+    }
+    // wave-private tile: the LDS operations of one wave execute in order, no barrier needed
+    const int c = lane & 7, rsub = lane >> 3;
+    const float4 bb = *reinterpret_cast<const float4*>(bias + wave * 32 + 4 * c);
+    float* hrow = h_out + ((size_t)b * L + t0) * D + wave * 32 + 4 * c;
+    float4 v[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int tr = i * 8 + rsub;
+        v[i] = *reinterpret_cast<const float4*>(hrow + (size_t)(t0 + tr < L ? tr : 0) * D);
     }
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt) {
-        const int t = t0 + mt * 32 + lrow;
-        if (t < L) {
-            float* row = h_out + ((size_t)b * L + t) * D + wave * 32 + 4 * lhalf;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                float4 o = v[mt][q];
-                o.x += acc[mt][4 * q + 0] + bb[q].x;
-                o.y += acc[mt][4 * q + 1] + bb[q].y;
-                o.z += acc[mt][4 * q + 2] + bb[q].z;
-                o.w += acc[mt][4 * q + 3] + bb[q].w;
-                *reinterpret_cast<float4*>(row + 8 * q) = o;
-            }
-        }
+    for (int i = 0; i < 16; ++i) {
+        const int tr = i * 8 + rsub;
+        const float4 a = *reinterpret_cast<const float4*>(rs + tr * 32 + 4 * (c ^ (tr & 7)));
+        if (t0 + tr < L)
+            *reinterpret_cast<float4*>(hrow + (size_t)tr * D) =
+                make_float4(v[i].x + a.x + bb.x, v[i].y + a.y + bb.y, v[i].z + a.z + bb.z, v[i].w + a.w + bb.w);
     }
 }
 
@@ -207,7 +214,8 @@ __global__ __launch_bounds__(512) void out_proj16_kernel(GemmArgs a) {
     compute_km<PREC>(Ys, 0, lane, bs[0], acc);
     compute_km<PREC>(Ys, 1, lane, bs[1], acc);
     __builtin_amdgcn_sched_barrier(0);
-    resid_epilogue(a.h_out, a.bias, acc, b, t0, L, wave, lrow, lhalf);
+    __syncthreads();                                       // every wave is done reading Ys: reuse it as the staging tile
+    resid_epilogue(a.h_out, a.bias, acc, b, t0, L, wave, lane, reinterpret_cast<float*>(smem));
 }
 
 // ================================================================================================ fused MLP
@@ -220,6 +228,10 @@ struct MlpArgs {
     float eps;
 };
 
+// One workgroup per 128-token tile.  Two variants were measured and rejected (r01 notes in DESIGN.md): a persistent
+// loop that prefetches the next tile's rows during the epilogue, and taking the residual as the accumulator's initial
+// value through an LDS half-tile (store-only epilogue): the extra barriers / LDS traffic / register pressure cost more
+// than the 1 KiB/token re-read they save (4.0 ms vs 3.25 ms per 64 reads for this stage).
 template <int PREC>
 __global__ __launch_bounds__(512) void mlp16_kernel(MlpArgs m) {
     using elem = typename CT<PREC>::elem;
@@ -283,7 +295,8 @@ __global__ __launch_bounds__(512) void mlp16_kernel(MlpArgs m) {
         compute_tm<PREC, true>(Hs, 1, lrow, lhalf, bs[1], acc2);
         __builtin_amdgcn_sched_barrier(0);
     }
-    resid_epilogue(m.h, m.b2, acc2, b, t0, L, wave, lrow, lhalf);
+    __syncthreads();                                       // As / Hs are dead: reuse them as the staging tiles
+    resid_epilogue(m.h, m.b2, acc2, b, t0, L, wave, lane, reinterpret_cast<float*>(smem));
 }
 
 // ================================================================================================ launchers
@@ -313,7 +326,8 @@ void launch_outproj16(int prec, const void* y, const void* w, const float* bias,
                       hipStream_t st) {
     GemmArgs a{};
     a.a_in = y; a.w = w; a.bias = bias; a.h_out = h; a.B = B; a.L = L; a.Lp = Lp;
-    constexpr size_t lds = (size_t)D * RSKM * 2;
+    constexpr size_t lds = (size_t)8 * 128 * 32 * 4;       // staging tiles of the residual epilogue (>= 256*RSKM*2)
+    static_assert(lds >= (size_t)D * RSKM * 2, "k-major tile must fit");
     dim3 grid((L + 127) / 128, B), block(512);
     if (prec == PREC_BF16) {
         static bool once = (set_lds(out_proj16_kernel<PREC_BF16>, lds), true);
