@@ -64,6 +64,7 @@ struct clm_handle {
     int last_B = 0, last_L = 0, last_Lp = 0;
     // debug / profiling
     int stop_layer = -1, stop_stage = -1;
+    bool split_tail = false;      // CLM_SPLIT_TAIL=1: separate out_proj16 + mlp16 kernels instead of the fused tail (A/B runs)
     bool force_generic = false;   // CLM_GENERIC_GEMM=1: route 16-bit modes through the generic kernels (A/B runs)
     bool prof = false;
     std::vector<ProfRec> recs;
@@ -370,23 +371,30 @@ int forward_chunk(clm_handle* h, const void* ids, int ids_dtype, int64_t row_str
                                       h->carry, Bc, L, Lp, fs->S, st);
         }
         if (stop_here(h, i, CLM_STAGE_CONV)) return CLM_OK;
-        {
-            StageTimer t(h, st, CLM_STAGE_OUTPROJ);
-            if (tuned16) launch_outproj16(prec, h->y, lw.w_out, lw.b_out, h->h, Bc, L, Lp, st);
-            else launch_outproj(prec, h->y, lw.w_out, lw.b_out, h->h, Bc, L, Lp, st);
-        }
-        if (stop_here(h, i, CLM_STAGE_OUTPROJ)) return CLM_OK;
-        if (tuned16) {   // fc1 + GELU + fc2 + residual fused; reported under the fc1 stage
+        const bool stop_mid = stop_here(h, i, CLM_STAGE_OUTPROJ);
+        if (tuned16 && !h->split_tail && !stop_mid) {   // out_proj + LN2 + fc1 + GELU + fc2 + both residuals: one kernel
             StageTimer t(h, st, CLM_STAGE_FC1);
-            launch_mlp16(prec, h->h, lw.ln2_g, lw.ln2_b, lw.w_fc1, lw.b_fc1, lw.w_fc2, lw.b_fc2, Bc, L, eps, st);
+            launch_tail16(prec, h->y, lw.w_out, lw.b_out, h->h, lw.ln2_g, lw.ln2_b, lw.w_fc1, lw.b_fc1, lw.w_fc2, lw.b_fc2,
+                          Bc, L, Lp, eps, st);
         } else {
             {
-                StageTimer t(h, st, CLM_STAGE_FC1);
-                launch_fc1(prec, h->h, lw.ln2_g, lw.ln2_b, lw.w_fc1, lw.b_fc1, h->u, Bc, L, eps, st);
+                StageTimer t(h, st, CLM_STAGE_OUTPROJ);
+                if (tuned16) launch_outproj16(prec, h->y, lw.w_out, lw.b_out, h->h, Bc, L, Lp, st);
+                else launch_outproj(prec, h->y, lw.w_out, lw.b_out, h->h, Bc, L, Lp, st);
             }
-            if (stop_here(h, i, CLM_STAGE_FC1)) return CLM_OK;
-            StageTimer t(h, st, CLM_STAGE_FC2);
-            launch_fc2(prec, h->u, lw.w_fc2, lw.b_fc2, h->h, Bc, L, st);
+            if (stop_mid) return CLM_OK;
+            if (tuned16) {   // fc1 + GELU + fc2 + residual fused; reported under the fc1 stage
+                StageTimer t(h, st, CLM_STAGE_FC1);
+                launch_mlp16(prec, h->h, lw.ln2_g, lw.ln2_b, lw.w_fc1, lw.b_fc1, lw.w_fc2, lw.b_fc2, Bc, L, eps, st);
+            } else {
+                {
+                    StageTimer t(h, st, CLM_STAGE_FC1);
+                    launch_fc1(prec, h->h, lw.ln2_g, lw.ln2_b, lw.w_fc1, lw.b_fc1, h->u, Bc, L, eps, st);
+                }
+                if (stop_here(h, i, CLM_STAGE_FC1)) return CLM_OK;
+                StageTimer t(h, st, CLM_STAGE_FC2);
+                launch_fc2(prec, h->u, lw.w_fc2, lw.b_fc2, h->h, Bc, L, st);
+            }
         }
         if (stop_here(h, i, CLM_STAGE_FC2) || (tuned16 && stop_here(h, i, CLM_STAGE_FC1))) return CLM_OK;
     }
@@ -449,6 +457,7 @@ int clm_create(const clm_config* cfg, int device, clm_handle** out) {
         return fail(nullptr, CLM_E_UNSUPPORTED, std::string("this engine is built for gfx950 (MI355X) only, found ") + prop.gcnArchName);
     clm_handle* h = new clm_handle();
     h->force_generic = std::getenv("CLM_GENERIC_GEMM") && std::getenv("CLM_GENERIC_GEMM")[0] == '1';
+    h->split_tail = std::getenv("CLM_SPLIT_TAIL") && std::getenv("CLM_SPLIT_TAIL")[0] == '1';
     h->cfg = *cfg;
     h->device = device;
     *out = h;
@@ -659,6 +668,8 @@ int clm_destroy(clm_handle* h) {
     if (!h) return CLM_OK;
     (void)hipSetDevice(h->device);
     (void)hipDeviceSynchronize();
+    tail16_dump_stamps();
+    conv_dump_stamps();
     for (auto& r : h->recs) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
     for (auto& e : h->free_events) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     free_workspace(h);

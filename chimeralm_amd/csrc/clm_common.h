@@ -135,6 +135,12 @@ void launch_outproj16(int prec, const void* y, const void* w, const float* bias,
 // h += fc2(gelu_tanh(fc1(LN2(h)))) in one kernel (hidden activations stay on chip)
 void launch_mlp16(int prec, float* h, const float* g, const float* b, const void* w1, const float* b1, const void* w2,
                   const float* b2, int B, int L, float eps, hipStream_t st);
+// second half of a block in one kernel: h = r + fc2(gelu(fc1(LN2(r)))), r = h + out_proj(y^T)
+void launch_tail16(int prec, const void* y, const void* w_out, const float* b_out, float* h, const float* g,
+                   const float* b, const void* w1, const float* b1, const void* w2, const float* b2, int B, int L, int Lp,
+                   float eps, hipStream_t st);
+void tail16_dump_stamps();   // developer build only (CLM_STAMP=1)
+void conv_dump_stamps();
 size_t packed_weight_bytes(int prec, int n, int k);
 // pack W [n][k] fp32 (device) into MFMA fragment order of the compute dtype
 void launch_pack_weight(int prec, const float* w, void* out, int n, int k, hipStream_t st);

@@ -22,7 +22,9 @@
 // per wave (64 accumulator registers per GEMM), so a wave needs < 256 registers and the second wave on each SIMD
 // runs MFMAs while the first sits in a wait, a GELU or a store phase.  (rocprofv3 --pmc on the 4-wave version:
 // SQ_WAIT_ANY 47 % of wave cycles, MFMA busy 15 %.)
+#include <cstdio>
 #include <cstdlib>
+#include <vector>
 
 #include "gemm_common.h"
 
@@ -299,6 +301,226 @@ __global__ __launch_bounds__(512) void mlp16_kernel(MlpArgs m) {
     resid_epilogue(m.h, m.b2, acc2, b, t0, L, wave, lane, reinterpret_cast<float*>(smem));
 }
 
+// ================================================================================================ out_proj + MLP fused
+// h_new = r + fc2(gelu(fc1(LN2(r)))),  r = h + out_proj(y^T)        (second half of a HyenaBlock, one kernel)
+// The out_proj accumulator (rows = output feature, cols = token) already IS the layout the fc2 accumulator needs, so r never
+// leaves the registers: it is the initial value of the fc2 accumulation, and LayerNorm-2 is computed from the
+// accumulator registers (row statistics across the 8 waves through an 8 KiB LDS table).  Compared with the separate
+// out_proj16 + mlp16 kernels this removes one write and two reads of the fp32 residual stream (3 KiB of 6.5 KiB per
+// token), both latency-bound row phases of the MLP kernel, and one launch.
+struct TailArgs {
+    const void* y;            // [B, 256, Lp] channel-major, 16-bit
+    float* h;                 // residual stream [B, L, 256]
+    const void *w_out, *w1, *w2;
+    const float *b_out, *ln_g, *ln_b, *b1, *b2;
+    int B, L, Lp;
+    float eps;
+};
+
+// STAMP: developer build (CLM_STAMP=1) that records s_memtime at the phase boundaries of wave 0 of every workgroup into
+// a side buffer nothing else reads; the product instantiation (STAMP = false) contains no stamp.
+constexpr int TAIL_NSTAMP = 20;
+
+template <int PREC, bool STAMP = false>
+__global__ __launch_bounds__(512) void tail16_kernel(TailArgs m, unsigned long long* stamps) {
+#define CLM_STAMP_AT(k)                                                                                   \
+    do {                                                                                                  \
+        if (STAMP && threadIdx.x == 0)                                                                    \
+            stamps[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * TAIL_NSTAMP + (k)] = __builtin_amdgcn_s_memtime(); \
+    } while (0)
+    using elem = typename CT<PREC>::elem;
+    using frag = u16x8;
+    constexpr int BM = 128, NCH = DI / 256;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    elem* As = reinterpret_cast<elem*>(smem);              // LN2(r) tile [128][RS16]      (aliases Ys during out_proj)
+    elem* Hs = As + BM * RS16;                              // gelu(fc1) chunk [128][RS16]
+    elem* Ys = reinterpret_cast<elem*>(smem);              // y tile [256 channels][RSKM], k-major
+    float* P1 = reinterpret_cast<float*>(smem + (size_t)2 * BM * RS16 * 2);   // row-sum partials [16][128]
+    float* P2 = P1 + 16 * BM;                                                 // squared-deviation partials
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lrow = lane & 31, lhalf = lane >> 5;
+    const int b = blockIdx.y, t0 = blockIdx.x * BM, L = m.L, Lp = m.Lp;
+    const frag* wo = reinterpret_cast<const frag*>(m.w_out);
+    const frag* w1 = reinterpret_cast<const frag*>(m.w1);
+    const frag* w2 = reinterpret_cast<const frag*>(m.w2);
+    f32x16 acc1[4], acc2[4];
+    frag bs[2][1][SETK];
+
+    CLM_STAMP_AT(0);
+    // ---- 0. everything that only depends on addresses is requested first
+    load_set<PREC, D, 1>(wo, 0, 0, 0, wave, lane, bs[0]);
+    load_set<PREC, D, 1>(wo, 0, 0, 1, wave, lane, bs[1]);
+    float4 hv[4][4];                                       // residual in accumulator layout: token mt*32+lrow, 4 features
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+        const int t = t0 + mt * 32 + lrow;
+        const float* row = m.h + ((size_t)b * L + (t < L ? t : 0)) * D + wave * 32 + 4 * lhalf;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) hv[mt][q] = *reinterpret_cast<const float4*>(row + 8 * q);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    {
+        const elem* src = reinterpret_cast<const elem*>(m.y) + (size_t)b * D * Lp + t0;
+        const int tk = (tid & 15) * 8;
+        const bool in_row = t0 + tk < Lp;
+        uint4 x[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            x[i] = make_uint4(0, 0, 0, 0);
+            if (in_row) x[i] = *reinterpret_cast<const uint4*>(src + (size_t)((tid >> 4) + 32 * i) * Lp + tk);
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) *reinterpret_cast<uint4*>(Ys + ((tid >> 4) + 32 * i) * RSKM + tk) = x[i];
+    }
+    __syncthreads();
+    CLM_STAMP_AT(1);
+    // ---- 1. out_proj, then r = acc + h + b_out (kept in acc2)
+    zero_acc(acc2);
+    compute_km<PREC>(Ys, 0, lane, bs[0], acc2);
+    __builtin_amdgcn_sched_barrier(0);
+    load_set<PREC, D, 1>(w1, 0, 0, 0, wave, lane, bs[0]);             // first fc1 set under the second half
+    __builtin_amdgcn_sched_barrier(0);
+    compute_km<PREC>(Ys, 1, lane, bs[1], acc2);
+    __builtin_amdgcn_sched_barrier(0);
+    {
+        const float* bo = m.b_out + wave * 32 + 4 * lhalf;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4 bb = *reinterpret_cast<const float4*>(bo + 8 * q);
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+                acc2[mt][4 * q + 0] += hv[mt][q].x + bb.x;
+                acc2[mt][4 * q + 1] += hv[mt][q].y + bb.y;
+                acc2[mt][4 * q + 2] += hv[mt][q].z + bb.z;
+                acc2[mt][4 * q + 3] += hv[mt][q].w + bb.w;
+            }
+        }
+    }
+    CLM_STAMP_AT(2);
+    // ---- 2. LayerNorm-2 statistics of r: per-lane partial over its 16 features -> LDS -> totals over 16 partials
+    float mean[4], rstd[4];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+        float s = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s += acc2[mt][r];
+        P1[(wave * 2 + lhalf) * BM + mt * 32 + lrow] = s;
+    }
+    __syncthreads();                                       // also: every wave is done reading Ys
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+        float s = 0.f;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) s += P1[w * BM + mt * 32 + lrow];
+        mean[mt] = s * (1.0f / D);
+        float v = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float d = acc2[mt][r] - mean[mt];
+            v += d * d;
+        }
+        P2[(wave * 2 + lhalf) * BM + mt * 32 + lrow] = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+        float v = 0.f;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) v += P2[w * BM + mt * 32 + lrow];
+        rstd[mt] = 1.0f / sqrtf(v * (1.0f / D) + m.eps);
+    }
+    CLM_STAMP_AT(3);
+    // ---- 3. normalised tile -> As (16-bit); rows beyond L are written as zeros like the staged version
+    {
+        const float* gp = m.ln_g + wave * 32 + 4 * lhalf;
+        const float* bp = m.ln_b + wave * 32 + 4 * lhalf;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4 g4 = *reinterpret_cast<const float4*>(gp + 8 * q);
+            const float4 b4 = *reinterpret_cast<const float4*>(bp + 8 * q);
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+                const bool ok = t0 + mt * 32 + lrow < L;
+                const float y0 = ok ? (acc2[mt][4 * q + 0] - mean[mt]) * rstd[mt] * g4.x + b4.x : 0.f;
+                const float y1 = ok ? (acc2[mt][4 * q + 1] - mean[mt]) * rstd[mt] * g4.y + b4.y : 0.f;
+                const float y2 = ok ? (acc2[mt][4 * q + 2] - mean[mt]) * rstd[mt] * g4.z + b4.z : 0.f;
+                const float y3 = ok ? (acc2[mt][4 * q + 3] - mean[mt]) * rstd[mt] * g4.w + b4.w : 0.f;
+                u16x4 pk = {to_bits<PREC>(y0), to_bits<PREC>(y1), to_bits<PREC>(y2), to_bits<PREC>(y3)};
+                *reinterpret_cast<u16x4*>(As + (mt * 32 + lrow) * RS16 + wave * 32 + 8 * q + 4 * lhalf) = pk;
+            }
+        }
+    }
+    __syncthreads();
+    CLM_STAMP_AT(4);
+    // ---- 4. MLP chunks (acc2 already holds r)
+#pragma unroll 1
+    for (int j = 0; j < NCH; ++j) {
+        zero_acc(acc1);
+        load_set<PREC, D, 1>(w1, j, 0, 1, wave, lane, bs[1]);
+        __builtin_amdgcn_sched_barrier(0);
+        compute_tm<PREC, true>(As, 0, lrow, lhalf, bs[0], acc1);
+        __builtin_amdgcn_sched_barrier(0);
+        load_set<PREC, DI, 1>(w2, 0, j, 0, wave, lane, bs[0]);
+        __builtin_amdgcn_sched_barrier(0);
+        compute_tm<PREC, true>(As, 1, lrow, lhalf, bs[1], acc1);
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();
+        CLM_STAMP_AT(5 + 3 * j);
+        {
+            const float* b1 = m.b1 + j * 256 + wave * 32 + 4 * lhalf;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 bb = *reinterpret_cast<const float4*>(b1 + 8 * q);
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) {
+                    const f32x2 g0 = gelu_tanh2(f32x2{acc1[mt][4 * q + 0] + bb.x, acc1[mt][4 * q + 1] + bb.y});
+                    const f32x2 g1 = gelu_tanh2(f32x2{acc1[mt][4 * q + 2] + bb.z, acc1[mt][4 * q + 3] + bb.w});
+                    u16x4 pk = {to_bits<PREC>(g0.x), to_bits<PREC>(g0.y), to_bits<PREC>(g1.x), to_bits<PREC>(g1.y)};
+                    *reinterpret_cast<u16x4*>(Hs + (mt * 32 + lrow) * RS16 + wave * 32 + 8 * q + 4 * lhalf) = pk;
+                }
+            }
+        }
+        __syncthreads();
+        CLM_STAMP_AT(6 + 3 * j);
+        load_set<PREC, DI, 1>(w2, 0, j, 1, wave, lane, bs[1]);
+        __builtin_amdgcn_sched_barrier(0);
+        compute_tm<PREC, true>(Hs, 0, lrow, lhalf, bs[0], acc2);
+        __builtin_amdgcn_sched_barrier(0);
+        load_set<PREC, D, 1>(w1, j + 1 < NCH ? j + 1 : 0, 0, 0, wave, lane, bs[0]);
+        __builtin_amdgcn_sched_barrier(0);
+        compute_tm<PREC, true>(Hs, 1, lrow, lhalf, bs[1], acc2);
+        __builtin_amdgcn_sched_barrier(0);
+        CLM_STAMP_AT(7 + 3 * j);
+    }
+    __syncthreads();                                       // As / Hs are dead: reuse them as the staging tiles
+    CLM_STAMP_AT(17);
+    // ---- 5. h_new = acc2 + b2: transposed through LDS, stored as whole 128-byte lines (no read)
+    {
+        float* rs = reinterpret_cast<float*>(smem) + wave * (128 * 32);
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            const int tok = mt * 32 + lrow;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int chunk = (2 * q + lhalf) ^ (tok & 7);
+                *reinterpret_cast<float4*>(rs + tok * 32 + 4 * chunk) =
+                    make_float4(acc2[mt][4 * q + 0], acc2[mt][4 * q + 1], acc2[mt][4 * q + 2], acc2[mt][4 * q + 3]);
+            }
+        }
+        const int c = lane & 7, rsub = lane >> 3;
+        const float4 bb = *reinterpret_cast<const float4*>(m.b2 + wave * 32 + 4 * c);
+        float* hrow = m.h + ((size_t)b * L + t0) * D + wave * 32 + 4 * c;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int tr = i * 8 + rsub;
+            const float4 a = *reinterpret_cast<const float4*>(rs + tr * 32 + 4 * (c ^ (tr & 7)));
+            if (t0 + tr < L)
+                *reinterpret_cast<float4*>(hrow + (size_t)tr * D) = make_float4(a.x + bb.x, a.y + bb.y, a.z + bb.z, a.w + bb.w);
+        }
+    }
+    CLM_STAMP_AT(18);
+#undef CLM_STAMP_AT
+}
+
 // ================================================================================================ launchers
 template <typename Kern>
 static void set_lds(Kern kern, size_t lds) {
@@ -353,6 +575,61 @@ void launch_mlp16(int prec, float* h, const float* g, const float* bta, const vo
         static bool once = (set_lds(mlp16_kernel<PREC_F16>, lds), true);
         (void)once;
         hipLaunchKernelGGL(mlp16_kernel<PREC_F16>, grid, block, lds, st, m);
+    }
+}
+
+// developer stamps (CLM_STAMP=1): per-phase mean cycles of wave 0 over all workgroups, printed by clm_destroy
+static unsigned long long* s_stamp_buf = nullptr;
+static size_t s_stamp_wgs = 0;
+void tail16_dump_stamps() {
+    if (!s_stamp_buf || !s_stamp_wgs) return;
+    std::vector<unsigned long long> hst(s_stamp_wgs * TAIL_NSTAMP);
+    if (hipMemcpy(hst.data(), s_stamp_buf, hst.size() * 8, hipMemcpyDeviceToHost) != hipSuccess) return;
+    double sum[TAIL_NSTAMP] = {};
+    size_t n = 0;
+    for (size_t w = 0; w < s_stamp_wgs; ++w) {
+        const unsigned long long* p = &hst[w * TAIL_NSTAMP];
+        if (!p[0] || !p[18]) continue;
+        for (int k = 1; k <= 18; ++k) sum[k] += double(p[k] - p[k - 1]);
+        ++n;
+    }
+    const char* names[19] = {"", "issue+y_stage", "out_proj", "ln_stats", "ln_write", "fc1.0", "gelu.0", "fc2.0", "fc1.1", "gelu.1",
+                             "fc2.1", "fc1.2", "gelu.2", "fc2.2", "fc1.3", "gelu.3", "fc2.3", "barrier", "epilogue"};
+    double tot = 0;
+    for (int k = 1; k <= 18; ++k) tot += sum[k] / (n ? n : 1);
+    std::fprintf(stderr, "[tail16 stamps] %zu workgroups, mean s_memtime ticks per phase (total %.0f):\n", n, tot);
+    for (int k = 1; k <= 18; ++k) std::fprintf(stderr, "  %-14s %9.0f  %5.1f %%\n", names[k], sum[k] / (n ? n : 1), 100.0 * sum[k] / (n ? n : 1) / tot);
+}
+
+void launch_tail16(int prec, const void* y, const void* w_out, const float* b_out, float* h, const float* g,
+                   const float* bta, const void* w1, const float* b1, const void* w2, const float* b2, int B, int L, int Lp,
+                   float eps, hipStream_t st) {
+    TailArgs m{y, h, w_out, w1, w2, b_out, g, bta, b1, b2, B, L, Lp, eps};
+    constexpr size_t lds = (size_t)2 * 128 * RS16 * 2 + (size_t)2 * 16 * 128 * 4;
+    static_assert((size_t)D * RSKM * 2 <= (size_t)2 * 128 * RS16 * 2, "y tile must fit under the partial tables");
+    dim3 grid((L + 127) / 128, B), block(512);
+    static const bool stamp = std::getenv("CLM_STAMP") && std::getenv("CLM_STAMP")[0] == '1';
+    if (stamp && prec == PREC_F16) {
+        const size_t wgs = (size_t)grid.x * grid.y;
+        if (wgs > s_stamp_wgs) {
+            if (s_stamp_buf) (void)hipFree(s_stamp_buf);
+            (void)hipMalloc((void**)&s_stamp_buf, wgs * TAIL_NSTAMP * 8);
+            s_stamp_wgs = wgs;
+        }
+        (void)hipMemsetAsync(s_stamp_buf, 0, wgs * TAIL_NSTAMP * 8, st);
+        static bool once = (set_lds(tail16_kernel<PREC_F16, true>, lds), true);
+        (void)once;
+        hipLaunchKernelGGL((tail16_kernel<PREC_F16, true>), grid, block, lds, st, m, s_stamp_buf);
+        return;
+    }
+    if (prec == PREC_BF16) {
+        static bool once = (set_lds(tail16_kernel<PREC_BF16, false>, lds), true);
+        (void)once;
+        hipLaunchKernelGGL((tail16_kernel<PREC_BF16, false>), grid, block, lds, st, m, (unsigned long long*)nullptr);
+    } else {
+        static bool once = (set_lds(tail16_kernel<PREC_F16, false>, lds), true);
+        (void)once;
+        hipLaunchKernelGGL((tail16_kernel<PREC_F16, false>), grid, block, lds, st, m, (unsigned long long*)nullptr);
     }
 }
 

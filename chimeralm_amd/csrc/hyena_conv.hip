@@ -14,6 +14,11 @@
 // (the filter is real, so it acts on both parts independently: no untangling pass, and the filter spectrum
 // is fetched once per pair).  N == 2L-2 (the 8193-token case) aliases exactly one product, k[L-1]*g[L-1],
 // onto output 0; it is subtracted explicitly.  One workgroup = one (channel, read pair).
+#include <cstdio>
+#include <cstdlib>
+#include <type_traits>
+#include <vector>
+
 #include "clm_common.h"
 #include "fft_passes.h"
 
@@ -220,6 +225,62 @@ __device__ __forceinline__ float short_filter1(const T* row, int t, float w0, fl
     return bias + w0 * xm2 + w1 * xm1 + w2 * to_float(row[t]);
 }
 
+// Raw samples of one 8-token chunk of one row (+ the two preceding samples), loaded with no control flow in between so
+// that ALL of a thread's loads are in flight together: stamps showed the branchy load->wait->filter sequence costing
+// six serialized HBM round trips (23k of the kernel's 63k cycles).
+template <typename T>
+struct Raw;
+template <>
+struct Raw<float> {
+    float4 a, b;
+    float2 p;
+};
+template <>
+struct Raw<bf16_t> {
+    uint4 d;
+    unsigned p;
+};
+template <>
+struct Raw<f16_t> {
+    uint4 d;
+    unsigned p;
+};
+__device__ __forceinline__ void raw_load(Raw<float>& r, const float* row, int t0, bool valid) {
+    const float* q = row + (valid ? t0 : 0);
+    r.a = *reinterpret_cast<const float4*>(q);
+    r.b = *reinterpret_cast<const float4*>(q + 4);
+    r.p = *reinterpret_cast<const float2*>(row + ((valid && t0 > 0) ? t0 - 2 : 0));
+}
+template <typename T>
+__device__ __forceinline__ void raw_load(Raw<T>& r, const T* row, int t0, bool valid) {
+    r.d = *reinterpret_cast<const uint4*>(row + (valid ? t0 : 0));                       // clamped, never out of the row
+    r.p = *reinterpret_cast<const unsigned*>(row + ((valid && t0 > 0) ? t0 - 2 : 0));
+}
+// x[0..1] = samples t0-2, t0-1 (zero at the start of the read), x[2..9] = samples t0 .. t0+7; all zero if !valid
+__device__ __forceinline__ void raw_decode(const Raw<float>& r, int t0, bool valid, float* x) {
+    const float v = valid ? 1.f : 0.f, vp = (valid && t0 > 0) ? 1.f : 0.f;
+    x[0] = vp * r.p.x; x[1] = vp * r.p.y;
+    x[2] = v * r.a.x; x[3] = v * r.a.y; x[4] = v * r.a.z; x[5] = v * r.a.w;
+    x[6] = v * r.b.x; x[7] = v * r.b.y; x[8] = v * r.b.z; x[9] = v * r.b.w;
+}
+template <typename T>
+__device__ __forceinline__ void raw_decode(const Raw<T>& r, int t0, bool valid, float* x) {
+    const unsigned w[5] = {(valid && t0 > 0) ? r.p : 0u, valid ? r.d.x : 0u, valid ? r.d.y : 0u, valid ? r.d.z : 0u,
+                           valid ? r.d.w : 0u};
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+        T lo, hi;
+        lo.bits = (unsigned short)(w[i] & 0xffffu);
+        hi.bits = (unsigned short)(w[i] >> 16);
+        x[2 * i] = to_float(lo);
+        x[2 * i + 1] = to_float(hi);
+    }
+}
+__device__ __forceinline__ void fir3(const float* x /*[10]*/, float w0, float w1, float w2, float bias, float* out /*[8]*/) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) out[e] = bias + w0 * x[e] + w1 * x[e + 1] + w2 * x[e + 2];
+}
+
 // 8 consecutive floats to / from an LDS array whose padding never splits an aligned group of 8
 __device__ __forceinline__ void lds_store8(float* dst, const float* v) {
     *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
@@ -236,11 +297,18 @@ __device__ __forceinline__ void lds_load8(const float* src, float* v) {
 //   phase B  forward passes; last forward pass fused with the spectrum product and the first inverse pass;
 //            inverse passes (the filter spectrum bins are fetched one pass ahead)
 //   phase C  LDS -> * x0 -> y
-template <int LOGN, typename T>
+// STAMP: developer build (CLM_STAMP=1, 16384-point f16 instantiation only) recording s_memtime at phase boundaries.
+constexpr int CONV_NSTAMP = 16;
+template <int LOGN, typename T, bool STAMP = false>
 __global__ __launch_bounds__(Plan<LOGN>::NT) void hyena_conv_kernel(
     const T* __restrict__ z, T* __restrict__ y, const float2* __restrict__ kf, const float2* __restrict__ tw,
     const float* __restrict__ ktime, const float* __restrict__ short_w, const float* __restrict__ short_b, int B, int L,
-    int Lp) {
+    int Lp, unsigned long long* stamps) {
+#define CLM_STAMP_AT(k)                                                                                   \
+    do {                                                                                                  \
+        if (STAMP && threadIdx.x == 0)                                                                    \
+            stamps[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * CONV_NSTAMP + (k)] = __builtin_amdgcn_s_memtime(); \
+    } while (0)
     using P = Plan<LOGN>;
     using TL = TwLayout<LOGN>;
     constexpr int N = P::N, NT = P::NT, LAST = P::LAST, HALF = N / 2;
@@ -258,6 +326,7 @@ __global__ __launch_bounds__(Plan<LOGN>::NT) void hyena_conv_kernel(
     const float2* kfc = kf + (size_t)c * N;
 
     // ---------------------------------------------------------------- phase 0: twiddles of every pass
+    CLM_STAMP_AT(0);
     Cx2 wall[TL::TOTAL];
     {
         int ns = 16;
@@ -284,58 +353,82 @@ __global__ __launch_bounds__(Plan<LOGN>::NT) void hyena_conv_kernel(
         sb[q] = short_b[q * D + c];
     }
 
+    CLM_STAMP_AT(12);
     // ---------------------------------------------------------------- phase A: load, short filter, gate
+    // every global load of the phase is issued before the first use (see Raw<T>)
+    constexpr int TAIL_TID = HALF / 8 - 1 - (CH - 1) * NT;   // owner of tokens [HALF-8, HALF): also computes token HALF
+    const bool tail = (L == HALF + 1);
+    Raw<T> raw[CH][2][3];
+    T ztail[2][3];
+#pragma unroll
+    for (int rd = 0; rd < 2; ++rd) {
+        const T* zr = rd == 0 ? zA : zB;
+#pragma unroll
+        for (int a3 = 0; a3 < 3; ++a3) {
+            const T* row = zr + (size_t)(a3 * D + c) * Lp;
+#pragma unroll
+            for (int ch = 0; ch < CH; ++ch) {
+                const int t0 = 8 * (tid + ch * NT);
+                raw_load(raw[ch][rd][a3], row, t0, t0 < HALF && t0 < L);
+            }
+            ztail[rd][a3] = row[(tail && tid == TAIL_TID) ? HALF : 0];
+        }
+    }
     float x0A[CH][8], x0B[CH][8];
+    float x0At = 0.f, gAt = 0.f, x0Bt = 0.f, gBt = 0.f;
 #pragma unroll
     for (int ch = 0; ch < CH; ++ch) {
         const int t0 = 8 * (tid + ch * NT);
         if (t0 < HALF) {
-            float gA[8], gB[8];
-            if (t0 < L) {
-                float x1[8], v[8];
-                short_filter8<T>(zA + (size_t)(0 * D + c) * Lp, t0, sw[0][0], sw[0][1], sw[0][2], sb[0], x0A[ch]);
-                short_filter8<T>(zA + (size_t)(1 * D + c) * Lp, t0, sw[1][0], sw[1][1], sw[1][2], sb[1], x1);
-                short_filter8<T>(zA + (size_t)(2 * D + c) * Lp, t0, sw[2][0], sw[2][1], sw[2][2], sb[2], v);
+            const bool valid = t0 < L;
+            float xa[3][10], xb[3][10], gA[8], gB[8], x1[8], v[8];
 #pragma unroll
-                for (int e = 0; e < 8; ++e) gA[e] = (t0 + e < L) ? v[e] * x1[e] : 0.f;
-                if (hasB) {
-                    short_filter8<T>(zB + (size_t)(0 * D + c) * Lp, t0, sw[0][0], sw[0][1], sw[0][2], sb[0], x0B[ch]);
-                    short_filter8<T>(zB + (size_t)(1 * D + c) * Lp, t0, sw[1][0], sw[1][1], sw[1][2], sb[1], x1);
-                    short_filter8<T>(zB + (size_t)(2 * D + c) * Lp, t0, sw[2][0], sw[2][1], sw[2][2], sb[2], v);
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) gB[e] = (t0 + e < L) ? v[e] * x1[e] : 0.f;
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) gB[e] = 0.f, x0B[ch][e] = 0.f;
-                }
-            } else {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) gA[e] = 0.f, gB[e] = 0.f, x0A[ch][e] = 0.f, x0B[ch][e] = 0.f;
+            for (int a3 = 0; a3 < 3; ++a3) {
+                raw_decode(raw[ch][0][a3], t0, valid, xa[a3]);
+                raw_decode(raw[ch][1][a3], t0, valid && hasB, xb[a3]);
             }
+            fir3(xa[0], sw[0][0], sw[0][1], sw[0][2], sb[0], x0A[ch]);
+            fir3(xa[1], sw[1][0], sw[1][1], sw[1][2], sb[1], x1);
+            fir3(xa[2], sw[2][0], sw[2][1], sw[2][2], sb[2], v);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) gA[e] = (t0 + e < L) ? v[e] * x1[e] : 0.f;
+            fir3(xb[0], sw[0][0], sw[0][1], sw[0][2], sb[0], x0B[ch]);
+            fir3(xb[1], sw[1][0], sw[1][1], sw[1][2], sb[1], x1);
+            fir3(xb[2], sw[2][0], sw[2][1], sw[2][2], sb[2], v);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) gB[e] = (hasB && t0 + e < L) ? v[e] * x1[e] : 0.f;
             lds_store8(bre + pad_index(t0), gA);
             lds_store8(bim + pad_index(t0), gB);
+            if (ch == CH - 1 && tail && tid == TAIL_TID) {   // token HALF: taps are x[8], x[9] of this chunk and z[HALF]
+                float ta[3], tb[3];
+#pragma unroll
+                for (int a3 = 0; a3 < 3; ++a3) {
+                    ta[a3] = sb[a3] + sw[a3][0] * xa[a3][8] + sw[a3][1] * xa[a3][9] + sw[a3][2] * to_float(ztail[0][a3]);
+                    tb[a3] = sb[a3] + sw[a3][0] * xb[a3][8] + sw[a3][1] * xb[a3][9] + sw[a3][2] * to_float(ztail[1][a3]);
+                }
+                x0At = ta[0];
+                gAt = ta[1] * ta[2];
+                x0Bt = tb[0];
+                gBt = hasB ? tb[1] * tb[2] : 0.f;
+            }
         }
     }
+    CLM_STAMP_AT(13);
     // upper half = zero padding, written with unit stride across lanes (conflict-free)
 #pragma unroll
     for (int i = 0; i < HALF / NT; ++i) bre[pad_index(HALF + tid + i * NT)] = 0.f, bim[pad_index(HALF + tid + i * NT)] = 0.f;
-    // ... except the single token t = N/2 when L == N/2 + 1 (8193 tokens in a 16384-point transform)
-    const bool tail = (L == HALF + 1);
-    float x0At = 0.f, gAt = 0.f, x0Bt = 0.f, gBt = 0.f;
-    if (tail && tid == 0) {
-        const int t = HALF;
-        x0At = short_filter1<T>(zA + (size_t)(0 * D + c) * Lp, t, sw[0][0], sw[0][1], sw[0][2], sb[0]);
-        gAt = short_filter1<T>(zA + (size_t)(1 * D + c) * Lp, t, sw[1][0], sw[1][1], sw[1][2], sb[1]) *
-              short_filter1<T>(zA + (size_t)(2 * D + c) * Lp, t, sw[2][0], sw[2][1], sw[2][2], sb[2]);
-        if (hasB) {
-            x0Bt = short_filter1<T>(zB + (size_t)(0 * D + c) * Lp, t, sw[0][0], sw[0][1], sw[0][2], sb[0]);
-            gBt = short_filter1<T>(zB + (size_t)(1 * D + c) * Lp, t, sw[1][0], sw[1][1], sw[1][2], sb[1]) *
-                  short_filter1<T>(zB + (size_t)(2 * D + c) * Lp, t, sw[2][0], sw[2][1], sw[2][2], sb[2]);
-        }
+    CLM_STAMP_AT(14);
+    float* gtail = bim + padded_size(N);                     // g[HALF] of both reads, for the alias correction by thread 0
+    CLM_STAMP_AT(1);
+    __syncthreads();
+    if (tail && tid == TAIL_TID) {      // token N/2 exists only when L == N/2 + 1 (8193 tokens in a 16384-point transform)
+        bre[pad_index(HALF)] = gAt;
+        bim[pad_index(HALF)] = gBt;
+        gtail[0] = gAt;
+        gtail[1] = gBt;
     }
     __syncthreads();
-    if (tail && tid == 0) bre[pad_index(HALF)] = gAt, bim[pad_index(HALF)] = gBt;
-    __syncthreads();
+    CLM_STAMP_AT(2);
 
     // ---------------------------------------------------------------- phase B: FFT, spectrum product, inverse FFT
     Cx2 v[16];   // 32 points per thread as 16 SoA pairs
@@ -348,6 +441,7 @@ __global__ __launch_bounds__(Plan<LOGN>::NT) void hyena_conv_kernel(
             __syncthreads();
             pass_store<LOGN, 16>(bre, bim, v, tid, Ns);
             __syncthreads();
+            CLM_STAMP_AT(3 + p);
             Ns *= 16;
         }
     }
@@ -361,6 +455,7 @@ __global__ __launch_bounds__(Plan<LOGN>::NT) void hyena_conv_kernel(
     __syncthreads();
     pass_store<LOGN, LAST>(bre, bim, v, tid, 1);
     __syncthreads();
+    CLM_STAMP_AT(7);
     {
         int Ns = LAST;
 #pragma unroll
@@ -370,6 +465,7 @@ __global__ __launch_bounds__(Plan<LOGN>::NT) void hyena_conv_kernel(
             __syncthreads();
             pass_store<LOGN, 16>(bre, bim, v, tid, Ns);
             __syncthreads();
+            CLM_STAMP_AT(7 + p);
             Ns *= 16;
         }
     }
@@ -386,8 +482,8 @@ __global__ __launch_bounds__(Plan<LOGN>::NT) void hyena_conv_kernel(
             lds_load8(bim + pad_index(t0), oB);
             if (tail && t0 == 0) {  // remove the one wrapped product k[L-1]*g[L-1] from output 0
                 const float kl = ktime[(size_t)(L - 1) * D + c];
-                oA[0] -= kl * gAt;
-                oB[0] -= kl * gBt;
+                oA[0] -= kl * gtail[0];
+                oB[0] -= kl * gtail[1];
             }
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
@@ -399,10 +495,12 @@ __global__ __launch_bounds__(Plan<LOGN>::NT) void hyena_conv_kernel(
             if (hasB) store8<T>(yB + t0, oB);
         }
     }
-    if (tail && tid == 0) {
+    if (tail && tid == TAIL_TID) {
         yA[HALF] = from_float<T>(bre[pad_index(HALF)] * x0At);
         if (hasB) yB[HALF] = from_float<T>(bim[pad_index(HALF)] * x0Bt);
     }
+    CLM_STAMP_AT(11);
+#undef CLM_STAMP_AT
 }
 
 
@@ -631,22 +729,73 @@ void launch_hyena_conv_seg(int prec, const void* z, void* y, const float2* kf, c
         launch_conv_seg_t<f16_t>(z, y, kf, tw, short_w, short_b, gscratch, carry, B, L, Lp, S, st);
 }
 
+static unsigned long long* s_conv_stamp_buf = nullptr;
+static size_t s_conv_stamp_wgs = 0;
+void conv_dump_stamps() {
+    if (!s_conv_stamp_buf || !s_conv_stamp_wgs) return;
+    std::vector<unsigned long long> hst(s_conv_stamp_wgs * CONV_NSTAMP);
+    if (hipMemcpy(hst.data(), s_conv_stamp_buf, hst.size() * 8, hipMemcpyDeviceToHost) != hipSuccess) return;
+    double sum[CONV_NSTAMP] = {};
+    size_t n = 0;
+    for (size_t w = 0; w < s_conv_stamp_wgs; ++w) {
+        const unsigned long long* p = &hst[w * CONV_NSTAMP];
+        if (!p[0] || !p[11]) continue;
+        for (int k = 1; k <= 11; ++k) sum[k] += double(p[k] - p[k - 1]);
+        ++n;
+    }
+    const char* names[12] = {"", "tw+phaseA", "barriers", "fwd0", "fwd1", "fwd2", "(unused)", "fwd3+kf+inv0", "inv1", "inv2", "inv3", "phaseC"};
+    {   // finer split of phase A: 0 -> 12 (twiddle issue + filter taps) -> 13 (z loads, FIR, gate, LDS) -> 14 (zero fill) -> 1 (tail)
+        double a[4] = {}; size_t m = 0;
+        for (size_t w = 0; w < s_conv_stamp_wgs; ++w) {
+            const unsigned long long* p = &hst[w * CONV_NSTAMP];
+            if (!p[0] || !p[14]) continue;
+            a[0] += double(p[12] - p[0]); a[1] += double(p[13] - p[12]); a[2] += double(p[14] - p[13]); a[3] += double(p[1] - p[14]); ++m;
+        }
+        if (m) std::fprintf(stderr, "[conv stamps] phase A split: setup %.0f  loads+fir+lds %.0f  zerofill %.0f  tail %.0f\n", a[0] / m, a[1] / m, a[2] / m, a[3] / m);
+        double mid = 0; size_t mm = 0;
+        for (size_t w = 0; w < s_conv_stamp_wgs; ++w) { const unsigned long long* p = &hst[w * CONV_NSTAMP]; if (p[5] && p[7]) { mid += double(p[7] - p[5]); ++mm; } }
+        if (mm) std::fprintf(stderr, "[conv stamps] fwd3+kf+inv0 = %.0f\n", mid / mm);
+    }
+    double tot = 0;
+    for (int k = 1; k <= 11; ++k) tot += sum[k] / (n ? n : 1);
+    std::fprintf(stderr, "[conv stamps] %zu workgroups, mean s_memtime ticks per phase (total %.0f):\n", n, tot);
+    for (int k = 1; k <= 11; ++k)
+        if (k != 6) std::fprintf(stderr, "  %-14s %9.0f  %5.1f %%\n", names[k], sum[k] / (n ? n : 1), 100.0 * sum[k] / (n ? n : 1) / tot);
+}
+
 template <int LOGN, typename T>
 static void launch_conv_t(const void* z, void* y, const float2* kf, const float2* tw, const float* ktime,
-                          const float* short_w, const float* short_b, int B, int L, int Lp,
-                          hipStream_t st) {
+                          const float* short_w, const float* short_b, int B, int L, int Lp, hipStream_t st) {
     using P = Plan<LOGN>;
-    constexpr size_t lds = (size_t)2 * padded_size(P::N) * sizeof(float);
-    auto kern = hyena_conv_kernel<LOGN, T>;
+    constexpr size_t lds = (size_t)2 * padded_size(P::N) * sizeof(float) + 16;
+    dim3 grid((B + 1) / 2, D), block(P::NT);
+    if constexpr (LOGN == 14 && std::is_same<T, f16_t>::value) {
+        static const bool stamp = std::getenv("CLM_STAMP") && std::getenv("CLM_STAMP")[0] == '1';
+        if (stamp) {
+            auto kern = hyena_conv_kernel<LOGN, T, true>;
+            static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), true);
+            (void)once;
+            const size_t wgs = (size_t)grid.x * grid.y;
+            if (wgs > s_conv_stamp_wgs) {
+                if (s_conv_stamp_buf) (void)hipFree(s_conv_stamp_buf);
+                (void)hipMalloc((void**)&s_conv_stamp_buf, wgs * CONV_NSTAMP * 8);
+                s_conv_stamp_wgs = wgs;
+            }
+            (void)hipMemsetAsync(s_conv_stamp_buf, 0, wgs * CONV_NSTAMP * 8, st);
+            hipLaunchKernelGGL(kern, grid, block, lds, st, reinterpret_cast<const T*>(z), reinterpret_cast<T*>(y), kf, tw, ktime,
+                               short_w, short_b, B, L, Lp, s_conv_stamp_buf);
+            return;
+        }
+    }
+    auto kern = hyena_conv_kernel<LOGN, T, false>;
     static bool attr_done = false;
     if (!attr_done) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)lds);
         attr_done = true;
     }
-    dim3 grid((B + 1) / 2, D), block(P::NT);
     hipLaunchKernelGGL(kern, grid, block, lds, st, reinterpret_cast<const T*>(z), reinterpret_cast<T*>(y), kf, tw,
-                       ktime, short_w, short_b, B, L, Lp);
+                       ktime, short_w, short_b, B, L, Lp, (unsigned long long*)nullptr);
 }
 
 template <int LOGN>
