@@ -202,14 +202,13 @@ __global__ __launch_bounds__(512) void out_proj16_kernel(GemmArgs a) {
         const elem* src = reinterpret_cast<const elem*>(a.a_in) + (size_t)b * D * Lp + t0;
         const int tk = (tid & 15) * 8;
         const bool in_row = t0 + tk < Lp;
+        const int tkc = in_row ? tk : 0;                       // clamped, branch-free loads; masked at the LDS store
         uint4 x[8];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            x[i] = make_uint4(0, 0, 0, 0);
-            if (in_row) x[i] = *reinterpret_cast<const uint4*>(src + (size_t)((tid >> 4) + 32 * i) * Lp + tk);
-        }
+        for (int i = 0; i < 8; ++i) x[i] = *reinterpret_cast<const uint4*>(src + (size_t)((tid >> 4) + 32 * i) * Lp + tkc);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) *reinterpret_cast<uint4*>(Ys + ((tid >> 4) + 32 * i) * RSKM + tk) = x[i];
+        for (int i = 0; i < 8; ++i)
+            *reinterpret_cast<uint4*>(Ys + ((tid >> 4) + 32 * i) * RSKM + tk) = in_row ? x[i] : make_uint4(0, 0, 0, 0);
     }
     __syncthreads();
     zero_acc(acc);
@@ -357,19 +356,20 @@ __global__ __launch_bounds__(512) void tail16_kernel(TailArgs m, unsigned long l
 #pragma unroll
         for (int q = 0; q < 4; ++q) hv[mt][q] = *reinterpret_cast<const float4*>(row + 8 * q);
     }
+    // (gathering these rows as whole 128-byte lines through a wave-private LDS transpose was measured: no faster -- the
+    // phase is bound by how many misses one workgroup per CU keeps in flight, not by the address unit)
     __builtin_amdgcn_sched_barrier(0);
     {
         const elem* src = reinterpret_cast<const elem*>(m.y) + (size_t)b * D * Lp + t0;
         const int tk = (tid & 15) * 8;
         const bool in_row = t0 + tk < Lp;
+        const int tkc = in_row ? tk : 0;                   // clamped, branch-free loads; masked at the LDS store
         uint4 x[8];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            x[i] = make_uint4(0, 0, 0, 0);
-            if (in_row) x[i] = *reinterpret_cast<const uint4*>(src + (size_t)((tid >> 4) + 32 * i) * Lp + tk);
-        }
+        for (int i = 0; i < 8; ++i) x[i] = *reinterpret_cast<const uint4*>(src + (size_t)((tid >> 4) + 32 * i) * Lp + tkc);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) *reinterpret_cast<uint4*>(Ys + ((tid >> 4) + 32 * i) * RSKM + tk) = x[i];
+        for (int i = 0; i < 8; ++i)
+            *reinterpret_cast<uint4*>(Ys + ((tid >> 4) + 32 * i) * RSKM + tk) = in_row ? x[i] : make_uint4(0, 0, 0, 0);
     }
     __syncthreads();
     CLM_STAMP_AT(1);

@@ -112,9 +112,8 @@ __device__ __forceinline__ void stage_a_tile(const GemmArgs& a, typename CT<PREC
             float4 x[BATCH];
 #pragma unroll
             for (int i = 0; i < BATCH; ++i) {
-                const int t = t0 + wave + (r0 + i) * NW;
-                x[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (t < L) x[i] = *reinterpret_cast<const float4*>(a.h_in + ((size_t)b * L + t) * D + lane * 4);
+                const int t = t0 + wave + (r0 + i) * NW;      // clamped, branch-free: all loads of the batch stay in flight
+                x[i] = *reinterpret_cast<const float4*>(a.h_in + ((size_t)b * L + (t < L ? t : L - 1)) * D + lane * 4);
             }
 #pragma unroll
             for (int i = 0; i < BATCH; ++i) {
