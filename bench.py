@@ -33,13 +33,34 @@ PEAK_TFLOPS = {"fp32": 157.3, "bf16": 2500.0, "fp16": 2500.0}      # dense MFMA 
 PEAK_HBM_GBS = 8000.0
 # algorithmic FLOPs per token of each GEMM stage
 STAGE_FLOPS_PER_TOKEN = {"ln1_in_proj": 2 * D * 3 * D, "out_proj": 2 * D * D, "ln2_fc1_gelu": 2 * D * DI,
-                         "fc2": 2 * D * DI, "lnf_pool_score": 2 * D * D + 2 * D}
+                         "fc2": 2 * D * DI, "lnf_pool_score": 2 * D * D + 2 * D,
+                         "out_proj_ln2_mlp": 2 * D * D + 4 * D * DI, "ln2_mlp": 4 * D * DI}
+
+
+# algorithmic HBM bytes per token of the GEMM stages, by activation element size (h is fp32 in every mode)
+TAIL_BYTES_PER_TOKEN = {"out_proj_ln2_mlp": {2: D * 2 + 2 * D * 4, 4: D * 4 + 2 * D * 4},
+                        "ln2_mlp": {2: 2 * D * 4, 4: 2 * D * 4},
+                        "ln1_in_proj": {2: D * 4 + 3 * D * 2, 4: D * 4 + 3 * D * 4}}
 
 
 def stage_bytes_per_token(stage: str, es: int) -> float:
     """Algorithmic HBM bytes per token and launch of the bandwidth-bound stages (es = activation element size)."""
     return {"short_long_conv": 3 * D * es + D * es,      # read z (x0|x1|v), write y
             "embed": 1 + D * 4, "softmax_pool": D * 4 + 8}.get(stage, 0.0)
+
+
+def measured_traffic(stage: str, config: dict, dtype: str):
+    """HBM bytes per launch of `stage` from the newest committed PMC digest (profiles/rNN_traffic.json, written by
+    tools/profile_round.sh + tools/profile_digest.py from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes with the
+    gfx950 FETCH_SIZE x2 correction) -- only if it was collected on exactly this workload, else None."""
+    for f in sorted(Path(__file__).resolve().parent.glob("profiles/r*_traffic.json"), reverse=True):
+        try:
+            d = json.loads(f.read_text())
+        except (OSError, ValueError):
+            continue
+        if d.get("config") == config and d.get("dtype") == dtype and stage in d.get("stages", {}):
+            return {"hbm_bytes_per_launch": d["stages"][stage]["hbm_bytes_per_dispatch"], "source": f"profiles/{f.name}"}
+    return None
 
 
 def synthetic_ids(batch_index: int, batch: int, bases: int) -> np.ndarray:
@@ -77,7 +98,7 @@ def main():
     ap.add_argument("--batch", type=int, default=256, help="global batch (reads per step)")
     ap.add_argument("--bases", type=int, default=8192)
     ap.add_argument("--precision", default=os.environ.get("CLM_PRECISION", "fp16"))
-    ap.add_argument("--chunk-reads", type=int, default=32)
+    ap.add_argument("--chunk-reads", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     a = ap.parse_args()
 
@@ -145,15 +166,20 @@ def main():
                     "frac": achieved / PEAK_HBM_GBS, "traffic": None}
         roof["avg_launch_ms"] = ms / max(1, launches)
         roof["launches"] = launches
+        config = {"workload": f"synthetic {a.bases}-bp reads, global batch {a.batch}, 1 forward per step",
+                  "global_batch": a.batch, "tokens_per_read": L, "reads_per_gpu": hi - lo, "chunk_reads": a.chunk_reads,
+                  "parallelism": f"read-sharded x{world}, logits all-gather" if world > 1 else "single GPU"}
+        tr = measured_traffic(dom, config, a.precision)
+        if tr:
+            roof["traffic"], roof["traffic_unit"], roof["traffic_source"] = tr["hbm_bytes_per_launch"], "bytes/launch", tr["source"]
+            roof["algorithmic_hbm_bytes_per_launch"] = (stage_bytes_per_token(dom, es) or TAIL_BYTES_PER_TOKEN.get(dom, {}).get(es, 0.0)) * tokens_per_launch
         res = {
             "metric": "reads/sec (whole node), 8k-bp reads batch=256", "value": a.batch * a.steps / elapsed,
             "unit": "reads/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": elapsed / a.steps * 1e3, "p50_batch_latency_ms": lat[len(lat) // 2],
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": a.precision,
             "data": "synthetic reads (seeded), seeded random-init weights of the production architecture",
-            "config": {"workload": f"synthetic {a.bases}-bp reads, global batch {a.batch}, 1 forward per step",
-                       "global_batch": a.batch, "tokens_per_read": L, "reads_per_gpu": hi - lo,
-                       "parallelism": f"read-sharded x{world}, logits all-gather" if world > 1 else "single GPU"},
+            "config": config,
             "dense_tflops_per_gpu": 6_423_040 * L * (hi - lo) * a.steps / elapsed / 1e12,
             "stage_ms_share": {k: round(v[0] / total_ms, 4) for k, v in prof.items() if v[1]},
             "roofline": roof,

@@ -373,7 +373,7 @@ int forward_chunk(clm_handle* h, const void* ids, int ids_dtype, int64_t row_str
         if (stop_here(h, i, CLM_STAGE_CONV)) return CLM_OK;
         const bool stop_mid = stop_here(h, i, CLM_STAGE_OUTPROJ);
         if (tuned16 && !h->split_tail && !stop_mid) {   // out_proj + LN2 + fc1 + GELU + fc2 + both residuals: one kernel
-            StageTimer t(h, st, CLM_STAGE_FC1);
+            StageTimer t(h, st, CLM_STAGE_TAIL);
             launch_tail16(prec, h->y, lw.w_out, lw.b_out, h->h, lw.ln2_g, lw.ln2_b, lw.w_fc1, lw.b_fc1, lw.w_fc2, lw.b_fc2,
                           Bc, L, Lp, eps, st);
         } else {
@@ -383,8 +383,8 @@ int forward_chunk(clm_handle* h, const void* ids, int ids_dtype, int64_t row_str
                 else launch_outproj(prec, h->y, lw.w_out, lw.b_out, h->h, Bc, L, Lp, st);
             }
             if (stop_mid) return CLM_OK;
-            if (tuned16) {   // fc1 + GELU + fc2 + residual fused; reported under the fc1 stage
-                StageTimer t(h, st, CLM_STAGE_FC1);
+            if (tuned16) {   // fc1 + GELU + fc2 + residual fused
+                StageTimer t(h, st, CLM_STAGE_MLP);
                 launch_mlp16(prec, h->h, lw.ln2_g, lw.ln2_b, lw.w_fc1, lw.b_fc1, lw.w_fc2, lw.b_fc2, Bc, L, eps, st);
             } else {
                 {
@@ -433,7 +433,7 @@ int clm_default_config(clm_config* c) {
     c->emb_dim = EMB; c->max_seq_len = 32770; c->head_hidden = HH; c->n_classes = NCLS;
     c->ln_eps = 1e-5f;
     c->precision = CLM_PREC_F32;
-    c->chunk_reads = 32;
+    c->chunk_reads = 64;
     return CLM_OK;
 }
 
@@ -658,7 +658,8 @@ int clm_profile_read(clm_handle* h, double* ms_out, int64_t* launches_out, int r
 
 const char* clm_profile_stage_name(int stage) {
     static const char* names[CLM_N_STAGES] = {"embed", "ln1_in_proj", "short_long_conv", "out_proj", "ln2_fc1_gelu",
-                                              "fc2", "lnf_pool_score", "softmax_pool", "head_mlp", "filter"};
+                                              "fc2", "lnf_pool_score", "softmax_pool", "head_mlp", "filter",
+                                              "out_proj_ln2_mlp", "ln2_mlp"};
     return (stage >= 0 && stage < CLM_N_STAGES) ? names[stage] : "?";
 }
 

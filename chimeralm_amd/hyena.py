@@ -180,7 +180,7 @@ class HyenaDna(nn.Module):
     """
 
     def __init__(self, number_of_classes: int, head: nn.Module, backbone_name: str = "hyenadna-small-32k-seqlen", *,
-                 freeze_backbone: bool = False, precision: str = "fp32", chunk_reads: int = 32):
+                 freeze_backbone: bool = False, precision: str = "fp32", chunk_reads: int = 64):
         super().__init__()
         if number_of_classes != 2:
             raise NotImplementedError("the engine implements the binary (2-class) head only")

@@ -127,7 +127,9 @@ int clm_debug_stop_after(clm_handle* h, int layer, int stage);
 #define CLM_STAGE_POOL 7
 #define CLM_STAGE_HEADMLP 8
 #define CLM_STAGE_FILTER 9
-#define CLM_N_STAGES 10
+#define CLM_STAGE_TAIL 10   /* profile only: fused out_proj + LN2 + fc1 + GELU + fc2 (16-bit modes) */
+#define CLM_STAGE_MLP 11    /* profile only: fused LN2 + fc1 + GELU + fc2 (16-bit modes, CLM_SPLIT_TAIL=1) */
+#define CLM_N_STAGES 12
 int clm_profile_enable(clm_handle* h, int on);
 /* Synchronises, then returns accumulated milliseconds and launch counts per stage since the last reset. */
 int clm_profile_read(clm_handle* h, double* ms_out /*[CLM_N_STAGES]*/, int64_t* launches_out /*[CLM_N_STAGES]*/,

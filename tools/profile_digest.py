@@ -1,0 +1,87 @@
+"""Condense gpurun_out/<tag>/ (written by tools/profile_round.sh on the GPU box) into the small files kept under profiles/:
+
+    profiles/<tag>_bench.json          the default bench line of the round
+    profiles/<tag>_kernel_stats.csv    rocprofv3 --kernel-trace --stats summary of the same command
+    profiles/<tag>_pmc_summary.txt     per kernel: mean duration and mean counter values per dispatch
+    profiles/<tag>_traffic.json        per kernel HBM bytes per dispatch = (2*FETCH_SIZE + WRITE_SIZE) * 1024
+                                       (gfx950 correction of MI355X_MICROARCH.md "HBM": FETCH_SIZE tallies 128-B requests
+                                        at 64 B), keyed by engine stage for bench.py's roofline.traffic
+
+    python tools/profile_digest.py r01
+"""
+import csv
+import glob
+import json
+import shutil
+import sys
+from collections import defaultdict
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent.parent
+STAGE_OF = {"tail16_kernel": "out_proj_ln2_mlp", "mlp16_kernel": "ln2_mlp", "in_proj16_kernel": "ln1_in_proj",
+            "out_proj16_kernel": "out_proj", "hyena_conv_kernel": "short_long_conv", "hyena_conv_seg_kernel": "short_long_conv",
+            "embed_kernel": "embed", "gemm_kernel": "lnf_pool_score", "softmax_stats_kernel": "softmax_pool", "pool_kernel": "softmax_pool",
+            "head_mlp_kernel": "head_mlp"}
+
+
+def short(name: str) -> str:
+    n = name.replace("void ", "").replace("clm::", "")
+    return n.split("(")[0].split("<")[0]
+
+
+def counters(path_glob):
+    acc = defaultdict(lambda: defaultdict(list))
+    dur = defaultdict(dict)
+    for f in glob.glob(path_glob, recursive=True):
+        for r in csv.DictReader(open(f)):
+            n = short(r["Kernel_Name"])
+            acc[n][r["Counter_Name"]].append(float(r["Counter_Value"]))
+            dur[n][r["Dispatch_Id"]] = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+    return acc, dur
+
+
+def main(tag):
+    src = ROOT / "gpurun_out" / tag
+    dst = ROOT / "profiles"
+    dst.mkdir(exist_ok=True)
+    bench = [l for l in open(src / "bench_default.json") if l.startswith("{")]
+    if bench:
+        (dst / f"{tag}_bench.json").write_text(bench[-1])
+    stats = glob.glob(str(src / "kt" / "**" / "*kernel_stats.csv"), recursive=True)
+    if stats:
+        shutil.copy(stats[0], dst / f"{tag}_kernel_stats.csv")
+    lines, traffic = [], defaultdict(lambda: {"fetch_kb": None, "write_kb": None})
+    for sub in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_inst"):
+        acc, dur = counters(str(src / sub / "**" / "*counter_collection.csv"))
+        if not acc:
+            continue
+        lines.append(f"==== {sub} (counter run: kernels are serialised, durations are for reference only)")
+        for n in sorted(acc, key=lambda k: -sum(dur[k].values())):
+            d = list(dur[n].values())
+            if sum(d) < 100:
+                continue
+            lines.append(f"{n:28s} dispatches={len(d):4d} avg_us={sum(d)/len(d):9.1f}")
+            for c, v in sorted(acc[n].items()):
+                lines.append(f"    {c:28s} {sum(v)/len(v):18.1f}")
+                if c == "FETCH_SIZE":
+                    traffic[n]["fetch_kb"] = sum(v) / len(v)
+                if c == "WRITE_SIZE":
+                    traffic[n]["write_kb"] = sum(v) / len(v)
+    (dst / f"{tag}_pmc_summary.txt").write_text("\n".join(lines) + "\n")
+    out = {}
+    for n, t in traffic.items():
+        if t["fetch_kb"] is None or t["write_kb"] is None:
+            continue
+        stage = next((s for k, s in STAGE_OF.items() if n.startswith(k) or k in n), None)
+        e = {"kernel": n, "fetch_size_kb": t["fetch_kb"], "write_size_kb": t["write_kb"],
+             "hbm_bytes_per_dispatch": (2.0 * t["fetch_kb"] + t["write_kb"]) * 1024.0}
+        if stage and (stage not in out or e["hbm_bytes_per_dispatch"] > out[stage]["hbm_bytes_per_dispatch"]):
+            out[stage] = e
+    cfg = json.loads(bench[-1])["config"] if bench else {}
+    (dst / f"{tag}_traffic.json").write_text(json.dumps({"config": cfg, "dtype": json.loads(bench[-1])["dtype"] if bench else None,
+                                                         "stages": out}, indent=1) + "\n")
+    print("\n".join(lines[:60]))
+
+
+if __name__ == "__main__":
+    main(sys.argv[1] if len(sys.argv) > 1 else "r01")
