@@ -73,7 +73,8 @@ def synthetic_ids(batch_index: int, batch: int, bases: int) -> np.ndarray:
 def cpu_baseline(bases: int, budget_s: float = 20.0) -> dict:
     from oracle import hyena_oracle as ho
 
-    cores = os.cpu_count() or 1
+    # the threads this process may really use: its affinity mask, capped at the GPU box's CPU share (16 per GPU)
+    cores = int(os.environ.get("CLM_CPU_THREADS", min(len(os.sched_getaffinity(0)), os.cpu_count() or 1, 16)))
     torch.set_num_threads(cores)
     sd = ho.make_state_dict(0)
     b = 4
