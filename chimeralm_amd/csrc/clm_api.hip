@@ -6,6 +6,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <algorithm>
 #include <string>
 #include <vector>
 
@@ -232,7 +233,10 @@ int ensure_workspace(clm_handle* h, int Bc, int L, hipStream_t st) {
     HIPCHK(h, hipMalloc(&h->u, n_u));
     HIPCHK(h, hipMalloc((void**)&h->scores, (size_t)nb * nl * 4));
     HIPCHK(h, hipMalloc((void**)&h->stats, (size_t)nb * 2 * 4));
-    HIPCHK(h, hipMalloc((void**)&h->partial, (size_t)nb * POOL_SPLIT * 4 * D * 4));
+    {   // pooling partials: [POOL_SPLIT][4][256] per read (fp32 path) or one POOL_PSTRIDE row per 128-token tile
+        const size_t per_read = std::max((size_t)POOL_SPLIT * 4 * D, (size_t)((nl + 127) / 128) * POOL_PSTRIDE);
+        HIPCHK(h, hipMalloc((void**)&h->partial, (size_t)nb * per_read * 4));
+    }
     HIPCHK(h, hipMalloc((void**)&h->pooled, (size_t)nb * D * 4));
     if (conv_segments_for(nl) > 1) {
         const size_t pairs = (size_t)(nb + 1) / 2, S = (size_t)conv_segments_for(nl);
@@ -352,9 +356,9 @@ int forward_chunk(clm_handle* h, const void* ids, int ids_dtype, int64_t row_str
         launch_embed(ids, ids_dtype, row_stride, W(h, "bb.embeddings.word_embeddings.weight"), h->h, Bc, L, st);
     }
     if (stop_here(h, -1, CLM_STAGE_EMBED)) return CLM_OK;
+    const bool tuned16 = prec != PREC_F32 && !h->force_generic;
     for (int i = 0; i < NLAYER; ++i) {
         const LayerW& lw = h->lw[i];
-        const bool tuned16 = prec != PREC_F32 && !h->force_generic;
         {
             StageTimer t(h, st, CLM_STAGE_INPROJ);
             if (tuned16) launch_inproj16(prec, h->h, lw.ln1_g, lw.ln1_b, lw.w_in, lw.b_in, h->z, Bc, L, Lp, eps, st);
@@ -398,19 +402,28 @@ int forward_chunk(clm_handle* h, const void* ids, int ids_dtype, int64_t row_str
         }
         if (stop_here(h, i, CLM_STAGE_FC2) || (tuned16 && stop_here(h, i, CLM_STAGE_FC1))) return CLM_OK;
     }
-    {
-        StageTimer t(h, st, CLM_STAGE_SCORE);
-        launch_score(prec, h->h, W(h, "bb.ln_f.weight"), W(h, "bb.ln_f.bias"), h->packed_score,
-                     W(h, "head.attention.0.bias"), W(h, "head.attention.2.weight"), W(h, "head.attention.2.bias"),
-                     h->scores, Bc, L, eps, st);
-    }
-    {
-        StageTimer t(h, st, CLM_STAGE_POOL);
-        launch_softmax_stats(h->scores, h->stats, Bc, L, st);
-        launch_pool(h->h, W(h, "bb.ln_f.weight"), W(h, "bb.ln_f.bias"), h->scores, h->stats, h->partial, Bc, L, eps,
-                    st);
-    }
-    {
+    if (tuned16) {   // score + pooling partials in one pass over h, merged by the classifier kernel
+        {
+            StageTimer t(h, st, CLM_STAGE_SCORE);
+            launch_score_pool16(prec, h->h, W(h, "bb.ln_f.weight"), W(h, "bb.ln_f.bias"), h->packed_score,
+                                W(h, "head.attention.0.bias"), W(h, "head.attention.2.weight"),
+                                W(h, "head.attention.2.bias"), h->scores, h->partial, Bc, L, eps, st);
+        }
+        StageTimer t(h, st, CLM_STAGE_HEADMLP);
+        launch_head_tiles(h->partial, (L + 127) / 128, h->hw, h->pooled, logits, Bc, st);
+    } else {
+        {
+            StageTimer t(h, st, CLM_STAGE_SCORE);
+            launch_score(prec, h->h, W(h, "bb.ln_f.weight"), W(h, "bb.ln_f.bias"), h->packed_score,
+                         W(h, "head.attention.0.bias"), W(h, "head.attention.2.weight"), W(h, "head.attention.2.bias"),
+                         h->scores, Bc, L, eps, st);
+        }
+        {
+            StageTimer t(h, st, CLM_STAGE_POOL);
+            launch_softmax_stats(h->scores, h->stats, Bc, L, st);
+            launch_pool(h->h, W(h, "bb.ln_f.weight"), W(h, "bb.ln_f.bias"), h->scores, h->stats, h->partial, Bc, L, eps,
+                        st);
+        }
         StageTimer t(h, st, CLM_STAGE_HEADMLP);
         launch_head_mlp(h->partial, h->hw, h->pooled, logits, Bc, st);
     }

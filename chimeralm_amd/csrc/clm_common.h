@@ -175,6 +175,13 @@ struct HeadW {  // transposed [in][out] fp32
     const float *w0t, *b0, *w3t, *b3, *w60t, *b60, *w63t, *b63, *wot, *bo;
 };
 void launch_head_mlp(const float* partial, const HeadW& hw, float* pooled_out, float* logits, int B, hipStream_t st);
+// 16-bit modes: score + per-tile online-softmax pooling partials in one pass over h (gemm16.hip), merged by the head kernel
+constexpr int POOL_PSTRIDE = 264;   // floats per tile partial: vec[256], max, sum, pad
+void launch_score_pool16(int prec, const float* h, const float* g, const float* bta, const void* w1, const float* b1,
+                         const float* w2, const float* b2, float* scores, float* partial /*[B][ntiles][POOL_PSTRIDE]*/,
+                         int B, int L, float eps, hipStream_t st);
+void launch_head_tiles(const float* partial, int ntiles, const HeadW& hw, float* pooled_out, float* logits, int B,
+                       hipStream_t st);
 void launch_transpose(const float* in, float* out, int rows, int cols, hipStream_t st);
 
 }  // namespace clm

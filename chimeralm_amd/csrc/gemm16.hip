@@ -521,6 +521,115 @@ __global__ __launch_bounds__(512) void tail16_kernel(TailArgs m, unsigned long l
 #undef CLM_STAMP_AT
 }
 
+// ================================================================================================ score + pool
+// ln_f + attention.0 (256 -> 256) + GELU(erf) + attention.2 (256 -> 1) give the pooling score of every token; the same
+// staged ln_f tile then feeds this tile's share of the attention pooling as an online-softmax partial
+//     m = max_t s_t,   S = sum_t exp(s_t - m),   vec[c] = sum_t exp(s_t - m) * ln_f(h_t)[c]
+// (BinarySequenceClassifier.forward, /root/reference/chimeralm/models/components/hyena.py:117-146; softmax over all L
+// positions).  head_tiles_kernel (head.hip) merges the per-tile partials in a fixed order.  One pass over the residual
+// stream instead of two (the separate score and pool kernels each read all of h).
+struct ScorePoolArgs {
+    const float* h;           // [B, L, 256]
+    const float *ln_g, *ln_b;
+    const void* w1;           // packed attention.0.weight
+    const float *b1, *w2, *b2;
+    float* scores;            // [B, L]
+    float* partial;           // [B, ntiles, POOL_PSTRIDE]: vec[256], m, S
+    int B, L, ntiles;
+    float eps;
+};
+
+template <int PREC>
+__global__ __launch_bounds__(512) void score_pool16_kernel(ScorePoolArgs m) {
+    using elem = typename CT<PREC>::elem;
+    using frag = u16x8;
+    constexpr int BM = 128;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    elem* As = reinterpret_cast<elem*>(smem);
+    float* P = reinterpret_cast<float*>(As + BM * RS16);    // [8 waves][128 tokens] score partials
+    float* E = P + 8 * BM;                                  // [128] softmax numerators
+    float* V = E + BM;                                      // [4 token groups][256] pooled partials
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lrow = lane & 31, lhalf = lane >> 5;
+    const int b = blockIdx.y, tile = blockIdx.x, t0 = tile * BM, L = m.L;
+    const frag* wp = reinterpret_cast<const frag*>(m.w1);
+    f32x16 acc[4];
+    frag bs[2][1][SETK];
+    load_set<PREC, D, 1>(wp, 0, 0, 0, wave, lane, bs[0]);
+    load_set<PREC, D, 1>(wp, 0, 0, 1, wave, lane, bs[1]);
+    __builtin_amdgcn_sched_barrier(0);
+    GemmArgs a{};
+    a.h_in = m.h; a.ln_g = m.ln_g; a.ln_b = m.ln_b; a.L = L; a.eps = m.eps;
+    stage_a_tile<PREC, A_LN, D, 8>(a, As, b, t0, 0);
+    __syncthreads();
+    zero_acc(acc);
+    compute_tm<PREC, true>(As, 0, lrow, lhalf, bs[0], acc);   // rows = features (register quads), lane = token
+    compute_tm<PREC, true>(As, 1, lrow, lhalf, bs[1], acc);
+    {
+        float4 b1v[4], w2v[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            b1v[q] = *reinterpret_cast<const float4*>(m.b1 + wave * 32 + 8 * q + 4 * lhalf);
+            w2v[q] = *reinterpret_cast<const float4*>(m.w2 + wave * 32 + 8 * q + 4 * lhalf);
+        }
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            float s = 0.f;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                s = fmaf(gelu_erf(acc[mt][4 * q + 0] + b1v[q].x), w2v[q].x, s);
+                s = fmaf(gelu_erf(acc[mt][4 * q + 1] + b1v[q].y), w2v[q].y, s);
+                s = fmaf(gelu_erf(acc[mt][4 * q + 2] + b1v[q].z), w2v[q].z, s);
+                s = fmaf(gelu_erf(acc[mt][4 * q + 3] + b1v[q].w), w2v[q].w, s);
+            }
+            s += __shfl_xor(s, 32, 64);
+            if (lhalf == 0) P[wave * BM + mt * 32 + lrow] = s;
+        }
+    }
+    __syncthreads();
+    if (wave == 0) {                                         // 128 tokens: lane handles token lane and lane + 64
+        float sc[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int t = lane + 64 * j;
+            sc[j] = (((P[t] + P[BM + t]) + (P[2 * BM + t] + P[3 * BM + t])) +
+                     ((P[4 * BM + t] + P[5 * BM + t]) + (P[6 * BM + t] + P[7 * BM + t]))) + m.b2[0];
+            if (t0 + t < L) m.scores[(size_t)b * L + t0 + t] = sc[j];
+            else sc[j] = -INFINITY;
+        }
+        const float mx = wave_max(fmaxf(sc[0], sc[1]));       // token t0 is always valid: mx is finite
+        const float e0 = expf(sc[0] - mx), e1 = expf(sc[1] - mx);   // exp(-inf) = 0 for the rows past L
+        E[lane] = e0;
+        E[lane + 64] = e1;
+        const float ssum = wave_sum(e0 + e1);
+        if (lane == 0) {
+            float* out = m.partial + ((size_t)b * m.ntiles + tile) * POOL_PSTRIDE + D;
+            out[0] = mx;
+            out[1] = ssum;
+        }
+    }
+    __syncthreads();
+    {   // vec: thread = (channel pair, 32-token group); the staged ln_f tile is read back as packed pairs
+        const int c2 = tid & 127, g = tid >> 7;
+        float a0 = 0.f, a1 = 0.f;
+#pragma unroll 8
+        for (int i = 0; i < 32; ++i) {
+            const int t = g * 32 + i;
+            const unsigned int pk = *reinterpret_cast<const unsigned int*>(As + t * RS16 + 2 * c2);
+            const float e = E[t];
+            elem lo, hi;
+            lo.bits = (unsigned short)(pk & 0xffffu);
+            hi.bits = (unsigned short)(pk >> 16);
+            a0 = fmaf(e, to_float(lo), a0);
+            a1 = fmaf(e, to_float(hi), a1);
+        }
+        V[g * D + 2 * c2] = a0;
+        V[g * D + 2 * c2 + 1] = a1;
+    }
+    __syncthreads();
+    if (tid < D)
+        m.partial[((size_t)b * m.ntiles + tile) * POOL_PSTRIDE + tid] = (V[tid] + V[D + tid]) + (V[2 * D + tid] + V[3 * D + tid]);
+}
+
 // ================================================================================================ launchers
 template <typename Kern>
 static void set_lds(Kern kern, size_t lds) {
@@ -630,6 +739,22 @@ void launch_tail16(int prec, const void* y, const void* w_out, const float* b_ou
         static bool once = (set_lds(tail16_kernel<PREC_F16, false>, lds), true);
         (void)once;
         hipLaunchKernelGGL((tail16_kernel<PREC_F16, false>), grid, block, lds, st, m, (unsigned long long*)nullptr);
+    }
+}
+
+void launch_score_pool16(int prec, const float* h, const float* g, const float* bta, const void* w1, const float* b1,
+                         const float* w2, const float* b2, float* scores, float* partial, int B, int L, float eps,
+                         hipStream_t st) {
+    const int ntiles = (L + 127) / 128;
+    ScorePoolArgs m{h, g, bta, w1, b1, w2, b2, scores, partial, B, L, ntiles, eps};
+    constexpr size_t lds = (size_t)128 * RS16 * 2 + (size_t)(8 * 128 + 128 + 4 * D) * 4;
+    dim3 grid(ntiles, B), block(512);
+    if (prec == PREC_BF16) {
+        set_lds(score_pool16_kernel<PREC_BF16>, lds);
+        hipLaunchKernelGGL(score_pool16_kernel<PREC_BF16>, grid, block, lds, st, m);
+    } else {
+        set_lds(score_pool16_kernel<PREC_F16>, lds);
+        hipLaunchKernelGGL(score_pool16_kernel<PREC_F16>, grid, block, lds, st, m);
     }
 }
 

@@ -144,6 +144,130 @@ void launch_head_mlp(const float* partial, const HeadW& hw, float* pooled_out, f
     hipLaunchKernelGGL(head_mlp_kernel, dim3(B), dim3(256), 0, st, partial, hw, pooled_out, logits);
 }
 
+// ---------------------------------------------------------------------------------------- 16-bit modes: tiles -> logits
+// Merge of the per-tile online-softmax partials written by score_pool16_kernel, then the classifier for HR reads per
+// workgroup.  The classifier is a chain of four small matrix-vector products whose cost is the latency of streaming
+// the weights from L2, so: every weight element is fetched once per HR reads, each dot product is split in two halves
+// (1024 threads = 512 outputs x 2), and the weight stream runs 16 elements ahead of the FMAs in a register ping-pong.
+constexpr int HR = 4, HT = 1024, MAXTILES = (32770 + 127) / 128;
+
+template <int IN, bool GELU>
+__device__ __forceinline__ void dense_rows(const float* __restrict__ wt, const float* __restrict__ bias,
+                                           const float (*xin)[HH], float (*xout)[HH], const float (*resid)[HH],
+                                           float (*part)[HH]) {
+    constexpr int HALF = IN / 2, PF = 16;
+    static_assert(HALF % (2 * PF) == 0, "two prefetch sets per loop trip");
+    const int o = threadIdx.x & (HH - 1), kh = threadIdx.x >> 9;
+    const float* w = wt + (size_t)kh * HALF * HH + o;
+    float acc[HR];
+#pragma unroll
+    for (int r = 0; r < HR; ++r) acc[r] = 0.f;
+    float wa[PF], wb[PF];
+#pragma unroll
+    for (int j = 0; j < PF; ++j) wa[j] = w[(size_t)j * HH];
+#pragma unroll 1
+    for (int i0 = 0; i0 < HALF; i0 += 2 * PF) {
+#pragma unroll
+        for (int j = 0; j < PF; ++j) wb[j] = w[(size_t)(i0 + PF + j) * HH];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < PF; j += 4)
+#pragma unroll
+            for (int r = 0; r < HR; ++r) {
+                const float4 x = *reinterpret_cast<const float4*>(&xin[r][kh * HALF + i0 + j]);
+                acc[r] = fmaf(wa[j + 3], x.w, fmaf(wa[j + 2], x.z, fmaf(wa[j + 1], x.y, fmaf(wa[j], x.x, acc[r]))));
+            }
+        __builtin_amdgcn_sched_barrier(0);
+        const int nx = i0 + 2 * PF < HALF ? i0 + 2 * PF : 0;     // wrap-around keeps the prefetch unconditional
+#pragma unroll
+        for (int j = 0; j < PF; ++j) wa[j] = w[(size_t)(nx + j) * HH];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < PF; j += 4)
+#pragma unroll
+            for (int r = 0; r < HR; ++r) {
+                const float4 x = *reinterpret_cast<const float4*>(&xin[r][kh * HALF + i0 + PF + j]);
+                acc[r] = fmaf(wb[j + 3], x.w, fmaf(wb[j + 2], x.z, fmaf(wb[j + 1], x.y, fmaf(wb[j], x.x, acc[r]))));
+            }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    if (kh == 1) {
+#pragma unroll
+        for (int r = 0; r < HR; ++r) part[r][o] = acc[r];
+    }
+    __syncthreads();
+    if (kh == 0) {
+        const float bo = bias[o];
+#pragma unroll
+        for (int r = 0; r < HR; ++r) {
+            float v = (acc[r] + part[r][o]) + bo;
+            if (GELU) v = gelu_erf(v);
+            if (resid) v += resid[r][o];
+            xout[r][o] = v;
+        }
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(HT) void head_tiles_kernel(const float* __restrict__ partial, int ntiles, HeadW hw,
+                                                        float* __restrict__ pooled_out, float* __restrict__ logits,
+                                                        int B) {
+    __shared__ __attribute__((aligned(16))) float x0[HR][HH], x1[HR][HH], x2[HR][HH], x3[HR][HH], part[HR][HH];
+    __shared__ float wl[HR][MAXTILES + 3], sl[HR][MAXTILES + 3], red[HR][4];
+    const int tid = threadIdx.x, b0 = blockIdx.x * HR;
+    {   // 1024 threads = HR reads x 256 channels
+        const int r = tid >> 8, c = tid & 255, b = b0 + r, bc = b < B ? b : B - 1, wv = c >> 6, lane = c & 63;
+        const float* p = partial + (size_t)bc * ntiles * POOL_PSTRIDE;
+        float mx = -INFINITY;
+        for (int i = c; i < ntiles; i += 256) {
+            const float2 ms = *reinterpret_cast<const float2*>(p + (size_t)i * POOL_PSTRIDE + D);
+            wl[r][i] = ms.x;
+            sl[r][i] = ms.y;
+            mx = fmaxf(mx, ms.x);
+        }
+        mx = wave_max(mx);
+        if (lane == 0) red[r][wv] = mx;
+        __syncthreads();
+        mx = fmaxf(fmaxf(red[r][0], red[r][1]), fmaxf(red[r][2], red[r][3]));
+        for (int i = c; i < ntiles; i += 256) wl[r][i] = expf(wl[r][i] - mx);
+        __syncthreads();
+        float ssum = 0.f, a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        for (int i = 0; i < ntiles; ++i) ssum = fmaf(sl[r][i], wl[r][i], ssum);      // fixed order: tile 0 .. ntiles-1
+        int i = 0;
+        for (; i + 4 <= ntiles; i += 4) {                                             // four loads in flight, fixed order
+            const float v0 = p[(size_t)i * POOL_PSTRIDE + c], v1 = p[(size_t)(i + 1) * POOL_PSTRIDE + c],
+                        v2 = p[(size_t)(i + 2) * POOL_PSTRIDE + c], v3 = p[(size_t)(i + 3) * POOL_PSTRIDE + c];
+            a0 = fmaf(v0, wl[r][i], a0);
+            a1 = fmaf(v1, wl[r][i + 1], a1);
+            a2 = fmaf(v2, wl[r][i + 2], a2);
+            a3 = fmaf(v3, wl[r][i + 3], a3);
+        }
+        for (; i < ntiles; ++i) a0 = fmaf(p[(size_t)i * POOL_PSTRIDE + c], wl[r][i], a0);
+        const float pooled = ((a0 + a1) + (a2 + a3)) / ssum;
+        if (b < B) pooled_out[(size_t)b * D + c] = pooled;
+        x0[r][c] = pooled;
+    }
+    __syncthreads();
+    dense_rows<D, true>(hw.w0t, hw.b0, x0, x1, nullptr, part);       // classifier.0 + GELU
+    dense_rows<HH, true>(hw.w3t, hw.b3, x1, x2, nullptr, part);      // classifier.3 + GELU
+    dense_rows<HH, true>(hw.w60t, hw.b60, x2, x3, nullptr, part);    // ResidualBlock.layers.0 + GELU
+    dense_rows<HH, false>(hw.w63t, hw.b63, x3, x1, x2, part);        // ResidualBlock.layers.3 + residual
+    if (tid < HR * NCLS) {
+        const int r = tid / NCLS, k = tid % NCLS;
+        if (b0 + r < B) {
+            float acc = hw.bo[k];
+            for (int i = 0; i < HH; ++i) acc = fmaf(hw.wot[(size_t)i * NCLS + k], x1[r][i], acc);
+            logits[(size_t)(b0 + r) * NCLS + k] = acc;
+        }
+    }
+}
+
+void launch_head_tiles(const float* partial, int ntiles, const HeadW& hw, float* pooled_out, float* logits, int B,
+                       hipStream_t st) {
+    hipLaunchKernelGGL(head_tiles_kernel, dim3((B + HR - 1) / HR), dim3(HT), 0, st, partial, ntiles, hw, pooled_out,
+                       logits, B);
+}
+
 __global__ void transpose_kernel(const float* __restrict__ in, float* __restrict__ out, int rows, int cols) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < (size_t)rows * cols) {
