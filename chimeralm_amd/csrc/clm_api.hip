@@ -50,6 +50,8 @@ struct clm_handle {
     // packed / derived weights
     void* packed[NLAYER][4] = {};
     void* packed_score = nullptr;
+    float* ztab = nullptr;        // [16][768] block-0 in_proj rows per token id (16-bit modes)
+    unsigned char* ids8 = nullptr;   // workspace: clamped ids [B][Lp]
     float* head_t[5] = {};
     LayerW lw[NLAYER]{};
     HeadW hw{};
@@ -66,6 +68,7 @@ struct clm_handle {
     // debug / profiling
     int stop_layer = -1, stop_stage = -1;
     bool split_tail = false;      // CLM_SPLIT_TAIL=1: separate out_proj16 + mlp16 kernels instead of the fused tail (A/B runs)
+    bool no_idconv = false;       // CLM_NO_IDCONV=1: run block 0's in_proj instead of the id-table convolution (A/B runs)
     bool force_generic = false;   // CLM_GENERIC_GEMM=1: route 16-bit modes through the generic kernels (A/B runs)
     bool prof = false;
     std::vector<ProfRec> recs;
@@ -199,12 +202,13 @@ void free_filters(clm_handle* h) {
 
 void free_workspace(clm_handle* h) {
     for (void* p : {(void*)h->h, h->z, h->y, h->u, (void*)h->scores, (void*)h->stats, (void*)h->partial,
-                    (void*)h->pooled, (void*)h->gscratch, (void*)h->carry})
+                    (void*)h->pooled, (void*)h->gscratch, (void*)h->carry, (void*)h->ids8})
         if (p) (void)hipFree(p);
     h->gscratch = h->carry = nullptr;
     h->gscratch_elems = 0;
     h->h = nullptr; h->z = h->y = h->u = nullptr;
     h->scores = h->stats = h->partial = h->pooled = nullptr;
+    h->ids8 = nullptr;
     h->ws_B = h->ws_L = 0;
 }
 
@@ -213,6 +217,7 @@ void free_packed(clm_handle* h) {
         for (int j = 0; j < 4; ++j)
             if (h->packed[i][j]) { (void)hipFree(h->packed[i][j]); h->packed[i][j] = nullptr; }
     if (h->packed_score) { (void)hipFree(h->packed_score); h->packed_score = nullptr; }
+    if (h->ztab) { (void)hipFree(h->ztab); h->ztab = nullptr; }
     for (int j = 0; j < 5; ++j)
         if (h->head_t[j]) { (void)hipFree(h->head_t[j]); h->head_t[j] = nullptr; }
 }
@@ -238,6 +243,7 @@ int ensure_workspace(clm_handle* h, int Bc, int L, hipStream_t st) {
         HIPCHK(h, hipMalloc((void**)&h->partial, (size_t)nb * per_read * 4));
     }
     HIPCHK(h, hipMalloc((void**)&h->pooled, (size_t)nb * D * 4));
+    HIPCHK(h, hipMalloc((void**)&h->ids8, (size_t)nb * Lp));
     if (conv_segments_for(nl) > 1) {
         const size_t pairs = (size_t)(nb + 1) / 2, S = (size_t)conv_segments_for(nl);
         h->gscratch_elems = pairs * D * S * 16384;
@@ -353,13 +359,17 @@ int forward_chunk(clm_handle* h, const void* ids, int ids_dtype, int64_t row_str
     h->last_B = Bc; h->last_L = L; h->last_Lp = Lp;
     {
         StageTimer t(h, st, CLM_STAGE_EMBED);
-        launch_embed(ids, ids_dtype, row_stride, W(h, "bb.embeddings.word_embeddings.weight"), h->h, Bc, L, st);
+        launch_embed(ids, ids_dtype, row_stride, W(h, "bb.embeddings.word_embeddings.weight"), h->h, h->ids8, Bc, L, Lp,
+                     st);
     }
     if (stop_here(h, -1, CLM_STAGE_EMBED)) return CLM_OK;
     const bool tuned16 = prec != PREC_F32 && !h->force_generic;
     for (int i = 0; i < NLAYER; ++i) {
         const LayerW& lw = h->lw[i];
-        {
+        // block 0 in the 16-bit modes: its in_proj output is a function of the token id alone, the convolution looks it
+        // up (ztab) -- unless a debug stop asks for z itself, the read needs the segmented kernel, or CLM_NO_IDCONV=1
+        const bool idconv = tuned16 && i == 0 && fs->S == 1 && !h->no_idconv && !stop_here(h, 0, CLM_STAGE_INPROJ);
+        if (!idconv) {
             StageTimer t(h, st, CLM_STAGE_INPROJ);
             if (tuned16) launch_inproj16(prec, h->h, lw.ln1_g, lw.ln1_b, lw.w_in, lw.b_in, h->z, Bc, L, Lp, eps, st);
             else launch_inproj(prec, h->h, lw.ln1_g, lw.ln1_b, lw.w_in, lw.b_in, h->z, Bc, L, Lp, eps, st);
@@ -369,7 +379,7 @@ int forward_chunk(clm_handle* h, const void* ids, int ids_dtype, int64_t row_str
             StageTimer t(h, st, CLM_STAGE_CONV);
             if (fs->S == 1)
                 launch_hyena_conv(prec, h->z, h->y, fs->kf[i], fs->tw, fs->ktime[i], lw.short_w, lw.short_b, Bc, L, Lp,
-                                  fs->logn, st);
+                                  fs->logn, idconv ? h->ids8 : nullptr, idconv ? h->ztab : nullptr, st);
             else
                 launch_hyena_conv_seg(prec, h->z, h->y, fs->kf[i], fs->tw, lw.short_w, lw.short_b, h->gscratch,
                                       h->carry, Bc, L, Lp, fs->S, st);
@@ -470,6 +480,7 @@ int clm_create(const clm_config* cfg, int device, clm_handle** out) {
         return fail(nullptr, CLM_E_UNSUPPORTED, std::string("this engine is built for gfx950 (MI355X) only, found ") + prop.gcnArchName);
     clm_handle* h = new clm_handle();
     h->force_generic = std::getenv("CLM_GENERIC_GEMM") && std::getenv("CLM_GENERIC_GEMM")[0] == '1';
+    h->no_idconv = std::getenv("CLM_NO_IDCONV") && std::getenv("CLM_NO_IDCONV")[0] == '1';
     h->split_tail = std::getenv("CLM_SPLIT_TAIL") && std::getenv("CLM_SPLIT_TAIL")[0] == '1';
     h->cfg = *cfg;
     h->device = device;
@@ -558,6 +569,10 @@ int clm_finalize(clm_handle* h) {
         int rc;
         if ((rc = pack("head.attention.0.weight", D, D, &h->packed_score))) return rc;
     }
+    HIPCHK(h, hipMalloc((void**)&h->ztab, (size_t)VOCAB * D3 * 4));
+    launch_ztab(W(h, "bb.embeddings.word_embeddings.weight"), W(h, "bb.layers.0.norm1.weight"),
+                W(h, "bb.layers.0.norm1.bias"), W(h, "bb.layers.0.mixer.in_proj.weight"),
+                W(h, "bb.layers.0.mixer.in_proj.bias"), h->ztab, h->cfg.ln_eps, st);
     struct { const char* key; int rows, cols; } tr[5] = {
         {"head.classifier.0.weight", HH, D}, {"head.classifier.3.weight", HH, HH},
         {"head.classifier.6.layers.0.weight", HH, HH}, {"head.classifier.6.layers.3.weight", HH, HH},

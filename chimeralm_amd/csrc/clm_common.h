@@ -109,8 +109,8 @@ struct LayerW {            // device pointers, fp32 unless noted
 };
 
 // embedding gather: ids [B, L] (dtype code CLM_DT_*) -> h fp32 [B, L, 256]
-void launch_embed(const void* ids, int ids_dtype, int64_t row_stride, const float* table, float* h, int B, int L,
-                  hipStream_t st);
+void launch_embed(const void* ids, int ids_dtype, int64_t row_stride, const float* table, float* h,
+                  unsigned char* ids8 /*[B][Lp] clamped ids, may be null*/, int B, int L, int Lp, hipStream_t st);
 
 // GEMM family (gemm.hip).  `prec` selects compute dtype; T16 activations are bf16/f16 (or fp32 for PREC_F32).
 // z  = in_proj(LN1(h))      -> channel-major [B, 768, Lp]
@@ -158,8 +158,13 @@ void launch_filter_spectrum(const float* k /*[L][256]*/, const float* dskip /*[2
                             double2* scratch, int L, int logn, int seg_off, int seg_len, hipStream_t st);
 void launch_twiddles(float2* tw, int logn, hipStream_t st);   // tw[m] = exp(-2 pi i m / N), m < N/2
 // y = ((causal_conv(v*x1, k) + D*(v*x1)) * x0)   with (x0,x1,v) = short_filter(z)    [B,256,Lp]; D lives in kf
+// ids8/ztab non-null (16-bit modes, block 0): x0|x1|v come from the 16-row table ztab[id][768] via the token ids
+// ids8 [B][Lp] instead of z (in_proj of block 0 is not launched)
 void launch_hyena_conv(int prec, const void* z, void* y, const float2* kf, const float2* tw, const float* ktime,
-                       const float* short_w, const float* short_b, int B, int L, int Lp, int logn, hipStream_t st);
+                       const float* short_w, const float* short_b, int B, int L, int Lp, int logn,
+                       const unsigned char* ids8, const float* ztab, hipStream_t st);
+void launch_ztab(const float* emb, const float* g, const float* bta, const float* w, const float* bias, float* ztab,
+                 float eps, hipStream_t st);
 
 // long reads (L > 8193): overlap-add over S segments; kf [256][S][N], gscratch [pairs][256][S][N], carry [pairs][256][8192]
 void launch_hyena_conv_seg(int prec, const void* z, void* y, const float2* kf, const float2* tw, const float* short_w,

@@ -13,8 +13,8 @@ namespace clm {
 // ---------------------------------------------------------------------------------------- embedding
 template <typename IdT>
 __global__ __launch_bounds__(256) void embed_kernel(const IdT* __restrict__ ids, int64_t row_stride,
-                                                    const float* __restrict__ table, float* __restrict__ h, int B,
-                                                    int L) {
+                                                    const float* __restrict__ table, float* __restrict__ h,
+                                                    unsigned char* __restrict__ ids8, int B, int L, int Lp) {
     // one wave per token row: 64 lanes x float4 = 1 KiB
     const int lane = threadIdx.x & 63;
     const size_t tok = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -22,19 +22,20 @@ __global__ __launch_bounds__(256) void embed_kernel(const IdT* __restrict__ ids,
     const int b = int(tok / L), t = int(tok % L);
     int id = (int)ids[(size_t)b * row_stride + t];
     id = id < 0 ? 0 : (id >= VOCAB ? VOCAB - 1 : id);
+    if (ids8 && lane == 0) ids8[(size_t)b * Lp + t] = (unsigned char)id;   // compact copy for the block-0 conv
     const float4 v = *reinterpret_cast<const float4*>(table + (size_t)id * D + lane * 4);
     *reinterpret_cast<float4*>(h + tok * D + lane * 4) = v;
 }
 
-void launch_embed(const void* ids, int ids_dtype, int64_t row_stride, const float* table, float* h, int B, int L,
-                  hipStream_t st) {
+void launch_embed(const void* ids, int ids_dtype, int64_t row_stride, const float* table, float* h,
+                  unsigned char* ids8, int B, int L, int Lp, hipStream_t st) {
     dim3 grid((unsigned)(((size_t)B * L + 3) / 4)), block(256);
     if (ids_dtype == CLM_DT_I64)
-        hipLaunchKernelGGL(embed_kernel<int64_t>, grid, block, 0, st, (const int64_t*)ids, row_stride, table, h, B, L);
+        hipLaunchKernelGGL(embed_kernel<int64_t>, grid, block, 0, st, (const int64_t*)ids, row_stride, table, h, ids8, B, L, Lp);
     else if (ids_dtype == CLM_DT_I32)
-        hipLaunchKernelGGL(embed_kernel<int32_t>, grid, block, 0, st, (const int32_t*)ids, row_stride, table, h, B, L);
+        hipLaunchKernelGGL(embed_kernel<int32_t>, grid, block, 0, st, (const int32_t*)ids, row_stride, table, h, ids8, B, L, Lp);
     else
-        hipLaunchKernelGGL(embed_kernel<uint8_t>, grid, block, 0, st, (const uint8_t*)ids, row_stride, table, h, B, L);
+        hipLaunchKernelGGL(embed_kernel<uint8_t>, grid, block, 0, st, (const uint8_t*)ids, row_stride, table, h, ids8, B, L, Lp);
 }
 
 // ---------------------------------------------------------------------------------------- softmax statistics

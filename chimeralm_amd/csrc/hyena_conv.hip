@@ -276,6 +276,18 @@ __device__ __forceinline__ void raw_decode(const Raw<T>& r, int t0, bool valid, 
         x[2 * i + 1] = to_float(hi);
     }
 }
+// IDS source: x[a3][0..9] = table row a3 of the ten token ids t0-2 .. t0+7 (zero outside the read)
+__device__ __forceinline__ void ids_decode(uint2 d, unsigned short p, int t0, bool valid, const float* zt, float (*x)[10]) {
+    const unsigned w[3] = {p, d.x, d.y};
+#pragma unroll
+    for (int j = 0; j < 10; ++j) {
+        const int sh = j < 2 ? 8 * j : 8 * ((j - 2) & 3);
+        const unsigned id = (w[j < 2 ? 0 : 1 + ((j - 2) >> 2)] >> sh) & 15u;
+        const bool ok = j < 2 ? (valid && t0 > 0) : valid;
+#pragma unroll
+        for (int a3 = 0; a3 < 3; ++a3) x[a3][j] = ok ? zt[a3 * 16 + id] : 0.f;
+    }
+}
 __device__ __forceinline__ void fir3(const float* x /*[10]*/, float w0, float w1, float w2, float bias, float* out /*[8]*/) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) out[e] = bias + w0 * x[e] + w1 * x[e + 1] + w2 * x[e + 2];
@@ -299,11 +311,14 @@ __device__ __forceinline__ void lds_load8(const float* src, float* v) {
 //   phase C  LDS -> * x0 -> y
 // STAMP: developer build (CLM_STAMP=1, 16384-point f16 instantiation only) recording s_memtime at phase boundaries.
 constexpr int CONV_NSTAMP = 16;
-template <int LOGN, typename T, bool STAMP = false>
+// IDS: first block only.  The residual stream entering block 0 is the embedding row of the token id, so the block's
+// in_proj output is one of 16 precomputed rows (ztab, fp32): the kernel reads the ids (1 byte per token, shared by all 256
+// channel workgroups of a read) and looks x0 / x1 / v up instead of reading z -- in_proj of block 0 is never launched.
+template <int LOGN, typename T, bool STAMP = false, bool IDS = false>
 __global__ __launch_bounds__(Plan<LOGN>::NT) void hyena_conv_kernel(
     const T* __restrict__ z, T* __restrict__ y, const float2* __restrict__ kf, const float2* __restrict__ tw,
     const float* __restrict__ ktime, const float* __restrict__ short_w, const float* __restrict__ short_b, int B, int L,
-    int Lp, unsigned long long* stamps) {
+    int Lp, unsigned long long* stamps, const unsigned char* __restrict__ ids8, const float* __restrict__ ztab) {
 #define CLM_STAMP_AT(k)                                                                                   \
     do {                                                                                                  \
         if (STAMP && threadIdx.x == 0)                                                                    \
@@ -358,20 +373,41 @@ __global__ __launch_bounds__(Plan<LOGN>::NT) void hyena_conv_kernel(
     // every global load of the phase is issued before the first use (see Raw<T>)
     constexpr int TAIL_TID = HALF / 8 - 1 - (CH - 1) * NT;   // owner of tokens [HALF-8, HALF): also computes token HALF
     const bool tail = (L == HALF + 1);
-    Raw<T> raw[CH][2][3];
+    Raw<T> raw[IDS ? 1 : CH][2][IDS ? 1 : 3];
     T ztail[2][3];
+    uint2 idd[CH][2];                                        // IDS: 8 token ids of the chunk
+    unsigned short idp[CH][2];                               //      and the two before it
+    unsigned char idt[2] = {0, 0};
+    float* zt = bim + padded_size(N) + 4;                    // IDS: [3][16] rows x0 | x1 | v of this channel
+    if constexpr (IDS) {
+        if (tid < 48) zt[tid] = ztab[(size_t)(tid & 15) * D3 + (tid >> 4) * D + c];
 #pragma unroll
-    for (int rd = 0; rd < 2; ++rd) {
-        const T* zr = rd == 0 ? zA : zB;
-#pragma unroll
-        for (int a3 = 0; a3 < 3; ++a3) {
-            const T* row = zr + (size_t)(a3 * D + c) * Lp;
+        for (int rd = 0; rd < 2; ++rd) {
+            const unsigned char* ir = ids8 + (size_t)(rd == 0 ? bA : (hasB ? bB : bA)) * Lp;
 #pragma unroll
             for (int ch = 0; ch < CH; ++ch) {
                 const int t0 = 8 * (tid + ch * NT);
-                raw_load(raw[ch][rd][a3], row, t0, t0 < HALF && t0 < L);
+                const bool valid = t0 < HALF && t0 < L;
+                idd[ch][rd] = *reinterpret_cast<const uint2*>(ir + (valid ? t0 : 0));
+                idp[ch][rd] = *reinterpret_cast<const unsigned short*>(ir + ((valid && t0 > 0) ? t0 - 2 : 0));
             }
-            ztail[rd][a3] = row[(tail && tid == TAIL_TID) ? HALF : 0];
+            idt[rd] = ir[(tail && tid == TAIL_TID) ? HALF : 0];
+        }
+        __syncthreads();                                     // zt visible
+    } else {
+#pragma unroll
+        for (int rd = 0; rd < 2; ++rd) {
+            const T* zr = rd == 0 ? zA : zB;
+#pragma unroll
+            for (int a3 = 0; a3 < 3; ++a3) {
+                const T* row = zr + (size_t)(a3 * D + c) * Lp;
+#pragma unroll
+                for (int ch = 0; ch < CH; ++ch) {
+                    const int t0 = 8 * (tid + ch * NT);
+                    raw_load(raw[ch][rd][a3], row, t0, t0 < HALF && t0 < L);
+                }
+                ztail[rd][a3] = row[(tail && tid == TAIL_TID) ? HALF : 0];
+            }
         }
     }
     float x0A[CH][8], x0B[CH][8];
@@ -382,10 +418,15 @@ __global__ __launch_bounds__(Plan<LOGN>::NT) void hyena_conv_kernel(
         if (t0 < HALF) {
             const bool valid = t0 < L;
             float xa[3][10], xb[3][10], gA[8], gB[8], x1[8], v[8];
+            if constexpr (IDS) {
+                ids_decode(idd[ch][0], idp[ch][0], t0, valid, zt, xa);
+                ids_decode(idd[ch][1], idp[ch][1], t0, valid && hasB, zt, xb);
+            } else {
 #pragma unroll
-            for (int a3 = 0; a3 < 3; ++a3) {
-                raw_decode(raw[ch][0][a3], t0, valid, xa[a3]);
-                raw_decode(raw[ch][1][a3], t0, valid && hasB, xb[a3]);
+                for (int a3 = 0; a3 < 3; ++a3) {
+                    raw_decode(raw[ch][0][a3], t0, valid, xa[a3]);
+                    raw_decode(raw[ch][1][a3], t0, valid && hasB, xb[a3]);
+                }
             }
             fir3(xa[0], sw[0][0], sw[0][1], sw[0][2], sb[0], x0A[ch]);
             fir3(xa[1], sw[1][0], sw[1][1], sw[1][2], sb[1], x1);
@@ -403,8 +444,10 @@ __global__ __launch_bounds__(Plan<LOGN>::NT) void hyena_conv_kernel(
                 float ta[3], tb[3];
 #pragma unroll
                 for (int a3 = 0; a3 < 3; ++a3) {
-                    ta[a3] = sb[a3] + sw[a3][0] * xa[a3][8] + sw[a3][1] * xa[a3][9] + sw[a3][2] * to_float(ztail[0][a3]);
-                    tb[a3] = sb[a3] + sw[a3][0] * xb[a3][8] + sw[a3][1] * xb[a3][9] + sw[a3][2] * to_float(ztail[1][a3]);
+                    const float za = IDS ? zt[a3 * 16 + (idt[0] & 15)] : to_float(ztail[0][a3]);
+                    const float zb = IDS ? zt[a3 * 16 + (idt[1] & 15)] : to_float(ztail[1][a3]);
+                    ta[a3] = sb[a3] + sw[a3][0] * xa[a3][8] + sw[a3][1] * xa[a3][9] + sw[a3][2] * za;
+                    tb[a3] = sb[a3] + sw[a3][0] * xb[a3][8] + sw[a3][1] * xb[a3][9] + sw[a3][2] * zb;
                 }
                 x0At = ta[0];
                 gAt = ta[1] * ta[2];
@@ -729,6 +772,37 @@ void launch_hyena_conv_seg(int prec, const void* z, void* y, const float2* kf, c
         launch_conv_seg_t<f16_t>(z, y, kf, tw, short_w, short_b, gscratch, carry, B, L, Lp, S, st);
 }
 
+// ztab[id][n] = in_proj(LN1(embedding[id]))[n] of block 0, fp32: one workgroup per token id
+__global__ __launch_bounds__(256) void ztab_kernel(const float* __restrict__ emb, const float* __restrict__ g,
+                                                   const float* __restrict__ bta, const float* __restrict__ w,
+                                                   const float* __restrict__ bias, float* __restrict__ ztab, float eps) {
+    __shared__ float xn[D], red[4];
+    const int id = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float x = emb[(size_t)id * D + tid];
+    float s = wave_sum(x);
+    if (lane == 0) red[wave] = s;
+    __syncthreads();
+    const float mean = ((red[0] + red[1]) + (red[2] + red[3])) * (1.0f / D);
+    __syncthreads();
+    const float d = x - mean;
+    s = wave_sum(d * d);
+    if (lane == 0) red[wave] = s;
+    __syncthreads();
+    const float var = ((red[0] + red[1]) + (red[2] + red[3])) * (1.0f / D);
+    xn[tid] = d * (1.0f / sqrtf(var + eps)) * g[tid] + bta[tid];
+    __syncthreads();
+    for (int n = tid; n < D3; n += 256) {
+        const float* wr = w + (size_t)n * D;
+        float acc = 0.f;
+        for (int k = 0; k < D; ++k) acc = fmaf(wr[k], xn[k], acc);
+        ztab[(size_t)id * D3 + n] = acc + bias[n];
+    }
+}
+void launch_ztab(const float* emb, const float* g, const float* bta, const float* w, const float* bias, float* ztab,
+                 float eps, hipStream_t st) {
+    hipLaunchKernelGGL(ztab_kernel, dim3(VOCAB), dim3(256), 0, st, emb, g, bta, w, bias, ztab, eps);
+}
+
 static unsigned long long* s_conv_stamp_buf = nullptr;
 static size_t s_conv_stamp_wgs = 0;
 void conv_dump_stamps() {
@@ -765,10 +839,24 @@ void conv_dump_stamps() {
 
 template <int LOGN, typename T>
 static void launch_conv_t(const void* z, void* y, const float2* kf, const float2* tw, const float* ktime,
-                          const float* short_w, const float* short_b, int B, int L, int Lp, hipStream_t st) {
+                          const float* short_w, const float* short_b, int B, int L, int Lp, const unsigned char* ids8,
+                          const float* ztab, hipStream_t st) {
     using P = Plan<LOGN>;
-    constexpr size_t lds = (size_t)2 * padded_size(P::N) * sizeof(float) + 16;
+    constexpr size_t lds = (size_t)2 * padded_size(P::N) * sizeof(float) + 256;   // + g[N/2] pair + the 3x16 id table
     dim3 grid((B + 1) / 2, D), block(P::NT);
+    if constexpr (!std::is_same<T, float>::value) {
+        if (ids8) {
+            auto kern = hyena_conv_kernel<LOGN, T, false, true>;
+            static bool ids_attr_done = false;
+            if (!ids_attr_done) {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                ids_attr_done = true;
+            }
+            hipLaunchKernelGGL(kern, grid, block, lds, st, (const T*)nullptr, reinterpret_cast<T*>(y), kf, tw, ktime, short_w,
+                               short_b, B, L, Lp, (unsigned long long*)nullptr, ids8, ztab);
+            return;
+        }
+    }
     if constexpr (LOGN == 14 && std::is_same<T, f16_t>::value) {
         static const bool stamp = std::getenv("CLM_STAMP") && std::getenv("CLM_STAMP")[0] == '1';
         if (stamp) {
@@ -783,7 +871,7 @@ static void launch_conv_t(const void* z, void* y, const float2* kf, const float2
             }
             (void)hipMemsetAsync(s_conv_stamp_buf, 0, wgs * CONV_NSTAMP * 8, st);
             hipLaunchKernelGGL(kern, grid, block, lds, st, reinterpret_cast<const T*>(z), reinterpret_cast<T*>(y), kf, tw, ktime,
-                               short_w, short_b, B, L, Lp, s_conv_stamp_buf);
+                               short_w, short_b, B, L, Lp, s_conv_stamp_buf, (const unsigned char*)nullptr, (const float*)nullptr);
             return;
         }
     }
@@ -795,26 +883,27 @@ static void launch_conv_t(const void* z, void* y, const float2* kf, const float2
         attr_done = true;
     }
     hipLaunchKernelGGL(kern, grid, block, lds, st, reinterpret_cast<const T*>(z), reinterpret_cast<T*>(y), kf, tw,
-                       ktime, short_w, short_b, B, L, Lp, (unsigned long long*)nullptr);
+                       ktime, short_w, short_b, B, L, Lp, (unsigned long long*)nullptr, (const unsigned char*)nullptr,
+                       (const float*)nullptr);
 }
 
 template <int LOGN>
 static void launch_conv_p(int prec, const void* z, void* y, const float2* kf, const float2* tw, const float* ktime,
-                          const float* short_w, const float* short_b, int B, int L, int Lp,
-                          hipStream_t st) {
+                          const float* short_w, const float* short_b, int B, int L, int Lp, const unsigned char* ids8,
+                          const float* ztab, hipStream_t st) {
     if (prec == PREC_F32)
-        launch_conv_t<LOGN, float>(z, y, kf, tw, ktime, short_w, short_b, B, L, Lp, st);
+        launch_conv_t<LOGN, float>(z, y, kf, tw, ktime, short_w, short_b, B, L, Lp, nullptr, nullptr, st);
     else if (prec == PREC_BF16)
-        launch_conv_t<LOGN, bf16_t>(z, y, kf, tw, ktime, short_w, short_b, B, L, Lp, st);
+        launch_conv_t<LOGN, bf16_t>(z, y, kf, tw, ktime, short_w, short_b, B, L, Lp, ids8, ztab, st);
     else
-        launch_conv_t<LOGN, f16_t>(z, y, kf, tw, ktime, short_w, short_b, B, L, Lp, st);
+        launch_conv_t<LOGN, f16_t>(z, y, kf, tw, ktime, short_w, short_b, B, L, Lp, ids8, ztab, st);
 }
 
 void launch_hyena_conv(int prec, const void* z, void* y, const float2* kf, const float2* tw, const float* ktime,
                        const float* short_w, const float* short_b, int B, int L, int Lp, int logn,
-                       hipStream_t st) {
+                       const unsigned char* ids8, const float* ztab, hipStream_t st) {
 #define CLM_CONV_CASE(n) \
-    case n: launch_conv_p<n>(prec, z, y, kf, tw, ktime, short_w, short_b, B, L, Lp, st); break;
+    case n: launch_conv_p<n>(prec, z, y, kf, tw, ktime, short_w, short_b, B, L, Lp, ids8, ztab, st); break;
     switch (logn) {
         CLM_CONV_CASE(8)
         CLM_CONV_CASE(9)

@@ -114,6 +114,29 @@ def test_determinism_and_chunk_invariance(sd, built_lib):
     e1.close(), e2.close()
 
 
+@pytest.mark.parametrize("prec", ["fp16", "bf16"])
+def test_block0_id_table_convolution_matches_in_proj_path(sd, built_lib, monkeypatch, prec):
+    """16-bit modes skip block 0's in_proj: the convolution looks x0|x1|v up by token id (ztab).  Same logits as the
+    explicit in_proj path (CLM_NO_IDCONV=1) up to the 16-bit rounding of z that the table path does not have; covers every
+    token id (specials, N, out-of-vocabulary ids clamp) and both read parities of a pair."""
+    from chimeralm_amd.engine import Engine
+
+    ids = _ids(5, 1000, seed=5).astype(np.int64)
+    ids[0, :16] = np.arange(16)
+    ids[1, -3:] = [40, 200, 15]                 # clamped to the last row like the reference's 16-row table allows
+    t = torch.from_numpy(ids).cuda()
+    e1 = Engine("cuda:0", precision=prec, chunk_reads=8)
+    monkeypatch.setenv("CLM_NO_IDCONV", "1")
+    e2 = Engine("cuda:0", precision=prec, chunk_reads=8)
+    monkeypatch.delenv("CLM_NO_IDCONV")
+    e1.load_state_dict(sd), e2.load_state_dict(sd)
+    a, b = e1.forward(t).cpu(), e2.forward(t).cpu()
+    assert (a - b).abs().max() < TOL[prec]
+    decided = (b[:, 0] - b[:, 1]).abs() > MARGIN[prec]
+    assert torch.equal(a.argmax(1)[decided], b.argmax(1)[decided])
+    e1.close(), e2.close()
+
+
 @pytest.mark.parametrize("prec", ["fp32", "fp16"])
 def test_full_size_8k_reads(engines, sd, prec):
     """BASELINE config size (8192 bases + [SEP] = 8193 tokens, FFT size 16384 with the aliased tail)."""
