@@ -357,18 +357,21 @@ int forward_chunk(clm_handle* h, const void* ids, int ids_dtype, int64_t row_str
     rc = ensure_workspace(h, Bc, L, st);
     if (rc) return rc;
     h->last_B = Bc; h->last_L = L; h->last_Lp = Lp;
+    const bool tuned16 = prec != PREC_F32 && !h->force_generic;
+    // 16-bit modes, reads that fit one transform, no debug stop: block 0 never touches the fp32 embedding rows in HBM --
+    // its in_proj is a 16-row table looked up by the convolution and its residual is gathered from the embedding table
+    const bool idpath = tuned16 && fs->S == 1 && !h->no_idconv && !h->split_tail && h->stop_stage < 0;
     {
         StageTimer t(h, st, CLM_STAGE_EMBED);
-        launch_embed(ids, ids_dtype, row_stride, W(h, "bb.embeddings.word_embeddings.weight"), h->h, h->ids8, Bc, L, Lp,
-                     st);
+        launch_embed(ids, ids_dtype, row_stride, W(h, "bb.embeddings.word_embeddings.weight"), idpath ? nullptr : h->h,
+                     h->ids8, Bc, L, Lp, st);
     }
     if (stop_here(h, -1, CLM_STAGE_EMBED)) return CLM_OK;
-    const bool tuned16 = prec != PREC_F32 && !h->force_generic;
     for (int i = 0; i < NLAYER; ++i) {
         const LayerW& lw = h->lw[i];
         // block 0 in the 16-bit modes: its in_proj output is a function of the token id alone, the convolution looks it
         // up (ztab) -- unless a debug stop asks for z itself, the read needs the segmented kernel, or CLM_NO_IDCONV=1
-        const bool idconv = tuned16 && i == 0 && fs->S == 1 && !h->no_idconv && !stop_here(h, 0, CLM_STAGE_INPROJ);
+        const bool idconv = i == 0 && (idpath || (tuned16 && fs->S == 1 && !h->no_idconv && !stop_here(h, 0, CLM_STAGE_INPROJ)));
         if (!idconv) {
             StageTimer t(h, st, CLM_STAGE_INPROJ);
             if (tuned16) launch_inproj16(prec, h->h, lw.ln1_g, lw.ln1_b, lw.w_in, lw.b_in, h->z, Bc, L, Lp, eps, st);
@@ -389,7 +392,8 @@ int forward_chunk(clm_handle* h, const void* ids, int ids_dtype, int64_t row_str
         if (tuned16 && !h->split_tail && !stop_mid) {   // out_proj + LN2 + fc1 + GELU + fc2 + both residuals: one kernel
             StageTimer t(h, st, CLM_STAGE_TAIL);
             launch_tail16(prec, h->y, lw.w_out, lw.b_out, h->h, lw.ln2_g, lw.ln2_b, lw.w_fc1, lw.b_fc1, lw.w_fc2, lw.b_fc2,
-                          Bc, L, Lp, eps, st);
+                          Bc, L, Lp, eps, (idpath && i == 0) ? h->ids8 : nullptr,
+                          W(h, "bb.embeddings.word_embeddings.weight"), st);
         } else {
             {
                 StageTimer t(h, st, CLM_STAGE_OUTPROJ);

@@ -137,8 +137,9 @@ void launch_mlp16(int prec, float* h, const float* g, const float* b, const void
                   const float* b2, int B, int L, float eps, hipStream_t st);
 // second half of a block in one kernel: h = r + fc2(gelu(fc1(LN2(r)))), r = h + out_proj(y^T)
 void launch_tail16(int prec, const void* y, const void* w_out, const float* b_out, float* h, const float* g,
-                   const float* b, const void* w1, const float* b1, const void* w2, const float* b2, int B, int L, int Lp,
-                   float eps, hipStream_t st);
+                   const float* bta, const void* w1, const float* b1, const void* w2, const float* b2, int B, int L, int Lp,
+                   float eps, const unsigned char* ids8 /*block 0: residual = emb[id], else null*/, const float* emb,
+                   hipStream_t st);
 void tail16_dump_stamps();   // developer build only (CLM_STAMP=1)
 void conv_dump_stamps();
 size_t packed_weight_bytes(int prec, int n, int k);

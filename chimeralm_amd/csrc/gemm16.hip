@@ -314,6 +314,8 @@ struct TailArgs {
     const float *b_out, *ln_g, *ln_b, *b1, *b2;
     int B, L, Lp;
     float eps;
+    const unsigned char* ids8;   // block 0 only (else null): the incoming residual row of token t is emb[ids8[b][t]],
+    const float* emb;            // read from the 16-row table instead of h (the embedding kernel then never writes h)
 };
 
 // STAMP: developer build (CLM_STAMP=1) that records s_memtime at the phase boundaries of wave 0 of every workgroup into
@@ -351,8 +353,9 @@ __global__ __launch_bounds__(512) void tail16_kernel(TailArgs m, unsigned long l
     float4 hv[4][4];                                       // residual in accumulator layout: token mt*32+lrow, 4 features
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) {
-        const int t = t0 + mt * 32 + lrow;
-        const float* row = m.h + ((size_t)b * L + (t < L ? t : 0)) * D + wave * 32 + 4 * lhalf;
+        const int t = t0 + mt * 32 + lrow, tc = t < L ? t : 0;
+        const float* row = m.ids8 ? m.emb + (size_t)m.ids8[(size_t)b * Lp + tc] * D + wave * 32 + 4 * lhalf
+                                  : m.h + ((size_t)b * L + tc) * D + wave * 32 + 4 * lhalf;
 #pragma unroll
         for (int q = 0; q < 4; ++q) hv[mt][q] = *reinterpret_cast<const float4*>(row + 8 * q);
     }
@@ -712,8 +715,8 @@ void tail16_dump_stamps() {
 
 void launch_tail16(int prec, const void* y, const void* w_out, const float* b_out, float* h, const float* g,
                    const float* bta, const void* w1, const float* b1, const void* w2, const float* b2, int B, int L, int Lp,
-                   float eps, hipStream_t st) {
-    TailArgs m{y, h, w_out, w1, w2, b_out, g, bta, b1, b2, B, L, Lp, eps};
+                   float eps, const unsigned char* ids8, const float* emb, hipStream_t st) {
+    TailArgs m{y, h, w_out, w1, w2, b_out, g, bta, b1, b2, B, L, Lp, eps, ids8, emb};
     constexpr size_t lds = (size_t)2 * 128 * RS16 * 2 + (size_t)2 * 16 * 128 * 4;
     static_assert((size_t)D * RSKM * 2 <= (size_t)2 * 128 * RS16 * 2, "y tile must fit under the partial tables");
     dim3 grid((L + 127) / 128, B), block(512);

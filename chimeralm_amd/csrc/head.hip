@@ -23,12 +23,35 @@ __global__ __launch_bounds__(256) void embed_kernel(const IdT* __restrict__ ids,
     int id = (int)ids[(size_t)b * row_stride + t];
     id = id < 0 ? 0 : (id >= VOCAB ? VOCAB - 1 : id);
     if (ids8 && lane == 0) ids8[(size_t)b * Lp + t] = (unsigned char)id;   // compact copy for the block-0 conv
-    const float4 v = *reinterpret_cast<const float4*>(table + (size_t)id * D + lane * 4);
-    *reinterpret_cast<float4*>(h + tok * D + lane * 4) = v;
+    if (h) {
+        const float4 v = *reinterpret_cast<const float4*>(table + (size_t)id * D + lane * 4);
+        *reinterpret_cast<float4*>(h + tok * D + lane * 4) = v;
+    }
+}
+
+// ids only (16-bit modes, block 0 reads the embedding through the id tables): one thread per token
+template <typename IdT>
+__global__ __launch_bounds__(256) void ids8_kernel(const IdT* __restrict__ ids, int64_t row_stride,
+                                                   unsigned char* __restrict__ ids8, int B, int L, int Lp) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (size_t)B * Lp) return;
+    const int b = int(i / Lp), t = int(i % Lp);
+    int id = t < L ? (int)ids[(size_t)b * row_stride + t] : 0;
+    ids8[i] = (unsigned char)(id < 0 ? 0 : (id >= VOCAB ? VOCAB - 1 : id));
 }
 
 void launch_embed(const void* ids, int ids_dtype, int64_t row_stride, const float* table, float* h,
                   unsigned char* ids8, int B, int L, int Lp, hipStream_t st) {
+    if (!h) {
+        dim3 g1((unsigned)(((size_t)B * Lp + 255) / 256)), b1(256);
+        if (ids_dtype == CLM_DT_I64)
+            hipLaunchKernelGGL(ids8_kernel<int64_t>, g1, b1, 0, st, (const int64_t*)ids, row_stride, ids8, B, L, Lp);
+        else if (ids_dtype == CLM_DT_I32)
+            hipLaunchKernelGGL(ids8_kernel<int32_t>, g1, b1, 0, st, (const int32_t*)ids, row_stride, ids8, B, L, Lp);
+        else
+            hipLaunchKernelGGL(ids8_kernel<uint8_t>, g1, b1, 0, st, (const uint8_t*)ids, row_stride, ids8, B, L, Lp);
+        return;
+    }
     dim3 grid((unsigned)(((size_t)B * L + 3) / 4)), block(256);
     if (ids_dtype == CLM_DT_I64)
         hipLaunchKernelGGL(embed_kernel<int64_t>, grid, block, 0, st, (const int64_t*)ids, row_stride, table, h, ids8, B, L, Lp);
