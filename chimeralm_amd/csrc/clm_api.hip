@@ -68,6 +68,7 @@ struct clm_handle {
     // debug / profiling
     int stop_layer = -1, stop_stage = -1;
     bool split_tail = false;      // CLM_SPLIT_TAIL=1: separate out_proj16 + mlp16 kernels instead of the fused tail (A/B runs)
+    bool no_fuse_next = false;    // CLM_NO_FUSE_NEXT=1: separate in_proj / score kernels instead of fusing them into the tail
     bool no_idconv = false;       // CLM_NO_IDCONV=1: run block 0's in_proj instead of the id-table convolution (A/B runs)
     bool force_generic = false;   // CLM_GENERIC_GEMM=1: route 16-bit modes through the generic kernels (A/B runs)
     bool prof = false;
@@ -361,6 +362,12 @@ int forward_chunk(clm_handle* h, const void* ids, int ids_dtype, int64_t row_str
     // 16-bit modes, reads that fit one transform, no debug stop: block 0 never touches the fp32 embedding rows in HBM --
     // its in_proj is a 16-row table looked up by the convolution and its residual is gathered from the embedding table
     const bool idpath = tuned16 && fs->S == 1 && !h->no_idconv && !h->split_tail && h->stop_stage < 0;
+    // ... and every block's tail kernel goes on, on the tile it has just produced, with LayerNorm-1 + in_proj of the next
+    // block (the last block: ln_f + attention scores + pooling partials): no separate in_proj / score launches
+    const bool fuse_next = tuned16 && !h->split_tail && !h->no_fuse_next && h->stop_stage < 0;
+    const ScorePoolArgs spa{h->h, W(h, "bb.ln_f.weight"), W(h, "bb.ln_f.bias"), h->packed_score,
+                            W(h, "head.attention.0.bias"), W(h, "head.attention.2.weight"),
+                            W(h, "head.attention.2.bias"), h->scores, h->partial, Bc, L, (L + 127) / 128, eps};
     {
         StageTimer t(h, st, CLM_STAGE_EMBED);
         launch_embed(ids, ids_dtype, row_stride, W(h, "bb.embeddings.word_embeddings.weight"), idpath ? nullptr : h->h,
@@ -372,7 +379,7 @@ int forward_chunk(clm_handle* h, const void* ids, int ids_dtype, int64_t row_str
         // block 0 in the 16-bit modes: its in_proj output is a function of the token id alone, the convolution looks it
         // up (ztab) -- unless a debug stop asks for z itself, the read needs the segmented kernel, or CLM_NO_IDCONV=1
         const bool idconv = i == 0 && (idpath || (tuned16 && fs->S == 1 && !h->no_idconv && !stop_here(h, 0, CLM_STAGE_INPROJ)));
-        if (!idconv) {
+        if (!idconv && !(fuse_next && i > 0)) {
             StageTimer t(h, st, CLM_STAGE_INPROJ);
             if (tuned16) launch_inproj16(prec, h->h, lw.ln1_g, lw.ln1_b, lw.w_in, lw.b_in, h->z, Bc, L, Lp, eps, st);
             else launch_inproj(prec, h->h, lw.ln1_g, lw.ln1_b, lw.w_in, lw.b_in, h->z, Bc, L, Lp, eps, st);
@@ -391,9 +398,18 @@ int forward_chunk(clm_handle* h, const void* ids, int ids_dtype, int64_t row_str
         const bool stop_mid = stop_here(h, i, CLM_STAGE_OUTPROJ);
         if (tuned16 && !h->split_tail && !stop_mid) {   // out_proj + LN2 + fc1 + GELU + fc2 + both residuals: one kernel
             StageTimer t(h, st, CLM_STAGE_TAIL);
-            launch_tail16(prec, h->y, lw.w_out, lw.b_out, h->h, lw.ln2_g, lw.ln2_b, lw.w_fc1, lw.b_fc1, lw.w_fc2, lw.b_fc2,
-                          Bc, L, Lp, eps, (idpath && i == 0) ? h->ids8 : nullptr,
-                          W(h, "bb.embeddings.word_embeddings.weight"), st);
+            TailArgs ta{h->y, h->h, lw.w_out, lw.w_fc1, lw.w_fc2, lw.b_out, lw.ln2_g, lw.ln2_b, lw.b_fc1, lw.b_fc2, Bc, L, Lp,
+                        eps, (idpath && i == 0) ? h->ids8 : nullptr, W(h, "bb.embeddings.word_embeddings.weight"),
+                        nullptr, nullptr, nullptr, nullptr, nullptr, spa};
+            int next = NEXT_NONE;
+            if (fuse_next && i + 1 < NLAYER) {
+                const LayerW& nx = h->lw[i + 1];
+                ta.n_w = nx.w_in; ta.n_bias = nx.b_in; ta.n_g = nx.ln1_g; ta.n_b = nx.ln1_b; ta.n_z = h->z;
+                next = NEXT_INPROJ;
+            } else if (fuse_next) {
+                next = NEXT_SCORE;
+            }
+            launch_tail16(prec, ta, next, st);
         } else {
             {
                 StageTimer t(h, st, CLM_STAGE_OUTPROJ);
@@ -417,7 +433,7 @@ int forward_chunk(clm_handle* h, const void* ids, int ids_dtype, int64_t row_str
         if (stop_here(h, i, CLM_STAGE_FC2) || (tuned16 && stop_here(h, i, CLM_STAGE_FC1))) return CLM_OK;
     }
     if (tuned16) {   // score + pooling partials in one pass over h, merged by the classifier kernel
-        {
+        if (!fuse_next) {
             StageTimer t(h, st, CLM_STAGE_SCORE);
             launch_score_pool16(prec, h->h, W(h, "bb.ln_f.weight"), W(h, "bb.ln_f.bias"), h->packed_score,
                                 W(h, "head.attention.0.bias"), W(h, "head.attention.2.weight"),
@@ -484,6 +500,7 @@ int clm_create(const clm_config* cfg, int device, clm_handle** out) {
         return fail(nullptr, CLM_E_UNSUPPORTED, std::string("this engine is built for gfx950 (MI355X) only, found ") + prop.gcnArchName);
     clm_handle* h = new clm_handle();
     h->force_generic = std::getenv("CLM_GENERIC_GEMM") && std::getenv("CLM_GENERIC_GEMM")[0] == '1';
+    h->no_fuse_next = std::getenv("CLM_NO_FUSE_NEXT") && std::getenv("CLM_NO_FUSE_NEXT")[0] == '1';
     h->no_idconv = std::getenv("CLM_NO_IDCONV") && std::getenv("CLM_NO_IDCONV")[0] == '1';
     h->split_tail = std::getenv("CLM_SPLIT_TAIL") && std::getenv("CLM_SPLIT_TAIL")[0] == '1';
     h->cfg = *cfg;

@@ -136,10 +136,36 @@ void launch_outproj16(int prec, const void* y, const void* w, const float* bias,
 void launch_mlp16(int prec, float* h, const float* g, const float* b, const void* w1, const float* b1, const void* w2,
                   const float* b2, int B, int L, float eps, hipStream_t st);
 // second half of a block in one kernel: h = r + fc2(gelu(fc1(LN2(r)))), r = h + out_proj(y^T)
-void launch_tail16(int prec, const void* y, const void* w_out, const float* b_out, float* h, const float* g,
-                   const float* bta, const void* w1, const float* b1, const void* w2, const float* b2, int B, int L, int Lp,
-                   float eps, const unsigned char* ids8 /*block 0: residual = emb[id], else null*/, const float* emb,
-                   hipStream_t st);
+struct ScorePoolArgs {
+    const float* h;           // [B, L, 256]
+    const float *ln_g, *ln_b;
+    const void* w1;           // packed attention.0.weight
+    const float *b1, *w2, *b2;
+    float* scores;            // [B, L]
+    float* partial;           // [B, ntiles, POOL_PSTRIDE]: vec[256], m, S
+    int B, L, ntiles;
+    float eps;
+};
+
+struct TailArgs {
+    const void* y;            // [B, 256, Lp] channel-major, 16-bit
+    float* h;                 // residual stream [B, L, 256]
+    const void *w_out, *w1, *w2;
+    const float *b_out, *ln_g, *ln_b, *b1, *b2;
+    int B, L, Lp;
+    float eps;
+    const unsigned char* ids8;   // block 0 only (else null): the incoming residual row of token t is emb[ids8[b][t]],
+    const float* emb;            // read from the 16-row table instead of h (the embedding kernel then never writes h)
+    // NEXT_INPROJ: LayerNorm-1 + in_proj of the FOLLOWING block on the tile just produced (z written for its convolution)
+    const void* n_w;
+    const float *n_bias, *n_g, *n_b;
+    void* n_z;
+    // NEXT_SCORE (last block): ln_f + attention scores + pooling partials, see score_pool_tile
+    ScorePoolArgs sp;
+};
+constexpr int NEXT_NONE = 0, NEXT_INPROJ = 1, NEXT_SCORE = 2;
+// out_proj + LN2 + MLP (+ what follows on the same tile: NEXT_*), 16-bit modes (gemm16.hip)
+void launch_tail16(int prec, const TailArgs& m, int next, hipStream_t st);
 void tail16_dump_stamps();   // developer build only (CLM_STAMP=1)
 void conv_dump_stamps();
 size_t packed_weight_bytes(int prec, int n, int k);

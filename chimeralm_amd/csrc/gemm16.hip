@@ -126,25 +126,17 @@ __device__ __forceinline__ void resid_epilogue(float* h_out, const float* bias, 
 }
 
 // ================================================================================================ in_proj
+// in_proj over a staged LN tile: three 256-feature blocks, z written channel-major [B, 768, Lp].  On entry bs[0]
+// holds (or has in flight) the first half-set of block 0; Zs = 8 wave-private staging tiles [32 features][RSOUT].
 template <int PREC>
-__global__ __launch_bounds__(512) void in_proj16_kernel(GemmArgs a) {
+__device__ __forceinline__ void inproj_blocks(const typename CT<PREC>::elem* As, typename CT<PREC>::elem* Zs,
+                                              const u16x8* wp, const float* __restrict__ bias_all, void* zout, int b,
+                                              int t0, int Lp, int wave, int lane, u16x8 (&bs)[2][1][SETK],
+                                              f32x16 (&acc)[4]) {
     using elem = typename CT<PREC>::elem;
-    using frag = u16x8;
-    constexpr int BM = 128, K = D, NBLOCKS = D3 / 256;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    elem* As = reinterpret_cast<elem*>(smem);
-    elem* Zs = As + BM * RS16;                              // 8 wave-private tiles [32 features][RSOUT]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lrow = lane & 31, lhalf = lane >> 5;
-    const int b = blockIdx.y, t0 = blockIdx.x * BM, Lp = a.Lp;
-    const frag* wp = reinterpret_cast<const frag*>(a.w);
+    constexpr int K = D, NBLOCKS = D3 / 256;
+    const int lrow = lane & 31, lhalf = lane >> 5;
     elem* zs = Zs + wave * 32 * RSOUT;
-    f32x16 acc[4];
-    frag bs[2][1][SETK];
-
-    load_set<PREC, K, 1>(wp, 0, 0, 0, wave, lane, bs[0]);
-    __builtin_amdgcn_sched_barrier(0);
-    stage_a_tile<PREC, A_LN, K, 8>(a, As, b, t0, 0);
-    __syncthreads();
 #pragma unroll 1
     for (int nb = 0; nb < NBLOCKS; ++nb) {
         zero_acc(acc);
@@ -158,7 +150,7 @@ __global__ __launch_bounds__(512) void in_proj16_kernel(GemmArgs a) {
         __builtin_amdgcn_sched_barrier(0);
         // epilogue: rows = tokens (register quads = 4 consecutive tokens), cols = feature (lane) -> zs[feature][token]
         const int nbase = nb * 256 + wave * 32;
-        const float bias = a.bias[nbase + lrow];
+        const float bias = bias_all[nbase + lrow];
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
@@ -168,7 +160,7 @@ __global__ __launch_bounds__(512) void in_proj16_kernel(GemmArgs a) {
                 *reinterpret_cast<u16x4*>(zs + lrow * RSOUT + mt * 32 + 8 * q + 4 * lhalf) = pk;
             }
         __builtin_amdgcn_sched_barrier(0);
-        elem* zg = reinterpret_cast<elem*>(a.out) + ((size_t)b * D3 + nbase) * Lp + t0;
+        elem* zg = reinterpret_cast<elem*>(zout) + ((size_t)b * D3 + nbase) * Lp + t0;
         const int col8 = (lane & 15) * 8;
         const bool in_row = t0 + col8 < Lp;                    // Lp is a multiple of 64: whole vectors in or out
 #pragma unroll
@@ -179,6 +171,27 @@ __global__ __launch_bounds__(512) void in_proj16_kernel(GemmArgs a) {
         }
         __builtin_amdgcn_sched_barrier(0);
     }
+}
+
+template <int PREC>
+__global__ __launch_bounds__(512) void in_proj16_kernel(GemmArgs a) {
+    using elem = typename CT<PREC>::elem;
+    using frag = u16x8;
+    constexpr int BM = 128, K = D;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    elem* As = reinterpret_cast<elem*>(smem);
+    elem* Zs = As + BM * RS16;                              // 8 wave-private tiles [32 features][RSOUT]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.y, t0 = blockIdx.x * BM;
+    const frag* wp = reinterpret_cast<const frag*>(a.w);
+    f32x16 acc[4];
+    frag bs[2][1][SETK];
+
+    load_set<PREC, K, 1>(wp, 0, 0, 0, wave, lane, bs[0]);
+    __builtin_amdgcn_sched_barrier(0);
+    stage_a_tile<PREC, A_LN, K, 8>(a, As, b, t0, 0);
+    __syncthreads();
+    inproj_blocks<PREC>(As, Zs, wp, a.bias, a.out, b, t0, a.Lp, wave, lane, bs, acc);
 }
 
 // ================================================================================================ out_proj
@@ -300,230 +313,6 @@ __global__ __launch_bounds__(512) void mlp16_kernel(MlpArgs m) {
     resid_epilogue(m.h, m.b2, acc2, b, t0, L, wave, lane, reinterpret_cast<float*>(smem));
 }
 
-// ================================================================================================ out_proj + MLP fused
-// h_new = r + fc2(gelu(fc1(LN2(r)))),  r = h + out_proj(y^T)        (second half of a HyenaBlock, one kernel)
-// The out_proj accumulator (rows = output feature, cols = token) already IS the layout the fc2 accumulator needs, so r never
-// leaves the registers: it is the initial value of the fc2 accumulation, and LayerNorm-2 is computed from the
-// accumulator registers (row statistics across the 8 waves through an 8 KiB LDS table).  Compared with the separate
-// out_proj16 + mlp16 kernels this removes one write and two reads of the fp32 residual stream (3 KiB of 6.5 KiB per
-// token), both latency-bound row phases of the MLP kernel, and one launch.
-struct TailArgs {
-    const void* y;            // [B, 256, Lp] channel-major, 16-bit
-    float* h;                 // residual stream [B, L, 256]
-    const void *w_out, *w1, *w2;
-    const float *b_out, *ln_g, *ln_b, *b1, *b2;
-    int B, L, Lp;
-    float eps;
-    const unsigned char* ids8;   // block 0 only (else null): the incoming residual row of token t is emb[ids8[b][t]],
-    const float* emb;            // read from the 16-row table instead of h (the embedding kernel then never writes h)
-};
-
-// STAMP: developer build (CLM_STAMP=1) that records s_memtime at the phase boundaries of wave 0 of every workgroup into
-// a side buffer nothing else reads; the product instantiation (STAMP = false) contains no stamp.
-constexpr int TAIL_NSTAMP = 20;
-
-template <int PREC, bool STAMP = false>
-__global__ __launch_bounds__(512) void tail16_kernel(TailArgs m, unsigned long long* stamps) {
-#define CLM_STAMP_AT(k)                                                                                   \
-    do {                                                                                                  \
-        if (STAMP && threadIdx.x == 0)                                                                    \
-            stamps[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * TAIL_NSTAMP + (k)] = __builtin_amdgcn_s_memtime(); \
-    } while (0)
-    using elem = typename CT<PREC>::elem;
-    using frag = u16x8;
-    constexpr int BM = 128, NCH = DI / 256;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    elem* As = reinterpret_cast<elem*>(smem);              // LN2(r) tile [128][RS16]      (aliases Ys during out_proj)
-    elem* Hs = As + BM * RS16;                              // gelu(fc1) chunk [128][RS16]
-    elem* Ys = reinterpret_cast<elem*>(smem);              // y tile [256 channels][RSKM], k-major
-    float* P1 = reinterpret_cast<float*>(smem + (size_t)2 * BM * RS16 * 2);   // row-sum partials [16][128]
-    float* P2 = P1 + 16 * BM;                                                 // squared-deviation partials
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lrow = lane & 31, lhalf = lane >> 5;
-    const int b = blockIdx.y, t0 = blockIdx.x * BM, L = m.L, Lp = m.Lp;
-    const frag* wo = reinterpret_cast<const frag*>(m.w_out);
-    const frag* w1 = reinterpret_cast<const frag*>(m.w1);
-    const frag* w2 = reinterpret_cast<const frag*>(m.w2);
-    f32x16 acc1[4], acc2[4];
-    frag bs[2][1][SETK];
-
-    CLM_STAMP_AT(0);
-    // ---- 0. everything that only depends on addresses is requested first
-    load_set<PREC, D, 1>(wo, 0, 0, 0, wave, lane, bs[0]);
-    load_set<PREC, D, 1>(wo, 0, 0, 1, wave, lane, bs[1]);
-    float4 hv[4][4];                                       // residual in accumulator layout: token mt*32+lrow, 4 features
-#pragma unroll
-    for (int mt = 0; mt < 4; ++mt) {
-        const int t = t0 + mt * 32 + lrow, tc = t < L ? t : 0;
-        const float* row = m.ids8 ? m.emb + (size_t)m.ids8[(size_t)b * Lp + tc] * D + wave * 32 + 4 * lhalf
-                                  : m.h + ((size_t)b * L + tc) * D + wave * 32 + 4 * lhalf;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) hv[mt][q] = *reinterpret_cast<const float4*>(row + 8 * q);
-    }
-    // (gathering these rows as whole 128-byte lines through a wave-private LDS transpose was measured: no faster -- the
-    // phase is bound by how many misses one workgroup per CU keeps in flight, not by the address unit)
-    __builtin_amdgcn_sched_barrier(0);
-    {
-        const elem* src = reinterpret_cast<const elem*>(m.y) + (size_t)b * D * Lp + t0;
-        const int tk = (tid & 15) * 8;
-        const bool in_row = t0 + tk < Lp;
-        const int tkc = in_row ? tk : 0;                   // clamped, branch-free loads; masked at the LDS store
-        uint4 x[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) x[i] = *reinterpret_cast<const uint4*>(src + (size_t)((tid >> 4) + 32 * i) * Lp + tkc);
-#pragma unroll
-        for (int i = 0; i < 8; ++i)
-            *reinterpret_cast<uint4*>(Ys + ((tid >> 4) + 32 * i) * RSKM + tk) = in_row ? x[i] : make_uint4(0, 0, 0, 0);
-    }
-    __syncthreads();
-    CLM_STAMP_AT(1);
-    // ---- 1. out_proj, then r = acc + h + b_out (kept in acc2)
-    zero_acc(acc2);
-    compute_km<PREC>(Ys, 0, lane, bs[0], acc2);
-    __builtin_amdgcn_sched_barrier(0);
-    load_set<PREC, D, 1>(w1, 0, 0, 0, wave, lane, bs[0]);             // first fc1 set under the second half
-    __builtin_amdgcn_sched_barrier(0);
-    compute_km<PREC>(Ys, 1, lane, bs[1], acc2);
-    __builtin_amdgcn_sched_barrier(0);
-    {
-        const float* bo = m.b_out + wave * 32 + 4 * lhalf;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const float4 bb = *reinterpret_cast<const float4*>(bo + 8 * q);
-#pragma unroll
-            for (int mt = 0; mt < 4; ++mt) {
-                acc2[mt][4 * q + 0] += hv[mt][q].x + bb.x;
-                acc2[mt][4 * q + 1] += hv[mt][q].y + bb.y;
-                acc2[mt][4 * q + 2] += hv[mt][q].z + bb.z;
-                acc2[mt][4 * q + 3] += hv[mt][q].w + bb.w;
-            }
-        }
-    }
-    CLM_STAMP_AT(2);
-    // ---- 2. LayerNorm-2 statistics of r: per-lane partial over its 16 features -> LDS -> totals over 16 partials
-    float mean[4], rstd[4];
-#pragma unroll
-    for (int mt = 0; mt < 4; ++mt) {
-        float s = 0.f;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) s += acc2[mt][r];
-        P1[(wave * 2 + lhalf) * BM + mt * 32 + lrow] = s;
-    }
-    __syncthreads();                                       // also: every wave is done reading Ys
-#pragma unroll
-    for (int mt = 0; mt < 4; ++mt) {
-        float s = 0.f;
-#pragma unroll
-        for (int w = 0; w < 16; ++w) s += P1[w * BM + mt * 32 + lrow];
-        mean[mt] = s * (1.0f / D);
-        float v = 0.f;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const float d = acc2[mt][r] - mean[mt];
-            v += d * d;
-        }
-        P2[(wave * 2 + lhalf) * BM + mt * 32 + lrow] = v;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int mt = 0; mt < 4; ++mt) {
-        float v = 0.f;
-#pragma unroll
-        for (int w = 0; w < 16; ++w) v += P2[w * BM + mt * 32 + lrow];
-        rstd[mt] = 1.0f / sqrtf(v * (1.0f / D) + m.eps);
-    }
-    CLM_STAMP_AT(3);
-    // ---- 3. normalised tile -> As (16-bit); rows beyond L are written as zeros like the staged version
-    {
-        const float* gp = m.ln_g + wave * 32 + 4 * lhalf;
-        const float* bp = m.ln_b + wave * 32 + 4 * lhalf;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const float4 g4 = *reinterpret_cast<const float4*>(gp + 8 * q);
-            const float4 b4 = *reinterpret_cast<const float4*>(bp + 8 * q);
-#pragma unroll
-            for (int mt = 0; mt < 4; ++mt) {
-                const bool ok = t0 + mt * 32 + lrow < L;
-                const float y0 = ok ? (acc2[mt][4 * q + 0] - mean[mt]) * rstd[mt] * g4.x + b4.x : 0.f;
-                const float y1 = ok ? (acc2[mt][4 * q + 1] - mean[mt]) * rstd[mt] * g4.y + b4.y : 0.f;
-                const float y2 = ok ? (acc2[mt][4 * q + 2] - mean[mt]) * rstd[mt] * g4.z + b4.z : 0.f;
-                const float y3 = ok ? (acc2[mt][4 * q + 3] - mean[mt]) * rstd[mt] * g4.w + b4.w : 0.f;
-                u16x4 pk = {to_bits<PREC>(y0), to_bits<PREC>(y1), to_bits<PREC>(y2), to_bits<PREC>(y3)};
-                *reinterpret_cast<u16x4*>(As + (mt * 32 + lrow) * RS16 + wave * 32 + 8 * q + 4 * lhalf) = pk;
-            }
-        }
-    }
-    __syncthreads();
-    CLM_STAMP_AT(4);
-    // ---- 4. MLP chunks (acc2 already holds r)
-#pragma unroll 1
-    for (int j = 0; j < NCH; ++j) {
-        zero_acc(acc1);
-        load_set<PREC, D, 1>(w1, j, 0, 1, wave, lane, bs[1]);
-        __builtin_amdgcn_sched_barrier(0);
-        compute_tm<PREC, true>(As, 0, lrow, lhalf, bs[0], acc1);
-        __builtin_amdgcn_sched_barrier(0);
-        load_set<PREC, DI, 1>(w2, 0, j, 0, wave, lane, bs[0]);
-        __builtin_amdgcn_sched_barrier(0);
-        compute_tm<PREC, true>(As, 1, lrow, lhalf, bs[1], acc1);
-        __builtin_amdgcn_sched_barrier(0);
-        __syncthreads();
-        CLM_STAMP_AT(5 + 3 * j);
-        {
-            const float* b1 = m.b1 + j * 256 + wave * 32 + 4 * lhalf;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const float4 bb = *reinterpret_cast<const float4*>(b1 + 8 * q);
-#pragma unroll
-                for (int mt = 0; mt < 4; ++mt) {
-                    const f32x2 g0 = gelu_tanh2(f32x2{acc1[mt][4 * q + 0] + bb.x, acc1[mt][4 * q + 1] + bb.y});
-                    const f32x2 g1 = gelu_tanh2(f32x2{acc1[mt][4 * q + 2] + bb.z, acc1[mt][4 * q + 3] + bb.w});
-                    u16x4 pk = {to_bits<PREC>(g0.x), to_bits<PREC>(g0.y), to_bits<PREC>(g1.x), to_bits<PREC>(g1.y)};
-                    *reinterpret_cast<u16x4*>(Hs + (mt * 32 + lrow) * RS16 + wave * 32 + 8 * q + 4 * lhalf) = pk;
-                }
-            }
-        }
-        __syncthreads();
-        CLM_STAMP_AT(6 + 3 * j);
-        load_set<PREC, DI, 1>(w2, 0, j, 1, wave, lane, bs[1]);
-        __builtin_amdgcn_sched_barrier(0);
-        compute_tm<PREC, true>(Hs, 0, lrow, lhalf, bs[0], acc2);
-        __builtin_amdgcn_sched_barrier(0);
-        load_set<PREC, D, 1>(w1, j + 1 < NCH ? j + 1 : 0, 0, 0, wave, lane, bs[0]);
-        __builtin_amdgcn_sched_barrier(0);
-        compute_tm<PREC, true>(Hs, 1, lrow, lhalf, bs[1], acc2);
-        __builtin_amdgcn_sched_barrier(0);
-        CLM_STAMP_AT(7 + 3 * j);
-    }
-    __syncthreads();                                       // As / Hs are dead: reuse them as the staging tiles
-    CLM_STAMP_AT(17);
-    // ---- 5. h_new = acc2 + b2: transposed through LDS, stored as whole 128-byte lines (no read)
-    {
-        float* rs = reinterpret_cast<float*>(smem) + wave * (128 * 32);
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt) {
-            const int tok = mt * 32 + lrow;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int chunk = (2 * q + lhalf) ^ (tok & 7);
-                *reinterpret_cast<float4*>(rs + tok * 32 + 4 * chunk) =
-                    make_float4(acc2[mt][4 * q + 0], acc2[mt][4 * q + 1], acc2[mt][4 * q + 2], acc2[mt][4 * q + 3]);
-            }
-        }
-        const int c = lane & 7, rsub = lane >> 3;
-        const float4 bb = *reinterpret_cast<const float4*>(m.b2 + wave * 32 + 4 * c);
-        float* hrow = m.h + ((size_t)b * L + t0) * D + wave * 32 + 4 * c;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int tr = i * 8 + rsub;
-            const float4 a = *reinterpret_cast<const float4*>(rs + tr * 32 + 4 * (c ^ (tr & 7)));
-            if (t0 + tr < L)
-                *reinterpret_cast<float4*>(hrow + (size_t)tr * D) = make_float4(a.x + bb.x, a.y + bb.y, a.z + bb.z, a.w + bb.w);
-        }
-    }
-    CLM_STAMP_AT(18);
-#undef CLM_STAMP_AT
-}
-
 // ================================================================================================ score + pool
 // ln_f + attention.0 (256 -> 256) + GELU(erf) + attention.2 (256 -> 1) give the pooling score of every token; the same
 // staged ln_f tile then feeds this tile's share of the attention pooling as an online-softmax partial
@@ -531,39 +320,17 @@ __global__ __launch_bounds__(512) void tail16_kernel(TailArgs m, unsigned long l
 // (BinarySequenceClassifier.forward, /root/reference/chimeralm/models/components/hyena.py:117-146; softmax over all L
 // positions).  head_tiles_kernel (head.hip) merges the per-tile partials in a fixed order.  One pass over the residual
 // stream instead of two (the separate score and pool kernels each read all of h).
-struct ScorePoolArgs {
-    const float* h;           // [B, L, 256]
-    const float *ln_g, *ln_b;
-    const void* w1;           // packed attention.0.weight
-    const float *b1, *w2, *b2;
-    float* scores;            // [B, L]
-    float* partial;           // [B, ntiles, POOL_PSTRIDE]: vec[256], m, S
-    int B, L, ntiles;
-    float eps;
-};
 
+// Scores and the online-softmax pooling partial of one staged ln_f tile.  On entry bs[0] / bs[1] hold the two half-sets
+// of attention.0.weight; P / E / V: [8][128] + [128] + [4][256] floats of LDS behind the tile.
 template <int PREC>
-__global__ __launch_bounds__(512) void score_pool16_kernel(ScorePoolArgs m) {
+__device__ __forceinline__ void score_pool_tile(const ScorePoolArgs& m, const typename CT<PREC>::elem* As, float* P, int b,
+                                                int tile, int tid, u16x8 (&bs)[2][1][SETK], f32x16 (&acc)[4]) {
     using elem = typename CT<PREC>::elem;
-    using frag = u16x8;
     constexpr int BM = 128;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    elem* As = reinterpret_cast<elem*>(smem);
-    float* P = reinterpret_cast<float*>(As + BM * RS16);    // [8 waves][128 tokens] score partials
-    float* E = P + 8 * BM;                                  // [128] softmax numerators
-    float* V = E + BM;                                      // [4 token groups][256] pooled partials
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lrow = lane & 31, lhalf = lane >> 5;
-    const int b = blockIdx.y, tile = blockIdx.x, t0 = tile * BM, L = m.L;
-    const frag* wp = reinterpret_cast<const frag*>(m.w1);
-    f32x16 acc[4];
-    frag bs[2][1][SETK];
-    load_set<PREC, D, 1>(wp, 0, 0, 0, wave, lane, bs[0]);
-    load_set<PREC, D, 1>(wp, 0, 0, 1, wave, lane, bs[1]);
-    __builtin_amdgcn_sched_barrier(0);
-    GemmArgs a{};
-    a.h_in = m.h; a.ln_g = m.ln_g; a.ln_b = m.ln_b; a.L = L; a.eps = m.eps;
-    stage_a_tile<PREC, A_LN, D, 8>(a, As, b, t0, 0);
-    __syncthreads();
+    float* E = P + 8 * BM;
+    float* V = E + BM;
+    const int lane = tid & 63, wave = tid >> 6, lrow = lane & 31, lhalf = lane >> 5, t0 = tile * BM, L = m.L;
     zero_acc(acc);
     compute_tm<PREC, true>(As, 0, lrow, lhalf, bs[0], acc);   // rows = features (register quads), lane = token
     compute_tm<PREC, true>(As, 1, lrow, lhalf, bs[1], acc);
@@ -631,6 +398,283 @@ __global__ __launch_bounds__(512) void score_pool16_kernel(ScorePoolArgs m) {
     __syncthreads();
     if (tid < D)
         m.partial[((size_t)b * m.ntiles + tile) * POOL_PSTRIDE + tid] = (V[tid] + V[D + tid]) + (V[2 * D + tid] + V[3 * D + tid]);
+}
+
+template <int PREC>
+__global__ __launch_bounds__(512) void score_pool16_kernel(ScorePoolArgs m) {
+    using elem = typename CT<PREC>::elem;
+    using frag = u16x8;
+    constexpr int BM = 128;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    elem* As = reinterpret_cast<elem*>(smem);
+    float* P = reinterpret_cast<float*>(As + BM * RS16);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.y, tile = blockIdx.x, t0 = tile * BM;
+    const frag* wp = reinterpret_cast<const frag*>(m.w1);
+    f32x16 acc[4];
+    frag bs[2][1][SETK];
+    load_set<PREC, D, 1>(wp, 0, 0, 0, wave, lane, bs[0]);
+    load_set<PREC, D, 1>(wp, 0, 0, 1, wave, lane, bs[1]);
+    __builtin_amdgcn_sched_barrier(0);
+    GemmArgs a{};
+    a.h_in = m.h; a.ln_g = m.ln_g; a.ln_b = m.ln_b; a.L = m.L; a.eps = m.eps;
+    stage_a_tile<PREC, A_LN, D, 8>(a, As, b, t0, 0);
+    __syncthreads();
+    score_pool_tile<PREC>(m, As, P, b, tile, tid, bs, acc);
+}
+
+// LayerNorm over the 256 features of every token of a tile whose values sit in accumulator registers (rows = this wave's
+// 32 features as register quads, lane = token): per-lane partial over 16 features -> LDS tables -> totals over the 16
+// partials of the 8 waves, two-pass variance; the normalised tile goes to As in the compute dtype (rows beyond L as zeros).
+// P1 / P2: [16][128] floats each, outside As.  Ends with a barrier (As complete); the first internal barrier also orders
+// every earlier LDS access of the workgroup before the As writes.
+template <int PREC>
+__device__ __forceinline__ void ln_acc_to_tile(const f32x16 (&acc2)[4], float* P1, float* P2, const float* __restrict__ g,
+                                               const float* __restrict__ bta, float eps, typename CT<PREC>::elem* As,
+                                               int t0, int L, int wave, int lrow, int lhalf) {
+    constexpr int BM = 128;
+    float mean[4], rstd[4];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+        float s = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s += acc2[mt][r];
+        P1[(wave * 2 + lhalf) * BM + mt * 32 + lrow] = s;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+        float s = 0.f;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) s += P1[w * BM + mt * 32 + lrow];
+        mean[mt] = s * (1.0f / D);
+        float v = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float d = acc2[mt][r] - mean[mt];
+            v += d * d;
+        }
+        P2[(wave * 2 + lhalf) * BM + mt * 32 + lrow] = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+        float v = 0.f;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) v += P2[w * BM + mt * 32 + lrow];
+        rstd[mt] = 1.0f / sqrtf(v * (1.0f / D) + eps);
+    }
+    const float* gp = g + wave * 32 + 4 * lhalf;
+    const float* bp = bta + wave * 32 + 4 * lhalf;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const float4 g4 = *reinterpret_cast<const float4*>(gp + 8 * q);
+        const float4 b4 = *reinterpret_cast<const float4*>(bp + 8 * q);
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            const bool ok = t0 + mt * 32 + lrow < L;
+            const float y0 = ok ? (acc2[mt][4 * q + 0] - mean[mt]) * rstd[mt] * g4.x + b4.x : 0.f;
+            const float y1 = ok ? (acc2[mt][4 * q + 1] - mean[mt]) * rstd[mt] * g4.y + b4.y : 0.f;
+            const float y2 = ok ? (acc2[mt][4 * q + 2] - mean[mt]) * rstd[mt] * g4.z + b4.z : 0.f;
+            const float y3 = ok ? (acc2[mt][4 * q + 3] - mean[mt]) * rstd[mt] * g4.w + b4.w : 0.f;
+            u16x4 pk = {to_bits<PREC>(y0), to_bits<PREC>(y1), to_bits<PREC>(y2), to_bits<PREC>(y3)};
+            *reinterpret_cast<u16x4*>(As + (mt * 32 + lrow) * RS16 + wave * 32 + 8 * q + 4 * lhalf) = pk;
+        }
+    }
+    __syncthreads();
+}
+
+// ================================================================================================ out_proj + MLP fused
+// h_new = r + fc2(gelu(fc1(LN2(r)))),  r = h + out_proj(y^T)        (second half of a HyenaBlock, one kernel)
+// The out_proj accumulator (rows = output feature, cols = token) already IS the layout the fc2 accumulator needs, so r never
+// leaves the registers: it is the initial value of the fc2 accumulation, and LayerNorm-2 is computed from the
+// accumulator registers (row statistics across the 8 waves through an 8 KiB LDS table).  Compared with the separate
+// out_proj16 + mlp16 kernels this removes one write and two reads of the fp32 residual stream (3 KiB of 6.5 KiB per
+// token), both latency-bound row phases of the MLP kernel, and one launch.
+
+// STAMP: developer build (CLM_STAMP=1) that records s_memtime at the phase boundaries of wave 0 of every workgroup into
+// a side buffer nothing else reads; the product instantiation (STAMP = false) contains no stamp.
+// NEXT: what follows the block on the same tile while it is still on chip -- the residual stream is then read once and
+// written once per block, and the separate in_proj / score launches (latency-bound on their own) disappear.
+constexpr int TAIL_NSTAMP = 24;
+
+template <int PREC, bool STAMP = false, int NEXT = NEXT_NONE>
+__global__ __launch_bounds__(512) void tail16_kernel(TailArgs m, unsigned long long* stamps) {
+#define CLM_STAMP_AT(k)                                                                                   \
+    do {                                                                                                  \
+        if (STAMP && threadIdx.x == 0)                                                                    \
+            stamps[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * TAIL_NSTAMP + (k)] = __builtin_amdgcn_s_memtime(); \
+    } while (0)
+    using elem = typename CT<PREC>::elem;
+    using frag = u16x8;
+    constexpr int BM = 128, NCH = DI / 256;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    elem* As = reinterpret_cast<elem*>(smem);              // LN2(r) tile [128][RS16]      (aliases Ys during out_proj)
+    elem* Hs = As + BM * RS16;                              // gelu(fc1) chunk [128][RS16]
+    elem* Ys = reinterpret_cast<elem*>(smem);              // y tile [256 channels][RSKM], k-major
+    float* P1 = reinterpret_cast<float*>(smem + (size_t)2 * BM * RS16 * 2);   // row-sum partials [16][128]
+    float* P2 = P1 + 16 * BM;                                                 // squared-deviation partials
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lrow = lane & 31, lhalf = lane >> 5;
+    const int b = blockIdx.y, t0 = blockIdx.x * BM, L = m.L, Lp = m.Lp;
+    const frag* wo = reinterpret_cast<const frag*>(m.w_out);
+    const frag* w1 = reinterpret_cast<const frag*>(m.w1);
+    const frag* w2 = reinterpret_cast<const frag*>(m.w2);
+    const frag* wn = reinterpret_cast<const frag*>(NEXT == NEXT_SCORE ? m.sp.w1 : m.n_w);
+    f32x16 acc1[4], acc2[4];
+    frag bs[2][1][SETK];
+
+    CLM_STAMP_AT(0);
+    // ---- 0. everything that only depends on addresses is requested first
+    load_set<PREC, D, 1>(wo, 0, 0, 0, wave, lane, bs[0]);
+    load_set<PREC, D, 1>(wo, 0, 0, 1, wave, lane, bs[1]);
+    float4 hv[4][4];                                       // residual in accumulator layout: token mt*32+lrow, 4 features
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+        const int t = t0 + mt * 32 + lrow, tc = t < L ? t : 0;
+        const float* row = m.ids8 ? m.emb + (size_t)m.ids8[(size_t)b * Lp + tc] * D + wave * 32 + 4 * lhalf
+                                  : m.h + ((size_t)b * L + tc) * D + wave * 32 + 4 * lhalf;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) hv[mt][q] = *reinterpret_cast<const float4*>(row + 8 * q);
+    }
+    // (gathering these rows as whole 128-byte lines through a wave-private LDS transpose was measured: no faster -- the
+    // phase is bound by how many misses one workgroup per CU keeps in flight, not by the address unit)
+    __builtin_amdgcn_sched_barrier(0);
+    {
+        const elem* src = reinterpret_cast<const elem*>(m.y) + (size_t)b * D * Lp + t0;
+        const int tk = (tid & 15) * 8;
+        const bool in_row = t0 + tk < Lp;
+        const int tkc = in_row ? tk : 0;                   // clamped, branch-free loads; masked at the LDS store
+        uint4 x[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) x[i] = *reinterpret_cast<const uint4*>(src + (size_t)((tid >> 4) + 32 * i) * Lp + tkc);
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            *reinterpret_cast<uint4*>(Ys + ((tid >> 4) + 32 * i) * RSKM + tk) = in_row ? x[i] : make_uint4(0, 0, 0, 0);
+    }
+    __syncthreads();
+    CLM_STAMP_AT(1);
+    // ---- 1. out_proj, then r = acc + h + b_out (kept in acc2)
+    zero_acc(acc2);
+    compute_km<PREC>(Ys, 0, lane, bs[0], acc2);
+    __builtin_amdgcn_sched_barrier(0);
+    load_set<PREC, D, 1>(w1, 0, 0, 0, wave, lane, bs[0]);             // first fc1 set under the second half
+    __builtin_amdgcn_sched_barrier(0);
+    compute_km<PREC>(Ys, 1, lane, bs[1], acc2);
+    __builtin_amdgcn_sched_barrier(0);
+    {
+        const float* bo = m.b_out + wave * 32 + 4 * lhalf;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4 bb = *reinterpret_cast<const float4*>(bo + 8 * q);
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+                acc2[mt][4 * q + 0] += hv[mt][q].x + bb.x;
+                acc2[mt][4 * q + 1] += hv[mt][q].y + bb.y;
+                acc2[mt][4 * q + 2] += hv[mt][q].z + bb.z;
+                acc2[mt][4 * q + 3] += hv[mt][q].w + bb.w;
+            }
+        }
+    }
+    CLM_STAMP_AT(2);
+    // ---- 2./3. LayerNorm-2 of r straight from the accumulators -> As (16-bit)
+    ln_acc_to_tile<PREC>(acc2, P1, P2, m.ln_g, m.ln_b, m.eps, As, t0, L, wave, lrow, lhalf);
+    CLM_STAMP_AT(3);
+    CLM_STAMP_AT(4);
+    // ---- 4. MLP chunks (acc2 already holds r)
+#pragma unroll 1
+    for (int j = 0; j < NCH; ++j) {
+        zero_acc(acc1);
+        load_set<PREC, D, 1>(w1, j, 0, 1, wave, lane, bs[1]);
+        __builtin_amdgcn_sched_barrier(0);
+        compute_tm<PREC, true>(As, 0, lrow, lhalf, bs[0], acc1);
+        __builtin_amdgcn_sched_barrier(0);
+        load_set<PREC, DI, 1>(w2, 0, j, 0, wave, lane, bs[0]);
+        __builtin_amdgcn_sched_barrier(0);
+        compute_tm<PREC, true>(As, 1, lrow, lhalf, bs[1], acc1);
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();
+        CLM_STAMP_AT(5 + 3 * j);
+        {
+            const float* b1 = m.b1 + j * 256 + wave * 32 + 4 * lhalf;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 bb = *reinterpret_cast<const float4*>(b1 + 8 * q);
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) {
+                    const f32x2 g0 = gelu_tanh2(f32x2{acc1[mt][4 * q + 0] + bb.x, acc1[mt][4 * q + 1] + bb.y});
+                    const f32x2 g1 = gelu_tanh2(f32x2{acc1[mt][4 * q + 2] + bb.z, acc1[mt][4 * q + 3] + bb.w});
+                    u16x4 pk = {to_bits<PREC>(g0.x), to_bits<PREC>(g0.y), to_bits<PREC>(g1.x), to_bits<PREC>(g1.y)};
+                    *reinterpret_cast<u16x4*>(Hs + (mt * 32 + lrow) * RS16 + wave * 32 + 8 * q + 4 * lhalf) = pk;
+                }
+            }
+        }
+        __syncthreads();
+        CLM_STAMP_AT(6 + 3 * j);
+        load_set<PREC, DI, 1>(w2, 0, j, 1, wave, lane, bs[1]);
+        __builtin_amdgcn_sched_barrier(0);
+        compute_tm<PREC, true>(Hs, 0, lrow, lhalf, bs[0], acc2);
+        __builtin_amdgcn_sched_barrier(0);
+        // next fc1 set; on the last trip the first set of what follows (wrap-around keeps the prefetch unconditional)
+        load_set<PREC, D, 1>((NEXT != NEXT_NONE && j + 1 == NCH) ? wn : w1, j + 1 < NCH ? j + 1 : 0, 0, 0, wave, lane, bs[0]);
+        __builtin_amdgcn_sched_barrier(0);
+        compute_tm<PREC, true>(Hs, 1, lrow, lhalf, bs[1], acc2);
+        __builtin_amdgcn_sched_barrier(0);
+        CLM_STAMP_AT(7 + 3 * j);
+    }
+    __syncthreads();                                       // As / Hs are dead: reuse them as the staging tiles
+    CLM_STAMP_AT(17);
+    // ---- 5. h_new = acc2 + b2: transposed through LDS, stored as whole 128-byte lines (no read)
+    {
+        const float* b2p = m.b2 + wave * 32 + 4 * lhalf;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4 bb = *reinterpret_cast<const float4*>(b2p + 8 * q);
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+                acc2[mt][4 * q + 0] += bb.x;
+                acc2[mt][4 * q + 1] += bb.y;
+                acc2[mt][4 * q + 2] += bb.z;
+                acc2[mt][4 * q + 3] += bb.w;
+            }
+        }
+        float* rs = reinterpret_cast<float*>(smem) + wave * (128 * 32);
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            const int tok = mt * 32 + lrow;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int chunk = (2 * q + lhalf) ^ (tok & 7);
+                *reinterpret_cast<float4*>(rs + tok * 32 + 4 * chunk) =
+                    make_float4(acc2[mt][4 * q + 0], acc2[mt][4 * q + 1], acc2[mt][4 * q + 2], acc2[mt][4 * q + 3]);
+            }
+        }
+        const int c = lane & 7, rsub = lane >> 3;
+        float* hrow = m.h + ((size_t)b * L + t0) * D + wave * 32 + 4 * c;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int tr = i * 8 + rsub;
+            const float4 a = *reinterpret_cast<const float4*>(rs + tr * 32 + 4 * (c ^ (tr & 7)));
+            if (t0 + tr < L) *reinterpret_cast<float4*>(hrow + (size_t)tr * D) = a;
+        }
+    }
+    CLM_STAMP_AT(18);
+    // ---- 6. what follows, on the tile still in registers
+    if constexpr (NEXT != NEXT_NONE) {
+        load_set<PREC, D, 1>(wn, 0, 0, 1, wave, lane, bs[1]);
+        __builtin_amdgcn_sched_barrier(0);
+        // (the first barrier inside orders the staging reads above before the As writes)
+        ln_acc_to_tile<PREC>(acc2, P1, P2, NEXT == NEXT_SCORE ? m.sp.ln_g : m.n_g, NEXT == NEXT_SCORE ? m.sp.ln_b : m.n_b,
+                             m.eps, As, t0, L, wave, lrow, lhalf);
+        CLM_STAMP_AT(19);
+        if constexpr (NEXT == NEXT_INPROJ) {
+            // bs[1] is re-requested by the block loop (same addresses, L2-resident): keeps the loop identical to in_proj16
+            inproj_blocks<PREC>(As, Hs, wn, m.n_bias, m.n_z, b, t0, Lp, wave, lane, bs, acc1);
+        } else {
+            score_pool_tile<PREC>(m.sp, As, reinterpret_cast<float*>(Hs), b, blockIdx.x, tid, bs, acc1);
+        }
+        CLM_STAMP_AT(20);
+    }
+#undef CLM_STAMP_AT
 }
 
 // ================================================================================================ launchers
@@ -701,27 +745,33 @@ void tail16_dump_stamps() {
     size_t n = 0;
     for (size_t w = 0; w < s_stamp_wgs; ++w) {
         const unsigned long long* p = &hst[w * TAIL_NSTAMP];
-        if (!p[0] || !p[18]) continue;
-        for (int k = 1; k <= 18; ++k) sum[k] += double(p[k] - p[k - 1]);
+        if (!p[0] || !p[20]) continue;
+        for (int k = 1; k <= 20; ++k) sum[k] += double(p[k] - p[k - 1]);
         ++n;
     }
-    const char* names[19] = {"", "issue+y_stage", "out_proj", "ln_stats", "ln_write", "fc1.0", "gelu.0", "fc2.0", "fc1.1", "gelu.1",
-                             "fc2.1", "fc1.2", "gelu.2", "fc2.2", "fc1.3", "gelu.3", "fc2.3", "barrier", "epilogue"};
+    const char* names[21] = {"", "issue+y_stage", "out_proj", "ln2", "-", "fc1.0", "gelu.0", "fc2.0", "fc1.1", "gelu.1",
+                             "fc2.1", "fc1.2", "gelu.2", "fc2.2", "fc1.3", "gelu.3", "fc2.3", "barrier", "epilogue", "next_ln", "next_inproj"};
     double tot = 0;
-    for (int k = 1; k <= 18; ++k) tot += sum[k] / (n ? n : 1);
+    for (int k = 1; k <= 20; ++k) tot += sum[k] / (n ? n : 1);
     std::fprintf(stderr, "[tail16 stamps] %zu workgroups, mean s_memtime ticks per phase (total %.0f):\n", n, tot);
-    for (int k = 1; k <= 18; ++k) std::fprintf(stderr, "  %-14s %9.0f  %5.1f %%\n", names[k], sum[k] / (n ? n : 1), 100.0 * sum[k] / (n ? n : 1) / tot);
+    for (int k = 1; k <= 20; ++k) std::fprintf(stderr, "  %-14s %9.0f  %5.1f %%\n", names[k], sum[k] / (n ? n : 1), 100.0 * sum[k] / (n ? n : 1) / tot);
 }
 
-void launch_tail16(int prec, const void* y, const void* w_out, const float* b_out, float* h, const float* g,
-                   const float* bta, const void* w1, const float* b1, const void* w2, const float* b2, int B, int L, int Lp,
-                   float eps, const unsigned char* ids8, const float* emb, hipStream_t st) {
-    TailArgs m{y, h, w_out, w1, w2, b_out, g, bta, b1, b2, B, L, Lp, eps, ids8, emb};
+template <int PREC, int NEXT>
+static void launch_tail_inst(const TailArgs& m, dim3 grid, size_t lds, hipStream_t st) {
+    static bool once = (set_lds(tail16_kernel<PREC, false, NEXT>, lds), true);
+    (void)once;
+    hipLaunchKernelGGL((tail16_kernel<PREC, false, NEXT>), grid, dim3(512), lds, st, m, (unsigned long long*)nullptr);
+}
+
+void launch_tail16(int prec, const TailArgs& m, int next, hipStream_t st) {
     constexpr size_t lds = (size_t)2 * 128 * RS16 * 2 + (size_t)2 * 16 * 128 * 4;
     static_assert((size_t)D * RSKM * 2 <= (size_t)2 * 128 * RS16 * 2, "y tile must fit under the partial tables");
-    dim3 grid((L + 127) / 128, B), block(512);
+    static_assert((size_t)8 * 32 * RSOUT * 2 <= (size_t)128 * RS16 * 2 + (size_t)2 * 16 * 128 * 4,
+                  "in_proj staging tiles must fit in the Hs region + the (by then dead) LayerNorm tables");
+    dim3 grid((m.L + 127) / 128, m.B), block(512);
     static const bool stamp = std::getenv("CLM_STAMP") && std::getenv("CLM_STAMP")[0] == '1';
-    if (stamp && prec == PREC_F16) {
+    if (stamp && prec == PREC_F16 && next == NEXT_INPROJ) {
         const size_t wgs = (size_t)grid.x * grid.y;
         if (wgs > s_stamp_wgs) {
             if (s_stamp_buf) (void)hipFree(s_stamp_buf);
@@ -729,19 +779,19 @@ void launch_tail16(int prec, const void* y, const void* w_out, const float* b_ou
             s_stamp_wgs = wgs;
         }
         (void)hipMemsetAsync(s_stamp_buf, 0, wgs * TAIL_NSTAMP * 8, st);
-        static bool once = (set_lds(tail16_kernel<PREC_F16, true>, lds), true);
+        static bool once = (set_lds(tail16_kernel<PREC_F16, true, NEXT_INPROJ>, lds), true);
         (void)once;
-        hipLaunchKernelGGL((tail16_kernel<PREC_F16, true>), grid, block, lds, st, m, s_stamp_buf);
+        hipLaunchKernelGGL((tail16_kernel<PREC_F16, true, NEXT_INPROJ>), grid, block, lds, st, m, s_stamp_buf);
         return;
     }
     if (prec == PREC_BF16) {
-        static bool once = (set_lds(tail16_kernel<PREC_BF16, false>, lds), true);
-        (void)once;
-        hipLaunchKernelGGL((tail16_kernel<PREC_BF16, false>), grid, block, lds, st, m, (unsigned long long*)nullptr);
+        if (next == NEXT_INPROJ) launch_tail_inst<PREC_BF16, NEXT_INPROJ>(m, grid, lds, st);
+        else if (next == NEXT_SCORE) launch_tail_inst<PREC_BF16, NEXT_SCORE>(m, grid, lds, st);
+        else launch_tail_inst<PREC_BF16, NEXT_NONE>(m, grid, lds, st);
     } else {
-        static bool once = (set_lds(tail16_kernel<PREC_F16, false>, lds), true);
-        (void)once;
-        hipLaunchKernelGGL((tail16_kernel<PREC_F16, false>), grid, block, lds, st, m, (unsigned long long*)nullptr);
+        if (next == NEXT_INPROJ) launch_tail_inst<PREC_F16, NEXT_INPROJ>(m, grid, lds, st);
+        else if (next == NEXT_SCORE) launch_tail_inst<PREC_F16, NEXT_SCORE>(m, grid, lds, st);
+        else launch_tail_inst<PREC_F16, NEXT_NONE>(m, grid, lds, st);
     }
 }
 
