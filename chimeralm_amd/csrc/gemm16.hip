@@ -128,23 +128,31 @@ __device__ __forceinline__ void resid_epilogue(float* h_out, const float* bias, 
 // ================================================================================================ in_proj
 // in_proj over a staged LN tile: three 256-feature blocks, z written channel-major [B, 768, Lp].  On entry bs[0]
 // holds (or has in flight) the first half-set of block 0; Zs = 8 wave-private staging tiles [32 features][RSOUT].
-template <int PREC>
+// `hook(step)`, step = 0..5, runs right after the weight request of each half-block: the caller may slip further global
+// loads in there (they queue BEHIND the weights the next MFMAs wait for -- vmcnt completes in order -- and have a whole
+// MFMA phase to land before the following weight request needs them out of the way).
+struct NoHook {
+    __device__ __forceinline__ void operator()(int) const {}
+};
+template <int PREC, typename Hook = NoHook>
 __device__ __forceinline__ void inproj_blocks(const typename CT<PREC>::elem* As, typename CT<PREC>::elem* Zs,
                                               const u16x8* wp, const float* __restrict__ bias_all, void* zout, int b,
                                               int t0, int Lp, int wave, int lane, u16x8 (&bs)[2][1][SETK],
-                                              f32x16 (&acc)[4]) {
+                                              f32x16 (&acc)[4], Hook hook = Hook()) {
     using elem = typename CT<PREC>::elem;
     constexpr int K = D, NBLOCKS = D3 / 256;
     const int lrow = lane & 31, lhalf = lane >> 5;
     elem* zs = Zs + wave * 32 * RSOUT;
-#pragma unroll 1
+#pragma unroll
     for (int nb = 0; nb < NBLOCKS; ++nb) {
         zero_acc(acc);
         load_set<PREC, K, 1>(wp, nb, 0, 1, wave, lane, bs[1]);
+        hook(2 * nb);
         __builtin_amdgcn_sched_barrier(0);
         compute_tm<PREC, false>(As, 0, lrow, lhalf, bs[0], acc);
         __builtin_amdgcn_sched_barrier(0);
         load_set<PREC, K, 1>(wp, nb + 1 < NBLOCKS ? nb + 1 : 0, 0, 0, wave, lane, bs[0]);
+        hook(2 * nb + 1);
         __builtin_amdgcn_sched_barrier(0);
         compute_tm<PREC, false>(As, 1, lrow, lhalf, bs[1], acc);
         __builtin_amdgcn_sched_barrier(0);
@@ -498,12 +506,37 @@ __device__ __forceinline__ void ln_acc_to_tile(const f32x16 (&acc2)[4], float* P
 // written once per block, and the separate in_proj / score launches (latency-bound on their own) disappear.
 constexpr int TAIL_NSTAMP = 24;
 
+// residual rows of tile (b, t0) in accumulator layout (block 0 of the id path: embedding rows by token id); one piece =
+// the 32 token rows of one accumulator tile
+__device__ __forceinline__ void tail_load_resid_piece(const TailArgs& m, float4 (&hv)[4], int mt, int b, int t0, int wave,
+                                                      int lrow, int lhalf) {
+    const int t = t0 + mt * 32 + lrow, tc = t < m.L ? t : 0;
+    const float* row = m.ids8 ? m.emb + (size_t)m.ids8[(size_t)b * m.Lp + tc] * D + wave * 32 + 4 * lhalf
+                              : m.h + ((size_t)b * m.L + tc) * D + wave * 32 + 4 * lhalf;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) hv[q] = *reinterpret_cast<const float4*>(row + 8 * q);
+}
+__device__ __forceinline__ void tail_load_resid(const TailArgs& m, float4 (&hv)[4][4], int b, int t0, int wave, int lrow,
+                                                int lhalf) {
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) tail_load_resid_piece(m, hv[mt], mt, b, t0, wave, lrow, lhalf);
+}
+// hook for inproj_blocks: the four pieces of the next tile's residual, one per half-block
+struct ResidHook {
+    const TailArgs& m;
+    float4 (&hv)[4][4];
+    int b, t0, wave, lrow, lhalf;
+    __device__ __forceinline__ void operator()(int step) const {
+        if (step < 4) tail_load_resid_piece(m, hv[step], step, b, t0, wave, lrow, lhalf);
+    }
+};
+
 template <int PREC, bool STAMP = false, int NEXT = NEXT_NONE>
 __global__ __launch_bounds__(512) void tail16_kernel(TailArgs m, unsigned long long* stamps) {
 #define CLM_STAMP_AT(k)                                                                                   \
     do {                                                                                                  \
         if (STAMP && threadIdx.x == 0)                                                                    \
-            stamps[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * TAIL_NSTAMP + (k)] = __builtin_amdgcn_s_memtime(); \
+            stamps[(size_t)tile * TAIL_NSTAMP + (k)] = __builtin_amdgcn_s_memtime(); \
     } while (0)
     using elem = typename CT<PREC>::elem;
     using frag = u16x8;
@@ -514,8 +547,7 @@ __global__ __launch_bounds__(512) void tail16_kernel(TailArgs m, unsigned long l
     elem* Ys = reinterpret_cast<elem*>(smem);              // y tile [256 channels][RSKM], k-major
     float* P1 = reinterpret_cast<float*>(smem + (size_t)2 * BM * RS16 * 2);   // row-sum partials [16][128]
     float* P2 = P1 + 16 * BM;                                                 // squared-deviation partials
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lrow = lane & 31, lhalf = lane >> 5;
-    const int b = blockIdx.y, t0 = blockIdx.x * BM, L = m.L, Lp = m.Lp;
+    const int L = m.L, Lp = m.Lp, tiles_x = (L + BM - 1) / BM, total = tiles_x * m.B;
     const frag* wo = reinterpret_cast<const frag*>(m.w_out);
     const frag* w1 = reinterpret_cast<const frag*>(m.w1);
     const frag* w2 = reinterpret_cast<const frag*>(m.w2);
@@ -523,19 +555,26 @@ __global__ __launch_bounds__(512) void tail16_kernel(TailArgs m, unsigned long l
     f32x16 acc1[4], acc2[4];
     frag bs[2][1][SETK];
 
+    // Persistent workgroup: tiles blockIdx.x, blockIdx.x + gridDim.x, ...  The residual rows of the NEXT tile are requested
+    // before the in_proj / score stage of the current one, so that 128 KiB of the 192 KiB a tile has to pull from HBM
+    // arrive under compute (one workgroup per CU: nothing else would hide them; stamps showed 20 % of a tile's time there).
+    // (Starting the workgroups staggered by fractions of a tile, to spread the HBM-heavy phases of the chip over time,
+    // was measured too: 2 % slower -- the phases are latency-bound per CU, not a chip-wide bandwidth burst.)
+    float4 hv[4][4];                                       // residual in accumulator layout: token mt*32+lrow, 4 features
+    tail_load_resid(m, hv, blockIdx.x / tiles_x, (blockIdx.x % tiles_x) * BM, (int)threadIdx.x >> 6, (int)threadIdx.x & 31,
+                    ((int)threadIdx.x >> 5) & 1);
+#pragma unroll 1
+    for (int tile = blockIdx.x; tile < total; tile += gridDim.x) {
+    // the thread index is made opaque once per trip: every address below is re-derived inside the trip instead of being
+    // hoisted out of the tile loop and kept (that costs ~190 spilled registers)
+    int tid_l = threadIdx.x;
+    asm volatile("" : "+v"(tid_l));
+    const int tid = tid_l, lane = tid & 63, wave = tid >> 6, lrow = lane & 31, lhalf = lane >> 5;
+    const int b = tile / tiles_x, t0 = (tile % tiles_x) * BM;
     CLM_STAMP_AT(0);
     // ---- 0. everything that only depends on addresses is requested first
     load_set<PREC, D, 1>(wo, 0, 0, 0, wave, lane, bs[0]);
     load_set<PREC, D, 1>(wo, 0, 0, 1, wave, lane, bs[1]);
-    float4 hv[4][4];                                       // residual in accumulator layout: token mt*32+lrow, 4 features
-#pragma unroll
-    for (int mt = 0; mt < 4; ++mt) {
-        const int t = t0 + mt * 32 + lrow, tc = t < L ? t : 0;
-        const float* row = m.ids8 ? m.emb + (size_t)m.ids8[(size_t)b * Lp + tc] * D + wave * 32 + 4 * lhalf
-                                  : m.h + ((size_t)b * L + tc) * D + wave * 32 + 4 * lhalf;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) hv[mt][q] = *reinterpret_cast<const float4*>(row + 8 * q);
-    }
     // (gathering these rows as whole 128-byte lines through a wave-private LDS transpose was measured: no faster -- the
     // phase is bound by how many misses one workgroup per CU keeps in flight, not by the address unit)
     __builtin_amdgcn_sched_barrier(0);
@@ -658,6 +697,13 @@ __global__ __launch_bounds__(512) void tail16_kernel(TailArgs m, unsigned long l
         }
     }
     CLM_STAMP_AT(18);
+    // residual rows of this workgroup's next tile (clamped to the current one on the last trip: unconditional loads)
+    const int nt = tile + (int)gridDim.x < total ? tile + (int)gridDim.x : tile;
+    const int nb_ = nt / tiles_x, nt0 = (nt % tiles_x) * BM;
+    if constexpr (NEXT != NEXT_INPROJ) {
+        tail_load_resid(m, hv, nb_, nt0, wave, lrow, lhalf);
+        __builtin_amdgcn_sched_barrier(0);
+    }
     // ---- 6. what follows, on the tile still in registers
     if constexpr (NEXT != NEXT_NONE) {
         load_set<PREC, D, 1>(wn, 0, 0, 1, wave, lane, bs[1]);
@@ -668,11 +714,16 @@ __global__ __launch_bounds__(512) void tail16_kernel(TailArgs m, unsigned long l
         CLM_STAMP_AT(19);
         if constexpr (NEXT == NEXT_INPROJ) {
             // bs[1] is re-requested by the block loop (same addresses, L2-resident): keeps the loop identical to in_proj16
-            inproj_blocks<PREC>(As, Hs, wn, m.n_bias, m.n_z, b, t0, Lp, wave, lane, bs, acc1);
+            // the 128 KiB of residual rows trickle in as four pieces behind the weight requests of the first four half-blocks
+            // (requested in one go before the LayerNorm they stalled every later load of the stage: +9k cycles)
+            inproj_blocks<PREC>(As, Hs, wn, m.n_bias, m.n_z, b, t0, Lp, wave, lane, bs, acc1,
+                                ResidHook{m, hv, nb_, nt0, wave, lrow, lhalf});
         } else {
-            score_pool_tile<PREC>(m.sp, As, reinterpret_cast<float*>(Hs), b, blockIdx.x, tid, bs, acc1);
+            score_pool_tile<PREC>(m.sp, As, reinterpret_cast<float*>(Hs), b, tile % tiles_x, tid, bs, acc1);
         }
         CLM_STAMP_AT(20);
+    }
+    __syncthreads();                                       // every wave is done with the tiles in LDS before the next y tile lands
     }
 #undef CLM_STAMP_AT
 }
@@ -769,10 +820,16 @@ void launch_tail16(int prec, const TailArgs& m, int next, hipStream_t st) {
     static_assert((size_t)D * RSKM * 2 <= (size_t)2 * 128 * RS16 * 2, "y tile must fit under the partial tables");
     static_assert((size_t)8 * 32 * RSOUT * 2 <= (size_t)128 * RS16 * 2 + (size_t)2 * 16 * 128 * 4,
                   "in_proj staging tiles must fit in the Hs region + the (by then dead) LayerNorm tables");
-    dim3 grid((m.L + 127) / 128, m.B), block(512);
+    const int total = ((m.L + 127) / 128) * m.B;
+    static const int cus = [] {
+        int dev = 0, n = 256;
+        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+        return n > 0 ? n : 256;
+    }();
+    dim3 grid(total < cus ? total : cus), block(512);          // persistent: one workgroup per CU (LDS-limited anyway)
     static const bool stamp = std::getenv("CLM_STAMP") && std::getenv("CLM_STAMP")[0] == '1';
     if (stamp && prec == PREC_F16 && next == NEXT_INPROJ) {
-        const size_t wgs = (size_t)grid.x * grid.y;
+        const size_t wgs = (size_t)total;
         if (wgs > s_stamp_wgs) {
             if (s_stamp_buf) (void)hipFree(s_stamp_buf);
             (void)hipMalloc((void**)&s_stamp_buf, wgs * TAIL_NSTAMP * 8);
