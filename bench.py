@@ -157,14 +157,21 @@ def main():
         dom = max(prof, key=lambda k: prof[k][0])
         ms, launches = prof[dom]
         tokens_per_launch = (hi - lo) * L * a.steps * (NLAYER if dom not in ("embed", "lnf_pool_score", "softmax_pool", "head_mlp") else 1) / max(1, launches)
+        flops_per_token = STAGE_FLOPS_PER_TOKEN.get(dom, 0)
+        fused_next = dom == "out_proj_ln2_mlp" and prof.get("ln1_in_proj", (0.0, 0))[1] == 0
+        if fused_next:
+            # the tail kernel of block i also runs LN1 + in_proj of block i+1 (3 of the 4 launches of a forward) or
+            # ln_f + the pooling-score GEMM (the last one): average over the launches of a forward
+            flops_per_token += ((NLAYER - 1) * STAGE_FLOPS_PER_TOKEN["ln1_in_proj"] + STAGE_FLOPS_PER_TOKEN["lnf_pool_score"]) / NLAYER
         if dom in STAGE_FLOPS_PER_TOKEN:
-            achieved = STAGE_FLOPS_PER_TOKEN[dom] * tokens_per_launch / (ms / launches * 1e-3) / 1e12
+            achieved = flops_per_token * tokens_per_launch / (ms / launches * 1e-3) / 1e12
             roof = {"bound": "mfma", "kernel": dom, "achieved": achieved, "peak": PEAK_TFLOPS[a.precision],
                     "unit": "TFLOP/s", "frac": achieved / PEAK_TFLOPS[a.precision], "traffic": None}
         else:
             achieved = stage_bytes_per_token(dom, es) * tokens_per_launch / (ms / launches * 1e-3) / 1e9
             roof = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                     "frac": achieved / PEAK_HBM_GBS, "traffic": None}
+        roof["flops_per_token_per_launch"] = flops_per_token if dom in STAGE_FLOPS_PER_TOKEN else None
         roof["avg_launch_ms"] = ms / max(1, launches)
         roof["launches"] = launches
         config = {"workload": f"synthetic {a.bases}-bp reads, global batch {a.batch}, 1 forward per step",
@@ -173,7 +180,10 @@ def main():
         tr = measured_traffic(dom, config, a.precision)
         if tr:
             roof["traffic"], roof["traffic_unit"], roof["traffic_source"] = tr["hbm_bytes_per_launch"], "bytes/launch", tr["source"]
-            roof["algorithmic_hbm_bytes_per_launch"] = (stage_bytes_per_token(dom, es) or TAIL_BYTES_PER_TOKEN.get(dom, {}).get(es, 0.0)) * tokens_per_launch
+            alg = stage_bytes_per_token(dom, es) or TAIL_BYTES_PER_TOKEN.get(dom, {}).get(es, 0.0)
+            if fused_next:   # + z of the next block (3 of 4 launches); block 0 reads ids instead of its residual rows
+                alg += 3 * D * es * (NLAYER - 1) / NLAYER - D * 4 / NLAYER
+            roof["algorithmic_hbm_bytes_per_launch"] = alg * tokens_per_launch
         res = {
             "metric": "reads/sec (whole node), 8k-bp reads batch=256", "value": a.batch * a.steps / elapsed,
             "unit": "reads/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
