@@ -37,6 +37,7 @@ def predict(
     ckpt_path: Path | None = typer.Option(None, "--ckpt", "-c", hidden=True, help="Path to the checkpoint file"),
     weights: str = typer.Option("yangliz5/chimeralm", "--weights", help="Directory/file with model.safetensors"),
     precision: str = typer.Option("fp32", "--precision", help="MFMA input type: fp32 | bf16 | fp16"),
+    feeder: str = typer.Option("native", "--feeder", help="BAM input: native (C++ decoder thread, pinned ring) | python"),
     random: bool = typer.Option(False, "--random", "-r", help="Make the prediction not deterministic"),
     verbose: bool = typer.Option(False, "--verbose", "-v", help="Enable verbose output"),
 ):
@@ -61,8 +62,10 @@ def predict(
     device = torch.device("cuda", local_rank)
     torch.cuda.set_device(device)
     tok = tokenizer.load_tokenizer_from_hyena_model("hyenadna-small-32k-seqlen")
-    dm = bam.BamDataModule(tokenizer=tok, train_data_path=Path("dummy.bam"), predict_data_path=data_path,
-                           batch_size=batch_size, num_workers=num_workers)
+    if feeder not in ("native", "python"):
+        raise typer.BadParameter("--feeder must be native or python")
+    if batch_size % world != 0:                   # bam.py:142-146
+        raise RuntimeError(f"Batch size ({batch_size}) is not divisible by the number of devices ({world}).")
     if ckpt_path is not None:
         log.info(f"Loading model from {ckpt_path}")
         model = lm.ChimeraLM.new(precision=precision).load_reference_checkpoint(ckpt_path)
@@ -70,9 +73,19 @@ def predict(
         log.info(f"Loading model weights {weights}")
         model = lm.ChimeraLM.from_pretrained(weights, precision=precision)
     output_path.mkdir(parents=True, exist_ok=True)
-    dm.setup("predict", world_size=world, rank=rank)
     writer = callbacks.PredictionWriter(output_dir=output_path, write_interval="batch")
-    n = loop.run_predict(model, dm, writer, device, rank=rank)
+    if feeder == "native":
+        from .feeder import BamFeeder
+
+        with BamFeeder(data_path, batch_size=batch_size // world, max_tokens=tok.max_len_single_sentence, rank=rank,
+                       world=world, pad_left=tok.padding_side == "left") as fd:
+            n = loop.run_predict_native(model, fd, writer, device, rank=rank)
+            log.info(f"[rank {rank}] feeder: {fd.stats()}")
+    else:
+        dm = bam.BamDataModule(tokenizer=tok, train_data_path=Path("dummy.bam"), predict_data_path=data_path,
+                               batch_size=batch_size, num_workers=num_workers)
+        dm.setup("predict", world_size=world, rank=rank)
+        n = loop.run_predict(model, dm, writer, device, rank=rank)
     distributed.barrier()
     log.info(f"[rank {rank}] {n} reads; predictions saved to {output_path}")
 

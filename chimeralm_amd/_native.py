@@ -30,7 +30,18 @@ class ClmConfig(C.Structure):
     ]
 
 
-# every symbol include/chimeralm_hip.h declares: name -> (restype, argtypes)
+class ClmFeederConfig(C.Structure):          # include/chimeralm_feed.h: struct clm_feeder_config
+    _fields_ = [("struct_size", C.c_int32), ("batch_size", C.c_int32), ("max_tokens", C.c_int32), ("slots", C.c_int32),
+                ("rank", C.c_int32), ("world", C.c_int32), ("pad_left", C.c_int32), ("pinned", C.c_int32),
+                ("max_reads", C.c_int64)]
+
+
+class ClmFeedBatch(C.Structure):              # include/chimeralm_feed.h: struct clm_feed_batch
+    _fields_ = [("slot", C.c_int32), ("n_reads", C.c_int32), ("n_tokens", C.c_int32), ("reserved", C.c_int32),
+                ("row_stride", C.c_int64), ("ids", C.c_void_p), ("names", C.c_void_p), ("first_index", C.c_int64)]
+
+
+# every symbol include/chimeralm_hip.h and include/chimeralm_feed.h declare: name -> (restype, argtypes)
 _H = C.c_void_p
 SYMBOLS = {
     "clm_abi_version": (C.c_int, []),
@@ -40,6 +51,9 @@ SYMBOLS = {
     "clm_finalize": (C.c_int, [_H]),
     "clm_reserve": (C.c_int, [_H, C.c_int, C.c_int]),
     "clm_forward": (C.c_int, [_H, C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "clm_stage_ids": (C.c_int, [_H, C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_int, C.POINTER(C.c_int)]),
+    "clm_forward_staged": (C.c_int, [_H, C.c_int, C.c_void_p, C.c_void_p]),
+    "clm_stage_wait": (C.c_int, [_H, C.c_int]),
     "clm_debug_fetch": (C.c_int, [_H, C.c_char_p, C.c_void_p, C.c_size_t]),
     "clm_debug_stop_after": (C.c_int, [_H, C.c_int, C.c_int]),
     "clm_profile_enable": (C.c_int, [_H, C.c_int]),
@@ -47,6 +61,14 @@ SYMBOLS = {
     "clm_profile_stage_name": (C.c_char_p, [C.c_int]),
     "clm_last_error": (C.c_char_p, [_H]),
     "clm_destroy": (C.c_int, [_H]),
+    "clm_feeder_default_config": (C.c_int, [C.POINTER(ClmFeederConfig)]),
+    "clm_feeder_open": (C.c_int, [C.c_char_p, C.POINTER(ClmFeederConfig), C.POINTER(_H)]),
+    "clm_feeder_next": (C.c_int, [_H, C.POINTER(ClmFeedBatch)]),
+    "clm_feeder_release": (C.c_int, [_H, C.c_int32]),
+    "clm_feeder_stats": (C.c_int, [_H, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64),
+                                   C.POINTER(C.c_int64)]),
+    "clm_feeder_last_error": (C.c_char_p, [_H]),
+    "clm_feeder_close": (C.c_int, [_H]),
 }
 
 _lib = None

@@ -13,7 +13,7 @@ from pathlib import Path
 CSRC = Path(__file__).resolve().parent / "csrc"
 INCLUDE = Path(__file__).resolve().parent.parent / "include"
 LIB = CSRC / "libchimeralm_hip.so"
-SOURCES = ["clm_api.hip", "gemm.hip", "gemm16.hip", "hyena_conv.hip", "head.hip"]
+SOURCES = ["clm_api.hip", "gemm.hip", "gemm16.hip", "hyena_conv.hip", "head.hip", "bam_feeder.cpp"]
 HEADERS = ["clm_common.h", "gemm_common.h", "fft_core.h", "fft_passes.h"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast", "-Wall", "-Wno-unused-function",
          "-Wno-pass-failed"]
@@ -23,7 +23,7 @@ def _stale() -> bool:
     if not LIB.exists():
         return True
     t = LIB.stat().st_mtime
-    deps = [CSRC / s for s in SOURCES + HEADERS] + [INCLUDE / "chimeralm_hip.h"]
+    deps = [CSRC / s for s in SOURCES + HEADERS] + [INCLUDE / "chimeralm_hip.h", INCLUDE / "chimeralm_feed.h"]
     return any(d.stat().st_mtime > t for d in deps)
 
 
@@ -34,7 +34,8 @@ def build(force: bool = False, verbose: bool = False) -> Path:
     procs = []
     for s in SOURCES:
         obj = CSRC / (Path(s).stem + ".o")
-        cmd = ["hipcc", *FLAGS, f"-I{INCLUDE}", f"-I{CSRC}", "-c", str(CSRC / s), "-o", str(obj)]
+        flags = FLAGS if s.endswith(".hip") else [f for f in FLAGS if not f.startswith("--offload-arch")]   # host-only C++
+        cmd = ["hipcc", *flags, f"-I{INCLUDE}", f"-I{CSRC}", "-c", str(CSRC / s), "-o", str(obj)]
         if verbose:
             cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
         procs.append((s, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
@@ -47,7 +48,7 @@ def build(force: bool = False, verbose: bool = False) -> Path:
         failed |= p.returncode != 0
     if failed:
         raise RuntimeError("hipcc failed building the gfx950 engine")
-    subprocess.run(["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", str(LIB), *objs], check=True)
+    subprocess.run(["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", str(LIB), *objs, "-lz", "-lpthread"], check=True)
     return LIB
 
 

@@ -50,6 +50,17 @@ struct clm_handle {
     // packed / derived weights
     void* packed[NLAYER][4] = {};
     void* packed_score = nullptr;
+    // host batches: two device staging buffers fed by the handle's own copy stream
+    struct Stage {
+        void* buf = nullptr;
+        size_t cap = 0;
+        int dtype = 0, B = 0, L = 0;
+        int64_t stride = 0;
+        hipEvent_t copied = nullptr, consumed = nullptr;
+        bool used = false, pending = false;
+    } stage[2];
+    hipStream_t copy_stream = nullptr;
+    int next_stage = 0;
     float* ztab = nullptr;        // [16][768] block-0 in_proj rows per token id (16-bit modes)
     unsigned char* ids8 = nullptr;   // workspace: clamped ids [B][Lp]
     float* head_t[5] = {};
@@ -645,6 +656,66 @@ int clm_forward(clm_handle* h, const void* ids, int ids_dtype, int64_t ids_row_s
     return CLM_OK;
 }
 
+int clm_stage_ids(clm_handle* h, const void* host_ids, int ids_dtype, int64_t ids_row_stride, int B, int L, int* staged) {
+    if (!h) return CLM_E_INVALID;
+    if (!host_ids || !staged || B < 1 || L < 1 || ids_row_stride < L)
+        return fail(h, CLM_E_INVALID, "clm_stage_ids: bad argument");
+    if (ids_dtype != CLM_DT_I64 && ids_dtype != CLM_DT_I32 && ids_dtype != CLM_DT_U8)
+        return fail(h, CLM_E_INVALID, "clm_stage_ids: ids dtype must be i64, i32 or u8");
+    HIPCHK(h, hipSetDevice(h->device));
+    if (!h->copy_stream) HIPCHK(h, hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking));
+    const int k = h->next_stage;
+    clm_handle::Stage& s = h->stage[k];
+    if (s.pending) return fail(h, CLM_E_STATE, "clm_stage_ids: both staging buffers hold batches not yet run (clm_forward_staged)");
+    const size_t ies = ids_dtype == CLM_DT_I64 ? 8 : (ids_dtype == CLM_DT_I32 ? 4 : 1);
+    const size_t bytes = (size_t)B * (size_t)ids_row_stride * ies;
+    if (!s.copied) {
+        HIPCHK(h, hipEventCreateWithFlags(&s.copied, hipEventDisableTiming));
+        HIPCHK(h, hipEventCreateWithFlags(&s.consumed, hipEventDisableTiming));
+    }
+    if (s.used) HIPCHK(h, hipStreamWaitEvent(h->copy_stream, s.consumed, 0));   // the forward that read this buffer is done
+    if (bytes > s.cap) {
+        if (s.buf) {
+            HIPCHK(h, hipEventSynchronize(s.consumed));
+            HIPCHK(h, hipFree(s.buf));
+            s.buf = nullptr;
+        }
+        HIPCHK(h, hipMalloc(&s.buf, bytes));
+        s.cap = bytes;
+    }
+    HIPCHK(h, hipMemcpyAsync(s.buf, host_ids, bytes, hipMemcpyHostToDevice, h->copy_stream));
+    HIPCHK(h, hipEventRecord(s.copied, h->copy_stream));
+    s.dtype = ids_dtype; s.B = B; s.L = L; s.stride = ids_row_stride;
+    s.pending = true;
+    h->next_stage = k ^ 1;
+    *staged = k;
+    return CLM_OK;
+}
+
+int clm_forward_staged(clm_handle* h, int staged, float* logits_out, void* stream) {
+    if (!h) return CLM_E_INVALID;
+    if (staged < 0 || staged > 1 || !h->stage[staged].pending)
+        return fail(h, CLM_E_STATE, "clm_forward_staged: no batch staged in that buffer");
+    clm_handle::Stage& s = h->stage[staged];
+    HIPCHK(h, hipSetDevice(h->device));
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    HIPCHK(h, hipStreamWaitEvent(st, s.copied, 0));
+    const int rc = clm_forward(h, s.buf, s.dtype, s.stride, s.B, s.L, logits_out, stream);
+    if (rc) return rc;
+    HIPCHK(h, hipEventRecord(s.consumed, st));
+    s.pending = false;
+    s.used = true;
+    return CLM_OK;
+}
+
+int clm_stage_wait(clm_handle* h, int staged) {
+    if (!h) return CLM_E_INVALID;
+    if (staged < 0 || staged > 1 || !h->stage[staged].copied) return fail(h, CLM_E_STATE, "clm_stage_wait: nothing was staged there");
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipEventSynchronize(h->stage[staged].copied));
+    return CLM_OK;
+}
+
 int clm_debug_stop_after(clm_handle* h, int layer, int stage) {
     if (!h) return CLM_E_INVALID;
     h->stop_layer = layer;
@@ -725,6 +796,12 @@ int clm_destroy(clm_handle* h) {
     free_workspace(h);
     free_filters(h);
     free_packed(h);
+    for (auto& sg : h->stage) {
+        if (sg.buf) (void)hipFree(sg.buf);
+        if (sg.copied) (void)hipEventDestroy(sg.copied);
+        if (sg.consumed) (void)hipEventDestroy(sg.consumed);
+    }
+    if (h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
     for (auto& kv : h->w)
         if (kv.second.d) (void)hipFree(kv.second.d);
     delete h;

@@ -108,6 +108,25 @@ class Engine:
 
     __call__ = forward
 
+    # ------------------------------------------------------------------ host batches (pinned slots of the BAM feeder)
+    def stage_host_ids(self, host_ptr: int, ids_dtype: int, row_stride: int, batch: int, length: int) -> int:
+        """Enqueue the H2D copy of a host batch on the engine's own copy stream (overlaps the running forward);
+        returns the staging-buffer index to pass to `forward_staged` / `stage_wait`."""
+        k = C.c_int(-1)
+        self._check(self._lib.clm_stage_ids(self._h, C.c_void_p(host_ptr), int(ids_dtype), int(row_stride), int(batch),
+                                            int(length), C.byref(k)))
+        return k.value
+
+    def forward_staged(self, staged: int, batch: int, out: torch.Tensor | None = None) -> torch.Tensor:
+        if out is None:
+            out = torch.empty((batch, self.cfg.n_classes), dtype=torch.float32, device=self.device)
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        self._check(self._lib.clm_forward_staged(self._h, int(staged), C.c_void_p(out.data_ptr()), C.c_void_p(stream)))
+        return out
+
+    def stage_wait(self, staged: int):
+        self._check(self._lib.clm_stage_wait(self._h, int(staged)))
+
     # ------------------------------------------------------------------ taps
     def debug_stop_after(self, layer: int = -1, stage: int = -1):
         self._check(self._lib.clm_debug_stop_after(self._h, layer, stage))

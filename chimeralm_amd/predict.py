@@ -5,6 +5,10 @@
         H2D copy on a side stream (pinned staging, overlapped with the previous batch's compute)
         logits, labels = model.predict_step(batch)      # MI355X engine
         writer.write_on_batch_end(...)                  # {rank}_{batch}.txt, "name<TAB>label"
+
+`run_predict_native` is the same loop fed by the native BAM feeder (csrc/bam_feeder.cpp): a C++ thread decodes, selects,
+tokenises and collates into a ring of page-locked slots; each batch crosses PCIe as uint8 on the engine's copy stream
+(`clm_stage_ids`) while the previous batch is computing, and the slot goes back to the ring once its copy has landed.
 """
 from __future__ import annotations
 
@@ -51,4 +55,36 @@ def run_predict(model, datamodule, writer, device: torch.device, *, rank: int = 
             writer.write_on_batch_end(trainer, model, (logits, labels), None, cur, batch_idx, 0)
             n_reads += logits.shape[0]
             batch_idx += 1
+    return n_reads
+
+
+def run_predict_native(model, feeder, writer, device: torch.device, *, rank: int = 0, gather: bool = False,
+                       on_batch=None) -> int:
+    """Predict loop over a `chimeralm_amd.feeder.BamFeeder`; same files as `run_predict` over `BamDataModule`."""
+    from ._native import DT_U8
+
+    model.eval()
+    eng = model.net.engine(device)
+    trainer = SimpleNamespace(global_rank=rank)
+    n_reads, batch_idx = 0, 0
+    cur = feeder.next()
+    staged = eng.stage_host_ids(cur.ids_ptr, DT_U8, cur.row_stride, cur.n_reads, cur.n_tokens) if cur is not None else -1
+    with torch.inference_mode():
+        while cur is not None:
+            nxt = feeder.next()                               # already decoded by the feeder thread, normally
+            nxt_staged = (eng.stage_host_ids(nxt.ids_ptr, DT_U8, nxt.row_stride, nxt.n_reads, nxt.n_tokens)
+                          if nxt is not None else -1)         # H2D of batch i+1 overlaps the forward of batch i
+            logits = eng.forward_staged(staged, cur.n_reads)
+            eng.stage_wait(staged)                            # the copy has left the slot ...
+            feeder.release(cur)                               # ... which goes back to the decoder
+            labels = torch.full((cur.n_reads,), -1, dtype=torch.int64)   # tokenizer.py:113: predict labels are all -1
+            batch = {"id": torch.from_numpy(cur.names), "labels": labels}
+            if gather:
+                logits_all = gather_logits(logits)
+                if on_batch is not None:
+                    on_batch(batch_idx, logits_all)
+            writer.write_on_batch_end(trainer, model, (logits, labels), None, batch, batch_idx, 0)
+            n_reads += cur.n_reads
+            batch_idx += 1
+            cur, staged = nxt, nxt_staged
     return n_reads

@@ -102,6 +102,18 @@ int clm_reserve(clm_handle* h, int B, int L);
 int clm_forward(clm_handle* h, const void* ids, int ids_dtype, int64_t ids_row_stride, int B, int L,
                 float* logits_out, void* stream);
 
+/* ---- batches that arrive in host memory ------------------------------------------------------------
+ * Replaces the `batch["input_ids"].to(device)` Lightning performs before predict_step (basic_module.py:177-187 receives a
+ * device batch).  Two device staging buffers per handle: clm_stage_ids enqueues the H2D copy of a batch on the HANDLE'S OWN
+ * copy stream (so it overlaps the forward pass running on the compute stream) and returns which buffer it used;
+ * clm_forward_staged makes the compute stream wait for exactly that copy and runs the forward on it; clm_stage_wait blocks
+ * the host until the copy has left the host buffer (a pinned slot of the BAM feeder, chimeralm_feed.h, can then be
+ * released).  A staging buffer is not overwritten before the forward that read it has finished (event-ordered).
+ * `host_ids` should be page-locked for the copy to be asynchronous. */
+int clm_stage_ids(clm_handle* h, const void* host_ids, int ids_dtype, int64_t ids_row_stride, int B, int L, int* staged);
+int clm_forward_staged(clm_handle* h, int staged, float* logits_out, void* stream);
+int clm_stage_wait(clm_handle* h, int staged);
+
 /* ---- test / measurement taps (not on the product path) -------------------------------------------- */
 
 /* Copy a named intermediate of the LAST clm_forward to host memory (synchronises the device).  Names:

@@ -193,6 +193,52 @@ def test_module_boundary_and_writer(sd, tmp_path, built_lib):
     assert ((logits2 - logits).cpu() - 1.0).abs().max() < 1e-5
 
 
+def test_native_feeder_predict_loop(sd, tmp_path, golden_dir, built_lib):
+    """BAM -> C++ feeder (pinned ring) -> clm_stage_ids on the copy stream -> clm_forward_staged -> prediction files:
+    the same files as the Python data module + `run_predict`, and the labels the oracle gives for those batches."""
+    from chimeralm_amd import bam, lm, predict as loop, tokenizer as T
+    from chimeralm_amd.callbacks import PredictionWriter
+    from chimeralm_amd.feeder import BamFeeder
+
+    path = golden_dir / "test_chimric_reads.bam"
+    device = torch.device("cuda", 0)
+    model = lm.ChimeraLM.new(precision="fp32")
+    model.load_state_dict(sd, strict=True)
+    tok = T.CharTokenizer(model_max_length=2501, padding_side="left")
+    dm = bam.BamDataModule(tokenizer=tok, predict_data_path=path, batch_size=10, max_predict_samples=25)
+    dm.setup("predict")
+    n_py = loop.run_predict(model, dm, PredictionWriter(tmp_path / "py"), device)
+    with BamFeeder(path, batch_size=10, max_tokens=tok.max_len_single_sentence, max_reads=25, slots=2) as fd:
+        n_nat = loop.run_predict_native(model, fd, PredictionWriter(tmp_path / "native"), device)
+        assert fd.stats()["delivered"] == 25
+    assert n_py == n_nat == 25
+    names = sorted(p.name for p in (tmp_path / "py").iterdir())
+    assert names == ["0_0.txt", "0_1.txt", "0_2.txt"] == sorted(p.name for p in (tmp_path / "native").iterdir())
+    for n in names:
+        assert (tmp_path / "py" / n).read_text() == (tmp_path / "native" / n).read_text()
+    batch0 = next(iter(dm.predict_dataloader()))
+    ref = ho.forward(batch0["input_ids"], sd).numpy()
+    assert (tmp_path / "native" / "0_0.txt").read_text() == "".join(do.prediction_lines(ref, batch0["id"].numpy()))
+
+
+def test_staging_api_state_machine(engines):
+    from chimeralm_amd import _native as N
+    from chimeralm_amd.engine import EngineError
+
+    e = engines["fp16"]
+    ids = torch.from_numpy(_ids(3, 300)).pin_memory()
+    k0 = e.stage_host_ids(ids.data_ptr(), N.DT_U8, ids.stride(0), 3, 300)
+    k1 = e.stage_host_ids(ids.data_ptr(), N.DT_U8, ids.stride(0), 3, 300)
+    assert {k0, k1} == {0, 1}
+    with pytest.raises(EngineError, match="both staging buffers"):
+        e.stage_host_ids(ids.data_ptr(), N.DT_U8, ids.stride(0), 3, 300)
+    a, b = e.forward_staged(k0, 3), e.forward_staged(k1, 3)
+    e.stage_wait(k0), e.stage_wait(k1)
+    assert torch.equal(a.cpu(), b.cpu()) and torch.equal(a.cpu(), e.forward(ids.cuda()).cpu())
+    with pytest.raises(EngineError, match="no batch staged"):
+        e.forward_staged(k0, 3)
+
+
 def test_error_behaviour(engines):
     from chimeralm_amd.engine import EngineError
 

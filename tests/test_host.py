@@ -15,7 +15,7 @@ REPO = Path(__file__).resolve().parent.parent
 
 
 def test_abi_exports_every_header_symbol(built_lib):
-    header = (REPO / "include" / "chimeralm_hip.h").read_text()
+    header = (REPO / "include" / "chimeralm_hip.h").read_text() + (REPO / "include" / "chimeralm_feed.h").read_text()
     declared = set(re.findall(r"\b(clm_[a-z_]+)\s*\(", header))
     lib = ctypes.CDLL(str(built_lib))
     for name in sorted(declared):
@@ -137,6 +137,114 @@ def test_bam_module_batches_like_the_reference(golden_dir):
     dm.setup("predict", world_size=2, rank=1)                                # rank r sees reads r, r+G, ...
     first = next(iter(dm.predict_dataloader()))
     assert first["input_ids"].shape[0] == 6
+
+
+def _feeder_batches(path, **kw):
+    from chimeralm_amd.feeder import BamFeeder
+
+    with BamFeeder(path, pinned=False, **kw) as f:          # plain host memory: the decoder itself needs no GPU
+        out = list(f)
+        return out, f.stats()
+
+
+def test_native_feeder_matches_the_reference_data_path(golden_dir):
+    """C++ feeder (BGZF inflate, record decode, SA/primary selection, tokenisation from the 4-bit codes, [SEP],
+    truncation, id rows, left-padded collation, per-rank batches) == oracle restatement of the reference's Python path."""
+    from oracle import data_oracle as do
+
+    path = golden_dir / "test_chimric_reads.bam"
+    reads = list(do.chimeric_reads(path))
+    assert len(reads) == 100                                                 # tests/test_data_module.py: all selected
+    feats = [{"input_ids": do.tokenize(r["seq"], 32769), "id": do.pack_read_name(r["id"]), "labels": -1} for r in reads]
+    for world, rank, bs in ((1, 0, 12), (2, 0, 6), (2, 1, 6), (4, 3, 3), (1, 0, 7)):
+        mine = feats[rank::world]
+        got, st = _feeder_batches(path, batch_size=bs, world=world, rank=rank, max_tokens=32769)
+        assert len(got) == -(-len(mine) // bs)
+        for i, (ids, names) in enumerate(got):
+            want = do.collate(mine[i * bs: (i + 1) * bs], padding_side="left")
+            assert ids.dtype == np.uint8 and np.array_equal(ids.astype(np.int64), want["input_ids"])
+            assert names.dtype == np.int8 and np.array_equal(names, want["id"])
+        assert st["records"] == 100 and st["selected"] == 100 and st["delivered"] == len(mine)
+    # truncation length, right padding and max_reads are honoured
+    got, st = _feeder_batches(path, batch_size=5, max_tokens=1000, pad_left=False, max_reads=10)
+    assert len(got) == 2 and st["selected"] == 10 and st["truncated_bases"] > 0
+    want = do.collate([{"input_ids": do.tokenize(r["seq"], 1000), "id": do.pack_read_name(r["id"]), "labels": -1}
+                       for r in reads[:5]], padding_side="right")
+    assert np.array_equal(got[0][0].astype(np.int64), want["input_ids"]) and got[0][0].shape[1] <= 1000
+
+
+def test_native_feeder_selection_and_errors(tmp_path, golden_dir):
+    """Unmapped / secondary / supplementary / SA-less records are skipped like bam.py:21-23; broken files fail loudly."""
+    import gzip
+    import struct
+
+    from chimeralm_amd.feeder import BamFeeder, FeederError
+
+    def record(name, seq, flag, aux):
+        codes = {c: i for i, c in enumerate("=ACMGRSVTWYHKDBN")}
+        packed = bytearray((len(seq) + 1) // 2)
+        for i, ch in enumerate(seq):
+            packed[i // 2] |= codes[ch] << (4 if i % 2 == 0 else 0)
+        body = struct.pack("<iiBBHHHiiii", 0, 0, len(name) + 1, 60, 0, 1, flag, len(seq), -1, -1, 0) + name.encode() + b"\0"
+        body += struct.pack("<I", len(seq) << 4) + bytes(packed) + b"\xff" * len(seq) + aux
+        return struct.pack("<i", len(body)) + body
+
+    def bgzf(payload):
+        out = b""
+        for i in range(0, len(payload), 40000):                                   # several members, records straddle them
+            comp = __import__("zlib").compressobj(6, 8, -15)
+            chunk = payload[i: i + 40000]
+            data = comp.compress(chunk) + comp.flush()
+            out += struct.pack("<BBBBIBBHBBHH", 31, 139, 8, 4, 0, 0, 255, 6, 66, 67, 2, len(data) + 25)
+            out += data + struct.pack("<II", __import__("zlib").crc32(chunk), len(chunk))
+        return out + bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000")
+
+    sa = b"SAZchr1,1,+,10M,60,0;\0"
+    recs = [("keep1", "ACGTNACGTRY", 0, b"NMi\x01\0\0\0" + sa), ("unmapped", "ACGT", 4, sa), ("secondary", "ACGT", 256, sa),
+            ("supp", "ACGT", 2048, sa), ("no_sa", "ACGT", 0, b"NMi\x01\0\0\0"), ("keep2", "T" * 70001, 16, b"XBBc\x02\0\0\0\x01\x02" + sa),
+            ("n" * 200, "GATTACA", 0, sa)]
+    header = b"BAM\1" + struct.pack("<i", 4) + b"@HD\n" + struct.pack("<i", 1) + struct.pack("<i", 5) + b"chr1\0" + struct.pack("<i", 1000)
+    path = tmp_path / "t.bam"
+    path.write_bytes(bgzf(header + b"".join(record(*r) for r in recs)))
+    from chimeralm_amd import bam as pybam
+    assert [r["id"] for r in pybam.parse_bam_file(path)] == ["keep1", "keep2", "n" * 200]       # the Python mirror agrees
+    (ids, names), = _feeder_batches(path, batch_size=8, max_tokens=32769)[0]
+    assert ids.shape == (3, 32769)
+    assert ids[0, -12:].tolist() == [7, 8, 9, 10, 11, 7, 8, 9, 10, 6, 6, 1]          # R, Y -> [UNK]; trailing [SEP]
+    assert (ids[0, :-12] == 4).all() and (ids[1, :-1] == 10).all() and ids[1, -1] == 1   # left pad; truncated to 32768 bases
+    assert names[0, 0] == 5 and bytes(names[0, 1:6].view(np.uint8)) == b"keep1" and names[2, 0] == np.int8(200 - 256)
+    # not a BAM / truncated file / bad arguments
+    (tmp_path / "x.bam").write_bytes(gzip.compress(b"not a bam"))
+    with pytest.raises(FeederError, match="BGZF|BAM"):
+        BamFeeder(tmp_path / "x.bam", pinned=False)
+    with pytest.raises(FeederError, match="cannot open"):
+        BamFeeder(tmp_path / "missing.bam", pinned=False)
+    data = path.read_bytes()
+    (tmp_path / "cut.bam").write_bytes(data[: len(data) // 2])
+    with pytest.raises(FeederError, match="truncated|corrupt|ends inside"):
+        with BamFeeder(tmp_path / "cut.bam", pinned=False, batch_size=8) as f:
+            list(f)
+    with pytest.raises(FeederError, match="bad batch_size"):
+        BamFeeder(path, pinned=False, batch_size=0)
+
+
+def test_native_feeder_ring_backpressure(golden_dir):
+    """A consumer that holds slots stalls the decoder instead of being overwritten; releasing resumes it."""
+    from chimeralm_amd.feeder import BamFeeder
+
+    with BamFeeder(golden_dir / "test_chimric_reads.bam", batch_size=4, slots=2, pinned=False, max_tokens=500) as f:
+        a, b = f.next(), f.next()
+        a_ids, b_ids = a.ids.copy(), b.ids.copy()
+        import time
+        time.sleep(0.2)                                       # decoder would have lapped the ring by now if it could
+        assert np.array_equal(a.ids, a_ids) and np.array_equal(b.ids, b_ids) and a.first_index == 0 and b.first_index == 4
+        f.release(a), f.release(b)
+        n = 8
+        while (c := f.next()) is not None:
+            assert c.first_index == n
+            n += c.n_reads
+            f.release(c)
+        assert n == 100
 
 
 def test_prediction_writer_file_format(tmp_path):
