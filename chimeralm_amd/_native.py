@@ -6,9 +6,11 @@ engine fails loudly.  Build it with `python -m chimeralm_amd.build` (hipcc, gfx9
 from __future__ import annotations
 
 import ctypes as C
+import os
 from pathlib import Path
 
-LIB_PATH = Path(__file__).resolve().parent / "csrc" / "libchimeralm_hip.so"
+# CLM_LIB points development A/B runs at another build of the same ABI; the product default is the in-tree library
+LIB_PATH = Path(os.environ.get("CLM_LIB") or Path(__file__).resolve().parent / "csrc" / "libchimeralm_hip.so")
 
 # error codes / enums (mirror include/chimeralm_hip.h)
 OK, E_INVALID, E_HIP, E_MISSING, E_UNSUPPORTED, E_STATE = 0, -1, -2, -3, -4, -5

@@ -522,12 +522,24 @@ __device__ __forceinline__ void tail_load_resid(const TailArgs& m, float4 (&hv)[
     for (int mt = 0; mt < 4; ++mt) tail_load_resid_piece(m, hv[mt], mt, b, t0, wave, lrow, lhalf);
 }
 // hook for inproj_blocks: the four pieces of the next tile's residual, one per half-block
+// ... and the next tile's y tile (8 x 16 bytes per thread) behind the last two
+template <typename E>
+__device__ __forceinline__ void tail_load_y_piece(const TailArgs& m, uint4 (&yx)[8], int half, int b, int t0, int tid) {
+    const E* src = reinterpret_cast<const E*>(m.y) + (size_t)b * D * m.Lp + t0;
+    const int tk = (tid & 15) * 8, tkc = t0 + tk < m.Lp ? tk : 0;   // clamped, branch-free; masked at the LDS store
+#pragma unroll
+    for (int i = 4 * half; i < 4 * half + 4; ++i)
+        yx[i] = *reinterpret_cast<const uint4*>(src + (size_t)((tid >> 4) + 32 * i) * m.Lp + tkc);
+}
+template <typename E>
 struct ResidHook {
     const TailArgs& m;
     float4 (&hv)[4][4];
-    int b, t0, wave, lrow, lhalf;
+    uint4 (&yx)[8];
+    int b, t0, wave, lrow, lhalf, tid;
     __device__ __forceinline__ void operator()(int step) const {
         if (step < 4) tail_load_resid_piece(m, hv[step], step, b, t0, wave, lrow, lhalf);
+        else tail_load_y_piece<E>(m, yx, step - 4, b, t0, tid);
     }
 };
 
@@ -561,8 +573,11 @@ __global__ __launch_bounds__(512) void tail16_kernel(TailArgs m, unsigned long l
     // (Starting the workgroups staggered by fractions of a tile, to spread the HBM-heavy phases of the chip over time,
     // was measured too: 2 % slower -- the phases are latency-bound per CU, not a chip-wide bandwidth burst.)
     float4 hv[4][4];                                       // residual in accumulator layout: token mt*32+lrow, 4 features
+    uint4 yx[8];                                           // y tile pieces of this thread
     tail_load_resid(m, hv, blockIdx.x / tiles_x, (blockIdx.x % tiles_x) * BM, (int)threadIdx.x >> 6, (int)threadIdx.x & 31,
                     ((int)threadIdx.x >> 5) & 1);
+    tail_load_y_piece<elem>(m, yx, 0, blockIdx.x / tiles_x, (blockIdx.x % tiles_x) * BM, threadIdx.x);
+    tail_load_y_piece<elem>(m, yx, 1, blockIdx.x / tiles_x, (blockIdx.x % tiles_x) * BM, threadIdx.x);
 #pragma unroll 1
     for (int tile = blockIdx.x; tile < total; tile += gridDim.x) {
     // the thread index is made opaque once per trip: every address below is re-derived inside the trip instead of being
@@ -578,17 +593,12 @@ __global__ __launch_bounds__(512) void tail16_kernel(TailArgs m, unsigned long l
     // (gathering these rows as whole 128-byte lines through a wave-private LDS transpose was measured: no faster -- the
     // phase is bound by how many misses one workgroup per CU keeps in flight, not by the address unit)
     __builtin_amdgcn_sched_barrier(0);
-    {
-        const elem* src = reinterpret_cast<const elem*>(m.y) + (size_t)b * D * Lp + t0;
+    {   // y tile: requested during the previous tile's in_proj (or before the loop) -> LDS, k-major
         const int tk = (tid & 15) * 8;
         const bool in_row = t0 + tk < Lp;
-        const int tkc = in_row ? tk : 0;                   // clamped, branch-free loads; masked at the LDS store
-        uint4 x[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) x[i] = *reinterpret_cast<const uint4*>(src + (size_t)((tid >> 4) + 32 * i) * Lp + tkc);
 #pragma unroll
         for (int i = 0; i < 8; ++i)
-            *reinterpret_cast<uint4*>(Ys + ((tid >> 4) + 32 * i) * RSKM + tk) = in_row ? x[i] : make_uint4(0, 0, 0, 0);
+            *reinterpret_cast<uint4*>(Ys + ((tid >> 4) + 32 * i) * RSKM + tk) = in_row ? yx[i] : make_uint4(0, 0, 0, 0);
     }
     __syncthreads();
     CLM_STAMP_AT(1);
@@ -700,9 +710,10 @@ __global__ __launch_bounds__(512) void tail16_kernel(TailArgs m, unsigned long l
     // residual rows of this workgroup's next tile (clamped to the current one on the last trip: unconditional loads)
     const int nt = tile + (int)gridDim.x < total ? tile + (int)gridDim.x : tile;
     const int nb_ = nt / tiles_x, nt0 = (nt % tiles_x) * BM;
-    if constexpr (NEXT != NEXT_INPROJ) {
+    if constexpr (NEXT == NEXT_NONE) {
         tail_load_resid(m, hv, nb_, nt0, wave, lrow, lhalf);
-        __builtin_amdgcn_sched_barrier(0);
+        tail_load_y_piece<elem>(m, yx, 0, nb_, nt0, tid);
+        tail_load_y_piece<elem>(m, yx, 1, nb_, nt0, tid);
     }
     // ---- 6. what follows, on the tile still in registers
     if constexpr (NEXT != NEXT_NONE) {
@@ -717,9 +728,13 @@ __global__ __launch_bounds__(512) void tail16_kernel(TailArgs m, unsigned long l
             // the 128 KiB of residual rows trickle in as four pieces behind the weight requests of the first four half-blocks
             // (requested in one go before the LayerNorm they stalled every later load of the stage: +9k cycles)
             inproj_blocks<PREC>(As, Hs, wn, m.n_bias, m.n_z, b, t0, Lp, wave, lane, bs, acc1,
-                                ResidHook{m, hv, nb_, nt0, wave, lrow, lhalf});
+                                ResidHook<elem>{m, hv, yx, nb_, nt0, wave, lrow, lhalf, tid});
         } else {
             score_pool_tile<PREC>(m.sp, As, reinterpret_cast<float*>(Hs), b, tile % tiles_x, tid, bs, acc1);
+            // (requested before the score stage these 96 registers spill through its erf epilogue: one launch in four)
+            tail_load_resid(m, hv, nb_, nt0, wave, lrow, lhalf);
+            tail_load_y_piece<elem>(m, yx, 0, nb_, nt0, tid);
+            tail_load_y_piece<elem>(m, yx, 1, nb_, nt0, tid);
         }
         CLM_STAMP_AT(20);
     }
