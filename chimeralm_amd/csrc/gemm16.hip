@@ -641,13 +641,22 @@ __global__ __launch_bounds__(512) void tail16_kernel(TailArgs m, unsigned long l
         __builtin_amdgcn_sched_barrier(0);
         compute_tm<PREC, true>(As, 1, lrow, lhalf, bs[1], acc1);
         __builtin_amdgcn_sched_barrier(0);
-        __syncthreads();
-        CLM_STAMP_AT(5 + 3 * j);
+        // GELU biases first, then the second fc2 half-set: it streams in while the workgroup is in its VALU-only GELU
+        // phase and the L2 -> CU path is otherwise idle (the MFMA phases are bound by exactly that path)
+        float4 b1v[4];
         {
             const float* b1 = m.b1 + j * 256 + wave * 32 + 4 * lhalf;
 #pragma unroll
+            for (int q = 0; q < 4; ++q) b1v[q] = *reinterpret_cast<const float4*>(b1 + 8 * q);
+        }
+        load_set<PREC, DI, 1>(w2, 0, j, 1, wave, lane, bs[1]);
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();
+        CLM_STAMP_AT(5 + 3 * j);
+        {
+#pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const float4 bb = *reinterpret_cast<const float4*>(b1 + 8 * q);
+                const float4 bb = b1v[q];
 #pragma unroll
                 for (int mt = 0; mt < 4; ++mt) {
                     const f32x2 g0 = gelu_tanh2(f32x2{acc1[mt][4 * q + 0] + bb.x, acc1[mt][4 * q + 1] + bb.y});
@@ -659,8 +668,6 @@ __global__ __launch_bounds__(512) void tail16_kernel(TailArgs m, unsigned long l
         }
         __syncthreads();
         CLM_STAMP_AT(6 + 3 * j);
-        load_set<PREC, DI, 1>(w2, 0, j, 1, wave, lane, bs[1]);
-        __builtin_amdgcn_sched_barrier(0);
         compute_tm<PREC, true>(Hs, 0, lrow, lhalf, bs[0], acc2);
         __builtin_amdgcn_sched_barrier(0);
         // next fc1 set; on the last trip the first set of what follows (wrap-around keeps the prefetch unconditional)

@@ -6,7 +6,7 @@ A=$R/chimeralm_amd/csrc/$1; B=$R/chimeralm_amd/csrc/$2; shift 2
 for i in 1 2 3; do
   for v in A B; do
     lib=$A; [ $v = B ] && lib=$B
-    CLM_LIB=$lib timeout -k 10 150 python3 $R/bench.py --steps 6 --warmup 2 --no-cpu-baseline "$@" > $R/gpurun_out/ab_$v.log 2>&1 || { echo "run $v failed"; tail -3 $R/gpurun_out/ab_$v.log; exit 1; }
+    CLM_LIB=$lib timeout -k 10 150 python3 $R/bench.py --steps 12 --warmup 3 --no-cpu-baseline "$@" > $R/gpurun_out/ab_$v.log 2>&1 || { echo "run $v failed"; tail -3 $R/gpurun_out/ab_$v.log; exit 1; }
     python3 - <<PY
 import json
 d=json.loads([l for l in open("$R/gpurun_out/ab_$v.log") if l.startswith("{")][-1])
