@@ -103,9 +103,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     a = ap.parse_args()
 
-    from chimeralm_amd import distributed as cdist
+    from chimeralm_amd import distributed as cdist, lm
     from chimeralm_amd.engine import Engine
-    from oracle import hyena_oracle as ho       # weights generator + CPU baseline only
 
     rank, local_rank, world = cdist.init_process_group("nccl")
     if world != a.gpus:
@@ -115,8 +114,11 @@ def main():
     lo, hi = cdist.shard_bounds(a.batch, rank, world)
     L = a.bases + 1
 
+    # seeded random-init weights of the production architecture, from the product's own module (the same on every rank);
+    # the oracle package is only touched by the cpu_baseline leg
+    torch.manual_seed(0)
     eng = Engine(device, precision=a.precision, chunk_reads=a.chunk_reads)
-    eng.load_state_dict(ho.make_state_dict(0))
+    eng.load_state_dict(lm.ChimeraLM.new(precision=a.precision).state_dict())
     eng.reserve(hi - lo, L)
     n_data = max(1, min(4, a.steps))                 # a few distinct resident batches, cycled
     batches = [torch.from_numpy(synthetic_ids(i, a.batch, a.bases)[lo:hi]).to(device) for i in range(n_data)]

@@ -1,6 +1,6 @@
 """Stage-by-stage comparison of the HIP engine with the CPU oracle (developer diagnostic, run on the GPU box):
 
-    python tools/gpu_diag.py [--precision fp32] [--B 3] [--L 300] [--seed 0]
+    python tests/gpu_diag.py [--precision fp32] [--B 3] [--L 300] [--seed 0]
 
 For every stage of block 0 the forward is stopped there (clm_debug_stop_after) and the raw buffer is compared with the
 oracle's trace; then the full forward is compared (hidden, scores, pooled, logits).  Prints max-abs / relative errors.
