@@ -12,6 +12,9 @@ Fixtures written:
                        `DataCollator.torch_call` (:136-187) with the in-tree `CharacterTokenizer`
                        (left padding) on hand-made reads incl. truncation / long-name cases.
   readname_golden.json reference `resume_read_name` (callbacks.py:38-63) on packed id rows.
+  transformer_golden.npz  reference `SequenceCNNTransformer` (models/components/transformer.py:28-104) in eval mode on the
+                       seeded weights / ids that oracle.transformer_oracle regenerates: logits (production configuration of
+                       configs/model/transformer.yaml and a small one), pooled vector, pooling weights.
   test_chimric_reads.bam, tests.parquet   data files copied from the reference's tests/data/.
 """
 from __future__ import annotations
@@ -129,6 +132,37 @@ def readname_golden():
     print("readname_golden.json", [(r["name"][:8], r["resumed"] if isinstance(r["resumed"], dict) else r["resumed"][:8]) for r in rows])
 
 
+def transformer_golden():
+    from oracle import transformer_oracle as to
+
+    ref = _load("ref_transformer", "chimeralm/models/components/transformer.py")
+    small = to.Config(max_len=512, d_model=64, num_encoder_layers=2, nhead=4, dim_feedforward=128)
+    out = {}
+    cases = [("prod", to.PRODUCTION, 0, 2, 1000, 0), ("prod_pad", to.PRODUCTION, 1, 3, 777, 40), ("small", small, 2, 4, 301, 9)]
+    for name, cfg, seed, B, L, pads in cases:
+        sd = to.make_state_dict(seed, cfg, scale=3.0)
+        net = ref.SequenceCNNTransformer(vocab_size=cfg.vocab_size, max_len=cfg.max_len, d_model=cfg.d_model,
+                                         cnn_kernel_size=cfg.cnn_kernel_size, dropout=0.1,
+                                         num_encoder_layers=cfg.num_encoder_layers, nhead=cfg.nhead,
+                                         dim_feedforward=cfg.dim_feedforward, number_of_classes=cfg.number_of_classes,
+                                         padding_idx=cfg.padding_idx).eval()
+        net.load_state_dict(sd, strict=True)
+        ids = torch.from_numpy(to.synthetic_ids(100 + seed, B, L, pads))
+        with torch.no_grad():
+            logits = net(ids)
+            # intermediates through the reference's own submodules, for stage-level pins
+            x = net.cnn(net.embedding(ids).transpose(1, 2)).transpose(1, 2)
+            x = net.norm(net.pos_encoder(x))
+            enc = net.transformer_encoder(x)
+        out[f"{name}_logits"] = logits.numpy()
+        out[f"{name}_embedded_sample"] = x[:, ::37, ::5].numpy()
+        out[f"{name}_encoded_sample"] = enc[:, ::37, ::5].numpy()
+        out[f"{name}_meta"] = np.array([seed, B, L, pads], dtype=np.int64)
+        mine = to.forward(ids, sd, cfg)
+        print(f"transformer {name}: logits {logits.numpy().round(4).tolist()}  |oracle - reference| = {(mine - logits).abs().max():.2e}")
+    np.savez(HERE / "transformer_golden.npz", **out)
+
+
 def data_files():
     for f in ("test_chimric_reads.bam", "tests.parquet"):
         shutil.copyfile(REF / "tests/data" / f, HERE / f)
@@ -139,4 +173,5 @@ if __name__ == "__main__":
     head_golden()
     collate_golden()
     readname_golden()
+    transformer_golden()
     data_files()

@@ -121,3 +121,26 @@ def test_synthetic_batch_spec():
     assert set(np.unique(ids[:, :-1])) <= {7, 8, 9, 10, 11} and names[0] == "synthetic_00000012"
     ids2, _ = ho.synthetic_batch(3, 4, 1000)
     assert (ids == ids2).all()
+
+
+def test_transformer_oracle_matches_reference_module(golden_dir):
+    """SequenceCNNTransformer: oracle restatement vs the reference module's own outputs
+    (tests/golden/make_golden.py::transformer_golden) -- production configuration, padded batch, small configuration."""
+    from oracle import transformer_oracle as to
+
+    g = np.load(golden_dir / "transformer_golden.npz")
+    small = to.Config(max_len=512, d_model=64, num_encoder_layers=2, nhead=4, dim_feedforward=128)
+    for name, cfg in (("prod", to.PRODUCTION), ("prod_pad", to.PRODUCTION), ("small", small)):
+        seed, B, L, pads = (int(v) for v in g[f"{name}_meta"])
+        sd = to.make_state_dict(seed, cfg, scale=3.0)
+        ids = torch.from_numpy(to.synthetic_ids(100 + seed, B, L, pads))
+        trace = {}
+        logits = to.forward(ids, sd, cfg, trace=trace).numpy()
+        assert np.abs(logits - g[f"{name}_logits"]).max() < 5e-5
+        assert np.abs(trace["embedded"][:, ::37, ::5].numpy() - g[f"{name}_embedded_sample"]).max() < 1e-5
+        last = trace[f"layer{cfg.num_encoder_layers - 1}"]
+        assert np.abs(last[:, ::37, ::5].numpy() - g[f"{name}_encoded_sample"]).max() < 5e-5
+        assert trace["embedded"].shape[1] == L // 8                      # three floor-halvings
+        assert abs(float(trace["pool_weights"].sum(dim=1).mean()) - 1.0) < 1e-5
+    ref64 = to.forward(ids, sd, cfg, dtype=torch.float64).numpy()       # fp64 referee close to the fp32 run
+    assert np.abs(ref64 - logits).max() < 1e-4
