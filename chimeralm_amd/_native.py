@@ -56,6 +56,7 @@ SYMBOLS = {
     "clm_stage_ids": (C.c_int, [_H, C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_int, C.POINTER(C.c_int)]),
     "clm_forward_staged": (C.c_int, [_H, C.c_int, C.c_void_p, C.c_void_p]),
     "clm_stage_wait": (C.c_int, [_H, C.c_int]),
+    "clm_attention_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "clm_debug_fetch": (C.c_int, [_H, C.c_char_p, C.c_void_p, C.c_size_t]),
     "clm_debug_stop_after": (C.c_int, [_H, C.c_int, C.c_int]),
     "clm_profile_enable": (C.c_int, [_H, C.c_int]),

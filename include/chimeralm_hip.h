@@ -114,6 +114,13 @@ int clm_stage_ids(clm_handle* h, const void* host_ids, int ids_dtype, int64_t id
 int clm_forward_staged(clm_handle* h, int staged, float* logits_out, void* stream);
 int clm_stage_wait(clm_handle* h, int staged);
 
+/* ---- SequenceCNNTransformer encoder pieces (under construction) -------------------------
+ * Multi-head self-attention of nn.TransformerEncoderLayer as the reference builds it
+ * (/root/reference/chimeralm/models/components/transformer.py:64-68,98: d_model 256, 8 heads of 32, no masks):
+ *   qkv  device, [B, L, 768] 16-bit, the in_proj output q | k | v per token;  out  device, [B, L, 256] 16-bit, heads concatenated
+ *   precision CLM_PREC_F16 or CLM_PREC_BF16 (element type of qkv / out; statistics and accumulation are fp32). */
+int clm_attention_fwd(const void* qkv, void* out, int B, int L, int precision, void* stream);
+
 /* ---- test / measurement taps (not on the product path) -------------------------------------------- */
 
 /* Copy a named intermediate of the LAST clm_forward to host memory (synchronises the device).  Names:
