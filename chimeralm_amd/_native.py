@@ -57,6 +57,13 @@ SYMBOLS = {
     "clm_forward_staged": (C.c_int, [_H, C.c_int, C.c_void_p, C.c_void_p]),
     "clm_stage_wait": (C.c_int, [_H, C.c_int]),
     "clm_attention_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "clm_tf_create": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(_H)]),
+    "clm_tf_load_weight": (C.c_int, [_H, C.c_char_p, C.c_void_p, C.c_int, C.POINTER(C.c_int64), C.c_int]),
+    "clm_tf_finalize": (C.c_int, [_H]),
+    "clm_tf_forward": (C.c_int, [_H, C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "clm_tf_debug_fetch": (C.c_int, [_H, C.c_char_p, C.c_void_p, C.c_size_t]),
+    "clm_tf_last_error": (C.c_char_p, [_H]),
+    "clm_tf_destroy": (C.c_int, [_H]),
     "clm_debug_fetch": (C.c_int, [_H, C.c_char_p, C.c_void_p, C.c_size_t]),
     "clm_debug_stop_after": (C.c_int, [_H, C.c_int, C.c_int]),
     "clm_profile_enable": (C.c_int, [_H, C.c_int]),

@@ -1,0 +1,133 @@
+// gemm16_common.h -- device helpers shared by the 16-bit MFMA kernels (gemm16.hip: Hyena blocks; tf_model.hip: the
+// SequenceCNNTransformer encoder): LDS tile strides, MFMA loops over an LDS-resident activation tile with register-resident
+// weight half-sets, LayerNorm straight from accumulator registers.  See gemm16.hip / gemm.hip for the design notes.
+#pragma once
+#include "gemm_common.h"
+
+namespace clm {
+
+using v4i16 = short __attribute__((ext_vector_type(4)));
+typedef v4i16 __attribute__((address_space(3))) * lds_v4i16_ptr;
+
+constexpr int RS16 = 264;     // row stride (elements) of token-major LDS tiles: 528 B, conflict-free ds_read_b128
+constexpr int RSKM = 160;     // row stride of the k-major (channel-major) tile: 320 B = 256 B + 64 B, so the four
+                              // rows of a transposing read land on four different 64-byte bank groups
+constexpr int RSOUT = 136;    // row stride of the wave-private output staging tile: 272 B (16-byte aligned rows)
+
+template <int PREC>
+__device__ __forceinline__ unsigned short to_bits(float v) {
+    return from_float<typename CT<PREC>::elem>(v).bits;
+}
+
+// acc[mt][nt] += A-tile(token-major LDS) x weight set.  ROWS_N: accumulator rows are output features (lane = token).
+template <int PREC, bool ROWS_N>
+__device__ __forceinline__ void compute_tm(const typename CT<PREC>::elem* As, int part, int lrow, int lhalf,
+                                           const u16x8 (&src)[1][SETK], f32x16 (&acc)[4]) {
+#pragma unroll
+    for (int ks = 0; ks < SETK; ++ks) {
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            u16x8 af = *reinterpret_cast<const u16x8*>(As + (mt * 32 + lrow) * RS16 + (part * SETK + ks) * 16 + lhalf * 8);
+            if (ROWS_N) acc[mt] = mfma<PREC>(src[0][ks], af, acc[mt]);
+            else acc[mt] = mfma<PREC>(af, src[0][ks], acc[mt]);
+        }
+    }
+}
+
+// Same, A operand taken from the k-major tile Ys[k][token] with the transposing read: a 16-lane group reads a
+// 4(k) x 16(token) block and lane i receives token i's four k values (cdna_hip_programming.md T10).
+template <int PREC>
+__device__ __forceinline__ void compute_km(const typename CT<PREC>::elem* Ys, int part, int lane,
+                                           const u16x8 (&src)[1][SETK], f32x16 (&acc)[4]) {
+    const int li = lane & 15, g1 = (lane >> 4) & 1, h = lane >> 5, q = li >> 2, p = li & 3;
+    const typename CT<PREC>::elem* base = Ys + (8 * h + q) * RSKM + 16 * g1 + 4 * p;
+#pragma unroll
+    for (int ks = 0; ks < SETK; ++ks) {
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            const typename CT<PREC>::elem* p0 = base + ((part * SETK + ks) * 16) * RSKM + mt * 32;
+            v4i16 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4i16_ptr)(p0));
+            v4i16 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4i16_ptr)(p0 + 4 * RSKM));
+            u16x8 af = {(unsigned short)lo[0], (unsigned short)lo[1], (unsigned short)lo[2], (unsigned short)lo[3],
+                        (unsigned short)hi[0], (unsigned short)hi[1], (unsigned short)hi[2], (unsigned short)hi[3]};
+            acc[mt] = mfma<PREC>(src[0][ks], af, acc[mt]);     // rows = output feature, cols = token
+        }
+    }
+}
+
+__device__ __forceinline__ void zero_acc(f32x16 (&acc)[4]) {
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[mt][r] = 0.f;
+}
+
+// LayerNorm over the 256 features of every token of a tile whose values sit in accumulator registers (rows = this wave's
+// 32 features as register quads, lane = token): per-lane partial over 16 features -> LDS tables -> totals over the 16
+// partials of the 8 waves, two-pass variance; the normalised tile goes to As in the compute dtype (rows beyond L as zeros).
+// P1 / P2: [16][128] floats each, outside As.  Ends with a barrier (As complete); the first internal barrier also orders
+// every earlier LDS access of the workgroup before the As writes.
+// KEEP: the normalised fp32 values also replace the accumulator contents (post-norm blocks: they are the next residual).
+template <int PREC, bool KEEP = false>
+__device__ __forceinline__ void ln_acc_to_tile(f32x16 (&acc2)[4], float* P1, float* P2, const float* __restrict__ g,
+                                               const float* __restrict__ bta, float eps, typename CT<PREC>::elem* As,
+                                               int t0, int L, int wave, int lrow, int lhalf) {
+    constexpr int BM = 128;
+    float mean[4], rstd[4];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+        float s = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s += acc2[mt][r];
+        P1[(wave * 2 + lhalf) * BM + mt * 32 + lrow] = s;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+        float s = 0.f;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) s += P1[w * BM + mt * 32 + lrow];
+        mean[mt] = s * (1.0f / D);
+        float v = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float d = acc2[mt][r] - mean[mt];
+            v += d * d;
+        }
+        P2[(wave * 2 + lhalf) * BM + mt * 32 + lrow] = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+        float v = 0.f;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) v += P2[w * BM + mt * 32 + lrow];
+        rstd[mt] = 1.0f / sqrtf(v * (1.0f / D) + eps);
+    }
+    const float* gp = g + wave * 32 + 4 * lhalf;
+    const float* bp = bta + wave * 32 + 4 * lhalf;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const float4 g4 = *reinterpret_cast<const float4*>(gp + 8 * q);
+        const float4 b4 = *reinterpret_cast<const float4*>(bp + 8 * q);
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            const bool ok = t0 + mt * 32 + lrow < L;
+            const float y0 = ok ? (acc2[mt][4 * q + 0] - mean[mt]) * rstd[mt] * g4.x + b4.x : 0.f;
+            const float y1 = ok ? (acc2[mt][4 * q + 1] - mean[mt]) * rstd[mt] * g4.y + b4.y : 0.f;
+            const float y2 = ok ? (acc2[mt][4 * q + 2] - mean[mt]) * rstd[mt] * g4.z + b4.z : 0.f;
+            const float y3 = ok ? (acc2[mt][4 * q + 3] - mean[mt]) * rstd[mt] * g4.w + b4.w : 0.f;
+            if (KEEP) {
+                acc2[mt][4 * q + 0] = y0;
+                acc2[mt][4 * q + 1] = y1;
+                acc2[mt][4 * q + 2] = y2;
+                acc2[mt][4 * q + 3] = y3;
+            }
+            u16x4 pk = {to_bits<PREC>(y0), to_bits<PREC>(y1), to_bits<PREC>(y2), to_bits<PREC>(y3)};
+            *reinterpret_cast<u16x4*>(As + (mt * 32 + lrow) * RS16 + wave * 32 + 8 * q + 4 * lhalf) = pk;
+        }
+    }
+    __syncthreads();
+}
+
+}  // namespace clm

@@ -1,0 +1,640 @@
+// tf_model.hip -- SequenceCNNTransformer forward on MI355X: kernels + engine + C ABI.
+//
+// Reference: /root/reference/chimeralm/models/components/transformer.py
+//   :28-86  modules   Embedding(12, 256, padding_idx 4) ; 3 x [Conv1d(256, 256, k=3, padding=1), ReLU, MaxPool1d(2, 2)] ;
+//                     SinusoidalPositionalEncoding ; LayerNorm ; TransformerEncoder(12 x post-norm layer: 8 heads of 32,
+//                     feed-forward 1024, ReLU) ; Linear(256, 1) softmax pooling ; Linear(256, 128), ReLU, Linear(128, 2)
+//   :88-104 forward   (no masks anywhere: pads are ordinary tokens)
+// configured by /root/reference/configs/model/transformer.yaml:3-12.  Oracle: oracle/transformer_oracle.py (pinned against the
+// reference module itself, tests/golden/transformer_golden.npz).
+//
+// First correct version: every stage is its own kernel (the Hyena path's fusion lessons are not applied yet); the dense work is
+// on MFMA with the same LDS-resident 128-token activation tile / register-resident weight half-set scheme as gemm16.hip, the
+// attention is attention.hip.  Data layout, one batch of B reads (L tokens -> L3 = L / 8 positions, M = B * L3 rows):
+//   x1 [B, L/2, 256], x2 [B, L/4, 256], x3 [B, L3, 256]     16-bit, token-major          conv stack
+//   h  [M, 256] fp32 (residual stream, post-norm: always a LayerNorm output)   hx [M, 256] 16-bit copy = next GEMM operand
+//   qkv [M, 768], att [M, 256], u [M, 1024]                  16-bit
+// The convolution is a GEMM with K = 3 * 256: one 130-row tile of the input (1 halo row each side) feeds three passes with the
+// row offset 0 / 1 / 2 and the weight slice W[:, :, dk]; ReLU and the max-pool happen on the accumulator quads (4 consecutive
+// positions of one channel) before anything is written.
+#include <algorithm>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "chimeralm_hip.h"
+#include "gemm16_common.h"
+
+namespace clm {
+namespace tf {
+
+constexpr int TFF = 1024, TQKV = 768, TVOC = 12, TCH = 128 /* classifier hidden */;
+constexpr int ZRS = 40;   // row stride (elements) of the wave-private [token][32 features] output staging tiles: 80 bytes
+
+// ------------------------------------------------------------------------------------------------ small helpers
+__global__ void conv_w_split_kernel(const float* __restrict__ w, float* __restrict__ out) {   // [co][ci][3] -> [3][co][ci]
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= D * D * 3) return;
+    const int dk = i % 3, ci = (i / 3) % D, co = i / (3 * D);
+    out[((size_t)dk * D + co) * D + ci] = w[i];
+}
+
+// wave-private [128 tokens][32 features] 16-bit tile -> global rows (64 bytes per token and wave), 16 rows per instruction
+template <typename E>
+__device__ __forceinline__ void store_wave_tile(const E* zs, E* out, size_t row0, size_t nrows_valid, int ld, int col0, int lane,
+                                                int ntok) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int row = i * 16 + (lane >> 2), piece = lane & 3;
+        if (row < ntok && (size_t)row < nrows_valid) {
+            const uint4 v = *reinterpret_cast<const uint4*>(zs + row * ZRS + piece * 8);
+            *reinterpret_cast<uint4*>(out + (row0 + row) * ld + col0 + piece * 8) = v;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ conv + ReLU + max-pool
+template <int PREC, bool FROM_IDS>
+__global__ __launch_bounds__(512) void conv3_relu_pool_kernel(const unsigned char* __restrict__ ids8, int ids_stride,
+                                                              const float* __restrict__ emb,
+                                                              const typename CT<PREC>::elem* __restrict__ xin,
+                                                              const void* __restrict__ wpk, const float* __restrict__ bias,
+                                                              typename CT<PREC>::elem* __restrict__ xout, int Lin, int Lout) {
+    using elem = typename CT<PREC>::elem;
+    using frag = u16x8;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    elem* As = reinterpret_cast<elem*>(smem);                 // [130][RS16]: input rows t0 - 1 .. t0 + 128
+    elem* Zs = As + 130 * RS16;                               // 8 x [64 pooled positions][ZRS]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lrow = lane & 31, lhalf = lane >> 5;
+    const int b = blockIdx.y, t0 = blockIdx.x * 128;
+    const frag* wp = reinterpret_cast<const frag*>(wpk);
+    constexpr size_t WSLICE = (size_t)D * D / 8;              // fragments per [256 x 256] slice
+    f32x16 acc[4];
+    frag bs[2][1][SETK];
+    load_set<PREC, D, 1>(wp, 0, 0, 0, wave, lane, bs[0]);
+    __builtin_amdgcn_sched_barrier(0);
+    {
+        const int piece = tid & 31;
+#pragma unroll 1
+        for (int r = tid >> 5; r < 130; r += 16) {
+            const int tg = t0 - 1 + r;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (tg >= 0 && tg < Lin) {
+                if (FROM_IDS) {
+                    const int id = ids8[(size_t)b * ids_stride + tg];
+                    const float* e = emb + (size_t)(id < TVOC ? id : TVOC - 1) * D + piece * 8;
+                    const float4 a = *reinterpret_cast<const float4*>(e), c4 = *reinterpret_cast<const float4*>(e + 4);
+                    u16x8 pk = {to_bits<PREC>(a.x), to_bits<PREC>(a.y), to_bits<PREC>(a.z), to_bits<PREC>(a.w),
+                                to_bits<PREC>(c4.x), to_bits<PREC>(c4.y), to_bits<PREC>(c4.z), to_bits<PREC>(c4.w)};
+                    v = __builtin_bit_cast(uint4, pk);
+                } else {
+                    v = *reinterpret_cast<const uint4*>(xin + ((size_t)b * Lin + tg) * D + piece * 8);
+                }
+            }
+            *reinterpret_cast<uint4*>(As + r * RS16 + piece * 8) = v;
+        }
+    }
+    __syncthreads();
+    zero_acc(acc);
+#pragma unroll
+    for (int dk = 0; dk < 3; ++dk) {                          // y[t] += W[:, :, dk] x[t + dk - 1]
+        load_set<PREC, D, 1>(wp + dk * WSLICE, 0, 0, 1, wave, lane, bs[1]);
+        __builtin_amdgcn_sched_barrier(0);
+        compute_tm<PREC, false>(As + dk * RS16, 0, lrow, lhalf, bs[0], acc);
+        __builtin_amdgcn_sched_barrier(0);
+        load_set<PREC, D, 1>(wp + (dk < 2 ? dk + 1 : 0) * WSLICE, 0, 0, 0, wave, lane, bs[0]);
+        __builtin_amdgcn_sched_barrier(0);
+        compute_tm<PREC, false>(As + dk * RS16, 1, lrow, lhalf, bs[1], acc);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    // rows = positions (register quads = 4 consecutive positions), lane = output channel wave*32 + lrow
+    elem* zs = Zs + wave * 64 * ZRS;
+    const float bv = bias[wave * 32 + lrow];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const float v0 = fmaxf(acc[mt][4 * g + 0] + bv, 0.f), v1 = fmaxf(acc[mt][4 * g + 1] + bv, 0.f);
+            const float v2 = fmaxf(acc[mt][4 * g + 2] + bv, 0.f), v3 = fmaxf(acc[mt][4 * g + 3] + bv, 0.f);
+            const int pl = 16 * mt + 4 * g + 2 * lhalf;       // pooled position inside the tile
+            zs[pl * ZRS + lrow] = from_float<elem>(fmaxf(v0, v1));
+            zs[(pl + 1) * ZRS + lrow] = from_float<elem>(fmaxf(v2, v3));
+        }
+    const size_t p0 = (size_t)(t0 / 2);
+    const size_t valid = (size_t)Lout > p0 ? (size_t)Lout - p0 : 0;
+    store_wave_tile<elem>(zs, xout + (size_t)b * Lout * D, p0, valid, D, wave * 32, lane, 64);
+}
+
+// ------------------------------------------------------------------------------------------------ + PE, LayerNorm
+template <int PREC>
+__global__ __launch_bounds__(256) void pe_ln_kernel(const typename CT<PREC>::elem* __restrict__ x, const float* __restrict__ pe,
+                                                    const float* __restrict__ g, const float* __restrict__ bta,
+                                                    float* __restrict__ h, typename CT<PREC>::elem* __restrict__ hx,
+                                                    size_t M, int L3, float eps) {
+    using elem = typename CT<PREC>::elem;
+    const int lane = threadIdx.x & 63;
+    const size_t row = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const int t = (int)(row % (size_t)L3);
+    const u16x4 raw = *reinterpret_cast<const u16x4*>(x + row * D + lane * 4);
+    const float4 p = *reinterpret_cast<const float4*>(pe + (size_t)t * D + lane * 4);
+    elem e0, e1, e2, e3;
+    e0.bits = raw[0]; e1.bits = raw[1]; e2.bits = raw[2]; e3.bits = raw[3];
+    const float x0 = to_float(e0) + p.x, x1 = to_float(e1) + p.y, x2 = to_float(e2) + p.z, x3 = to_float(e3) + p.w;
+    const float mean = wave_sum((x0 + x1) + (x2 + x3)) * (1.0f / D);
+    const float d0 = x0 - mean, d1 = x1 - mean, d2 = x2 - mean, d3 = x3 - mean;
+    const float var = wave_sum((d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3)) * (1.0f / D);
+    const float rstd = 1.0f / sqrtf(var + eps);
+    const float4 g4 = *reinterpret_cast<const float4*>(g + lane * 4), b4 = *reinterpret_cast<const float4*>(bta + lane * 4);
+    const float y0 = d0 * rstd * g4.x + b4.x, y1 = d1 * rstd * g4.y + b4.y, y2 = d2 * rstd * g4.z + b4.z,
+                y3 = d3 * rstd * g4.w + b4.w;
+    *reinterpret_cast<float4*>(h + row * D + lane * 4) = make_float4(y0, y1, y2, y3);
+    store4<elem>(hx + row * D + lane * 4, y0, y1, y2, y3);
+}
+
+// ------------------------------------------------------------------------------------------------ dense layers
+struct LinArgs {
+    const void* a;            // [M, K] 16-bit, token-major
+    const void* w;            // packed [N, K]
+    const float* bias;        // [N]
+    void* out16;              // E_ACT: [M, N] 16-bit
+    float* h;                 // E_RES_LN: residual in, LayerNorm(residual + a W^T + bias) out, [M, 256] fp32
+    void* hx;                 // E_RES_LN: 16-bit copy of the new h
+    const float *ln_g, *ln_b;
+    size_t M;
+    float eps;
+    int relu;
+};
+enum { E_ACT = 0, E_RES_LN = 1 };
+
+template <int PREC>
+__device__ __forceinline__ void stage_rows16(const typename CT<PREC>::elem* a, size_t row0, size_t M, int K, int kc,
+                                             typename CT<PREC>::elem* As, int tid) {
+    const int piece = tid & 31;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int r = (tid >> 5) + 16 * i;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (row0 + r < M) v = *reinterpret_cast<const uint4*>(a + (row0 + r) * K + kc * 256 + piece * 8);
+        *reinterpret_cast<uint4*>(As + r * RS16 + piece * 8) = v;
+    }
+}
+
+template <int PREC, int EPI, int K, int N>
+__global__ __launch_bounds__(512) void linear16_kernel(LinArgs m) {
+    using elem = typename CT<PREC>::elem;
+    using frag = u16x8;
+    static_assert(K % 256 == 0 && N % 256 == 0, "256-wide chunks");
+    static_assert(EPI == E_ACT ? K == 256 : N == 256, "E_ACT keeps one activation tile; E_RES_LN normalises one 256-wide row");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    elem* As = reinterpret_cast<elem*>(smem);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lrow = lane & 31, lhalf = lane >> 5;
+    const size_t row0 = (size_t)blockIdx.x * 128;
+    const elem* a = reinterpret_cast<const elem*>(m.a);
+    const frag* wp = reinterpret_cast<const frag*>(m.w);
+    f32x16 acc[4];
+    frag bs[2][1][SETK];
+    if constexpr (EPI == E_ACT) {
+        elem* zs = As + 128 * RS16 + wave * 128 * ZRS;        // wave-private [128 tokens][32 features]
+        load_set<PREC, K, 1>(wp, 0, 0, 0, wave, lane, bs[0]);
+        __builtin_amdgcn_sched_barrier(0);
+        stage_rows16<PREC>(a, row0, m.M, K, 0, As, tid);
+        __syncthreads();
+#pragma unroll 1
+        for (int nb = 0; nb < N / 256; ++nb) {
+            zero_acc(acc);
+            load_set<PREC, K, 1>(wp, nb, 0, 1, wave, lane, bs[1]);
+            __builtin_amdgcn_sched_barrier(0);
+            compute_tm<PREC, true>(As, 0, lrow, lhalf, bs[0], acc);
+            __builtin_amdgcn_sched_barrier(0);
+            load_set<PREC, K, 1>(wp, nb + 1 < N / 256 ? nb + 1 : 0, 0, 0, wave, lane, bs[0]);
+            __builtin_amdgcn_sched_barrier(0);
+            compute_tm<PREC, true>(As, 1, lrow, lhalf, bs[1], acc);
+            __builtin_amdgcn_sched_barrier(0);
+            // rows = features (register quads), lane = token
+            const float* bp = m.bias + nb * 256 + wave * 32 + 4 * lhalf;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 bb = *reinterpret_cast<const float4*>(bp + 8 * q);
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) {
+                    float v0 = acc[mt][4 * q + 0] + bb.x, v1 = acc[mt][4 * q + 1] + bb.y, v2 = acc[mt][4 * q + 2] + bb.z,
+                          v3 = acc[mt][4 * q + 3] + bb.w;
+                    if (m.relu) v0 = fmaxf(v0, 0.f), v1 = fmaxf(v1, 0.f), v2 = fmaxf(v2, 0.f), v3 = fmaxf(v3, 0.f);
+                    u16x4 pk = {to_bits<PREC>(v0), to_bits<PREC>(v1), to_bits<PREC>(v2), to_bits<PREC>(v3)};
+                    *reinterpret_cast<u16x4*>(zs + (mt * 32 + lrow) * ZRS + 8 * q + 4 * lhalf) = pk;
+                }
+            }
+            const size_t valid = m.M > row0 ? m.M - row0 : 0;
+            store_wave_tile<elem>(zs, reinterpret_cast<elem*>(m.out16), row0, valid, N, nb * 256 + wave * 32, lane, 128);
+        }
+    } else {
+        float* P1 = reinterpret_cast<float*>(smem + (size_t)2 * 128 * RS16 * 2);   // tables behind the 128 KiB staging area
+        float* P2 = P1 + 16 * 128;
+        zero_acc(acc);
+#pragma unroll 1
+        for (int kc = 0; kc < K / 256; ++kc) {
+            load_set<PREC, K, 1>(wp, 0, kc, 0, wave, lane, bs[0]);
+            load_set<PREC, K, 1>(wp, 0, kc, 1, wave, lane, bs[1]);
+            __builtin_amdgcn_sched_barrier(0);
+            if (kc > 0) __syncthreads();                       // every wave is done with the previous chunk of the tile
+            stage_rows16<PREC>(a, row0, m.M, K, kc, As, tid);
+            __syncthreads();
+            compute_tm<PREC, true>(As, 0, lrow, lhalf, bs[0], acc);
+            compute_tm<PREC, true>(As, 1, lrow, lhalf, bs[1], acc);
+        }
+        // r = acc + bias + residual (this lane's token, 4 consecutive features per quad)
+        {
+            const float* bp = m.bias + wave * 32 + 4 * lhalf;
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+                const size_t row = row0 + mt * 32 + lrow;
+                const float* hr = m.h + (row < m.M ? row : 0) * D + wave * 32 + 4 * lhalf;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float4 bb = *reinterpret_cast<const float4*>(bp + 8 * q);
+                    const float4 hv = *reinterpret_cast<const float4*>(hr + 8 * q);
+                    acc[mt][4 * q + 0] += bb.x + hv.x;
+                    acc[mt][4 * q + 1] += bb.y + hv.y;
+                    acc[mt][4 * q + 2] += bb.z + hv.z;
+                    acc[mt][4 * q + 3] += bb.w + hv.w;
+                }
+            }
+        }
+        const int l_valid = (int)std::min<size_t>(m.M > row0 ? m.M - row0 : 0, 128);
+        ln_acc_to_tile<PREC, true>(acc, P1, P2, m.ln_g, m.ln_b, m.eps, As, 0, l_valid, wave, lrow, lhalf);
+        // 16-bit copy: rows of the normalised tile as they lie in LDS
+        {
+            const int piece = tid & 31;
+            elem* hx = reinterpret_cast<elem*>(m.hx);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int r = (tid >> 5) + 16 * i;
+                if (r < l_valid) *reinterpret_cast<uint4*>(hx + (row0 + r) * D + piece * 8) = *reinterpret_cast<const uint4*>(As + r * RS16 + piece * 8);
+            }
+        }
+        __syncthreads();
+        // fp32 h: transposed through LDS (XOR-swizzled 16-byte chunks), stored as whole 128-byte lines
+        {
+            float* rs = reinterpret_cast<float*>(smem) + wave * (128 * 32);
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+                const int tok = mt * 32 + lrow;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int chunk = (2 * q + lhalf) ^ (tok & 7);
+                    *reinterpret_cast<float4*>(rs + tok * 32 + 4 * chunk) =
+                        make_float4(acc[mt][4 * q + 0], acc[mt][4 * q + 1], acc[mt][4 * q + 2], acc[mt][4 * q + 3]);
+                }
+            }
+            const int c = lane & 7, rsub = lane >> 3;
+            float* hrow = m.h + row0 * D + wave * 32 + 4 * c;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int tr = i * 8 + rsub;
+                const float4 v = *reinterpret_cast<const float4*>(rs + tr * 32 + 4 * (c ^ (tr & 7)));
+                if (tr < l_valid) *reinterpret_cast<float4*>(hrow + (size_t)tr * D) = v;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ pooling + classifier
+// attn_weights = softmax_t(h[t] . w + b) over ALL positions of the read; pooled = sum_t a_t h[t]; Linear(256,128) ReLU Linear(128,2)
+__global__ __launch_bounds__(256) void pool_head_kernel(const float* __restrict__ h, const float* __restrict__ pw,
+                                                        const float* __restrict__ pb, const float* __restrict__ w0,
+                                                        const float* __restrict__ b0, const float* __restrict__ w1,
+                                                        const float* __restrict__ b1, float* __restrict__ scores,
+                                                        float* __restrict__ pooled_out, float* __restrict__ logits, int L3) {
+    __shared__ float red[4], vec[4][D], xin[D], hid[TCH];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* hb = h + (size_t)b * L3 * D;
+    float* sc = scores + (size_t)b * L3;
+    const float4 w4 = *reinterpret_cast<const float4*>(pw + lane * 4);
+    const float bias = pb[0];
+    float mx = -INFINITY;
+    for (int t = wave; t < L3; t += 4) {                      // one wave per position
+        const float4 x = *reinterpret_cast<const float4*>(hb + (size_t)t * D + lane * 4);
+        const float s = wave_sum((x.x * w4.x + x.y * w4.y) + (x.z * w4.z + x.w * w4.w)) + bias;
+        if (lane == 0) sc[t] = s;
+        mx = fmaxf(mx, s);
+    }
+    if (lane == 0) red[wave] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    __syncthreads();
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, ssum = 0.f;
+    for (int t = wave; t < L3; t += 4) {
+        const float e = expf(sc[t] - mx);                     // written by lane 0 of this same wave above
+        const float4 x = *reinterpret_cast<const float4*>(hb + (size_t)t * D + lane * 4);
+        ssum += e;
+        a0 = fmaf(e, x.x, a0); a1 = fmaf(e, x.y, a1); a2 = fmaf(e, x.z, a2); a3 = fmaf(e, x.w, a3);
+    }
+    *reinterpret_cast<float4*>(&vec[wave][lane * 4]) = make_float4(a0, a1, a2, a3);
+    if (lane == 0) red[wave] = ssum;
+    __syncthreads();
+    {
+        const float tot = (red[0] + red[1]) + (red[2] + red[3]);
+        const float p = ((vec[0][tid] + vec[1][tid]) + (vec[2][tid] + vec[3][tid])) / tot;
+        xin[tid] = p;
+        pooled_out[(size_t)b * D + tid] = p;
+    }
+    __syncthreads();
+    if (tid < TCH) {
+        float acc = b0[tid];
+        const float* wr = w0 + (size_t)tid * D;
+        for (int i = 0; i < D; ++i) acc = fmaf(wr[i], xin[i], acc);
+        hid[tid] = fmaxf(acc, 0.f);
+    }
+    __syncthreads();
+    if (tid < NCLS) {
+        float acc = b1[tid];
+        for (int i = 0; i < TCH; ++i) acc = fmaf(w1[(size_t)tid * TCH + i], hid[i], acc);
+        logits[(size_t)b * NCLS + tid] = acc;
+    }
+}
+
+}  // namespace tf
+
+void launch_attention_fwd(int prec, const void* qkv, void* out, int B, int L, hipStream_t st);   // attention.hip
+
+}  // namespace clm
+
+// ================================================================================================ engine + C ABI
+using namespace clm;
+
+struct clm_tf_handle {
+    int device = 0, prec = PREC_F16, n_layers = 12;
+    std::string err;
+    std::map<std::string, float*> w;              // fp32 device copies by reference key
+    std::map<std::string, std::vector<int64_t>> shape;
+    std::map<std::string, void*> packed;
+    bool finalized = false;
+    // workspace
+    size_t cap_rows = 0, cap_tok = 0;
+    unsigned char* ids8 = nullptr;
+    void *x1 = nullptr, *x2 = nullptr, *x3 = nullptr, *hx = nullptr, *qkv = nullptr, *att = nullptr, *u = nullptr;
+    float *h = nullptr, *scores = nullptr, *pooled = nullptr;
+    int last_B = 0, last_L3 = 0;
+};
+
+namespace {
+
+std::string g_tf_create_error;
+
+int tf_fail(clm_tf_handle* h, int code, const std::string& msg) {
+    if (h) h->err = msg; else g_tf_create_error = msg;
+    return code;
+}
+#define TFCHK(h, call)                                                                              \
+    do {                                                                                            \
+        hipError_t e_ = (call);                                                                     \
+        if (e_ != hipSuccess) return tf_fail(h, CLM_E_HIP, std::string(#call) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+std::string tf_canon(const char* key) {
+    std::string k(key);
+    if (k.rfind("net.", 0) == 0) k = k.substr(4);
+    return k;
+}
+
+std::map<std::string, std::vector<int64_t>> tf_expected(int n_layers) {
+    std::map<std::string, std::vector<int64_t>> e;
+    e["embedding.weight"] = {tf::TVOC, D};
+    for (int i : {0, 3, 6}) {
+        e["cnn." + std::to_string(i) + ".weight"] = {D, D, 3};
+        e["cnn." + std::to_string(i) + ".bias"] = {D};
+    }
+    e["norm.weight"] = {D}; e["norm.bias"] = {D};
+    for (int i = 0; i < n_layers; ++i) {
+        const std::string p = "transformer_encoder.layers." + std::to_string(i) + ".";
+        e[p + "self_attn.in_proj_weight"] = {tf::TQKV, D}; e[p + "self_attn.in_proj_bias"] = {tf::TQKV};
+        e[p + "self_attn.out_proj.weight"] = {D, D}; e[p + "self_attn.out_proj.bias"] = {D};
+        e[p + "linear1.weight"] = {tf::TFF, D}; e[p + "linear1.bias"] = {tf::TFF};
+        e[p + "linear2.weight"] = {D, tf::TFF}; e[p + "linear2.bias"] = {D};
+        e[p + "norm1.weight"] = {D}; e[p + "norm1.bias"] = {D}; e[p + "norm2.weight"] = {D}; e[p + "norm2.bias"] = {D};
+    }
+    e["attn_pool.weight"] = {1, D}; e["attn_pool.bias"] = {1};
+    e["classifier.0.weight"] = {tf::TCH, D}; e["classifier.0.bias"] = {tf::TCH};
+    e["classifier.3.weight"] = {NCLS, tf::TCH}; e["classifier.3.bias"] = {NCLS};
+    return e;
+}
+
+void tf_free_ws(clm_tf_handle* h) {
+    for (void* p : {(void*)h->ids8, h->x1, h->x2, h->x3, h->hx, h->qkv, h->att, h->u, (void*)h->h, (void*)h->scores,
+                    (void*)h->pooled})
+        if (p) (void)hipFree(p);
+    h->ids8 = nullptr; h->x1 = h->x2 = h->x3 = h->hx = h->qkv = h->att = h->u = nullptr;
+    h->h = h->scores = h->pooled = nullptr;
+    h->cap_rows = h->cap_tok = 0;
+}
+
+template <int PREC, int EPI, int K, int N>
+void tf_launch_linear(const tf::LinArgs& a, hipStream_t st) {
+    constexpr size_t lds = EPI == tf::E_ACT ? (size_t)(128 * RS16 + 8 * 128 * tf::ZRS) * 2
+                                            : (size_t)2 * 128 * RS16 * 2 + (size_t)2 * 16 * 128 * 4;
+    auto kern = tf::linear16_kernel<PREC, EPI, K, N>;
+    static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), true);
+    (void)once;
+    hipLaunchKernelGGL(kern, dim3((unsigned)((a.M + 127) / 128)), dim3(512), lds, st, a);
+}
+
+template <int PREC>
+int tf_forward_t(clm_tf_handle* h, const void* ids, int ids_dtype, int64_t stride, int B, int L, float* logits, hipStream_t st) {
+    using elem = typename CT<PREC>::elem;
+    const int L1 = L / 2, L2 = L1 / 2, L3 = L2 / 2, Lp = (L + 63) / 64 * 64;
+    const size_t M = (size_t)B * L3;
+    auto W = [&](const std::string& k) { return h->w.at(k); };
+    launch_embed(ids, ids_dtype, stride, nullptr, nullptr, h->ids8, B, L, Lp, st);      // ids of any dtype -> clamped uint8
+    constexpr size_t conv_lds = (size_t)(130 * RS16 + 8 * 64 * tf::ZRS) * 2;
+    {
+        auto k1 = tf::conv3_relu_pool_kernel<PREC, true>;
+        auto k2 = tf::conv3_relu_pool_kernel<PREC, false>;
+        static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(k1), hipFuncAttributeMaxDynamicSharedMemorySize, (int)conv_lds),
+                            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k2), hipFuncAttributeMaxDynamicSharedMemorySize, (int)conv_lds), true);
+        (void)once;
+        hipLaunchKernelGGL(k1, dim3((2 * L1 + 127) / 128, B), dim3(512), conv_lds, st, h->ids8, Lp, W("embedding.weight"),
+                           (const elem*)nullptr, h->packed.at("cnn.0"), W("cnn.0.bias"), (elem*)h->x1, L, L1);
+        hipLaunchKernelGGL(k2, dim3((2 * L2 + 127) / 128, B), dim3(512), conv_lds, st, (const unsigned char*)nullptr, 0,
+                           (const float*)nullptr, (const elem*)h->x1, h->packed.at("cnn.3"), W("cnn.3.bias"), (elem*)h->x2, L1, L2);
+        hipLaunchKernelGGL(k2, dim3((2 * L3 + 127) / 128, B), dim3(512), conv_lds, st, (const unsigned char*)nullptr, 0,
+                           (const float*)nullptr, (const elem*)h->x2, h->packed.at("cnn.6"), W("cnn.6.bias"), (elem*)h->x3, L2, L3);
+    }
+    hipLaunchKernelGGL(tf::pe_ln_kernel<PREC>, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, st, (const elem*)h->x3,
+                       W("pos_encoder.pe"), W("norm.weight"), W("norm.bias"), h->h, (elem*)h->hx, M, L3, 1e-5f);
+    for (int i = 0; i < h->n_layers; ++i) {
+        const std::string p = "transformer_encoder.layers." + std::to_string(i) + ".";
+        tf::LinArgs a{};
+        a.M = M; a.eps = 1e-5f;
+        a.a = h->hx; a.w = h->packed.at(p + "in"); a.bias = W(p + "self_attn.in_proj_bias"); a.out16 = h->qkv; a.relu = 0;
+        tf_launch_linear<PREC, tf::E_ACT, D, tf::TQKV>(a, st);
+        launch_attention_fwd(PREC, h->qkv, h->att, B, L3, st);
+        a.a = h->att; a.w = h->packed.at(p + "out"); a.bias = W(p + "self_attn.out_proj.bias"); a.h = h->h; a.hx = h->hx;
+        a.ln_g = W(p + "norm1.weight"); a.ln_b = W(p + "norm1.bias");
+        tf_launch_linear<PREC, tf::E_RES_LN, D, D>(a, st);
+        a.a = h->hx; a.w = h->packed.at(p + "ff1"); a.bias = W(p + "linear1.bias"); a.out16 = h->u; a.relu = 1;
+        tf_launch_linear<PREC, tf::E_ACT, D, tf::TFF>(a, st);
+        a.a = h->u; a.w = h->packed.at(p + "ff2"); a.bias = W(p + "linear2.bias");
+        a.ln_g = W(p + "norm2.weight"); a.ln_b = W(p + "norm2.bias");
+        tf_launch_linear<PREC, tf::E_RES_LN, tf::TFF, D>(a, st);
+    }
+    hipLaunchKernelGGL(tf::pool_head_kernel, dim3(B), dim3(256), 0, st, h->h, W("attn_pool.weight"), W("attn_pool.bias"),
+                       W("classifier.0.weight"), W("classifier.0.bias"), W("classifier.3.weight"), W("classifier.3.bias"),
+                       h->scores, h->pooled, logits, L3);
+    h->last_B = B; h->last_L3 = L3;
+    return hipGetLastError() == hipSuccess ? CLM_OK : CLM_E_HIP;
+}
+
+}  // namespace
+
+extern "C" {
+
+int clm_tf_create(int device, int precision, int n_layers, clm_tf_handle** out) {
+    if (!out || n_layers < 1 || n_layers > 64) return tf_fail(nullptr, CLM_E_INVALID, "clm_tf_create: bad argument");
+    if (precision != CLM_PREC_F16 && precision != CLM_PREC_BF16)
+        return tf_fail(nullptr, CLM_E_UNSUPPORTED, "clm_tf_create: the encoder path runs with 16-bit MFMA inputs (fp16 or bf16)");
+    if (hipSetDevice(device) != hipSuccess) return tf_fail(nullptr, CLM_E_HIP, "clm_tf_create: hipSetDevice failed");
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess || std::string(prop.gcnArchName).rfind("gfx950", 0) != 0)
+        return tf_fail(nullptr, CLM_E_UNSUPPORTED, "clm_tf_create: this engine is built for gfx950 (MI355X) only");
+    clm_tf_handle* h = new clm_tf_handle();
+    h->device = device;
+    h->prec = precision == CLM_PREC_BF16 ? PREC_BF16 : PREC_F16;
+    h->n_layers = n_layers;
+    *out = h;
+    return CLM_OK;
+}
+
+int clm_tf_load_weight(clm_tf_handle* h, const char* key, const void* data, int dtype, const int64_t* shape, int ndim) {
+    if (!h || !key || !data || !shape) return tf_fail(h, CLM_E_INVALID, "clm_tf_load_weight: null argument");
+    if (dtype != CLM_DT_F32) return tf_fail(h, CLM_E_INVALID, "clm_tf_load_weight: fp32 tensors only");
+    const std::string k = tf_canon(key);
+    std::vector<int64_t> shp(shape, shape + ndim);
+    if (k == "pos_encoder.pe") {                               // buffer [1, max_len, 256]
+        if (ndim != 3 || shp[0] != 1 || shp[2] != D) return tf_fail(h, CLM_E_INVALID, "pos_encoder.pe: expected [1, max_len, 256]");
+    } else {
+        const auto exp = tf_expected(h->n_layers);
+        auto it = exp.find(k);
+        if (it == exp.end()) return tf_fail(h, CLM_E_INVALID, "clm_tf_load_weight: unknown key " + k);
+        if (it->second != shp) return tf_fail(h, CLM_E_INVALID, "clm_tf_load_weight: wrong shape for " + k);
+    }
+    size_t n = 1;
+    for (int64_t s : shp) n *= (size_t)s;
+    TFCHK(h, hipSetDevice(h->device));
+    if (h->w.count(k)) { (void)hipFree(h->w[k]); h->w.erase(k); }
+    float* d = nullptr;
+    TFCHK(h, hipMalloc((void**)&d, n * 4));
+    TFCHK(h, hipMemcpy(d, data, n * 4, hipMemcpyDefault));
+    h->w[k] = d;
+    h->shape[k] = shp;
+    h->finalized = false;
+    return CLM_OK;
+}
+
+int clm_tf_finalize(clm_tf_handle* h) {
+    if (!h) return CLM_E_INVALID;
+    TFCHK(h, hipSetDevice(h->device));
+    for (const auto& kv : tf_expected(h->n_layers))
+        if (!h->w.count(kv.first)) return tf_fail(h, CLM_E_MISSING, "clm_tf_finalize: missing weight " + kv.first);
+    if (!h->w.count("pos_encoder.pe")) return tf_fail(h, CLM_E_MISSING, "clm_tf_finalize: missing buffer pos_encoder.pe");
+    for (auto& kv : h->packed) (void)hipFree(kv.second);
+    h->packed.clear();
+    auto pack = [&](const std::string& name, const float* w, int n, int k) -> int {
+        void* p = nullptr;
+        TFCHK(h, hipMalloc(&p, packed_weight_bytes(h->prec, n, k)));
+        launch_pack_weight(h->prec, w, p, n, k, 0);
+        h->packed[name] = p;
+        return CLM_OK;
+    };
+    float* split = nullptr;
+    TFCHK(h, hipMalloc((void**)&split, (size_t)3 * D * D * 4));
+    for (int i : {0, 3, 6}) {
+        const std::string name = "cnn." + std::to_string(i);
+        hipLaunchKernelGGL(tf::conv_w_split_kernel, dim3((3 * D * D + 255) / 256), dim3(256), 0, 0, h->w.at(name + ".weight"), split);
+        void* p = nullptr;
+        TFCHK(h, hipMalloc(&p, 3 * packed_weight_bytes(h->prec, D, D)));
+        for (int dk = 0; dk < 3; ++dk)
+            launch_pack_weight(h->prec, split + (size_t)dk * D * D, (char*)p + dk * packed_weight_bytes(h->prec, D, D), D, D, 0);
+        TFCHK(h, hipDeviceSynchronize());                     // `split` is reused by the next layer
+        h->packed[name] = p;
+    }
+    (void)hipFree(split);
+    for (int i = 0; i < h->n_layers; ++i) {
+        const std::string p = "transformer_encoder.layers." + std::to_string(i) + ".";
+        int rc;
+        if ((rc = pack(p + "in", h->w.at(p + "self_attn.in_proj_weight"), tf::TQKV, D))) return rc;
+        if ((rc = pack(p + "out", h->w.at(p + "self_attn.out_proj.weight"), D, D))) return rc;
+        if ((rc = pack(p + "ff1", h->w.at(p + "linear1.weight"), tf::TFF, D))) return rc;
+        if ((rc = pack(p + "ff2", h->w.at(p + "linear2.weight"), D, tf::TFF))) return rc;
+    }
+    TFCHK(h, hipDeviceSynchronize());
+    h->finalized = true;
+    return CLM_OK;
+}
+
+int clm_tf_forward(clm_tf_handle* h, const void* ids, int ids_dtype, int64_t ids_row_stride, int B, int L, float* logits_out,
+                   void* stream) {
+    if (!h) return CLM_E_INVALID;
+    if (!h->finalized) return tf_fail(h, CLM_E_STATE, "clm_tf_forward before clm_tf_finalize");
+    if (!ids || !logits_out || B < 1 || L < 8 || ids_row_stride < L) return tf_fail(h, CLM_E_INVALID, "clm_tf_forward: bad argument (L >= 8)");
+    if (ids_dtype != CLM_DT_I64 && ids_dtype != CLM_DT_I32 && ids_dtype != CLM_DT_U8)
+        return tf_fail(h, CLM_E_INVALID, "clm_tf_forward: ids dtype must be i64, i32 or u8");
+    const int L3 = L / 8;
+    if ((int64_t)L3 > h->shape.at("pos_encoder.pe")[1])
+        return tf_fail(h, CLM_E_INVALID, "clm_tf_forward: Sequence too long (" + std::to_string(L3) + " > max_len of pos_encoder.pe)");
+    TFCHK(h, hipSetDevice(h->device));
+    const size_t M = (size_t)B * L3, tok = (size_t)B * ((L + 63) / 64 * 64);
+    if (M > h->cap_rows || tok > h->cap_tok) {
+        TFCHK(h, hipDeviceSynchronize());
+        tf_free_ws(h);
+        TFCHK(h, hipMalloc((void**)&h->ids8, tok));
+        TFCHK(h, hipMalloc(&h->x1, (size_t)B * (L / 2) * D * 2));
+        TFCHK(h, hipMalloc(&h->x2, (size_t)B * (L / 4) * D * 2));
+        TFCHK(h, hipMalloc(&h->x3, M * D * 2));
+        TFCHK(h, hipMalloc(&h->hx, M * D * 2));
+        TFCHK(h, hipMalloc(&h->qkv, M * tf::TQKV * 2));
+        TFCHK(h, hipMalloc(&h->att, M * D * 2));
+        TFCHK(h, hipMalloc(&h->u, M * tf::TFF * 2));
+        TFCHK(h, hipMalloc((void**)&h->h, M * D * 4));
+        TFCHK(h, hipMalloc((void**)&h->scores, M * 4));
+        TFCHK(h, hipMalloc((void**)&h->pooled, (size_t)B * D * 4));
+        h->cap_rows = M; h->cap_tok = tok;
+    }
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const int rc = h->prec == PREC_BF16 ? tf_forward_t<PREC_BF16>(h, ids, ids_dtype, ids_row_stride, B, L, logits_out, st)
+                                        : tf_forward_t<PREC_F16>(h, ids, ids_dtype, ids_row_stride, B, L, logits_out, st);
+    if (rc) return tf_fail(h, rc, std::string("clm_tf_forward: ") + hipGetErrorString(hipGetLastError()));
+    return CLM_OK;
+}
+
+int clm_tf_debug_fetch(clm_tf_handle* h, const char* name, void* host_out, size_t bytes) {
+    if (!h || !name || !host_out) return tf_fail(h, CLM_E_INVALID, "clm_tf_debug_fetch: bad argument");
+    TFCHK(h, hipSetDevice(h->device));
+    TFCHK(h, hipDeviceSynchronize());
+    const std::string n(name);
+    const size_t M = (size_t)h->last_B * h->last_L3;
+    const void* src = nullptr;
+    size_t have = 0;
+    if (n == "hidden") { src = h->h; have = M * D * 4; }
+    else if (n == "scores") { src = h->scores; have = M * 4; }
+    else if (n == "pooled") { src = h->pooled; have = (size_t)h->last_B * D * 4; }
+    else return tf_fail(h, CLM_E_INVALID, "clm_tf_debug_fetch: unknown name " + n);
+    if (bytes > have) return tf_fail(h, CLM_E_INVALID, "clm_tf_debug_fetch: more bytes requested than the last forward produced");
+    TFCHK(h, hipMemcpy(host_out, src, bytes, hipMemcpyDeviceToHost));
+    return CLM_OK;
+}
+
+const char* clm_tf_last_error(const clm_tf_handle* h) { return h ? h->err.c_str() : g_tf_create_error.c_str(); }
+
+int clm_tf_destroy(clm_tf_handle* h) {
+    if (!h) return CLM_OK;
+    (void)hipSetDevice(h->device);
+    (void)hipDeviceSynchronize();
+    tf_free_ws(h);
+    for (auto& kv : h->w) (void)hipFree(kv.second);
+    for (auto& kv : h->packed) (void)hipFree(kv.second);
+    delete h;
+    return CLM_OK;
+}
+
+}  // extern "C"

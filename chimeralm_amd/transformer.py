@@ -1,0 +1,117 @@
+"""Drop-in for the reference's second net, `SequenceCNNTransformer`
+(/root/reference/chimeralm/models/components/transformer.py:28-104, configs/model/transformer.yaml:3-12), with the forward on MI355X.
+
+Same constructor arguments, same `state_dict()` keys (torch's own modules are used as parameter containers, so
+`transformer_encoder.layers.{i}.self_attn.in_proj_weight` etc. come out exactly as in the reference, and `pos_encoder.pe` is a
+buffer of the same shape), same `forward(input_ids, input_quals=None) -> logits [B, 2]`, same `number_of_classes` attribute that
+`ClassificationLit` reads.  The arithmetic runs in csrc/tf_model.hip + csrc/attention.hip behind the `clm_tf_*` C ABI; there is no
+CPU path.  Engine knob absent in the reference: `precision` in {"fp16", "bf16"}.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+
+import numpy as np
+import torch
+from torch import nn
+
+from . import _native as N
+
+
+class _PosEnc(nn.Module):
+    def __init__(self, d_model: int, max_len: int):
+        super().__init__()
+        pe = torch.zeros(max_len, d_model)
+        position = torch.arange(0, max_len, dtype=torch.float32).unsqueeze(1)
+        div_term = torch.exp(torch.arange(0, d_model, 2).float() * (-math.log(10000.0) / d_model))
+        pe[:, 0::2] = torch.sin(position * div_term)
+        pe[:, 1::2] = torch.cos(position * div_term)
+        self.register_buffer("pe", pe.unsqueeze(0))
+
+
+class TransformerEngineError(RuntimeError):
+    pass
+
+
+class SequenceCNNTransformer(nn.Module):
+    def __init__(self, vocab_size: int, max_len: int, d_model: int = 256, cnn_kernel_size: int = 3, dropout: float = 0.1,
+                 num_encoder_layers: int = 2, nhead: int = 8, dim_feedforward: int = 1024, number_of_classes: int = 2,
+                 padding_idx: int = 4, *, precision: str = "fp16"):
+        super().__init__()
+        if (vocab_size, d_model, cnn_kernel_size, nhead, dim_feedforward, number_of_classes) != (12, 256, 3, 8, 1024, 2):
+            raise NotImplementedError("the MI355X encoder implements the production shape: vocab 12, d_model 256, kernel 3, "
+                                      "8 heads, feed-forward 1024, 2 classes (configs/model/transformer.yaml)")
+        if precision not in ("fp16", "bf16"):
+            raise ValueError("precision must be fp16 or bf16 (16-bit MFMA inputs, fp32 accumulation and statistics)")
+        self.number_of_classes, self.precision, self.num_encoder_layers = number_of_classes, precision, num_encoder_layers
+        self.embedding = nn.Embedding(vocab_size, d_model, padding_idx=padding_idx)
+        self.pos_encoder = _PosEnc(d_model, max_len)
+        conv = lambda: nn.Conv1d(d_model, d_model, kernel_size=cnn_kernel_size, padding=1)  # noqa: E731
+        self.cnn = nn.Sequential(conv(), nn.ReLU(), nn.MaxPool1d(2, 2), conv(), nn.ReLU(), nn.MaxPool1d(2, 2), conv(), nn.ReLU(),
+                                 nn.MaxPool1d(2, 2))
+        self.norm = nn.LayerNorm(d_model)
+        layer = nn.TransformerEncoderLayer(d_model=d_model, nhead=nhead, dim_feedforward=dim_feedforward, dropout=dropout,
+                                           batch_first=True)
+        self.transformer_encoder = nn.TransformerEncoder(layer, num_layers=num_encoder_layers, enable_nested_tensor=False)
+        self.attn_pool = nn.Linear(d_model, 1)
+        self.classifier = nn.Sequential(nn.Linear(d_model, d_model // 2), nn.ReLU(), nn.Dropout(dropout),
+                                        nn.Linear(d_model // 2, number_of_classes))
+        self._h, self._dev, self._sig = None, None, None
+
+    # ------------------------------------------------------------------ engine plumbing
+    def _check(self, rc: int):
+        if rc != 0:
+            raise TransformerEngineError(N.load().clm_tf_last_error(self._h).decode())
+
+    def _engine(self, device: torch.device):
+        lib = N.load()
+        if self._h is None or self._dev != device:
+            self.close()
+            h = C.c_void_p()
+            rc = lib.clm_tf_create(device.index or 0, N.PRECISIONS[self.precision], self.num_encoder_layers, C.byref(h))
+            if rc != 0:
+                raise TransformerEngineError(lib.clm_tf_last_error(None).decode())
+            self._h, self._dev, self._sig = h, device, None
+        sig = tuple((t.data_ptr(), t._version) for t in list(self.parameters()) + list(self.buffers()))
+        if sig != self._sig:                                   # weights replaced or modified in place -> reload
+            for k, t in self.state_dict().items():
+                t = t.detach().float().contiguous()
+                shape = (C.c_int64 * t.dim())(*t.shape)
+                self._check(lib.clm_tf_load_weight(self._h, k.encode(), C.c_void_p(t.data_ptr()), N.DT_F32, shape, t.dim()))
+            self._check(lib.clm_tf_finalize(self._h))
+            self._sig = sig
+        return lib
+
+    def forward(self, input_ids: torch.Tensor, input_quals: torch.Tensor | None = None) -> torch.Tensor:
+        """`input_quals` is accepted and ignored, as in the reference (transformer.py:88)."""
+        if input_ids.device.type != "cuda":
+            raise RuntimeError("chimeralm_amd.SequenceCNNTransformer runs on an MI355X only; there is no CPU forward")
+        if input_ids.dim() != 2 or input_ids.dtype not in (torch.int64, torch.int32, torch.uint8):
+            raise ValueError("input_ids must be [batch, length] of int64 / int32 / uint8")
+        if input_ids.stride(1) != 1:
+            input_ids = input_ids.contiguous()
+        lib = self._engine(input_ids.device)
+        B, L = input_ids.shape
+        out = torch.empty((B, 2), dtype=torch.float32, device=input_ids.device)
+        dt = {torch.int64: N.DT_I64, torch.int32: N.DT_I32, torch.uint8: N.DT_U8}[input_ids.dtype]
+        self._check(lib.clm_tf_forward(self._h, C.c_void_p(input_ids.data_ptr()), dt, input_ids.stride(0), B, L,
+                                       C.c_void_p(out.data_ptr()),
+                                       C.c_void_p(torch.cuda.current_stream(input_ids.device).cuda_stream)))
+        return out
+
+    def debug_fetch(self, name: str, shape) -> np.ndarray:
+        arr = np.empty(shape, dtype=np.float32)
+        self._check(N.load().clm_tf_debug_fetch(self._h, name.encode(), arr.ctypes.data_as(C.c_void_p), arr.nbytes))
+        return arr
+
+    def close(self):
+        if getattr(self, "_h", None) is not None:
+            N.load().clm_tf_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -121,6 +121,23 @@ int clm_stage_wait(clm_handle* h, int staged);
  *   precision CLM_PREC_F16 or CLM_PREC_BF16 (element type of qkv / out; statistics and accumulation are fp32). */
 int clm_attention_fwd(const void* qkv, void* out, int B, int L, int precision, void* stream);
 
+/* The whole SequenceCNNTransformer forward (transformer.py:88-104; configuration of configs/model/transformer.yaml:3-12:
+ * vocab 12, d_model 256, kernel 3, 8 heads, feed-forward 1024, `n_layers` encoder layers) behind the same `net` boundary as
+ * HyenaDna: forward(input_ids[B, L], input_quals=None) -> logits fp32 [B, 2].  Same conventions as the clm_* calls above;
+ * weights are loaded under the reference module's state_dict keys (with or without the `net.` prefix), the buffer
+ * `pos_encoder.pe` [1, max_len, 256] included; fp32 tensors only.  L >= 8; L / 8 must not exceed max_len (the reference
+ * asserts the same, transformer.py:21).  clm_tf_debug_fetch names: "hidden" fp32 [B, L/8, 256] (encoder output),
+ * "scores" fp32 [B, L/8] (pooling scores before the softmax), "pooled" fp32 [B, 256]. */
+typedef struct clm_tf_handle clm_tf_handle;
+int clm_tf_create(int device, int precision /* CLM_PREC_F16 | CLM_PREC_BF16 */, int n_layers, clm_tf_handle** out);
+int clm_tf_load_weight(clm_tf_handle* h, const char* key, const void* data, int dtype, const int64_t* shape, int ndim);
+int clm_tf_finalize(clm_tf_handle* h);
+int clm_tf_forward(clm_tf_handle* h, const void* ids, int ids_dtype, int64_t ids_row_stride, int B, int L, float* logits_out,
+                   void* stream);
+int clm_tf_debug_fetch(clm_tf_handle* h, const char* name, void* host_out, size_t bytes);
+const char* clm_tf_last_error(const clm_tf_handle* h);
+int clm_tf_destroy(clm_tf_handle* h);
+
 /* ---- test / measurement taps (not on the product path) -------------------------------------------- */
 
 /* Copy a named intermediate of the LAST clm_forward to host memory (synchronises the device).  Names:
