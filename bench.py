@@ -91,6 +91,64 @@ def cpu_baseline(bases: int, budget_s: float = 20.0) -> dict:
             "sample": f"{n} synthetic {bases}-bp reads in batches of {b}, fp32 torch-CPU oracle (oracle/hyena_oracle.py)"}
 
 
+def bench_transformer(a):
+    """Same step / timing contract for the reference's second net (configs/model/transformer.yaml):
+    one forward of SequenceCNNTransformer over the global batch of synthetic reads, ids resident in HBM."""
+    from chimeralm_amd import distributed as cdist
+    from chimeralm_amd.transformer import SequenceCNNTransformer
+
+    rank, local_rank, world = cdist.init_process_group("nccl")
+    device = torch.device("cuda", local_rank)
+    torch.cuda.set_device(device)
+    lo, hi = cdist.shard_bounds(a.batch, rank, world)
+    L = a.bases + 1
+    torch.manual_seed(0)
+    net = SequenceCNNTransformer(vocab_size=12, max_len=32768, num_encoder_layers=12, precision=a.precision)
+    n_data = max(1, min(4, a.steps))
+    batches = [torch.from_numpy(synthetic_ids(i, a.batch, a.bases)[lo:hi]).to(device) for i in range(n_data)]
+
+    def step(i):
+        out = net(batches[i % n_data])
+        return cdist.gather_logits(out) if world > 1 else out
+
+    for i in range(a.warmup):
+        step(i)
+    cdist.barrier()
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    for i in range(a.steps):
+        out = step(i)
+    torch.cuda.synchronize(device)
+    cdist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t.item())
+    assert out.shape[0] == a.batch and bool(torch.isfinite(out).all())
+    if rank == 0:
+        L3 = L // 8
+        # dense FLOPs per read: conv stack (K = 768 GEMMs at L, L/2, L/4 positions) + 12 x (QKV, out, FFN) + attention products
+        conv = 2 * 768 * 256 * ((L // 2) * 2 + (L // 4) * 2 + L3 * 2)
+        enc = 12 * L3 * 2 * 256 * (768 + 256 + 2 * 1024)
+        att = 12 * 2 * 2 * L3 * L3 * 256
+        flops = (conv + enc + att) * a.batch * a.steps / elapsed / 1e12
+        res = {"metric": "reads/sec, SequenceCNNTransformer, 8k-bp reads batch=256", "value": a.batch * a.steps / elapsed,
+               "unit": "reads/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": elapsed / a.steps * 1e3,
+               "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": a.precision,
+               "data": "synthetic reads (seeded), seeded random-init weights of the configured architecture",
+               "config": {"workload": f"synthetic {a.bases}-bp reads, global batch {a.batch}, 1 forward per step, "
+                                      "SequenceCNNTransformer (12 layers)", "global_batch": a.batch, "tokens_per_read": L,
+                          "reads_per_gpu": hi - lo},
+               "roofline": {"bound": "mfma", "kernel": "whole forward (conv stack + encoder + attention)", "achieved": flops,
+                            "peak": PEAK_TFLOPS[a.precision], "unit": "TFLOP/s", "frac": flops / PEAK_TFLOPS[a.precision],
+                            "traffic": None}}
+        print(json.dumps(res), flush=True)
+    cdist.barrier()
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -101,7 +159,11 @@ def main():
     ap.add_argument("--precision", default=os.environ.get("CLM_PRECISION", "fp16"))
     ap.add_argument("--chunk-reads", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--net", default="hyena", choices=["hyena", "transformer"],
+                    help="hyena = the production predict path (the headline metric); transformer = SequenceCNNTransformer")
     a = ap.parse_args()
+    if a.net == "transformer":
+        return bench_transformer(a)
 
     from chimeralm_amd import distributed as cdist, lm
     from chimeralm_amd.engine import Engine
