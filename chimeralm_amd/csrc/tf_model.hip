@@ -18,6 +18,7 @@
 // row offset 0 / 1 / 2 and the weight slice W[:, :, dk]; ReLU and the max-pool happen on the accumulator quads (4 consecutive
 // positions of one channel) before anything is written.
 #include <algorithm>
+#include <cstdlib>
 #include <map>
 #include <string>
 #include <vector>
@@ -180,6 +181,68 @@ __device__ __forceinline__ void stage_rows16(const typename CT<PREC>::elem* a, s
     }
 }
 
+// acc (rows = this wave's 32 features, lane = token) + bias + residual h -> post-norm LayerNorm -> h (fp32, whole lines through
+// the XOR-swizzled LDS transpose) and hx (16-bit, rows of the normalised tile as they lie in LDS).  `smem`: >= 128 KiB staging
+// area starting at the tile As; P1 / P2 behind it.
+template <int PREC>
+__device__ __forceinline__ void res_ln_store(f32x16 (&acc)[4], const float* __restrict__ bias, float* __restrict__ h,
+                                             typename CT<PREC>::elem* __restrict__ hx, const float* ln_g, const float* ln_b,
+                                             float eps, size_t row0, size_t M, unsigned char* smem, typename CT<PREC>::elem* As,
+                                             float* P1, float* P2) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lrow = lane & 31, lhalf = lane >> 5;
+    // r = acc + bias + residual (this lane's token, 4 consecutive features per quad)
+    {
+        const float* bp = bias + wave * 32 + 4 * lhalf;
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            const size_t row = row0 + mt * 32 + lrow;
+            const float* hr = h + (row < M ? row : 0) * D + wave * 32 + 4 * lhalf;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 bb = *reinterpret_cast<const float4*>(bp + 8 * q);
+                const float4 hv = *reinterpret_cast<const float4*>(hr + 8 * q);
+                acc[mt][4 * q + 0] += bb.x + hv.x;
+                acc[mt][4 * q + 1] += bb.y + hv.y;
+                acc[mt][4 * q + 2] += bb.z + hv.z;
+                acc[mt][4 * q + 3] += bb.w + hv.w;
+            }
+        }
+    }
+    const int l_valid = (int)std::min<size_t>(M > row0 ? M - row0 : 0, 128);
+    ln_acc_to_tile<PREC, true>(acc, P1, P2, ln_g, ln_b, eps, As, 0, l_valid, wave, lrow, lhalf);
+    // 16-bit copy: rows of the normalised tile as they lie in LDS
+    {
+        const int piece = tid & 31;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int r = (tid >> 5) + 16 * i;
+            if (r < l_valid)
+                *reinterpret_cast<uint4*>(hx + (row0 + r) * D + piece * 8) = *reinterpret_cast<const uint4*>(As + r * RS16 + piece * 8);
+        }
+    }
+    __syncthreads();
+    // fp32 h: transposed through LDS (XOR-swizzled 16-byte chunks), stored as whole 128-byte lines
+    float* rs = reinterpret_cast<float*>(smem) + wave * (128 * 32);
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+        const int tok = mt * 32 + lrow;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int chunk = (2 * q + lhalf) ^ (tok & 7);
+            *reinterpret_cast<float4*>(rs + tok * 32 + 4 * chunk) =
+                make_float4(acc[mt][4 * q + 0], acc[mt][4 * q + 1], acc[mt][4 * q + 2], acc[mt][4 * q + 3]);
+        }
+    }
+    const int c = lane & 7, rsub = lane >> 3;
+    float* hrow = h + row0 * D + wave * 32 + 4 * c;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int tr = i * 8 + rsub;
+        const float4 v = *reinterpret_cast<const float4*>(rs + tr * 32 + 4 * (c ^ (tr & 7)));
+        if (tr < l_valid) *reinterpret_cast<float4*>(hrow + (size_t)tr * D) = v;
+    }
+}
+
 template <int PREC, int EPI, int K, int N>
 __global__ __launch_bounds__(512) void linear16_kernel(LinArgs m) {
     using elem = typename CT<PREC>::elem;
@@ -243,60 +306,81 @@ __global__ __launch_bounds__(512) void linear16_kernel(LinArgs m) {
             compute_tm<PREC, true>(As, 0, lrow, lhalf, bs[0], acc);
             compute_tm<PREC, true>(As, 1, lrow, lhalf, bs[1], acc);
         }
-        // r = acc + bias + residual (this lane's token, 4 consecutive features per quad)
+        res_ln_store<PREC>(acc, m.bias, m.h, reinterpret_cast<elem*>(m.hx), m.ln_g, m.ln_b, m.eps, row0, m.M, smem, As, P1, P2);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ fused feed-forward
+// h = LN2(h + relu(hx W1^T + b1) W2^T + b2): the 1024-wide activations never reach HBM -- per 256-wide hidden chunk the fc1
+// accumulator goes through bias + ReLU into an LDS tile that is the A operand of fc2's reduction chunk (same scheme as mlp16 in
+// gemm16.hip); the post-norm LayerNorm runs on the fc2 accumulators and the new h / hx leave as whole lines.
+struct FfnArgs {
+    const void* hx_in;        // [M, 256] 16-bit
+    const void *w1, *w2;      // packed [1024, 256], [256, 1024]
+    const float *b1, *b2, *ln_g, *ln_b;
+    float* h;                 // [M, 256] fp32, residual in / LayerNorm out
+    void* hx_out;             // [M, 256] 16-bit copy of the new h (may alias hx_in: a tile is read completely before it is written)
+    size_t M;
+    float eps;
+};
+
+template <int PREC>
+__global__ __launch_bounds__(512) void enc_ffn16_kernel(FfnArgs m) {
+    using elem = typename CT<PREC>::elem;
+    using frag = u16x8;
+    constexpr int NCH = TFF / 256;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    elem* As = reinterpret_cast<elem*>(smem);
+    elem* Hs = As + 128 * RS16;
+    float* P1 = reinterpret_cast<float*>(smem + (size_t)2 * 128 * RS16 * 2);
+    float* P2 = P1 + 16 * 128;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lrow = lane & 31, lhalf = lane >> 5;
+    const size_t row0 = (size_t)blockIdx.x * 128;
+    const frag* w1 = reinterpret_cast<const frag*>(m.w1);
+    const frag* w2 = reinterpret_cast<const frag*>(m.w2);
+    f32x16 acc1[4], acc2[4];
+    frag bs[2][1][SETK];
+    load_set<PREC, D, 1>(w1, 0, 0, 0, wave, lane, bs[0]);
+    __builtin_amdgcn_sched_barrier(0);
+    stage_rows16<PREC>(reinterpret_cast<const elem*>(m.hx_in), row0, m.M, D, 0, As, tid);
+    __syncthreads();
+    zero_acc(acc2);
+#pragma unroll 1
+    for (int j = 0; j < NCH; ++j) {
+        zero_acc(acc1);
+        load_set<PREC, D, 1>(w1, j, 0, 1, wave, lane, bs[1]);
+        __builtin_amdgcn_sched_barrier(0);
+        compute_tm<PREC, true>(As, 0, lrow, lhalf, bs[0], acc1);
+        __builtin_amdgcn_sched_barrier(0);
+        load_set<PREC, TFF, 1>(w2, 0, j, 0, wave, lane, bs[0]);
+        __builtin_amdgcn_sched_barrier(0);
+        compute_tm<PREC, true>(As, 1, lrow, lhalf, bs[1], acc1);
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();                                       // every wave is done reading the previous chunk of Hs
         {
-            const float* bp = m.bias + wave * 32 + 4 * lhalf;
+            const float* b1 = m.b1 + j * 256 + wave * 32 + 4 * lhalf;
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt) {
-                const size_t row = row0 + mt * 32 + lrow;
-                const float* hr = m.h + (row < m.M ? row : 0) * D + wave * 32 + 4 * lhalf;
+            for (int q = 0; q < 4; ++q) {
+                const float4 bb = *reinterpret_cast<const float4*>(b1 + 8 * q);
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const float4 bb = *reinterpret_cast<const float4*>(bp + 8 * q);
-                    const float4 hv = *reinterpret_cast<const float4*>(hr + 8 * q);
-                    acc[mt][4 * q + 0] += bb.x + hv.x;
-                    acc[mt][4 * q + 1] += bb.y + hv.y;
-                    acc[mt][4 * q + 2] += bb.z + hv.z;
-                    acc[mt][4 * q + 3] += bb.w + hv.w;
+                for (int mt = 0; mt < 4; ++mt) {
+                    u16x4 pk = {to_bits<PREC>(fmaxf(acc1[mt][4 * q + 0] + bb.x, 0.f)), to_bits<PREC>(fmaxf(acc1[mt][4 * q + 1] + bb.y, 0.f)),
+                                to_bits<PREC>(fmaxf(acc1[mt][4 * q + 2] + bb.z, 0.f)), to_bits<PREC>(fmaxf(acc1[mt][4 * q + 3] + bb.w, 0.f))};
+                    *reinterpret_cast<u16x4*>(Hs + (mt * 32 + lrow) * RS16 + wave * 32 + 8 * q + 4 * lhalf) = pk;
                 }
-            }
-        }
-        const int l_valid = (int)std::min<size_t>(m.M > row0 ? m.M - row0 : 0, 128);
-        ln_acc_to_tile<PREC, true>(acc, P1, P2, m.ln_g, m.ln_b, m.eps, As, 0, l_valid, wave, lrow, lhalf);
-        // 16-bit copy: rows of the normalised tile as they lie in LDS
-        {
-            const int piece = tid & 31;
-            elem* hx = reinterpret_cast<elem*>(m.hx);
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int r = (tid >> 5) + 16 * i;
-                if (r < l_valid) *reinterpret_cast<uint4*>(hx + (row0 + r) * D + piece * 8) = *reinterpret_cast<const uint4*>(As + r * RS16 + piece * 8);
             }
         }
         __syncthreads();
-        // fp32 h: transposed through LDS (XOR-swizzled 16-byte chunks), stored as whole 128-byte lines
-        {
-            float* rs = reinterpret_cast<float*>(smem) + wave * (128 * 32);
-#pragma unroll
-            for (int mt = 0; mt < 4; ++mt) {
-                const int tok = mt * 32 + lrow;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int chunk = (2 * q + lhalf) ^ (tok & 7);
-                    *reinterpret_cast<float4*>(rs + tok * 32 + 4 * chunk) =
-                        make_float4(acc[mt][4 * q + 0], acc[mt][4 * q + 1], acc[mt][4 * q + 2], acc[mt][4 * q + 3]);
-                }
-            }
-            const int c = lane & 7, rsub = lane >> 3;
-            float* hrow = m.h + row0 * D + wave * 32 + 4 * c;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int tr = i * 8 + rsub;
-                const float4 v = *reinterpret_cast<const float4*>(rs + tr * 32 + 4 * (c ^ (tr & 7)));
-                if (tr < l_valid) *reinterpret_cast<float4*>(hrow + (size_t)tr * D) = v;
-            }
-        }
+        load_set<PREC, TFF, 1>(w2, 0, j, 1, wave, lane, bs[1]);
+        __builtin_amdgcn_sched_barrier(0);
+        compute_tm<PREC, true>(Hs, 0, lrow, lhalf, bs[0], acc2);
+        __builtin_amdgcn_sched_barrier(0);
+        load_set<PREC, D, 1>(w1, j + 1 < NCH ? j + 1 : 0, 0, 0, wave, lane, bs[0]);
+        __builtin_amdgcn_sched_barrier(0);
+        compute_tm<PREC, true>(Hs, 1, lrow, lhalf, bs[1], acc2);
+        __builtin_amdgcn_sched_barrier(0);
     }
+    res_ln_store<PREC>(acc2, m.b2, m.h, reinterpret_cast<elem*>(m.hx_out), m.ln_g, m.ln_b, m.eps, row0, m.M, smem, As, P1, P2);
 }
 
 // ------------------------------------------------------------------------------------------------ pooling + classifier
@@ -472,11 +556,22 @@ int tf_forward_t(clm_tf_handle* h, const void* ids, int ids_dtype, int64_t strid
         a.a = h->att; a.w = h->packed.at(p + "out"); a.bias = W(p + "self_attn.out_proj.bias"); a.h = h->h; a.hx = h->hx;
         a.ln_g = W(p + "norm1.weight"); a.ln_b = W(p + "norm1.bias");
         tf_launch_linear<PREC, tf::E_RES_LN, D, D>(a, st);
-        a.a = h->hx; a.w = h->packed.at(p + "ff1"); a.bias = W(p + "linear1.bias"); a.out16 = h->u; a.relu = 1;
-        tf_launch_linear<PREC, tf::E_ACT, D, tf::TFF>(a, st);
-        a.a = h->u; a.w = h->packed.at(p + "ff2"); a.bias = W(p + "linear2.bias");
-        a.ln_g = W(p + "norm2.weight"); a.ln_b = W(p + "norm2.bias");
-        tf_launch_linear<PREC, tf::E_RES_LN, tf::TFF, D>(a, st);
+        static const bool unfused_ffn = std::getenv("CLM_TF_UNFUSED_FFN") && std::getenv("CLM_TF_UNFUSED_FFN")[0] == '1';
+        if (!unfused_ffn) {
+            tf::FfnArgs f{h->hx, h->packed.at(p + "ff1"), h->packed.at(p + "ff2"), W(p + "linear1.bias"), W(p + "linear2.bias"),
+                          W(p + "norm2.weight"), W(p + "norm2.bias"), h->h, h->hx, M, 1e-5f};
+            constexpr size_t lds = (size_t)2 * 128 * RS16 * 2 + (size_t)2 * 16 * 128 * 4;
+            auto kern = tf::enc_ffn16_kernel<PREC>;
+            static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), true);
+            (void)once;
+            hipLaunchKernelGGL(kern, dim3((unsigned)((M + 127) / 128)), dim3(512), lds, st, f);
+        } else {
+            a.a = h->hx; a.w = h->packed.at(p + "ff1"); a.bias = W(p + "linear1.bias"); a.out16 = h->u; a.relu = 1;
+            tf_launch_linear<PREC, tf::E_ACT, D, tf::TFF>(a, st);
+            a.a = h->u; a.w = h->packed.at(p + "ff2"); a.bias = W(p + "linear2.bias");
+            a.ln_g = W(p + "norm2.weight"); a.ln_b = W(p + "norm2.bias");
+            tf_launch_linear<PREC, tf::E_RES_LN, tf::TFF, D>(a, st);
+        }
     }
     hipLaunchKernelGGL(tf::pool_head_kernel, dim3(B), dim3(256), 0, st, h->h, W("attn_pool.weight"), W("attn_pool.bias"),
                        W("classifier.0.weight"), W("classifier.0.bias"), W("classifier.3.weight"), W("classifier.3.bias"),
