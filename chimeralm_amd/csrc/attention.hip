@@ -51,7 +51,7 @@ __device__ __forceinline__ int v_row(int k) { return (k & ~12) | ((k & 4) << 1) 
 }  // namespace
 
 template <int PREC>
-__global__ __launch_bounds__(256) void attention_fwd_kernel(const typename CT<PREC>::elem* __restrict__ qkv,
+__global__ __launch_bounds__(256, 4) void attention_fwd_kernel(const typename CT<PREC>::elem* __restrict__ qkv,
                                                             typename CT<PREC>::elem* __restrict__ out, int L) {
     using elem = typename CT<PREC>::elem;
     __shared__ __attribute__((aligned(16))) elem Ks[2][KT * KRS];
