@@ -4,7 +4,7 @@
 
 plus engine-only options `--weights` (directory/file with the released `model.safetensors`; the reference downloads
 `yangliz5/chimeralm` from the Hub) and `--precision`.  `--gpus 0` (the reference's CPU mode) is refused: this engine
-has no CPU path.  Only `predict` is built; `filter` and `web` are outside the hot path.
+has no CPU path.  `filter` (reference :320-331) is the host-only step after predict; `web` is not built.
 """
 from __future__ import annotations
 
@@ -88,6 +88,23 @@ def predict(
         n = loop.run_predict(model, dm, writer, device, rank=rank)
     distributed.barrier()
     log.info(f"[rank {rank}] {n} reads; predictions saved to {output_path}")
+
+
+@app.command()
+def filter(  # noqa: A001 - reference command name
+    bam_path: Path = typer.Argument(..., help="Path to the BAM file"),
+    predictions_path: Path = typer.Argument(..., help="Path to the predictions file"),
+    output_prediction: bool = typer.Option(False, "--output-prediction", "-p", help="write summary of the predictions"),
+    verbose: bool = typer.Option(False, "--verbose", "-v", help="Enable verbose output"),
+):
+    """Filter the BAM file by predictions."""
+    logging.basicConfig(level=logging.DEBUG if verbose else logging.INFO, format="%(message)s")
+    from .filter import filter_bam_by_predcition
+
+    log.info(f"Filtering {bam_path} by predictions from {predictions_path}")
+    res = filter_bam_by_predcition(bam_path, predictions_path, index=True, output_prediction=output_prediction)
+    if res:
+        log.info(f"kept {res['kept']} records, dropped {res['dropped']}: {res['sorted'] or res['filtered']}")
 
 
 if __name__ == "__main__":

@@ -79,6 +79,10 @@ SYMBOLS = {
                                    C.POINTER(C.c_int64)]),
     "clm_feeder_last_error": (C.c_char_p, [_H]),
     "clm_feeder_close": (C.c_int, [_H]),
+    "clm_bam_filter": (C.c_int, [C.c_char_p, C.c_char_p, C.POINTER(C.c_char_p), C.c_int64, C.POINTER(C.c_int64),
+                                 C.POINTER(C.c_int64)]),
+    "clm_bam_sort_index": (C.c_int, [C.c_char_p, C.c_char_p, C.c_char_p, C.POINTER(C.c_int64)]),
+    "clm_bam_last_error": (C.c_char_p, []),
 }
 
 _lib = None

@@ -16,7 +16,8 @@
 #include "chimeralm_hip.h"
 
 #include <hip/hip_runtime_api.h>
-#include <zlib.h>
+
+#include "bgzf.h"
 
 #include <atomic>
 #include <condition_variable>
@@ -51,7 +52,7 @@ struct Slot {
 struct clm_feeder {
     clm_feeder_config cfg{};
     std::string path, err;
-    FILE* fp = nullptr;
+    clmbgzf::Reader rd;
     std::vector<Slot> ring;
     uint8_t* slab_ids = nullptr;
     int8_t* slab_names = nullptr;
@@ -65,12 +66,6 @@ struct clm_feeder {
     bool done = false, failed = false, stop = false;
     std::thread worker;
     std::atomic<int64_t> n_records{0}, n_selected{0}, n_delivered{0}, n_truncated{0};
-
-    // ---- decoder thread state
-    std::vector<uint8_t> zin, buf;   // compressed block, inflated bytes not yet consumed
-    size_t buf_pos = 0;
-    z_stream zs{};
-    bool zs_ready = false;
 };
 
 namespace {
@@ -80,99 +75,15 @@ int fail_open(int code, const std::string& msg) {
     return code;
 }
 
-// ------------------------------------------------------------------------------------------------ BGZF
-// Appends the inflated payload of the next BGZF member to f->buf.  Returns 1, 0 at a clean end of file, -1 on error.
-int next_block(clm_feeder* f) {
-    uint8_t head[12];
-    size_t got = fread(head, 1, sizeof(head), f->fp);
-    if (got == 0) return 0;
-    if (got != sizeof(head) || head[0] != 31 || head[1] != 139 || head[2] != 8 || !(head[3] & 4)) {
-        f->err = f->path + ": not a BGZF block (bad gzip member header)";
-        return -1;
-    }
-    const unsigned xlen = head[10] | (head[11] << 8);
-    std::vector<uint8_t> extra(xlen);
-    if (fread(extra.data(), 1, xlen, f->fp) != xlen) {
-        f->err = f->path + ": truncated BGZF extra field";
-        return -1;
-    }
-    int bsize = -1;
-    for (size_t p = 0; p + 4 <= xlen;) {
-        const unsigned slen = extra[p + 2] | (extra[p + 3] << 8);
-        if (extra[p] == 'B' && extra[p + 1] == 'C' && slen == 2 && p + 6 <= xlen) bsize = extra[p + 4] | (extra[p + 5] << 8);
-        p += 4 + slen;
-    }
-    const long cdata = (long)bsize + 1 - 12 - (long)xlen - 8;
-    if (bsize < 0 || cdata < 0) {
-        f->err = f->path + ": BGZF block without a valid BC subfield";
-        return -1;
-    }
-    f->zin.resize((size_t)cdata + 8);
-    if (fread(f->zin.data(), 1, f->zin.size(), f->fp) != f->zin.size()) {
-        f->err = f->path + ": truncated BGZF block";
-        return -1;
-    }
-    const uint8_t* tail = f->zin.data() + cdata;
-    const uint32_t crc = tail[0] | (tail[1] << 8) | (tail[2] << 16) | ((uint32_t)tail[3] << 24);
-    const uint32_t isize = tail[4] | (tail[5] << 8) | (tail[6] << 16) | ((uint32_t)tail[7] << 24);
-    if (isize > 65536) {
-        f->err = f->path + ": BGZF block claims more than 64 KiB of payload";
-        return -1;
-    }
-    if (isize == 0) return 1;   // empty member (the EOF marker block)
-    if (!f->zs_ready) {
-        std::memset(&f->zs, 0, sizeof(f->zs));
-        if (inflateInit2(&f->zs, -15) != Z_OK) {
-            f->err = "zlib inflateInit2 failed";
-            return -1;
-        }
-        f->zs_ready = true;
-    } else {
-        inflateReset(&f->zs);
-    }
-    // compact the consumed prefix before growing
-    if (f->buf_pos > 0 && f->buf_pos == f->buf.size()) {
-        f->buf.clear();
-        f->buf_pos = 0;
-    } else if (f->buf_pos > (1u << 20)) {
-        f->buf.erase(f->buf.begin(), f->buf.begin() + (long)f->buf_pos);
-        f->buf_pos = 0;
-    }
-    const size_t old = f->buf.size();
-    f->buf.resize(old + isize);
-    f->zs.next_in = f->zin.data();
-    f->zs.avail_in = (uInt)cdata;
-    f->zs.next_out = f->buf.data() + old;
-    f->zs.avail_out = isize;
-    const int rc = inflate(&f->zs, Z_FINISH);
-    if (rc != Z_STREAM_END || f->zs.avail_out != 0) {
-        f->err = f->path + ": corrupt BGZF block (inflate failed)";
-        return -1;
-    }
-    if ((uint32_t)crc32(crc32(0L, Z_NULL, 0), f->buf.data() + old, isize) != crc) {
-        f->err = f->path + ": corrupt BGZF block (CRC mismatch)";
-        return -1;
-    }
-    return 1;
-}
+using clmbgzf::le16;
+using clmbgzf::le32;
 
-// Makes n inflated bytes available at buf[buf_pos ...].  1 = ok, 0 = clean EOF before the first byte, -1 = error.
+// makes n inflated bytes available; forwards the reader's error text
 int need(clm_feeder* f, size_t n) {
-    while (f->buf.size() - f->buf_pos < n) {
-        const bool empty = f->buf.size() == f->buf_pos;
-        const int rc = next_block(f);
-        if (rc < 0) return -1;
-        if (rc == 0) {
-            if (empty) return 0;
-            f->err = f->path + ": BAM stream ends inside a record";
-            return -1;
-        }
-    }
-    return 1;
+    const int rc = f->rd.need(n);
+    if (rc < 0) f->err = f->rd.err;
+    return rc;
 }
-
-inline int32_t le32(const uint8_t* p) { return (int32_t)(p[0] | (p[1] << 8) | (p[2] << 16) | ((uint32_t)p[3] << 24)); }
-inline uint16_t le16(const uint8_t* p) { return (uint16_t)(p[0] | (p[1] << 8)); }
 
 // auxiliary fields: TAG(2) TYPE(1) VALUE; true if a field with tag SA exists (bam.py:21-23 `read.has_tag("SA")`)
 int has_sa_tag(const uint8_t* aux, size_t n) {
@@ -255,18 +166,18 @@ void decode_loop(clm_feeder* f) {
     };
     // header: magic was checked by open(); skip text and references
     if (need(f, 8) <= 0) return finish(true);
-    const int32_t l_text = le32(f->buf.data() + f->buf_pos + 4);
-    f->buf_pos += 8;
+    const int32_t l_text = le32(f->rd.data() + 4);
+    f->rd.advance(8);
     if (l_text < 0 || need(f, (size_t)l_text + 4) <= 0) { if (f->err.empty()) f->err = f->path + ": corrupt BAM header"; return finish(true); }
-    f->buf_pos += (size_t)l_text;
-    const int32_t n_ref = le32(f->buf.data() + f->buf_pos);
-    f->buf_pos += 4;
+    f->rd.advance((size_t)l_text);
+    const int32_t n_ref = le32(f->rd.data());
+    f->rd.advance(4);
     for (int32_t i = 0; i < n_ref; ++i) {
         if (need(f, 4) <= 0) { if (f->err.empty()) f->err = f->path + ": corrupt BAM reference list"; return finish(true); }
-        const int32_t l_name = le32(f->buf.data() + f->buf_pos);
-        f->buf_pos += 4;
+        const int32_t l_name = le32(f->rd.data());
+        f->rd.advance(4);
         if (l_name < 0 || need(f, (size_t)l_name + 4) <= 0) { if (f->err.empty()) f->err = f->path + ": corrupt BAM reference list"; return finish(true); }
-        f->buf_pos += (size_t)l_name + 4;
+        f->rd.advance((size_t)l_name + 4);
     }
     std::vector<PendingRead> pend;
     pend.reserve((size_t)f->cfg.batch_size);
@@ -277,14 +188,14 @@ void decode_loop(clm_feeder* f) {
         int rc = need(f, 4);
         if (rc < 0) return finish(true);
         if (rc == 0) break;
-        const int32_t block_size = le32(f->buf.data() + f->buf_pos);
-        f->buf_pos += 4;
+        const int32_t block_size = le32(f->rd.data());
+        f->rd.advance(4);
         if (block_size < 32 || need(f, (size_t)block_size) <= 0) {
             if (f->err.empty()) f->err = f->path + ": corrupt BAM record";
             return finish(true);
         }
-        const uint8_t* rec = f->buf.data() + f->buf_pos;
-        f->buf_pos += (size_t)block_size;
+        const uint8_t* rec = f->rd.data();
+        f->rd.advance((size_t)block_size);
         ++f->n_records;
         const unsigned l_read_name = rec[8];
         const unsigned n_cigar = le16(rec + 12);
@@ -358,13 +269,13 @@ int clm_feeder_open(const char* bam_path, const clm_feeder_config* cfg, clm_feed
     clm_feeder* f = new clm_feeder();
     f->cfg = *cfg;
     f->path = bam_path;
-    f->fp = std::fopen(bam_path, "rb");
-    if (!f->fp) {
+    if (!f->rd.open(bam_path)) {
+        const std::string msg = f->rd.err;
         delete f;
-        return fail_open(CLM_E_INVALID, std::string(bam_path) + ": cannot open");
+        return fail_open(CLM_E_INVALID, msg);
     }
     // magic check up front so that a wrong file fails at open, like the reference's pysam.AlignmentFile
-    if (need(f, 4) <= 0 || std::memcmp(f->buf.data() + f->buf_pos, "BAM\1", 4) != 0) {
+    if (need(f, 4) <= 0 || std::memcmp(f->rd.data(), "BAM\1", 4) != 0) {
         const std::string msg = f->err.empty() ? std::string(bam_path) + ": not a BAM file" : f->err;
         clm_feeder_close(f);
         return fail_open(CLM_E_INVALID, msg);
@@ -455,8 +366,6 @@ int clm_feeder_close(clm_feeder* f) {
     }
     f->cv.notify_all();
     if (f->worker.joinable()) f->worker.join();
-    if (f->zs_ready) inflateEnd(&f->zs);
-    if (f->fp) std::fclose(f->fp);
     if (f->slab_ids) {
         if (f->slab_pinned) (void)hipHostFree(f->slab_ids);
         else std::free(f->slab_ids);

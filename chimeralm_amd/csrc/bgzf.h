@@ -1,0 +1,207 @@
+// bgzf.h -- BGZF (blocked gzip) stream reader / writer shared by the BAM feeder and the BAM filter (host C++, zlib).
+// Format: SAM/BAM specification section 4.1 -- a series of gzip members (<= 64 KiB of payload each) whose extra field carries
+// the member size in a "BC" subfield; a BAM file ends with an empty member.  A "virtual file offset" of a byte of the inflated
+// stream is (file offset of its member << 16) | offset inside the member's payload.
+#pragma once
+#include <zlib.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+namespace clmbgzf {
+
+struct Reader {
+    std::string path, err;
+    FILE* fp = nullptr;
+    std::vector<uint8_t> zin, buf;   // compressed member; inflated bytes, consumed up to `pos`
+    size_t pos = 0;
+    z_stream zs{};
+    bool zs_ready = false;
+
+    bool open(const std::string& p) {
+        path = p;
+        fp = std::fopen(p.c_str(), "rb");
+        if (!fp) err = p + ": cannot open";
+        return fp != nullptr;
+    }
+    ~Reader() {
+        if (zs_ready) inflateEnd(&zs);
+        if (fp) std::fclose(fp);
+    }
+    const uint8_t* data() const { return buf.data() + pos; }
+    void advance(size_t n) { pos += n; }
+
+    // appends the payload of the next member to buf: 1 = ok, 0 = clean end of file, -1 = error (err set)
+    int next_block() {
+        uint8_t head[12];
+        const size_t got = std::fread(head, 1, sizeof(head), fp);
+        if (got == 0) return 0;
+        if (got != sizeof(head) || head[0] != 31 || head[1] != 139 || head[2] != 8 || !(head[3] & 4)) {
+            err = path + ": not a BGZF block (bad gzip member header)";
+            return -1;
+        }
+        const unsigned xlen = head[10] | (head[11] << 8);
+        std::vector<uint8_t> extra(xlen);
+        if (std::fread(extra.data(), 1, xlen, fp) != xlen) {
+            err = path + ": truncated BGZF extra field";
+            return -1;
+        }
+        int bsize = -1;
+        for (size_t p = 0; p + 4 <= xlen;) {
+            const unsigned slen = extra[p + 2] | (extra[p + 3] << 8);
+            if (extra[p] == 'B' && extra[p + 1] == 'C' && slen == 2 && p + 6 <= xlen) bsize = extra[p + 4] | (extra[p + 5] << 8);
+            p += 4 + slen;
+        }
+        const long cdata = (long)bsize + 1 - 12 - (long)xlen - 8;
+        if (bsize < 0 || cdata < 0) {
+            err = path + ": BGZF block without a valid BC subfield";
+            return -1;
+        }
+        zin.resize((size_t)cdata + 8);
+        if (std::fread(zin.data(), 1, zin.size(), fp) != zin.size()) {
+            err = path + ": truncated BGZF block";
+            return -1;
+        }
+        const uint8_t* tail = zin.data() + cdata;
+        const uint32_t crc = tail[0] | (tail[1] << 8) | (tail[2] << 16) | ((uint32_t)tail[3] << 24);
+        const uint32_t isize = tail[4] | (tail[5] << 8) | (tail[6] << 16) | ((uint32_t)tail[7] << 24);
+        if (isize > 65536) {
+            err = path + ": BGZF block claims more than 64 KiB of payload";
+            return -1;
+        }
+        if (isize == 0) return 1;   // empty member (the EOF marker)
+        if (!zs_ready) {
+            std::memset(&zs, 0, sizeof(zs));
+            if (inflateInit2(&zs, -15) != Z_OK) {
+                err = "zlib inflateInit2 failed";
+                return -1;
+            }
+            zs_ready = true;
+        } else {
+            inflateReset(&zs);
+        }
+        if (pos > 0 && pos == buf.size()) {                    // compact the consumed prefix before growing
+            buf.clear();
+            pos = 0;
+        } else if (pos > (1u << 20)) {
+            buf.erase(buf.begin(), buf.begin() + (long)pos);
+            pos = 0;
+        }
+        const size_t old = buf.size();
+        buf.resize(old + isize);
+        zs.next_in = zin.data();
+        zs.avail_in = (uInt)cdata;
+        zs.next_out = buf.data() + old;
+        zs.avail_out = isize;
+        const int rc = inflate(&zs, Z_FINISH);
+        if (rc != Z_STREAM_END || zs.avail_out != 0) {
+            err = path + ": corrupt BGZF block (inflate failed)";
+            return -1;
+        }
+        if ((uint32_t)crc32(crc32(0L, Z_NULL, 0), buf.data() + old, isize) != crc) {
+            err = path + ": corrupt BGZF block (CRC mismatch)";
+            return -1;
+        }
+        return 1;
+    }
+
+    // makes n inflated bytes available at data(): 1 = ok, 0 = clean EOF before the first byte, -1 = error
+    int need(size_t n) {
+        while (buf.size() - pos < n) {
+            const bool empty = buf.size() == pos;
+            const int rc = next_block();
+            if (rc < 0) return -1;
+            if (rc == 0) {
+                if (empty) return 0;
+                err = path + ": BAM stream ends inside a record";
+                return -1;
+            }
+        }
+        return 1;
+    }
+};
+
+struct Writer {
+    std::string path, err;
+    FILE* fp = nullptr;
+    std::vector<uint8_t> pend, zout;
+    uint64_t file_off = 0;          // file offset at which the member holding `pend` will start
+    static constexpr size_t BLOCK = 0xff00;
+
+    bool open(const std::string& p) {
+        path = p;
+        fp = std::fopen(p.c_str(), "wb");
+        if (!fp) err = p + ": cannot create";
+        pend.reserve(BLOCK);
+        return fp != nullptr;
+    }
+    ~Writer() {
+        if (fp) std::fclose(fp);
+    }
+    uint64_t voffset() const { return (file_off << 16) | (uint64_t)pend.size(); }   // of the next byte written
+
+    bool flush_block() {
+        z_stream z;
+        std::memset(&z, 0, sizeof(z));
+        if (deflateInit2(&z, 6, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) {
+            err = "zlib deflateInit2 failed";
+            return false;
+        }
+        zout.resize(deflateBound(&z, (uLong)pend.size()) + 64);
+        z.next_in = pend.data();
+        z.avail_in = (uInt)pend.size();
+        z.next_out = zout.data() + 18;
+        z.avail_out = (uInt)(zout.size() - 18);
+        const int rc = deflate(&z, Z_FINISH);
+        const size_t clen = z.total_out;
+        deflateEnd(&z);
+        if (rc != Z_STREAM_END || clen + 26 > 65536) {
+            err = path + ": BGZF block does not fit 64 KiB after deflate";
+            return false;
+        }
+        const uint8_t head[18] = {31, 139, 8, 4, 0, 0, 0, 0, 0, 255, 6, 0, 'B', 'C', 2, 0,
+                                  (uint8_t)((clen + 25) & 255), (uint8_t)((clen + 25) >> 8)};
+        std::memcpy(zout.data(), head, 18);
+        const uint32_t crc = (uint32_t)crc32(crc32(0L, Z_NULL, 0), pend.data(), (uInt)pend.size()), isz = (uint32_t)pend.size();
+        uint8_t* t = zout.data() + 18 + clen;
+        for (int i = 0; i < 4; ++i) t[i] = (uint8_t)(crc >> (8 * i)), t[4 + i] = (uint8_t)(isz >> (8 * i));
+        if (std::fwrite(zout.data(), 1, clen + 26, fp) != clen + 26) {
+            err = path + ": write failed";
+            return false;
+        }
+        file_off += clen + 26;
+        pend.clear();
+        return true;
+    }
+    bool write(const uint8_t* p, size_t n) {
+        while (n) {
+            const size_t room = BLOCK - pend.size(), k = n < room ? n : room;
+            pend.insert(pend.end(), p, p + k);
+            p += k;
+            n -= k;
+            if (pend.size() == BLOCK && !flush_block()) return false;
+        }
+        return true;
+    }
+    // start a new member so that the next write begins a block (records then never straddle it unless they exceed 64 KiB)
+    bool align_block(size_t upcoming) {
+        if (!pend.empty() && pend.size() + upcoming > BLOCK) return flush_block();
+        return true;
+    }
+    bool finish() {                                            // last data block + the empty EOF member
+        if (!pend.empty() && !flush_block()) return false;
+        if (!flush_block()) return false;
+        const bool ok = std::fclose(fp) == 0;
+        fp = nullptr;
+        if (!ok) err = path + ": close failed";
+        return ok;
+    }
+};
+
+inline int32_t le32(const uint8_t* p) { return (int32_t)(p[0] | (p[1] << 8) | (p[2] << 16) | ((uint32_t)p[3] << 24)); }
+inline uint16_t le16(const uint8_t* p) { return (uint16_t)(p[0] | (p[1] << 8)); }
+
+}  // namespace clmbgzf

@@ -66,6 +66,17 @@ int clm_feeder_stats(const clm_feeder* f, int64_t* records, int64_t* selected, i
 const char* clm_feeder_last_error(const clm_feeder* f);   /* f may be NULL: error of the last failed clm_feeder_open */
 int clm_feeder_close(clm_feeder* f);                       /* stops the thread, frees the ring; f may be NULL       */
 
+/* ---- after predict: /root/reference/chimeralm/__main__.py:99-153 (filter_bam_by_predcition) ------------------------------
+ * clm_bam_filter copies `in_bam` to `out_bam` (same header, same order) without the records whose read name is in `drop_names`
+ * -- every record of such a read, primary or not, as the reference does (:131-134); counts of kept / dropped RECORDS come back.
+ * clm_bam_sort_index is the `pysam.sort` + `pysam.index` pair of :147-153: coordinate order (reference id with unplaced reads
+ * last, position, strand; stable), @HD SO:coordinate, and a BAI index next to the output (`out_bai` NULL: <out>.bai).
+ * The sort holds the file in memory.  Errors: negative CLM_E_* code, text from clm_bam_last_error() (per thread). */
+int clm_bam_filter(const char* in_bam, const char* out_bam, const char* const* drop_names, int64_t n_drop, int64_t* kept,
+                   int64_t* dropped);
+int clm_bam_sort_index(const char* in_bam, const char* out_sorted_bam, const char* out_bai, int64_t* n_records);
+const char* clm_bam_last_error(void);
+
 #ifdef __cplusplus
 }
 #endif
