@@ -185,32 +185,37 @@ __device__ __forceinline__ void stage_rows16(const typename CT<PREC>::elem* a, s
 // the XOR-swizzled LDS transpose) and hx (16-bit, rows of the normalised tile as they lie in LDS).  `smem`: >= 128 KiB staging
 // area starting at the tile As; P1 / P2 behind it.
 template <int PREC>
-__device__ __forceinline__ void res_ln_store(f32x16 (&acc)[4], const float* __restrict__ bias, float* __restrict__ h,
-                                             typename CT<PREC>::elem* __restrict__ hx, const float* ln_g, const float* ln_b,
-                                             float eps, size_t row0, size_t M, unsigned char* smem, typename CT<PREC>::elem* As,
-                                             float* P1, float* P2) {
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lrow = lane & 31, lhalf = lane >> 5;
+__device__ __forceinline__ int res_ln(f32x16 (&acc)[4], const float* __restrict__ bias, const float* __restrict__ h,
+                                      const float* ln_g, const float* ln_b, float eps, size_t row0, size_t M,
+                                      typename CT<PREC>::elem* As, float* P1, float* P2) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, lrow = lane & 31, lhalf = lane >> 5;
     // r = acc + bias + residual (this lane's token, 4 consecutive features per quad)
-    {
-        const float* bp = bias + wave * 32 + 4 * lhalf;
+    const float* bp = bias + wave * 32 + 4 * lhalf;
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt) {
-            const size_t row = row0 + mt * 32 + lrow;
-            const float* hr = h + (row < M ? row : 0) * D + wave * 32 + 4 * lhalf;
+    for (int mt = 0; mt < 4; ++mt) {
+        const size_t row = row0 + mt * 32 + lrow;
+        const float* hr = h + (row < M ? row : 0) * D + wave * 32 + 4 * lhalf;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const float4 bb = *reinterpret_cast<const float4*>(bp + 8 * q);
-                const float4 hv = *reinterpret_cast<const float4*>(hr + 8 * q);
-                acc[mt][4 * q + 0] += bb.x + hv.x;
-                acc[mt][4 * q + 1] += bb.y + hv.y;
-                acc[mt][4 * q + 2] += bb.z + hv.z;
-                acc[mt][4 * q + 3] += bb.w + hv.w;
-            }
+        for (int q = 0; q < 4; ++q) {
+            const float4 bb = *reinterpret_cast<const float4*>(bp + 8 * q);
+            const float4 hv = *reinterpret_cast<const float4*>(hr + 8 * q);
+            acc[mt][4 * q + 0] += bb.x + hv.x;
+            acc[mt][4 * q + 1] += bb.y + hv.y;
+            acc[mt][4 * q + 2] += bb.z + hv.z;
+            acc[mt][4 * q + 3] += bb.w + hv.w;
         }
     }
     const int l_valid = (int)std::min<size_t>(M > row0 ? M - row0 : 0, 128);
     ln_acc_to_tile<PREC, true>(acc, P1, P2, ln_g, ln_b, eps, As, 0, l_valid, wave, lrow, lhalf);
-    // 16-bit copy: rows of the normalised tile as they lie in LDS
+    return l_valid;
+}
+
+// the normalised tile (As, 16-bit) -> hx rows; the normalised accumulators -> h (fp32, whole 128-byte lines through the
+// XOR-swizzled LDS transpose, which overwrites the first 128 KiB of `smem`, As included)
+template <int PREC>
+__device__ __forceinline__ void store_h_hx(const f32x16 (&acc)[4], float* __restrict__ h, typename CT<PREC>::elem* __restrict__ hx,
+                                           size_t row0, int l_valid, unsigned char* smem, const typename CT<PREC>::elem* As) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lrow = lane & 31, lhalf = lane >> 5;
     {
         const int piece = tid & 31;
 #pragma unroll
@@ -221,7 +226,6 @@ __device__ __forceinline__ void res_ln_store(f32x16 (&acc)[4], const float* __re
         }
     }
     __syncthreads();
-    // fp32 h: transposed through LDS (XOR-swizzled 16-byte chunks), stored as whole 128-byte lines
     float* rs = reinterpret_cast<float*>(smem) + wave * (128 * 32);
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) {
@@ -240,6 +244,44 @@ __device__ __forceinline__ void res_ln_store(f32x16 (&acc)[4], const float* __re
         const int tr = i * 8 + rsub;
         const float4 v = *reinterpret_cast<const float4*>(rs + tr * 32 + 4 * (c ^ (tr & 7)));
         if (tr < l_valid) *reinterpret_cast<float4*>(hrow + (size_t)tr * D) = v;
+    }
+}
+
+// N / 256 blocks of a bias (+ReLU) linear layer over the staged tile As, 16-bit token-major output through the wave-private
+// tiles at `zs`.  On entry bs[0] holds the first half-set of block 0.
+template <int PREC, int N>
+__device__ __forceinline__ void act_blocks(const typename CT<PREC>::elem* As, typename CT<PREC>::elem* zs, const u16x8* wp,
+                                           const float* __restrict__ bias, typename CT<PREC>::elem* out, size_t row0, size_t M,
+                                           bool relu, u16x8 (&bs)[2][1][SETK], f32x16 (&acc)[4]) {
+    using elem = typename CT<PREC>::elem;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, lrow = lane & 31, lhalf = lane >> 5;
+#pragma unroll 1
+    for (int nb = 0; nb < N / 256; ++nb) {
+        zero_acc(acc);
+        load_set<PREC, D, 1>(wp, nb, 0, 1, wave, lane, bs[1]);
+        __builtin_amdgcn_sched_barrier(0);
+        compute_tm<PREC, true>(As, 0, lrow, lhalf, bs[0], acc);
+        __builtin_amdgcn_sched_barrier(0);
+        load_set<PREC, D, 1>(wp, nb + 1 < N / 256 ? nb + 1 : 0, 0, 0, wave, lane, bs[0]);
+        __builtin_amdgcn_sched_barrier(0);
+        compute_tm<PREC, true>(As, 1, lrow, lhalf, bs[1], acc);
+        __builtin_amdgcn_sched_barrier(0);
+        // rows = features (register quads), lane = token
+        const float* bp = bias + nb * 256 + wave * 32 + 4 * lhalf;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4 bb = *reinterpret_cast<const float4*>(bp + 8 * q);
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+                float v0 = acc[mt][4 * q + 0] + bb.x, v1 = acc[mt][4 * q + 1] + bb.y, v2 = acc[mt][4 * q + 2] + bb.z,
+                      v3 = acc[mt][4 * q + 3] + bb.w;
+                if (relu) v0 = fmaxf(v0, 0.f), v1 = fmaxf(v1, 0.f), v2 = fmaxf(v2, 0.f), v3 = fmaxf(v3, 0.f);
+                u16x4 pk = {to_bits<PREC>(v0), to_bits<PREC>(v1), to_bits<PREC>(v2), to_bits<PREC>(v3)};
+                *reinterpret_cast<u16x4*>(zs + (mt * 32 + lrow) * ZRS + 8 * q + 4 * lhalf) = pk;
+            }
+        }
+        const size_t valid = M > row0 ? M - row0 : 0;
+        store_wave_tile<elem>(zs, out, row0, valid, N, nb * 256 + wave * 32, lane, 128);
     }
 }
 
@@ -263,34 +305,7 @@ __global__ __launch_bounds__(512) void linear16_kernel(LinArgs m) {
         __builtin_amdgcn_sched_barrier(0);
         stage_rows16<PREC>(a, row0, m.M, K, 0, As, tid);
         __syncthreads();
-#pragma unroll 1
-        for (int nb = 0; nb < N / 256; ++nb) {
-            zero_acc(acc);
-            load_set<PREC, K, 1>(wp, nb, 0, 1, wave, lane, bs[1]);
-            __builtin_amdgcn_sched_barrier(0);
-            compute_tm<PREC, true>(As, 0, lrow, lhalf, bs[0], acc);
-            __builtin_amdgcn_sched_barrier(0);
-            load_set<PREC, K, 1>(wp, nb + 1 < N / 256 ? nb + 1 : 0, 0, 0, wave, lane, bs[0]);
-            __builtin_amdgcn_sched_barrier(0);
-            compute_tm<PREC, true>(As, 1, lrow, lhalf, bs[1], acc);
-            __builtin_amdgcn_sched_barrier(0);
-            // rows = features (register quads), lane = token
-            const float* bp = m.bias + nb * 256 + wave * 32 + 4 * lhalf;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const float4 bb = *reinterpret_cast<const float4*>(bp + 8 * q);
-#pragma unroll
-                for (int mt = 0; mt < 4; ++mt) {
-                    float v0 = acc[mt][4 * q + 0] + bb.x, v1 = acc[mt][4 * q + 1] + bb.y, v2 = acc[mt][4 * q + 2] + bb.z,
-                          v3 = acc[mt][4 * q + 3] + bb.w;
-                    if (m.relu) v0 = fmaxf(v0, 0.f), v1 = fmaxf(v1, 0.f), v2 = fmaxf(v2, 0.f), v3 = fmaxf(v3, 0.f);
-                    u16x4 pk = {to_bits<PREC>(v0), to_bits<PREC>(v1), to_bits<PREC>(v2), to_bits<PREC>(v3)};
-                    *reinterpret_cast<u16x4*>(zs + (mt * 32 + lrow) * ZRS + 8 * q + 4 * lhalf) = pk;
-                }
-            }
-            const size_t valid = m.M > row0 ? m.M - row0 : 0;
-            store_wave_tile<elem>(zs, reinterpret_cast<elem*>(m.out16), row0, valid, N, nb * 256 + wave * 32, lane, 128);
-        }
+        act_blocks<PREC, N>(As, zs, wp, m.bias, reinterpret_cast<elem*>(m.out16), row0, m.M, m.relu != 0, bs, acc);
     } else {
         float* P1 = reinterpret_cast<float*>(smem + (size_t)2 * 128 * RS16 * 2);   // tables behind the 128 KiB staging area
         float* P2 = P1 + 16 * 128;
@@ -306,7 +321,8 @@ __global__ __launch_bounds__(512) void linear16_kernel(LinArgs m) {
             compute_tm<PREC, true>(As, 0, lrow, lhalf, bs[0], acc);
             compute_tm<PREC, true>(As, 1, lrow, lhalf, bs[1], acc);
         }
-        res_ln_store<PREC>(acc, m.bias, m.h, reinterpret_cast<elem*>(m.hx), m.ln_g, m.ln_b, m.eps, row0, m.M, smem, As, P1, P2);
+        const int l_valid = res_ln<PREC>(acc, m.bias, m.h, m.ln_g, m.ln_b, m.eps, row0, m.M, As, P1, P2);
+        store_h_hx<PREC>(acc, m.h, reinterpret_cast<elem*>(m.hx), row0, l_valid, smem, As);
     }
 }
 
@@ -322,6 +338,9 @@ struct FfnArgs {
     void* hx_out;             // [M, 256] 16-bit copy of the new h (may alias hx_in: a tile is read completely before it is written)
     size_t M;
     float eps;
+    const void* w_qkv;        // next layer's packed in_proj (null after the last layer): QKV of the tile just normalised
+    const float* b_qkv;
+    void* qkv;                // [M, 768] 16-bit
 };
 
 template <int PREC>
@@ -380,7 +399,14 @@ __global__ __launch_bounds__(512) void enc_ffn16_kernel(FfnArgs m) {
         compute_tm<PREC, true>(Hs, 1, lrow, lhalf, bs[1], acc2);
         __builtin_amdgcn_sched_barrier(0);
     }
-    res_ln_store<PREC>(acc2, m.b2, m.h, reinterpret_cast<elem*>(m.hx_out), m.ln_g, m.ln_b, m.eps, row0, m.M, smem, As, P1, P2);
+    if (m.w_qkv) load_set<PREC, D, 1>(reinterpret_cast<const frag*>(m.w_qkv), 0, 0, 0, wave, lane, bs[0]);
+    const int l_valid = res_ln<PREC>(acc2, m.b2, m.h, m.ln_g, m.ln_b, m.eps, row0, m.M, As, P1, P2);
+    if (m.w_qkv) {   // in_proj of the next layer on the normalised tile while it is in LDS (wave tiles in the Hs + table region)
+        elem* zs = Hs + wave * 128 * ZRS;
+        act_blocks<PREC, TQKV>(As, zs, reinterpret_cast<const frag*>(m.w_qkv), m.b_qkv, reinterpret_cast<elem*>(m.qkv), row0, m.M,
+                               false, bs, acc1);
+    }
+    store_h_hx<PREC>(acc2, m.h, reinterpret_cast<elem*>(m.hx_out), row0, l_valid, smem, As);
 }
 
 // ------------------------------------------------------------------------------------------------ pooling + classifier
@@ -550,16 +576,21 @@ int tf_forward_t(clm_tf_handle* h, const void* ids, int ids_dtype, int64_t strid
         const std::string p = "transformer_encoder.layers." + std::to_string(i) + ".";
         tf::LinArgs a{};
         a.M = M; a.eps = 1e-5f;
-        a.a = h->hx; a.w = h->packed.at(p + "in"); a.bias = W(p + "self_attn.in_proj_bias"); a.out16 = h->qkv; a.relu = 0;
-        tf_launch_linear<PREC, tf::E_ACT, D, tf::TQKV>(a, st);
+        static const bool unfused_ffn = std::getenv("CLM_TF_UNFUSED_FFN") && std::getenv("CLM_TF_UNFUSED_FFN")[0] == '1';
+        if (i == 0 || unfused_ffn) {   // later layers: computed at the end of the previous layer's feed-forward kernel
+            a.a = h->hx; a.w = h->packed.at(p + "in"); a.bias = W(p + "self_attn.in_proj_bias"); a.out16 = h->qkv; a.relu = 0;
+            tf_launch_linear<PREC, tf::E_ACT, D, tf::TQKV>(a, st);
+        }
         launch_attention_fwd(PREC, h->qkv, h->att, B, L3, st);
         a.a = h->att; a.w = h->packed.at(p + "out"); a.bias = W(p + "self_attn.out_proj.bias"); a.h = h->h; a.hx = h->hx;
         a.ln_g = W(p + "norm1.weight"); a.ln_b = W(p + "norm1.bias");
         tf_launch_linear<PREC, tf::E_RES_LN, D, D>(a, st);
-        static const bool unfused_ffn = std::getenv("CLM_TF_UNFUSED_FFN") && std::getenv("CLM_TF_UNFUSED_FFN")[0] == '1';
         if (!unfused_ffn) {
+            const bool more = i + 1 < h->n_layers;
+            const std::string pn = "transformer_encoder.layers." + std::to_string(i + 1) + ".";
             tf::FfnArgs f{h->hx, h->packed.at(p + "ff1"), h->packed.at(p + "ff2"), W(p + "linear1.bias"), W(p + "linear2.bias"),
-                          W(p + "norm2.weight"), W(p + "norm2.bias"), h->h, h->hx, M, 1e-5f};
+                          W(p + "norm2.weight"), W(p + "norm2.bias"), h->h, h->hx, M, 1e-5f,
+                          more ? h->packed.at(pn + "in") : nullptr, more ? W(pn + "self_attn.in_proj_bias") : nullptr, h->qkv};
             constexpr size_t lds = (size_t)2 * 128 * RS16 * 2 + (size_t)2 * 16 * 128 * 4;
             auto kern = tf::enc_ffn16_kernel<PREC>;
             static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), true);

@@ -296,6 +296,11 @@ def test_hydra_style_configs_instantiate():
     model = build(cfg)
     assert type(model).__name__ == "ClassificationLit" and model.net.number_of_classes == 2
     assert model.net.precision == "fp16"
+    tcfg = yaml.safe_load((REPO / "configs" / "model" / "transformer.yaml").read_text())   # reference transformer.yaml:3-12
+    tmodel = build(tcfg)
+    assert type(tmodel.net).__name__ == "SequenceCNNTransformer" and tmodel.net.number_of_classes == 2
+    assert "transformer_encoder.layers.11.self_attn.in_proj_weight" in tmodel.net.state_dict()
+    assert tuple(tmodel.net.state_dict()["pos_encoder.pe"].shape) == (1, 32768, 256)
     data = yaml.safe_load((REPO / "configs" / "data" / "bam.yaml").read_text())
     dm = build({**data, "predict_data_path": str(REPO / "tests/golden/test_chimric_reads.bam"), "batch_size": 4})
     assert dm.tokenizer.padding_side == "left"
