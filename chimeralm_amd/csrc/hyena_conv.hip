@@ -617,33 +617,72 @@ __global__ __launch_bounds__(Plan<14>::NT) void hyena_conv_seg_kernel(
             asm volatile("" : "+v"(wall[i].re.x), "+v"(wall[i].re.y), "+v"(wall[i].im.x), "+v"(wall[i].im.y));
         // ---- phase A: segment m of the gated signal into the lower half, zeros above
         float x0A[CH][8], x0B[CH][8];
+        if constexpr (!std::is_same<T, float>::value) {
+            // all loads of the segment up front, no control flow in between (see Raw<T>): six serialized HBM round trips otherwise
+            Raw<T> raw[CH][2][3];
 #pragma unroll
-        for (int ch = 0; ch < CH; ++ch) {
-            const int tl = 8 * (ltid + ch * NT), t0 = seg0 + tl;
-            float gA[8], gB[8];
-            if (t0 < L) {
-                float x1[8], v[8];
-                short_filter8<T>(zA + (size_t)(0 * D + c) * Lp, t0, sw[0][0], sw[0][1], sw[0][2], sb[0], x0A[ch]);
-                short_filter8<T>(zA + (size_t)(1 * D + c) * Lp, t0, sw[1][0], sw[1][1], sw[1][2], sb[1], x1);
-                short_filter8<T>(zA + (size_t)(2 * D + c) * Lp, t0, sw[2][0], sw[2][1], sw[2][2], sb[2], v);
+            for (int rd = 0; rd < 2; ++rd)
+#pragma unroll
+                for (int a3 = 0; a3 < 3; ++a3) {
+                    const T* row = (rd == 0 ? zA : zB) + (size_t)(a3 * D + c) * Lp;
+#pragma unroll
+                    for (int ch = 0; ch < CH; ++ch) {
+                        const int t0 = seg0 + 8 * (ltid + ch * NT);
+                        raw_load(raw[ch][rd][a3], row, t0, t0 < L);
+                    }
+                }
+#pragma unroll
+            for (int ch = 0; ch < CH; ++ch) {
+                const int tl = 8 * (ltid + ch * NT), t0 = seg0 + tl;
+                const bool valid = t0 < L;
+                float xa[3][10], xb[3][10], gA[8], gB[8], x1[8], v[8];
+#pragma unroll
+                for (int a3 = 0; a3 < 3; ++a3) {
+                    raw_decode(raw[ch][0][a3], t0, valid, xa[a3]);
+                    raw_decode(raw[ch][1][a3], t0, valid && hasB, xb[a3]);
+                }
+                fir3(xa[0], sw[0][0], sw[0][1], sw[0][2], sb[0], x0A[ch]);
+                fir3(xa[1], sw[1][0], sw[1][1], sw[1][2], sb[1], x1);
+                fir3(xa[2], sw[2][0], sw[2][1], sw[2][2], sb[2], v);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) gA[e] = (t0 + e < L) ? v[e] * x1[e] : 0.f;
-                if (hasB) {
-                    short_filter8<T>(zB + (size_t)(0 * D + c) * Lp, t0, sw[0][0], sw[0][1], sw[0][2], sb[0], x0B[ch]);
-                    short_filter8<T>(zB + (size_t)(1 * D + c) * Lp, t0, sw[1][0], sw[1][1], sw[1][2], sb[1], x1);
-                    short_filter8<T>(zB + (size_t)(2 * D + c) * Lp, t0, sw[2][0], sw[2][1], sw[2][2], sb[2], v);
+                fir3(xb[0], sw[0][0], sw[0][1], sw[0][2], sb[0], x0B[ch]);
+                fir3(xb[1], sw[1][0], sw[1][1], sw[1][2], sb[1], x1);
+                fir3(xb[2], sw[2][0], sw[2][1], sw[2][2], sb[2], v);
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) gB[e] = (t0 + e < L) ? v[e] * x1[e] : 0.f;
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) gB[e] = 0.f, x0B[ch][e] = 0.f;
-                }
-            } else {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) gA[e] = 0.f, gB[e] = 0.f, x0A[ch][e] = 0.f, x0B[ch][e] = 0.f;
+                for (int e = 0; e < 8; ++e) gB[e] = (hasB && t0 + e < L) ? v[e] * x1[e] : 0.f;
+                lds_store8(bre + pad_index(tl), gA);
+                lds_store8(bim + pad_index(tl), gB);
             }
-            lds_store8(bre + pad_index(tl), gA);
-            lds_store8(bim + pad_index(tl), gB);
+        } else {
+    #pragma unroll
+            for (int ch = 0; ch < CH; ++ch) {
+                const int tl = 8 * (ltid + ch * NT), t0 = seg0 + tl;
+                float gA[8], gB[8];
+                if (t0 < L) {
+                    float x1[8], v[8];
+                    short_filter8<T>(zA + (size_t)(0 * D + c) * Lp, t0, sw[0][0], sw[0][1], sw[0][2], sb[0], x0A[ch]);
+                    short_filter8<T>(zA + (size_t)(1 * D + c) * Lp, t0, sw[1][0], sw[1][1], sw[1][2], sb[1], x1);
+                    short_filter8<T>(zA + (size_t)(2 * D + c) * Lp, t0, sw[2][0], sw[2][1], sw[2][2], sb[2], v);
+    #pragma unroll
+                    for (int e = 0; e < 8; ++e) gA[e] = (t0 + e < L) ? v[e] * x1[e] : 0.f;
+                    if (hasB) {
+                        short_filter8<T>(zB + (size_t)(0 * D + c) * Lp, t0, sw[0][0], sw[0][1], sw[0][2], sb[0], x0B[ch]);
+                        short_filter8<T>(zB + (size_t)(1 * D + c) * Lp, t0, sw[1][0], sw[1][1], sw[1][2], sb[1], x1);
+                        short_filter8<T>(zB + (size_t)(2 * D + c) * Lp, t0, sw[2][0], sw[2][1], sw[2][2], sb[2], v);
+    #pragma unroll
+                        for (int e = 0; e < 8; ++e) gB[e] = (t0 + e < L) ? v[e] * x1[e] : 0.f;
+                    } else {
+    #pragma unroll
+                        for (int e = 0; e < 8; ++e) gB[e] = 0.f, x0B[ch][e] = 0.f;
+                    }
+                } else {
+    #pragma unroll
+                    for (int e = 0; e < 8; ++e) gA[e] = 0.f, gB[e] = 0.f, x0A[ch][e] = 0.f, x0B[ch][e] = 0.f;
+                }
+                lds_store8(bre + pad_index(tl), gA);
+                lds_store8(bim + pad_index(tl), gB);
+            }
         }
 #pragma unroll
         for (int i = 0; i < HALF / NT; ++i) bre[pad_index(HALF + ltid + i * NT)] = 0.f, bim[pad_index(HALF + ltid + i * NT)] = 0.f;
