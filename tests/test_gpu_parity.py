@@ -7,6 +7,8 @@ Tolerances (north_star: identical labels, logits within 1e-3 in fp32):
 """
 from __future__ import annotations
 
+from pathlib import Path
+
 import numpy as np
 import pytest
 import torch
@@ -15,6 +17,7 @@ from oracle import data_oracle as do
 from oracle import hyena_oracle as ho
 
 pytestmark = pytest.mark.gpu
+REPO = Path(__file__).resolve().parent.parent
 
 TOL = {"fp32": 1e-3, "fp16": 5e-3, "bf16": 6e-2}
 MARGIN = {"fp32": 2e-3, "fp16": 2e-2, "bf16": 2e-1}
@@ -253,3 +256,34 @@ def test_error_behaviour(engines):
         e.load_weight("net.head.output_layer.bias", torch.zeros(3))
     with pytest.raises(EngineError, match="unknown"):
         e.load_weight("net.nope", torch.zeros(3))
+
+
+def test_cli_predict_then_filter_end_to_end(sd, tmp_path, golden_dir, built_lib):
+    """`python -m chimeralm_amd predict BAM --weights DIR` (native feeder) writes the reference's prediction files, and
+    `filter` consumes them: the two commands of the reference workflow (README: predict, then filter), as subprocesses."""
+    import shutil
+    import subprocess
+    import sys
+
+    from safetensors.torch import save_file
+
+    wdir = tmp_path / "weights"
+    wdir.mkdir()
+    save_file({k: v.contiguous() for k, v in sd.items() if not (k.endswith(".3.freq") or k.endswith(".5.freq"))},
+              str(wdir / "model.safetensors"))                    # safetensors drops the aliases of the shared sine module
+    bam = tmp_path / "reads.bam"
+    shutil.copyfile(golden_dir / "test_chimric_reads.bam", bam)
+    env = {**__import__("os").environ, "PYTHONPATH": str(REPO)}
+    r = subprocess.run([sys.executable, "-m", "chimeralm_amd", "predict", str(bam), "-g", "1", "-b", "25", "--weights", str(wdir),
+                        "--precision", "fp16"], capture_output=True, text=True, env=env, cwd=str(REPO), timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = bam.with_suffix(".predictions")
+    files = sorted(out.glob("*.txt"))
+    assert [f.name for f in files] == ["0_0.txt", "0_1.txt", "0_2.txt", "0_3.txt"]
+    lines = [ln for f in files for ln in f.read_text().splitlines()]
+    assert len(lines) == 100 and all(ln.split("\t")[1] in ("0", "1") for ln in lines)
+    r = subprocess.run([sys.executable, "-m", "chimeralm_amd", "filter", str(bam), str(out), "-p"], capture_output=True, text=True,
+                       env=env, cwd=str(REPO), timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert (out / "predictions.txt").exists() and bam.with_suffix(".filtered.sorted.bam").exists()
+    assert Path(str(bam.with_suffix(".filtered.sorted.bam")) + ".bai").exists()
