@@ -6,11 +6,13 @@
 # Everything lands in gpurun_out/<tag>/; tools/profile_digest.py turns it into the small files kept under profiles/.
 set -eo pipefail
 TAG=${1:-r01}
+shift || true
+EXTRA="$*"            # extra bench.py arguments, e.g.  bash tools/profile_round.sh r01_tf --net transformer
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 O=$R/gpurun_out/$TAG
 mkdir -p "$O"
 cd /tmp && export TMPDIR=/tmp
-BENCH="python3 $R/bench.py"
+BENCH="python3 $R/bench.py $EXTRA"
 
 timeout -k 10 300 $BENCH > "$O/bench_default.json" 2> "$O/bench_default.err"
 echo "[1/6] bench done"; cut -c1-200 "$O/bench_default.json"
