@@ -194,11 +194,12 @@ __device__ __forceinline__ int res_ln(f32x16 (&acc)[4], const float* __restrict_
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) {
         const size_t row = row0 + mt * 32 + lrow;
-        const float* hr = h + (row < M ? row : 0) * D + wave * 32 + 4 * lhalf;
+        const float* hr = (h ? h : bias) + (h && row < M ? row : 0) * D + wave * 32 + 4 * lhalf;   // h == nullptr: no residual here
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const float4 bb = *reinterpret_cast<const float4*>(bp + 8 * q);
-            const float4 hv = *reinterpret_cast<const float4*>(hr + 8 * q);
+            float4 hv = *reinterpret_cast<const float4*>(hr + 8 * q);
+            if (!h) hv = make_float4(0.f, 0.f, 0.f, 0.f);
             acc[mt][4 * q + 0] += bb.x + hv.x;
             acc[mt][4 * q + 1] += bb.y + hv.y;
             acc[mt][4 * q + 2] += bb.z + hv.z;
@@ -341,6 +342,11 @@ struct FfnArgs {
     const void* w_qkv;        // next layer's packed in_proj (null after the last layer): QKV of the tile just normalised
     const float* b_qkv;
     void* qkv;                // [M, 768] 16-bit
+    // whole-layer form (att != null): the kernel starts from the attention output -- x1 = LN1(h + att W_o^T + b_o) stays in the
+    // fc2 accumulators as the feed-forward residual and in LDS as its operand; h is read once and written once per layer
+    const void* att;          // [M, 256] 16-bit
+    const void* w_o;
+    const float *b_o, *ln1_g, *ln1_b;
 };
 
 template <int PREC>
@@ -359,11 +365,29 @@ __global__ __launch_bounds__(512) void enc_ffn16_kernel(FfnArgs m) {
     const frag* w2 = reinterpret_cast<const frag*>(m.w2);
     f32x16 acc1[4], acc2[4];
     frag bs[2][1][SETK];
-    load_set<PREC, D, 1>(w1, 0, 0, 0, wave, lane, bs[0]);
-    __builtin_amdgcn_sched_barrier(0);
-    stage_rows16<PREC>(reinterpret_cast<const elem*>(m.hx_in), row0, m.M, D, 0, As, tid);
-    __syncthreads();
-    zero_acc(acc2);
+    const bool whole = m.att != nullptr;                      // uniform
+    if (whole) {
+        const frag* wo = reinterpret_cast<const frag*>(m.w_o);
+        load_set<PREC, D, 1>(wo, 0, 0, 0, wave, lane, bs[0]);
+        load_set<PREC, D, 1>(wo, 0, 0, 1, wave, lane, bs[1]);
+        __builtin_amdgcn_sched_barrier(0);
+        stage_rows16<PREC>(reinterpret_cast<const elem*>(m.att), row0, m.M, D, 0, As, tid);
+        __syncthreads();
+        zero_acc(acc2);
+        compute_tm<PREC, true>(As, 0, lrow, lhalf, bs[0], acc2);
+        __builtin_amdgcn_sched_barrier(0);
+        load_set<PREC, D, 1>(w1, 0, 0, 0, wave, lane, bs[0]);   // first fc1 half-set under the second half
+        __builtin_amdgcn_sched_barrier(0);
+        compute_tm<PREC, true>(As, 1, lrow, lhalf, bs[1], acc2);
+        __builtin_amdgcn_sched_barrier(0);
+        res_ln<PREC>(acc2, m.b_o, m.h, m.ln1_g, m.ln1_b, m.eps, row0, m.M, As, P1, P2);   // acc2 = x1, As = x1 (16-bit)
+    } else {
+        load_set<PREC, D, 1>(w1, 0, 0, 0, wave, lane, bs[0]);
+        __builtin_amdgcn_sched_barrier(0);
+        stage_rows16<PREC>(reinterpret_cast<const elem*>(m.hx_in), row0, m.M, D, 0, As, tid);
+        __syncthreads();
+        zero_acc(acc2);
+    }
 #pragma unroll 1
     for (int j = 0; j < NCH; ++j) {
         zero_acc(acc1);
@@ -400,7 +424,7 @@ __global__ __launch_bounds__(512) void enc_ffn16_kernel(FfnArgs m) {
         __builtin_amdgcn_sched_barrier(0);
     }
     if (m.w_qkv) load_set<PREC, D, 1>(reinterpret_cast<const frag*>(m.w_qkv), 0, 0, 0, wave, lane, bs[0]);
-    const int l_valid = res_ln<PREC>(acc2, m.b2, m.h, m.ln_g, m.ln_b, m.eps, row0, m.M, As, P1, P2);
+    const int l_valid = res_ln<PREC>(acc2, m.b2, whole ? nullptr : m.h, m.ln_g, m.ln_b, m.eps, row0, m.M, As, P1, P2);
     if (m.w_qkv) {   // in_proj of the next layer on the normalised tile while it is in LDS (wave tiles in the Hs + table region)
         elem* zs = Hs + wave * 128 * ZRS;
         act_blocks<PREC, TQKV>(As, zs, reinterpret_cast<const frag*>(m.w_qkv), m.b_qkv, reinterpret_cast<elem*>(m.qkv), row0, m.M,
@@ -582,15 +606,21 @@ int tf_forward_t(clm_tf_handle* h, const void* ids, int ids_dtype, int64_t strid
             tf_launch_linear<PREC, tf::E_ACT, D, tf::TQKV>(a, st);
         }
         launch_attention_fwd(PREC, h->qkv, h->att, B, L3, st);
-        a.a = h->att; a.w = h->packed.at(p + "out"); a.bias = W(p + "self_attn.out_proj.bias"); a.h = h->h; a.hx = h->hx;
-        a.ln_g = W(p + "norm1.weight"); a.ln_b = W(p + "norm1.bias");
-        tf_launch_linear<PREC, tf::E_RES_LN, D, D>(a, st);
+        static const bool unfused_layer = std::getenv("CLM_TF_UNFUSED_LAYER") && std::getenv("CLM_TF_UNFUSED_LAYER")[0] == '1';
+        const bool whole_layer = !unfused_layer && !unfused_ffn;   // out_proj + LN1 at the head of the feed-forward kernel
+        if (!whole_layer) {
+            a.a = h->att; a.w = h->packed.at(p + "out"); a.bias = W(p + "self_attn.out_proj.bias"); a.h = h->h; a.hx = h->hx;
+            a.ln_g = W(p + "norm1.weight"); a.ln_b = W(p + "norm1.bias");
+            tf_launch_linear<PREC, tf::E_RES_LN, D, D>(a, st);
+        }
         if (!unfused_ffn) {
             const bool more = i + 1 < h->n_layers;
             const std::string pn = "transformer_encoder.layers." + std::to_string(i + 1) + ".";
             tf::FfnArgs f{h->hx, h->packed.at(p + "ff1"), h->packed.at(p + "ff2"), W(p + "linear1.bias"), W(p + "linear2.bias"),
                           W(p + "norm2.weight"), W(p + "norm2.bias"), h->h, h->hx, M, 1e-5f,
-                          more ? h->packed.at(pn + "in") : nullptr, more ? W(pn + "self_attn.in_proj_bias") : nullptr, h->qkv};
+                          more ? h->packed.at(pn + "in") : nullptr, more ? W(pn + "self_attn.in_proj_bias") : nullptr, h->qkv,
+                          whole_layer ? h->att : nullptr, h->packed.at(p + "out"), W(p + "self_attn.out_proj.bias"),
+                          W(p + "norm1.weight"), W(p + "norm1.bias")};
             constexpr size_t lds = (size_t)2 * 128 * RS16 * 2 + (size_t)2 * 16 * 128 * 4;
             auto kern = tf::enc_ffn16_kernel<PREC>;
             static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), true);
