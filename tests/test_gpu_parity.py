@@ -287,3 +287,25 @@ def test_cli_predict_then_filter_end_to_end(sd, tmp_path, golden_dir, built_lib)
     assert r.returncode == 0, r.stderr[-2000:]
     assert (out / "predictions.txt").exists() and bam.with_suffix(".filtered.sorted.bam").exists()
     assert Path(str(bam.with_suffix(".filtered.sorted.bam")) + ".bai").exists()
+
+
+def test_integration_md_ctypes_stub_runs_as_documented(sd, built_lib):
+    """The ctypes binding printed in INTEGRATION.md section 3 is executed verbatim (only the library path is made absolute) and
+    must give the same logits as the maintained binding."""
+    import re
+
+    from chimeralm_amd import lm
+
+    text = (REPO / "INTEGRATION.md").read_text()
+    block = next(b for b in re.findall(r"```python\n(.*?)```", text, flags=re.S) if "class HyenaDnaHip" in b)
+    block = block.replace('C.CDLL("libchimeralm_hip.so")', f'C.CDLL("{built_lib}")')
+    ns: dict = {}
+    exec(compile(block, "INTEGRATION.md", "exec"), ns)  # noqa: S102
+    model = lm.ChimeraLM.new(precision="fp16")
+    model.load_state_dict(sd, strict=True)
+    stub = ns["HyenaDnaHip"](model.net, device=0, precision=2)
+    ids = torch.from_numpy(_ids(3, 500).astype(np.int64)).cuda()
+    got = stub(ids)
+    torch.cuda.synchronize()
+    want = model.net(ids)
+    assert torch.equal(got.cpu(), want.cpu())
