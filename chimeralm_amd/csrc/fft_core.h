@@ -111,6 +111,16 @@ CLM_HD void dft4(C& a0, C& a1, C& a2, C& a3) {
     a3 = C::sub(t1, t3);
 }
 
+// dft4 whose inputs a2 and a3 are zero (their incoming values are ignored): 4 complex additions instead of 8
+template <bool INV, class C>
+CLM_HD void dft4_lo(C& a0, C& a1, C& a2, C& a3) {
+    C t3 = C::template mul_mi<INV>(a1), s = C::add(a0, a1), d = C::sub(a0, a1);
+    a3 = C::sub(a0, t3);
+    a1 = C::add(a0, t3);
+    a0 = s;
+    a2 = d;
+}
+
 // v * exp(-+ 2*pi*i * m / 16), m = 0..9 (m is a compile-time constant after unrolling)
 template <bool INV, class C>
 CLM_HD C mul_w16(C v, int m) {
@@ -178,6 +188,29 @@ struct Dft<16, INV> {  // R1 = R2 = 4
 #pragma unroll
         for (int k2 = 0; k2 < 4; ++k2) dft4<INV>(v[4 * k2], v[4 * k2 + 1], v[4 * k2 + 2], v[4 * k2 + 3]);
         // position p = k1 + 4*k2 holds X[4*k1 + k2]: transpose the 4x4 register grid (pure renaming)
+        C t[16];
+#pragma unroll
+        for (int p = 0; p < 16; ++p) t[p] = v[p];
+#pragma unroll
+        for (int k1 = 0; k1 < 4; ++k1)
+#pragma unroll
+            for (int k2 = 0; k2 < 4; ++k2) v[4 * k1 + k2] = t[k1 + 4 * k2];
+    }
+};
+
+// DFT16 of a vector whose upper half v[8..15] is zero (not read): the first pass over a zero-padded convolution input
+template <bool INV>
+struct Dft16Lo {
+    template <class C>
+    static CLM_HD void run(C* v) {
+#pragma unroll
+        for (int n1 = 0; n1 < 4; ++n1) dft4_lo<INV>(v[n1], v[n1 + 4], v[n1 + 8], v[n1 + 12]);
+#pragma unroll
+        for (int n1 = 1; n1 < 4; ++n1)
+#pragma unroll
+            for (int k2 = 1; k2 < 4; ++k2) v[n1 + 4 * k2] = mul_w16<INV>(v[n1 + 4 * k2], n1 * k2);
+#pragma unroll
+        for (int k2 = 0; k2 < 4; ++k2) dft4<INV>(v[4 * k2], v[4 * k2 + 1], v[4 * k2 + 2], v[4 * k2 + 3]);
         C t[16];
 #pragma unroll
         for (int p = 0; p < 16; ++p) t[p] = v[p];

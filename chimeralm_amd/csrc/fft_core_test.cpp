@@ -48,7 +48,11 @@ static double test_conv(int L, unsigned seed) {
     for (int m = 0; m < N / 2; ++m) tw[m] = make_float2(float(std::cos(2 * M_PI * m / N)), float(-std::sin(2 * M_PI * m / N)));
     // signal in padded "LDS"
     std::vector<float> bre(padded_size(N), 0.f), bim(padded_size(N), 0.f);
-    for (int t = 0; t < L; ++t) bre[pad_index(t)] = float(g0[t]), bim[pad_index(t)] = float(g1[t]);
+    // like the kernel: tokens < N/2 in the lower half; the upper half is never written (the pruned first pass does not read
+    // it); the single element at N/2 (only when L == N/2 + 1) is carried to the spectrum product
+    for (int i = 0; i < padded_size(N); ++i) bre[i] = bim[i] = 1e30f;     // poison: anything read by mistake shows
+    for (int t = 0; t < N / 2; ++t) bre[pad_index(t)] = t < L ? float(g0[t]) : 0.f, bim[pad_index(t)] = t < L ? float(g1[t]) : 0.f;
+    const float tail_re = L == N / 2 + 1 ? float(g0[N / 2]) : 0.f, tail_im = L == N / 2 + 1 ? float(g1[N / 2]) : 0.f;
     // all twiddles are fetched up front, exactly like the kernel does
     using TL = TwLayout<LOGN>;
     std::vector<Cx2> wall(size_t(NT) * TL::TOTAL);
@@ -66,15 +70,19 @@ static double test_conv(int L, unsigned seed) {
     // forward passes
     int Ns = 1;
     for (int p = 0; p < P::NPASS - 1; ++p) {
-        for (int tid = 0; tid < NT; ++tid) pass_load<LOGN, 16>(bre.data(), bim.data(), R(tid), tid);
-        for (int tid = 0; tid < NT; ++tid) pass_compute_w<LOGN, 16, false>(R(tid), tid, p > 0, W(tid) + (p > 0 ? TL::fwd(p) : 0));
+        if (p == 0) {
+            for (int tid = 0; tid < NT; ++tid) pass_first_lower<LOGN>(bre.data(), bim.data(), R(tid), tid);
+        } else {
+            for (int tid = 0; tid < NT; ++tid) pass_load<LOGN, 16>(bre.data(), bim.data(), R(tid), tid);
+            for (int tid = 0; tid < NT; ++tid) pass_compute_w<LOGN, 16, false>(R(tid), tid, true, W(tid) + TL::fwd(p));
+        }
         for (int tid = 0; tid < NT; ++tid) pass_store<LOGN, 16>(bre.data(), bim.data(), R(tid), tid, Ns);
         Ns *= 16;
     }
     for (int tid = 0; tid < NT; ++tid) spectrum_fetch<LOGN, LAST>(&kv[size_t(tid) * 16], tid, kff.data());
     for (int tid = 0; tid < NT; ++tid) pass_load<LOGN, LAST>(bre.data(), bim.data(), R(tid), tid);
     for (int tid = 0; tid < NT; ++tid) pass_compute_w<LOGN, LAST, false>(R(tid), tid, true, W(tid) + TL::fwd_last());
-    for (int tid = 0; tid < NT; ++tid) spectrum_multiply_and_first_inverse_v<LOGN, LAST>(R(tid), tid, &kv[size_t(tid) * 16]);
+    for (int tid = 0; tid < NT; ++tid) spectrum_multiply_and_first_inverse_v<LOGN, LAST>(R(tid), tid, &kv[size_t(tid) * 16], tail_re, tail_im);
     for (int tid = 0; tid < NT; ++tid) pass_store<LOGN, LAST>(bre.data(), bim.data(), R(tid), tid, 1);
     Ns = LAST;
     for (int p = 1; p <= P::NPASS - 1; ++p) {

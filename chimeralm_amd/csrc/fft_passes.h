@@ -47,6 +47,27 @@ CLM_HD void pass_load(const float* re, const float* im, Cx2* v, int tid) {
     }
 }
 
+// First forward pass of a zero-padded convolution input (elements N/2 .. N-1 are zero and are neither stored nor read):
+// only inputs r < 8 of each radix-16 butterfly are loaded, and the butterfly skips the additions with zero.  A single
+// non-zero element at index N/2 (reads of exactly N/2 + 1 tokens) is added back in the frequency domain, where it is
+// (-1)^m times its value (spectrum_multiply_and_first_inverse_v).
+template <int LOGN>
+CLM_HD void pass_first_lower(const float* re, const float* im, Cx2* v, int tid) {
+    using G = PassGeom<LOGN, 16>;
+#pragma unroll
+    for (int p = 0; p < G::NP; ++p) {
+        const bool ha = G::has_a(tid, p), hb = G::has_b(tid, p);
+        const int pa = pad_index(G::jba(tid, p)), pb = pad_index(G::jbb(tid, p));
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const int off = pad_offset(r * G::NB);
+            v[p * 16 + r].re = make_v2(ha ? re[pa + off] : 0.f, hb ? re[pb + off] : 0.f);
+            v[p * 16 + r].im = make_v2(ha ? im[pa + off] : 0.f, hb ? im[pb + off] : 0.f);
+        }
+        Dft16Lo<false>::run(v + p * 16);
+    }
+}
+
 template <int LOGN, int R>
 CLM_HD void pass_store(float* re, float* im, const Cx2* v, int tid, int Ns) {
     using G = PassGeom<LOGN, R>;
@@ -104,13 +125,18 @@ CLM_HD void spectrum_fetch(Cx2* kv, int tid, const float2* kf) {
 // Fused middle of the convolution: after the LAST forward pass a thread holds, for each of its butterflies jb, the
 // spectrum bins m = jb + q*N/R (q = 0..R-1) -- exactly the inputs of the FIRST inverse pass (Ns = 1) of the same
 // radix.  Multiply by the filter spectrum and run that inverse butterfly (no twiddles at Ns = 1).
+// `tail_re`, `tail_im`: the element at index N/2 of the packed input (zero unless L == N/2 + 1), left out of the pruned first
+// pass; its transform is (-1)^m, and every bin m = jb + q*N/R of a thread has the parity of tid (N/R and NT are even).
 template <int LOGN, int R>
-CLM_HD void spectrum_multiply_and_first_inverse_v(Cx2* v, int tid, const Cx2* kv) {
+CLM_HD void spectrum_multiply_and_first_inverse_v(Cx2* v, int tid, const Cx2* kv, float tail_re = 0.f, float tail_im = 0.f) {
     using G = PassGeom<LOGN, R>;
+    static_assert(((1 << LOGN) / R) % 2 == 0 && G::NT % 2 == 0, "bin parity == thread parity");
+    const float sg = (tid & 1) ? -1.f : 1.f;
+    const Cx2 tl{splat2(sg * tail_re), splat2(sg * tail_im)};
 #pragma unroll
     for (int p = 0; p < G::NP; ++p) {
 #pragma unroll
-        for (int q = 0; q < R; ++q) v[p * R + q] = Cx2::mul(v[p * R + q], kv[p * R + q]);
+        for (int q = 0; q < R; ++q) v[p * R + q] = Cx2::mul(Cx2::add(v[p * R + q], tl), kv[p * R + q]);
         Dft<R, true>::run(v + p * R);
     }
 }

@@ -457,18 +457,14 @@ __global__ __launch_bounds__(Plan<LOGN>::NT) void hyena_conv_kernel(
         }
     }
     CLM_STAMP_AT(13);
-    // upper half = zero padding, written with unit stride across lanes (conflict-free)
-#pragma unroll
-    for (int i = 0; i < HALF / NT; ++i) bre[pad_index(HALF + tid + i * NT)] = 0.f, bim[pad_index(HALF + tid + i * NT)] = 0.f;
+    // (the upper half of the transform input is zero padding: it is neither written nor read -- pass_first_lower)
     CLM_STAMP_AT(14);
     float* gtail = bim + padded_size(N);                     // g[HALF] of both reads, for the alias correction by thread 0
     CLM_STAMP_AT(1);
     __syncthreads();
-    if (tail && tid == TAIL_TID) {      // token N/2 exists only when L == N/2 + 1 (8193 tokens in a 16384-point transform)
-        bre[pad_index(HALF)] = gAt;
-        bim[pad_index(HALF)] = gBt;
-        gtail[0] = gAt;
-        gtail[1] = gBt;
+    if (tail && tid == TAIL_TID) {      // token N/2 exists only when L == N/2 + 1 (8193 tokens in a 16384-point transform):
+        gtail[0] = gAt;                 // it joins in the frequency domain (spectrum product) and is needed again for the
+        gtail[1] = gBt;                 // alias correction of output 0
     }
     __syncthreads();
     CLM_STAMP_AT(2);
@@ -479,8 +475,12 @@ __global__ __launch_bounds__(Plan<LOGN>::NT) void hyena_conv_kernel(
         int Ns = 1;
 #pragma unroll
         for (int p = 0; p < P::NPASS - 1; ++p) {
-            pass_load<LOGN, 16>(bre, bim, v, tid);
-            pass_compute_w<LOGN, 16, false>(v, tid, p > 0, wall + (p > 0 ? TL::fwd(p) : 0));
+            if (p == 0) {
+                pass_first_lower<LOGN>(bre, bim, v, tid);     // zero upper half: half the loads, a shorter butterfly
+            } else {
+                pass_load<LOGN, 16>(bre, bim, v, tid);
+                pass_compute_w<LOGN, 16, false>(v, tid, true, wall + TL::fwd(p));
+            }
             __syncthreads();
             pass_store<LOGN, 16>(bre, bim, v, tid, Ns);
             __syncthreads();
@@ -493,7 +493,7 @@ __global__ __launch_bounds__(Plan<LOGN>::NT) void hyena_conv_kernel(
         spectrum_fetch<LOGN, LAST>(kv, tid, kfc);          // L2 latency overlaps the LDS loads and the butterfly
         pass_load<LOGN, LAST>(bre, bim, v, tid);
         pass_compute_w<LOGN, LAST, false>(v, tid, true, wall + TL::fwd_last());
-        spectrum_multiply_and_first_inverse_v<LOGN, LAST>(v, tid, kv);
+        spectrum_multiply_and_first_inverse_v<LOGN, LAST>(v, tid, kv, tail ? gtail[0] : 0.f, tail ? gtail[1] : 0.f);
     }
     __syncthreads();
     pass_store<LOGN, LAST>(bre, bim, v, tid, 1);
@@ -684,9 +684,7 @@ __global__ __launch_bounds__(Plan<14>::NT) void hyena_conv_seg_kernel(
                 lds_store8(bim + pad_index(tl), gB);
             }
         }
-#pragma unroll
-        for (int i = 0; i < HALF / NT; ++i) bre[pad_index(HALF + ltid + i * NT)] = 0.f, bim[pad_index(HALF + ltid + i * NT)] = 0.f;
-        __syncthreads();
+        __syncthreads();                 // (upper half = zero padding: never written, never read -- pass_first_lower)
 
         // ---- forward transform
         Cx2 v[16];
@@ -694,8 +692,12 @@ __global__ __launch_bounds__(Plan<14>::NT) void hyena_conv_seg_kernel(
             int Ns = 1;
 #pragma unroll
             for (int p = 0; p < P::NPASS - 1; ++p) {
-                pass_load<LOGN, 16>(bre, bim, v, ltid);
-                pass_compute_w<LOGN, 16, false>(v, ltid, p > 0, wall + (p > 0 ? TL::fwd(p) : 0));
+                if (p == 0) {
+                    pass_first_lower<LOGN>(bre, bim, v, ltid);
+                } else {
+                    pass_load<LOGN, 16>(bre, bim, v, ltid);
+                    pass_compute_w<LOGN, 16, false>(v, ltid, true, wall + TL::fwd(p));
+                }
                 __syncthreads();
                 pass_store<LOGN, 16>(bre, bim, v, ltid, Ns);
                 __syncthreads();
