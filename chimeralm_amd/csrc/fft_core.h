@@ -221,6 +221,33 @@ struct Dft16Lo {
     }
 };
 
+// DFT16 of which only the outputs X[0..8] are wanted (the last inverse pass of a convolution whose upper output half is
+// discarded; X[8] is the element at N/2 of 8193-token reads): the second stage computes 2 (3 for k2 = 0) of its 4 outputs.
+// v[9..15] are left undefined.
+template <bool INV>
+struct Dft16HalfOut {
+    template <class C>
+    static CLM_HD void run(C* v) {
+#pragma unroll
+        for (int n1 = 0; n1 < 4; ++n1) dft4<INV>(v[n1], v[n1 + 4], v[n1 + 8], v[n1 + 12]);
+#pragma unroll
+        for (int n1 = 1; n1 < 4; ++n1)
+#pragma unroll
+            for (int k2 = 1; k2 < 4; ++k2) v[n1 + 4 * k2] = mul_w16<INV>(v[n1 + 4 * k2], n1 * k2);
+        C x[9];
+#pragma unroll
+        for (int k2 = 0; k2 < 4; ++k2) {   // X[4*k1 + k2], k1 = 0, 1 (and k1 = 2 for k2 = 0)
+            const C a0 = v[4 * k2], a1 = v[4 * k2 + 1], a2 = v[4 * k2 + 2], a3 = v[4 * k2 + 3];
+            const C t0 = C::add(a0, a2), t1 = C::sub(a0, a2), t2 = C::add(a1, a3), t3 = C::template mul_mi<INV>(C::sub(a1, a3));
+            x[k2] = C::add(t0, t2);
+            x[4 + k2] = C::add(t1, t3);
+            if (k2 == 0) x[8] = C::sub(t0, t2);
+        }
+#pragma unroll
+        for (int q = 0; q < 9; ++q) v[q] = x[q];
+    }
+};
+
 // v[r] *= w^r for r = 1..R-1 with a multiplication tree of depth <= 4 (error ~ 4 ulp instead of R ulp)
 template <int R, class C>
 CLM_HD void apply_twiddle_powers(C* v, C w1) {

@@ -89,6 +89,35 @@ CLM_HD void pass_store(float* re, float* im, const Cx2* v, int tid, int Ns) {
     }
 }
 
+// Last inverse pass of a convolution whose outputs N/2+1 .. N-1 are discarded: twiddle, the half-output butterfly, and a store
+// of outputs q < 8 only (Ns = N/16: output index jb + q*N/16); `keep_mid`: also output N/2 (butterfly 0, q = 8).
+template <int LOGN>
+CLM_HD void pass_compute_last_inverse_lower(Cx2* v, int tid, const Cx2* w) {
+    using G = PassGeom<LOGN, 16>;
+    static_assert(G::FULL, "every thread owns whole butterfly pairs");
+#pragma unroll
+    for (int p = 0; p < G::NP; ++p) {
+        apply_twiddle_powers<16>(v + p * 16, w[p]);
+        Dft16HalfOut<true>::run(v + p * 16);
+    }
+}
+template <int LOGN>
+CLM_HD void pass_store_lower(float* re, float* im, const Cx2* v, int tid, bool keep_mid) {
+    using G = PassGeom<LOGN, 16>;
+    constexpr int Ns = G::NB;                                   // last pass: sub-transform size N/16 = number of butterflies
+#pragma unroll
+    for (int p = 0; p < G::NP; ++p) {
+        const int pa = pad_index(G::jba(tid, p)), pb = pad_index(G::jbb(tid, p));     // k = jb, output jb + q*Ns
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int off = pad_offset(q * Ns);
+            re[pa + off] = v[p * 16 + q].re.x, im[pa + off] = v[p * 16 + q].im.x;
+            re[pb + off] = v[p * 16 + q].re.y, im[pb + off] = v[p * 16 + q].im.y;
+        }
+        if (keep_mid && G::jba(tid, p) == 0) re[pad_index(8 * Ns)] = v[p * 16 + 8].re.x, im[pad_index(8 * Ns)] = v[p * 16 + 8].im.x;
+    }
+}
+
 // Twiddle prefetch: w[p] for the butterfly pairs of one pass (issued at kernel start, consumed passes later).
 template <int LOGN, int R, bool INV>
 CLM_HD void pass_twiddles(Cx2* w, int tid, int Ns, const float2* tw) {

@@ -504,9 +504,20 @@ __global__ __launch_bounds__(Plan<LOGN>::NT) void hyena_conv_kernel(
 #pragma unroll
         for (int p = 1; p <= P::NPASS - 1; ++p) {
             pass_load<LOGN, 16>(bre, bim, v, tid);
-            pass_compute_w<LOGN, 16, true>(v, tid, true, wall + TL::inv(p));
-            __syncthreads();
-            pass_store<LOGN, 16>(bre, bim, v, tid, Ns);
+            bool lower = false;
+            if constexpr (PassGeom<LOGN, 16>::FULL) {
+                if (p == P::NPASS - 1) {   // outputs beyond N/2 are discarded: half-output butterfly, half the stores
+                    lower = true;
+                    pass_compute_last_inverse_lower<LOGN>(v, tid, wall + TL::inv(p));
+                    __syncthreads();
+                    pass_store_lower<LOGN>(bre, bim, v, tid, tail);
+                }
+            }
+            if (!lower) {
+                pass_compute_w<LOGN, 16, true>(v, tid, true, wall + TL::inv(p));
+                __syncthreads();
+                pass_store<LOGN, 16>(bre, bim, v, tid, Ns);
+            }
             __syncthreads();
             CLM_STAMP_AT(7 + p);
             Ns *= 16;
