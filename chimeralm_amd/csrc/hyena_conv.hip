@@ -293,6 +293,23 @@ __device__ __forceinline__ void fir3(const float* x /*[10]*/, float w0, float w1
     for (int e = 0; e < 8; ++e) out[e] = bias + w0 * x[e] + w1 * x[e + 1] + w2 * x[e + 2];
 }
 
+// the same filter on two rows at once (read A and read B of the pair share the channel's taps): packed fp32, one v_pk_fma per
+// two multiply-adds
+__device__ __forceinline__ void fir3_pair(const float* xa, const float* xb, float w0, float w1, float w2, float bias, float* oa,
+                                          float* ob) {
+    using clmfft::V2;
+    const V2 W0 = {w0, w0}, W1 = {w1, w1}, W2 = {w2, w2}, Bv = {bias, bias};
+    V2 x[10];
+#pragma unroll
+    for (int e = 0; e < 10; ++e) x[e] = V2{xa[e], xb[e]};
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const V2 r = Bv + W0 * x[e] + W1 * x[e + 1] + W2 * x[e + 2];
+        oa[e] = r.x;
+        ob[e] = r.y;
+    }
+}
+
 // 8 consecutive floats to / from an LDS array whose padding never splits an aligned group of 8
 __device__ __forceinline__ void lds_store8(float* dst, const float* v) {
     *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
@@ -428,16 +445,15 @@ __global__ __launch_bounds__(Plan<LOGN>::NT) void hyena_conv_kernel(
                     raw_decode(raw[ch][1][a3], t0, valid && hasB, xb[a3]);
                 }
             }
-            fir3(xa[0], sw[0][0], sw[0][1], sw[0][2], sb[0], x0A[ch]);
-            fir3(xa[1], sw[1][0], sw[1][1], sw[1][2], sb[1], x1);
-            fir3(xa[2], sw[2][0], sw[2][1], sw[2][2], sb[2], v);
+            float x1b[8], vb[8];
+            fir3_pair(xa[0], xb[0], sw[0][0], sw[0][1], sw[0][2], sb[0], x0A[ch], x0B[ch]);
+            fir3_pair(xa[1], xb[1], sw[1][0], sw[1][1], sw[1][2], sb[1], x1, x1b);
+            fir3_pair(xa[2], xb[2], sw[2][0], sw[2][1], sw[2][2], sb[2], v, vb);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) gA[e] = (t0 + e < L) ? v[e] * x1[e] : 0.f;
-            fir3(xb[0], sw[0][0], sw[0][1], sw[0][2], sb[0], x0B[ch]);
-            fir3(xb[1], sw[1][0], sw[1][1], sw[1][2], sb[1], x1);
-            fir3(xb[2], sw[2][0], sw[2][1], sw[2][2], sb[2], v);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) gB[e] = (hasB && t0 + e < L) ? v[e] * x1[e] : 0.f;
+            for (int e = 0; e < 8; ++e) {
+                gA[e] = (t0 + e < L) ? v[e] * x1[e] : 0.f;
+                gB[e] = (hasB && t0 + e < L) ? vb[e] * x1b[e] : 0.f;
+            }
             lds_store8(bre + pad_index(t0), gA);
             lds_store8(bim + pad_index(t0), gB);
             if (ch == CH - 1 && tail && tid == TAIL_TID) {   // token HALF: taps are x[8], x[9] of this chunk and z[HALF]
