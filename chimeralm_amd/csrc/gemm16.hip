@@ -387,7 +387,7 @@ __global__ __launch_bounds__(512) void score_pool16_kernel(ScorePoolArgs m) {
 // a side buffer nothing else reads; the product instantiation (STAMP = false) contains no stamp.
 // NEXT: what follows the block on the same tile while it is still on chip -- the residual stream is then read once and
 // written once per block, and the separate in_proj / score launches (latency-bound on their own) disappear.
-constexpr int TAIL_NSTAMP = 24;
+constexpr int TAIL_NSTAMP = 28;      // 0..20 phase boundaries, 21..26 the six half-block hooks of the in_proj stage
 
 // residual rows of tile (b, t0) in accumulator layout (block 0 of the id path: embedding rows by token id); one piece =
 // the 32 token rows of one accumulator tile
@@ -420,7 +420,9 @@ struct ResidHook {
     float4 (&hv)[4][4];
     uint4 (&yx)[8];
     int b, t0, wave, lrow, lhalf, tid;
+    unsigned long long* stamp;                             // developer build only (nullptr otherwise)
     __device__ __forceinline__ void operator()(int step) const {
+        if (stamp && tid == 0) stamp[21 + step] = __builtin_amdgcn_s_memtime();
         if (step < 4) tail_load_resid_piece(m, hv[step], step, b, t0, wave, lrow, lhalf);
         else tail_load_y_piece<E>(m, yx, step - 4, b, t0, tid);
     }
@@ -618,7 +620,8 @@ __global__ __launch_bounds__(512) void tail16_kernel(TailArgs m, unsigned long l
             // the 128 KiB of residual rows trickle in as four pieces behind the weight requests of the first four half-blocks
             // (requested in one go before the LayerNorm they stalled every later load of the stage: +9k cycles)
             inproj_blocks<PREC>(As, Hs, wn, m.n_bias, m.n_z, b, t0, Lp, wave, lane, bs, acc1,
-                                ResidHook<elem>{m, hv, yx, nb_, nt0, wave, lrow, lhalf, tid});
+                                ResidHook<elem>{m, hv, yx, nb_, nt0, wave, lrow, lhalf, tid,
+                                                STAMP ? stamps + (size_t)tile * TAIL_NSTAMP : nullptr});
         } else {
             score_pool_tile<PREC>(m.sp, As, reinterpret_cast<float*>(Hs), b, tile % tiles_x, tid, bs, acc1);
             // (requested before the score stage these 96 registers spill through its erf epilogue: one launch in four)
@@ -711,6 +714,18 @@ void tail16_dump_stamps() {
     for (int k = 1; k <= 20; ++k) tot += sum[k] / (n ? n : 1);
     std::fprintf(stderr, "[tail16 stamps] %zu workgroups, mean s_memtime ticks per phase (total %.0f):\n", n, tot);
     for (int k = 1; k <= 20; ++k) std::fprintf(stderr, "  %-14s %9.0f  %5.1f %%\n", names[k], sum[k] / (n ? n : 1), 100.0 * sum[k] / (n ? n : 1) / tot);
+    // in_proj stage by half-block hook: ln end -> hook 0 -> ... -> hook 5 -> end
+    double hs[7] = {};
+    for (size_t w = 0; w < s_stamp_wgs; ++w) {
+        const unsigned long long* p = &hst[w * TAIL_NSTAMP];
+        if (!p[0] || !p[20] || !p[21]) continue;
+        hs[0] += double(p[21] - p[19]);
+        for (int k = 1; k < 6; ++k) hs[k] += double(p[21 + k] - p[20 + k]);
+        hs[6] += double(p[20] - p[26]);
+    }
+    std::fprintf(stderr, "[tail16 stamps] in_proj stage at the hooks:");
+    for (int k = 0; k < 7; ++k) std::fprintf(stderr, " %.0f", hs[k] / (n ? n : 1));
+    std::fprintf(stderr, "\n");
 }
 
 template <int PREC, int NEXT>
