@@ -444,6 +444,14 @@ __global__ __launch_bounds__(512) void tail16_kernel(TailArgs m, unsigned long l
     elem* Ys = reinterpret_cast<elem*>(smem);              // y tile [256 channels][RSKM], k-major
     float* P1 = reinterpret_cast<float*>(smem + (size_t)2 * BM * RS16 * 2);   // row-sum partials [16][128]
     float* P2 = P1 + 16 * BM;                                                 // squared-deviation partials
+    // bias table, filled once per workgroup: b1[1024] | b2[256] | b_out[256] | in_proj bias of the next block[768].
+    // (Read from global memory each of these loads sat in front of an `s_waitcnt vmcnt(0)`: vmcnt retires in order, so the
+    // epilogues waited for every weight set and residual prefetch requested before them.)
+    float* Bt = P2 + 16 * BM;
+    constexpr int BT_B2 = DI, BT_BOUT = DI + D, BT_NB = DI + 2 * D, BT_SIZE = DI + 2 * D + D3;
+    for (int i = threadIdx.x; i < BT_SIZE; i += 512)
+        Bt[i] = i < BT_B2 ? m.b1[i] : i < BT_BOUT ? m.b2[i - BT_B2] : i < BT_NB ? m.b_out[i - BT_BOUT]
+                : (NEXT == NEXT_INPROJ ? m.n_bias[i - BT_NB] : 0.f);
     const int L = m.L, Lp = m.Lp, tiles_x = (L + BM - 1) / BM, total = tiles_x * m.B;
     const frag* wo = reinterpret_cast<const frag*>(m.w_out);
     const frag* w1 = reinterpret_cast<const frag*>(m.w1);
@@ -472,6 +480,7 @@ __global__ __launch_bounds__(512) void tail16_kernel(TailArgs m, unsigned long l
     const int tid = tid_l, lane = tid & 63, wave = tid >> 6, lrow = lane & 31, lhalf = lane >> 5;
     const int b = tile / tiles_x, t0 = (tile % tiles_x) * BM;
     CLM_STAMP_AT(0);
+    if (STAMP && threadIdx.x == 0) stamps[(size_t)tile * TAIL_NSTAMP + 27] = __builtin_amdgcn_s_memrealtime();   // 100 MHz
     // ---- 0. everything that only depends on addresses is requested first
     load_set<PREC, D, 1>(wo, 0, 0, 0, wave, lane, bs[0]);
     load_set<PREC, D, 1>(wo, 0, 0, 1, wave, lane, bs[1]);
@@ -496,7 +505,7 @@ __global__ __launch_bounds__(512) void tail16_kernel(TailArgs m, unsigned long l
     compute_km<PREC>(Ys, 1, lane, bs[1], acc2);
     __builtin_amdgcn_sched_barrier(0);
     {
-        const float* bo = m.b_out + wave * 32 + 4 * lhalf;
+        const float* bo = Bt + BT_BOUT + wave * 32 + 4 * lhalf;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const float4 bb = *reinterpret_cast<const float4*>(bo + 8 * q);
@@ -530,7 +539,7 @@ __global__ __launch_bounds__(512) void tail16_kernel(TailArgs m, unsigned long l
         // phase and the L2 -> CU path is otherwise idle (the MFMA phases are bound by exactly that path)
         float4 b1v[4];
         {
-            const float* b1 = m.b1 + j * 256 + wave * 32 + 4 * lhalf;
+            const float* b1 = Bt + j * 256 + wave * 32 + 4 * lhalf;
 #pragma unroll
             for (int q = 0; q < 4; ++q) b1v[q] = *reinterpret_cast<const float4*>(b1 + 8 * q);
         }
@@ -566,7 +575,7 @@ __global__ __launch_bounds__(512) void tail16_kernel(TailArgs m, unsigned long l
     CLM_STAMP_AT(17);
     // ---- 5. h_new = acc2 + b2: transposed through LDS, stored as whole 128-byte lines (no read)
     {
-        const float* b2p = m.b2 + wave * 32 + 4 * lhalf;
+        const float* b2p = Bt + BT_B2 + wave * 32 + 4 * lhalf;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const float4 bb = *reinterpret_cast<const float4*>(b2p + 8 * q);
@@ -619,7 +628,7 @@ __global__ __launch_bounds__(512) void tail16_kernel(TailArgs m, unsigned long l
             // bs[1] is re-requested by the block loop (same addresses, L2-resident): keeps the loop identical to in_proj16
             // the 128 KiB of residual rows trickle in as four pieces behind the weight requests of the first four half-blocks
             // (requested in one go before the LayerNorm they stalled every later load of the stage: +9k cycles)
-            inproj_blocks<PREC>(As, Hs, wn, m.n_bias, m.n_z, b, t0, Lp, wave, lane, bs, acc1,
+            inproj_blocks<PREC>(As, Hs, wn, Bt + BT_NB, m.n_z, b, t0, Lp, wave, lane, bs, acc1,
                                 ResidHook<elem>{m, hv, yx, nb_, nt0, wave, lrow, lhalf, tid,
                                                 STAMP ? stamps + (size_t)tile * TAIL_NSTAMP : nullptr});
         } else {
@@ -723,6 +732,20 @@ void tail16_dump_stamps() {
         for (int k = 1; k < 6; ++k) hs[k] += double(p[21 + k] - p[20 + k]);
         hs[6] += double(p[20] - p[26]);
     }
+    // shader clock during the kernel: s_memtime ticks per s_memrealtime tick (constant 100 MHz) between consecutive tiles of
+    // one workgroup (tile w and w + grid)
+    {
+        int dev = 0, cus = 256;
+        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        double dm = 0, dr = 0;
+        for (size_t w = 0; w + cus < s_stamp_wgs; ++w) {
+            const unsigned long long *p = &hst[w * TAIL_NSTAMP], *q = &hst[(w + cus) * TAIL_NSTAMP];
+            if (!p[0] || !q[0] || !p[27] || !q[27]) continue;
+            dm += double(q[0] - p[0]);
+            dr += double(q[27] - p[27]);
+        }
+        if (dr > 0) std::fprintf(stderr, "[tail16 stamps] s_memtime / s_memrealtime = %.3f -> %.0f MHz if s_memtime is the shader clock\n", dm / dr, dm / dr * 100.0);
+    }
     std::fprintf(stderr, "[tail16 stamps] in_proj stage at the hooks:");
     for (int k = 0; k < 7; ++k) std::fprintf(stderr, " %.0f", hs[k] / (n ? n : 1));
     std::fprintf(stderr, "\n");
@@ -736,7 +759,8 @@ static void launch_tail_inst(const TailArgs& m, dim3 grid, size_t lds, hipStream
 }
 
 void launch_tail16(int prec, const TailArgs& m, int next, hipStream_t st) {
-    constexpr size_t lds = (size_t)2 * 128 * RS16 * 2 + (size_t)2 * 16 * 128 * 4;
+    constexpr size_t lds = (size_t)2 * 128 * RS16 * 2 + (size_t)2 * 16 * 128 * 4 + (size_t)(DI + 2 * D + D3) * 4;
+    static_assert(lds <= 160 * 1024, "tail kernel LDS");
     static_assert((size_t)D * RSKM * 2 <= (size_t)2 * 128 * RS16 * 2, "y tile must fit under the partial tables");
     static_assert((size_t)8 * 32 * RSOUT * 2 <= (size_t)128 * RS16 * 2 + (size_t)2 * 16 * 128 * 4,
                   "in_proj staging tiles must fit in the Hs region + the (by then dead) LayerNorm tables");

@@ -20,17 +20,32 @@ __device__ __forceinline__ unsigned short to_bits(float v) {
 }
 
 // acc[mt][nt] += A-tile(token-major LDS) x weight set.  ROWS_N: accumulator rows are output features (lane = token).
-template <int PREC, bool ROWS_N>
+template <int PREC, bool ROWS_N, int AHEAD = 4>
 __device__ __forceinline__ void compute_tm(const typename CT<PREC>::elem* As, int part, int lrow, int lhalf,
                                            const u16x8 (&src)[1][SETK], f32x16 (&acc)[4]) {
+    // Explicitly software-pipelined over the 4*SETK (k-step, row tile) items: the A fragment of item i + AHEAD is requested
+    // before the MFMA of item i (ring of AHEAD + 1 fragments), and that order is pinned with sched_group_barrier.  Left to
+    // itself hipcc serialises `ds_read -> s_waitcnt lgkmcnt(0) -> mfma` wherever registers are tight (fc1: both accumulators
+    // and two half-sets live), and every MFMA then pays a full LDS latency: fc1 ran at half the rate of fc2.
+    constexpr int NI = 4 * SETK, R = AHEAD + 1;
+    const typename CT<PREC>::elem* a0 = As + lrow * RS16 + part * SETK * 16 + lhalf * 8;
+    u16x8 af[R];
 #pragma unroll
-    for (int ks = 0; ks < SETK; ++ks) {
+    for (int i = 0; i < AHEAD; ++i) af[i % R] = *reinterpret_cast<const u16x8*>(a0 + (i & 3) * 32 * RS16 + (i >> 2) * 16);
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt) {
-            u16x8 af = *reinterpret_cast<const u16x8*>(As + (mt * 32 + lrow) * RS16 + (part * SETK + ks) * 16 + lhalf * 8);
-            if (ROWS_N) acc[mt] = mfma<PREC>(src[0][ks], af, acc[mt]);
-            else acc[mt] = mfma<PREC>(af, src[0][ks], acc[mt]);
+    for (int i = 0; i < NI; ++i) {
+        if (i + AHEAD < NI) {
+            const int n = i + AHEAD;
+            af[n % R] = *reinterpret_cast<const u16x8*>(a0 + (n & 3) * 32 * RS16 + (n >> 2) * 16);
         }
+        if (ROWS_N) acc[i & 3] = mfma<PREC>(src[0][i >> 2], af[i % R], acc[i & 3]);
+        else acc[i & 3] = mfma<PREC>(af[i % R], src[0][i >> 2], acc[i & 3]);
+    }
+    __builtin_amdgcn_sched_group_barrier(0x100, AHEAD, 0);
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        if (i + AHEAD < NI) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
     }
 }
 
