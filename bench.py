@@ -30,6 +30,7 @@ sys.path.insert(0, str(Path(__file__).resolve().parent))
 
 D, DI, NLAYER = 256, 1024, 4
 PEAK_TFLOPS = {"fp32": 157.3, "bf16": 2500.0, "fp16": 2500.0}      # dense MFMA peaks, MI355X_MICROARCH.md
+SUSTAINED_MFMA16_TFLOPS = 1630.0   # measured, see roofline["peak_sustained_measured"]
 PEAK_HBM_GBS = 8000.0
 # algorithmic FLOPs per token of each GEMM stage
 STAGE_FLOPS_PER_TOKEN = {"ln1_in_proj": 2 * D * 3 * D, "out_proj": 2 * D * D, "ln2_fc1_gelu": 2 * D * DI,
@@ -253,6 +254,11 @@ def main():
             achieved = stage_bytes_per_token(dom, es) * tokens_per_launch / (ms / launches * 1e-3) / 1e9
             roof = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                     "frac": achieved / PEAK_HBM_GBS, "traffic": None}
+        if roof["bound"] == "mfma" and a.precision != "fp32":
+            # what the pool's MI355X sustains with every MFMA pipe busy (tools/micro/mfma_probe.cpp, profiles/r01_mfma_probe.txt:
+            # 32 cycles per 32x32x16 MFMA per SIMD at the 1.55 GHz the chip holds under that load, against 2.4 GHz nominal)
+            roof["peak_sustained_measured"] = SUSTAINED_MFMA16_TFLOPS
+            roof["frac_of_sustained"] = achieved / SUSTAINED_MFMA16_TFLOPS
         roof["flops_per_token_per_launch"] = flops_per_token if dom in STAGE_FLOPS_PER_TOKEN else None
         roof["avg_launch_ms"] = ms / max(1, launches)
         roof["launches"] = launches
