@@ -81,6 +81,16 @@ def main(tag):
     cfg = json.loads(bench[-1])["config"] if bench else {}
     (dst / f"{tag}_traffic.json").write_text(json.dumps({"config": cfg, "dtype": json.loads(bench[-1])["dtype"] if bench else None,
                                                          "stages": out}, indent=1) + "\n")
+    # the bench line of this round carries the traffic of the previous digest (bench.py reads profiles/*_traffic.json at run
+    # time): put the figure of THIS run's counter passes into the committed copy
+    if bench:
+        b = json.loads(bench[-1])
+        st = out.get(b.get("roofline", {}).get("kernel"))
+        if st:
+            b["roofline"]["traffic"] = st["hbm_bytes_per_dispatch"]
+            b["roofline"]["traffic_unit"] = "bytes/launch"
+            b["roofline"]["traffic_source"] = f"profiles/{tag}_traffic.json"
+            (dst / f"{tag}_bench.json").write_text(json.dumps(b) + "\n")
     print("\n".join(lines[:60]))
 
 
