@@ -359,6 +359,8 @@ __global__ __launch_bounds__(Plan<LOGN>::NT) void hyena_conv_kernel(
 
     // ---------------------------------------------------------------- phase 0: twiddles of every pass
     CLM_STAMP_AT(0);
+    if (STAMP && threadIdx.x == 0)    // 100-MHz counter at both ends of the unit: the shader clock the kernel runs at
+        stamps[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * CONV_NSTAMP + 15] = __builtin_amdgcn_s_memrealtime();
     Cx2 wall[TL::TOTAL];
     {
         int ns = 16;
@@ -570,6 +572,8 @@ __global__ __launch_bounds__(Plan<LOGN>::NT) void hyena_conv_kernel(
         if (hasB) yB[HALF] = from_float<T>(bim[pad_index(HALF)] * x0Bt);
     }
     CLM_STAMP_AT(11);
+    if (STAMP && threadIdx.x == 0)
+        stamps[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * CONV_NSTAMP + 6] = __builtin_amdgcn_s_memrealtime();
 #undef CLM_STAMP_AT
 }
 
@@ -882,7 +886,8 @@ void conv_dump_stamps() {
     for (size_t w = 0; w < s_conv_stamp_wgs; ++w) {
         const unsigned long long* p = &hst[w * CONV_NSTAMP];
         if (!p[0] || !p[11]) continue;
-        for (int k = 1; k <= 11; ++k) sum[k] += double(p[k] - p[k - 1]);
+        for (int k = 1; k <= 11; ++k)
+            if (k != 6) sum[k] += double(p[k] - p[k == 7 ? 5 : k - 1]);   // slot 6 holds the 100-MHz end stamp
         ++n;
     }
     const char* names[12] = {"", "tw+phaseA", "barriers", "fwd0", "fwd1", "fwd2", "(unused)", "fwd3+kf+inv0", "inv1", "inv2", "inv3", "phaseC"};
@@ -897,6 +902,16 @@ void conv_dump_stamps() {
         double mid = 0; size_t mm = 0;
         for (size_t w = 0; w < s_conv_stamp_wgs; ++w) { const unsigned long long* p = &hst[w * CONV_NSTAMP]; if (p[5] && p[7]) { mid += double(p[7] - p[5]); ++mm; } }
         if (mm) std::fprintf(stderr, "[conv stamps] fwd3+kf+inv0 = %.0f\n", mid / mm);
+    }
+    {
+        double dm = 0, dr = 0;
+        for (size_t w = 0; w < s_conv_stamp_wgs; ++w) {
+            const unsigned long long* p = &hst[w * CONV_NSTAMP];
+            if (!p[0] || !p[11] || !p[6] || !p[15]) continue;
+            dm += double(p[11] - p[0]);
+            dr += double(p[6] - p[15]);
+        }
+        if (dr > 0) std::fprintf(stderr, "[conv stamps] s_memtime / s_memrealtime = %.3f -> shader clock %.0f MHz\n", dm / dr, dm / dr * 100.0);
     }
     double tot = 0;
     for (int k = 1; k <= 11; ++k) tot += sum[k] / (n ? n : 1);
