@@ -153,6 +153,38 @@ def test_long_reads_segmented_convolution(engines, sd, prec, B, L):
     _check(engines[prec], prec, _ids(B, L, seed=21, pads=5), sd)
 
 
+def test_maximum_length_reads(engines, sd):
+    """The longest input the reference can produce: tokenizer.max_len_single_sentence = 32769 tokens (bam.py:155-166), i.e.
+    5 convolution segments, the last one holding a single token."""
+    _check(engines["fp16"], "fp16", _ids(2, 32769, seed=31), sd)
+
+
+def test_baseline_batch_size_independent_properties(sd, built_lib):
+    """BASELINE.json's bench configuration (256 reads of 8192 bases + [SEP], fp16, 64-read chunks), where the oracle is too
+    slow for the whole batch: reads are independent units, so (a) two runs are bit-identical, (b) reversing the batch reverses
+    the logits (each read gets another pair partner in the packed FFT: equal up to rounding, not bitwise), (c) reads computed
+    alone equal their rows of the full batch, (d) a sample of rows matches the oracle."""
+    from chimeralm_amd.engine import Engine
+
+    ids = _ids(256, 8193, seed=41)
+    t = torch.from_numpy(ids).cuda()
+    e = Engine("cuda:0", precision="fp16", chunk_reads=64)
+    e.load_state_dict(sd)
+    a = e.forward(t).cpu()
+    assert torch.isfinite(a).all()
+    assert torch.equal(a, e.forward(t).cpu())                                   # (a)
+    r = e.forward(torch.flip(t, dims=[0]).contiguous()).cpu()
+    assert (torch.flip(r, dims=[0]) - a).abs().max() < 2e-3                      # (b)
+    pick = [0, 63, 64, 200, 255]
+    solo = e.forward(t[pick].contiguous()).cpu()
+    assert (solo - a[pick]).abs().max() < 2e-3                                   # (c)
+    ref = ho.forward(torch.from_numpy(ids[pick[:3]].astype(np.int64)), sd)       # (d)
+    assert (a[pick[:3]] - ref).abs().max() <= TOL["fp16"]
+    decided = (ref[:, 0] - ref[:, 1]).abs() > MARGIN["fp16"]
+    assert torch.equal(a[pick[:3]].argmax(1)[decided], ref.argmax(1)[decided])
+    e.close()
+
+
 def test_collated_bam_batch_against_oracle(engines, sd, golden_dir):
     """configs[0] plumbing: real reads -> tokenizer -> collator (left pad) -> engine == oracle on the same batch."""
     from chimeralm_amd import bam, tokenizer as T
