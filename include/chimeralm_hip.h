@@ -114,7 +114,7 @@ int clm_stage_ids(clm_handle* h, const void* host_ids, int ids_dtype, int64_t id
 int clm_forward_staged(clm_handle* h, int staged, float* logits_out, void* stream);
 int clm_stage_wait(clm_handle* h, int staged);
 
-/* ---- SequenceCNNTransformer encoder pieces (under construction) -------------------------
+/* ---- SequenceCNNTransformer -----------------------------------------------------------
  * Multi-head self-attention of nn.TransformerEncoderLayer as the reference builds it
  * (/root/reference/chimeralm/models/components/transformer.py:64-68,98: d_model 256, 8 heads of 32, no masks):
  *   qkv  device, [B, L, 768] 16-bit, the in_proj output q | k | v per token;  out  device, [B, L, 256] 16-bit, heads concatenated

@@ -32,6 +32,25 @@ def test_abi_exports_every_header_symbol(built_lib):
     assert lib2.clm_profile_stage_name(2) == b"short_long_conv"
 
 
+def test_headers_are_plain_c_and_a_c_client_links(built_lib, tmp_path):
+    """The boundary is a C ABI: both headers compile as strict C99 on their own, and the plain-C client of
+    tests/c_abi/ (run on the GPU by tests/test_gpu_c_abi.py) compiles and links against the library with gcc."""
+    import shutil
+    import subprocess
+
+    inc = REPO / "include"
+    for h in ("chimeralm_hip.h", "chimeralm_feed.h"):
+        subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", "-x", "c",
+                        str(inc / h)], check=True)
+    if not (Path("/opt/rocm/include/hip/hip_runtime_api.h").exists() and shutil.which("gcc")):
+        pytest.skip("HIP runtime headers not installed")
+    lib = Path(built_lib)
+    subprocess.run(["gcc", "-std=gnu99", "-Wall", "-Werror", "-O1", f"-I{inc}", "-I/opt/rocm/include",
+                    str(REPO / "tests" / "c_abi" / "abi_client.c"), "-o", str(tmp_path / "abi_client"), f"-L{lib.parent}",
+                    "-lchimeralm_hip", "-L/opt/rocm/lib", "-lamdhip64", f"-Wl,-rpath,{lib.parent}",
+                    "-Wl,-rpath,/opt/rocm/lib"], check=True)
+
+
 def test_no_cpu_path_and_loud_failure(built_lib):
     from chimeralm_amd import lm
     from chimeralm_amd.engine import Engine, EngineError
