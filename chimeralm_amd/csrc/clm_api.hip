@@ -27,6 +27,8 @@ struct Tensor {
 struct FilterSet {
     int L = 0, logn = 0, S = 1;   // S > 1: segmented (overlap-add) long convolution, kf holds S spectra per channel
     float* ktime[NLAYER] = {};
+    float* krev[NLAYER] = {};     // conv_lone_tail(L) only: [256][krev_stride]
+    int krev_stride = 0;
     float2* kf[NLAYER] = {};
     float2* tw = nullptr;
     uint64_t stamp = 0;
@@ -200,8 +202,10 @@ void free_filter_set(FilterSet& f) {
     for (int i = 0; i < NLAYER; ++i) {
         if (f.ktime[i]) (void)hipFree(f.ktime[i]);
         if (f.kf[i]) (void)hipFree(f.kf[i]);
+        if (f.krev[i]) (void)hipFree(f.krev[i]);
         f.ktime[i] = nullptr;
         f.kf[i] = nullptr;
+        f.krev[i] = nullptr;
     }
     if (f.tw) (void)hipFree(f.tw);
     f.tw = nullptr;
@@ -308,6 +312,11 @@ int ensure_filters(clm_handle* h, int L, hipStream_t st, FilterSet** out) {
                       W(h, p + "implicit_filter.2.weight"), W(h, p + "implicit_filter.2.bias"),
                       W(h, p + "implicit_filter.4.weight"), W(h, p + "implicit_filter.4.bias"),
                       W(h, p + "implicit_filter.6.weight"), W(h, p + "modulation.deltas"), f.ktime[i], L, st);
+        if (conv_lone_tail(L)) {
+            f.krev_stride = round_up(L, 8);
+            HIPCHK(h, hipMalloc((void**)&f.krev[i], (size_t)D * f.krev_stride * 4));
+            launch_filter_reversed(f.ktime[i], W(h, p + "bias"), f.krev[i], L, f.krev_stride, st);
+        }
         if (S == 1) {
             launch_filter_spectrum(f.ktime[i], W(h, p + "bias"), f.kf[i], scratch, L, logn, 0, L, st);
         } else {   // kf [256][S][N]: one launch per segment writes the strided slice through a temporary
@@ -403,7 +412,7 @@ int forward_chunk(clm_handle* h, const void* ids, int ids_dtype, int64_t row_str
                                   fs->logn, idconv ? h->ids8 : nullptr, idconv ? h->ztab : nullptr, st);
             else
                 launch_hyena_conv_seg(prec, h->z, h->y, fs->kf[i], fs->tw, lw.short_w, lw.short_b, h->gscratch,
-                                      h->carry, Bc, L, Lp, fs->S, st);
+                                      h->carry, Bc, L, Lp, fs->S, fs->krev[i], fs->krev_stride, st);
         }
         if (stop_here(h, i, CLM_STAGE_CONV)) return CLM_OK;
         const bool stop_mid = stop_here(h, i, CLM_STAGE_OUTPROJ);

@@ -176,6 +176,9 @@ void launch_pack_weight(int prec, const float* w, void* out, int n, int k, hipSt
 constexpr int SEG_LEN = 8192;                     // tokens per segment of the overlap-add path (half a 16384 transform)
 int conv_logn_for(int L);                         // log2 of the single-shot FFT size for L tokens; <0 if L > 8193
 int conv_segments_for(int L);                     // 1 = single shot; >1 = number of 8192-token segments
+bool conv_lone_tail(int L);                       // long read of S*8192 + 1 tokens: the last output is a dot product (krev)
+// krev [256][stride] = the layer's filter reversed in time, channel-major (launch_hyena_conv_seg, lone-tail lengths)
+void launch_filter_reversed(const float* k /*[L][256]*/, const float* dskip, float* krev, int L, int stride, hipStream_t st);
 void launch_filter(const float* z /*[maxlen][5]*/, const float* t /*[maxlen]*/, const float* w0, const float* b0,
                    const float* freq, const float* w2, const float* b2, const float* w4, const float* b4,
                    const float* w6, const float* deltas, float* k_out /*[L][256]*/, int L, hipStream_t st);
@@ -196,7 +199,7 @@ void launch_ztab(const float* emb, const float* g, const float* bta, const float
 // long reads (L > 8193): overlap-add over S segments; kf [256][S][N], gscratch [pairs][256][S][N], carry [pairs][256][8192]
 void launch_hyena_conv_seg(int prec, const void* z, void* y, const float2* kf, const float2* tw, const float* short_w,
                            const float* short_b, float2* gscratch, float2* carry, int B, int L, int Lp, int S,
-                           hipStream_t st);
+                           const float* krev /*null unless conv_lone_tail(L)*/, int krev_stride, hipStream_t st);
 
 // head (head.hip)
 void launch_softmax_stats(const float* scores, float* stats /*[B][2] = max, sum*/, int B, int L, hipStream_t st);

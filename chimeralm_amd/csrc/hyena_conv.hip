@@ -68,6 +68,23 @@ void launch_filter(const float* z, const float* t, const float* w0, const float*
                        k_out, L);
 }
 
+// krev[c][t] = k[L-1-t][c] (+ the skip term D[c] on tap 0, i.e. at t = L-1), channel-major with row stride `stride`:
+// the last output of a read, y[L-1] = sum_t g[t] k[L-1-t], as a dot product over ascending t (long reads with a lone tail).
+__global__ __launch_bounds__(256) void krev_kernel(const float* __restrict__ k, const float* __restrict__ dskip,
+                                                   float* __restrict__ krev, int L, int stride) {
+    const int t = blockIdx.x * 256 + threadIdx.x, c = blockIdx.y;
+    if (t >= stride) return;
+    float v = 0.f;
+    if (t < L) {
+        v = k[(size_t)(L - 1 - t) * D + c];
+        if (t == L - 1) v += dskip[c];
+    }
+    krev[(size_t)c * stride + t] = v;
+}
+void launch_filter_reversed(const float* k, const float* dskip, float* krev, int L, int stride, hipStream_t st) {
+    hipLaunchKernelGGL(krev_kernel, dim3((stride + 255) / 256, D), dim3(256), 0, st, k, dskip, krev, L, stride);
+}
+
 // ---------------------------------------------------------------------------------------- filter spectrum
 // kf[c][m] = (1/N) sum_t k[t][c] exp(-2 pi i m t / N), double precision radix-2 in global scratch, one
 // workgroup per channel (runs once per distinct L).
@@ -133,7 +150,10 @@ int conv_logn_for(int L) {
 }
 
 // Long reads: S segments of SEG_LEN tokens, each convolved through the 16384-point transform (overlap-add).
-int conv_segments_for(int L) { return L <= SEG_LEN + 1 ? 1 : (L + SEG_LEN - 1) / SEG_LEN; }
+// A read of S*SEG_LEN + 1 tokens (every read truncated at a multiple of 8192 bases + [SEP]: 16385, 24577, 32769 = the model
+// maximum) does not get a segment of its own for the lone last token: see conv_lone_tail.
+int conv_segments_for(int L) { return L <= SEG_LEN + 1 ? 1 : (L - 1 + SEG_LEN - 1) / SEG_LEN; }
+bool conv_lone_tail(int L) { return L > SEG_LEN + 1 && (L - 1) % SEG_LEN == 0; }
 
 // 8 consecutive activations (one 16-byte vector for the 16-bit types, two for fp32) as floats
 template <typename T>
@@ -585,12 +605,16 @@ __global__ __launch_bounds__(Plan<LOGN>::NT) void hyena_conv_kernel(
 // convolution of two 8192-long pieces, 16383 <= N outputs: no wrap-around).  One workgroup walks the segments of
 // its (channel, read pair) in order; segment spectra G_i and the carried upper half p_{m-1}[Ls:] live in a global
 // scratch that each thread only ever re-reads where it wrote itself (no fences needed).
-template <typename T>
+// LONE: L = S*SEG_LEN + 1.  The S segments produce the outputs t < L-1 (causal: they need neither g[L-1] nor the taps beyond
+// S*SEG_LEN); the one remaining output is the full-length dot product y[L-1] = x0[L-1] * sum_t g[t] krev[c][t], whose partial
+// sums ride along with phase A of every segment -- instead of a whole transform pipeline for a single token (S+1 segments:
+// +25 % of the kernel at 32769 tokens, +50 % at 16385).
+template <typename T, bool LONE>
 __global__ __launch_bounds__(Plan<14>::NT) void hyena_conv_seg_kernel(
     const T* __restrict__ z, T* __restrict__ y, const float2* __restrict__ kf /*[256][S][N]*/,
     const float2* __restrict__ tw, const float* __restrict__ short_w, const float* __restrict__ short_b,
     float2* __restrict__ gscratch /*[pairs][256][S][N]*/, float2* __restrict__ carry /*[pairs][256][SEG_LEN]*/, int B,
-    int L, int Lp, int S) {
+    int L, int Lp, int S, const float* __restrict__ krev /*[256][krev_stride], LONE only*/, int krev_stride) {
     constexpr int LOGN = 14;
     using P = Plan<LOGN>;
     using TL = TwLayout<LOGN>;
@@ -611,6 +635,8 @@ __global__ __launch_bounds__(Plan<14>::NT) void hyena_conv_seg_kernel(
     const float2* kfc = kf + (size_t)c * S * N;
     float2* gs = gscratch + ((size_t)pair * D + c) * S * N;
     float2* cr = carry + ((size_t)pair * D + c) * SEG_LEN;
+    const float* kr = LONE ? krev + (size_t)c * krev_stride : nullptr;
+    float dotA = 0.f, dotB = 0.f;
 
     Cx2 wall[TL::TOTAL];
     {
@@ -715,6 +741,20 @@ __global__ __launch_bounds__(Plan<14>::NT) void hyena_conv_seg_kernel(
                 lds_store8(bim + pad_index(tl), gB);
             }
         }
+        if constexpr (LONE) {
+            // this segment's share of the last output's dot product: each thread re-reads the 16 gated samples it has just
+            // written (own data: no barrier needed) -- in phase A itself the 16 extra registers doubled the spills
+#pragma unroll
+            for (int ch = 0; ch < CH; ++ch) {
+                const int tl = 8 * (ltid + ch * NT);
+                float gA[8], gB[8], kk[8];
+                lds_load8(bre + pad_index(tl), gA);
+                lds_load8(bim + pad_index(tl), gB);
+                load8<float>(kr + seg0 + tl, kk);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) dotA = fmaf(gA[e], kk[e], dotA), dotB = fmaf(gB[e], kk[e], dotB);
+            }
+        }
         __syncthreads();                 // (upper half = zero padding: never written, never read -- pass_first_lower)
 
         // ---- forward transform
@@ -813,15 +853,47 @@ __global__ __launch_bounds__(Plan<14>::NT) void hyena_conv_seg_kernel(
         }
         __syncthreads();   // the LDS buffer is refilled by the next segment
     }
+    if constexpr (LONE) {
+        // y[L-1]: partial dot products of the 512 threads -> wave sums -> one thread; fixed order, deterministic
+        const float a = wave_sum(dotA), b = wave_sum(dotB);
+        if ((tid & 63) == 0) {
+            bre[tid >> 6] = a;
+            bim[tid >> 6] = b;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            const int t = L - 1;
+            float sa = 0.f, sbb = 0.f;
+#pragma unroll
+            for (int w = 0; w < NT / 64; ++w) sa += bre[w], sbb += bim[w];
+            const float k0 = kr[t];                          // tap 0 (+ skip term)
+            {
+                const float x0 = short_filter1<T>(zA + (size_t)(0 * D + c) * Lp, t, sw[0][0], sw[0][1], sw[0][2], sb[0]);
+                const float x1 = short_filter1<T>(zA + (size_t)(1 * D + c) * Lp, t, sw[1][0], sw[1][1], sw[1][2], sb[1]);
+                const float vv = short_filter1<T>(zA + (size_t)(2 * D + c) * Lp, t, sw[2][0], sw[2][1], sw[2][2], sb[2]);
+                yA[t] = from_float<T>(fmaf(vv * x1, k0, sa) * x0);
+            }
+            if (hasB) {
+                const float x0 = short_filter1<T>(zB + (size_t)(0 * D + c) * Lp, t, sw[0][0], sw[0][1], sw[0][2], sb[0]);
+                const float x1 = short_filter1<T>(zB + (size_t)(1 * D + c) * Lp, t, sw[1][0], sw[1][1], sw[1][2], sb[1]);
+                const float vv = short_filter1<T>(zB + (size_t)(2 * D + c) * Lp, t, sw[2][0], sw[2][1], sw[2][2], sb[2]);
+                yB[t] = from_float<T>(fmaf(vv * x1, k0, sbb) * x0);
+            }
+        }
+        for (int t = L + tid; t < Lp; t += NT) {             // padding columns stay zero
+            yA[t] = from_float<T>(0.f);
+            if (hasB) yB[t] = from_float<T>(0.f);
+        }
+    }
 }
 
-template <typename T>
-static void launch_conv_seg_t(const void* z, void* y, const float2* kf, const float2* tw, const float* short_w,
+template <typename T, bool LONE>
+static void launch_conv_seg_inst(const void* z, void* y, const float2* kf, const float2* tw, const float* short_w,
                               const float* short_b, float2* gscratch, float2* carry, int B, int L, int Lp, int S,
-                              hipStream_t st) {
+                              const float* krev, int krev_stride, hipStream_t st) {
     using P = Plan<14>;
     constexpr size_t lds = (size_t)2 * padded_size(P::N) * sizeof(float);
-    auto kern = hyena_conv_seg_kernel<T>;
+    auto kern = hyena_conv_seg_kernel<T, LONE>;
     static bool attr_done = false;
     if (!attr_done) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -830,18 +902,25 @@ static void launch_conv_seg_t(const void* z, void* y, const float2* kf, const fl
     }
     dim3 grid((B + 1) / 2, D), block(P::NT);
     hipLaunchKernelGGL(kern, grid, block, lds, st, reinterpret_cast<const T*>(z), reinterpret_cast<T*>(y), kf, tw,
-                       short_w, short_b, gscratch, carry, B, L, Lp, S);
+                       short_w, short_b, gscratch, carry, B, L, Lp, S, krev, krev_stride);
+}
+template <typename T>
+static void launch_conv_seg_t(const void* z, void* y, const float2* kf, const float2* tw, const float* short_w,
+                              const float* short_b, float2* gscratch, float2* carry, int B, int L, int Lp, int S,
+                              const float* krev, int krev_stride, hipStream_t st) {
+    if (krev) launch_conv_seg_inst<T, true>(z, y, kf, tw, short_w, short_b, gscratch, carry, B, L, Lp, S, krev, krev_stride, st);
+    else launch_conv_seg_inst<T, false>(z, y, kf, tw, short_w, short_b, gscratch, carry, B, L, Lp, S, nullptr, 0, st);
 }
 
 void launch_hyena_conv_seg(int prec, const void* z, void* y, const float2* kf, const float2* tw, const float* short_w,
                            const float* short_b, float2* gscratch, float2* carry, int B, int L, int Lp, int S,
-                           hipStream_t st) {
+                           const float* krev, int krev_stride, hipStream_t st) {
     if (prec == PREC_F32)
-        launch_conv_seg_t<float>(z, y, kf, tw, short_w, short_b, gscratch, carry, B, L, Lp, S, st);
+        launch_conv_seg_t<float>(z, y, kf, tw, short_w, short_b, gscratch, carry, B, L, Lp, S, krev, krev_stride, st);
     else if (prec == PREC_BF16)
-        launch_conv_seg_t<bf16_t>(z, y, kf, tw, short_w, short_b, gscratch, carry, B, L, Lp, S, st);
+        launch_conv_seg_t<bf16_t>(z, y, kf, tw, short_w, short_b, gscratch, carry, B, L, Lp, S, krev, krev_stride, st);
     else
-        launch_conv_seg_t<f16_t>(z, y, kf, tw, short_w, short_b, gscratch, carry, B, L, Lp, S, st);
+        launch_conv_seg_t<f16_t>(z, y, kf, tw, short_w, short_b, gscratch, carry, B, L, Lp, S, krev, krev_stride, st);
 }
 
 // ztab[id][n] = in_proj(LN1(embedding[id]))[n] of block 0, fp32: one workgroup per token id
