@@ -25,7 +25,7 @@ struct Tensor {
 };
 
 struct FilterSet {
-    int L = 0, logn = 0, S = 1;   // S > 1: segmented (overlap-add) long convolution, kf holds S spectra per channel
+    int L = 0, logn = 0, S = 1;   // S > 1: partitioned long convolution, kf holds S partition spectra per channel
     float* ktime[NLAYER] = {};
     float* krev[NLAYER] = {};     // conv_lone_tail(L) only: [256][krev_stride]
     int krev_stride = 0;
@@ -75,7 +75,7 @@ struct clm_handle {
     float* h = nullptr;
     void *z = nullptr, *y = nullptr, *u = nullptr;
     float *scores = nullptr, *stats = nullptr, *partial = nullptr, *pooled = nullptr;
-    float2 *gscratch = nullptr, *carry = nullptr;   // overlap-add scratch of the long-read convolution
+    float2* gscratch = nullptr;                     // segment spectra of the long-read convolution
     size_t gscratch_elems = 0;
     int last_B = 0, last_L = 0, last_Lp = 0;
     // debug / profiling
@@ -218,9 +218,9 @@ void free_filters(clm_handle* h) {
 
 void free_workspace(clm_handle* h) {
     for (void* p : {(void*)h->h, h->z, h->y, h->u, (void*)h->scores, (void*)h->stats, (void*)h->partial,
-                    (void*)h->pooled, (void*)h->gscratch, (void*)h->carry, (void*)h->ids8})
+                    (void*)h->pooled, (void*)h->gscratch, (void*)h->ids8})
         if (p) (void)hipFree(p);
-    h->gscratch = h->carry = nullptr;
+    h->gscratch = nullptr;
     h->gscratch_elems = 0;
     h->h = nullptr; h->z = h->y = h->u = nullptr;
     h->scores = h->stats = h->partial = h->pooled = nullptr;
@@ -264,7 +264,6 @@ int ensure_workspace(clm_handle* h, int Bc, int L, hipStream_t st) {
         const size_t pairs = (size_t)(nb + 1) / 2, S = (size_t)conv_segments_for(nl);
         h->gscratch_elems = pairs * D * S * 16384;
         HIPCHK(h, hipMalloc((void**)&h->gscratch, h->gscratch_elems * sizeof(float2)));
-        HIPCHK(h, hipMalloc((void**)&h->carry, pairs * D * SEG_LEN * sizeof(float2)));
     }
     HIPCHK(h, hipMemset(h->z, 0, n_z));   // padding columns [L, Lp) must never hold NaN garbage
     HIPCHK(h, hipMemset(h->y, 0, n_y));
@@ -318,12 +317,13 @@ int ensure_filters(clm_handle* h, int L, hipStream_t st, FilterSet** out) {
             launch_filter_reversed(f.ktime[i], W(h, p + "bias"), f.krev[i], L, f.krev_stride, st);
         }
         if (S == 1) {
-            launch_filter_spectrum(f.ktime[i], W(h, p + "bias"), f.kf[i], scratch, L, logn, 0, L, st);
+            launch_filter_spectrum(f.ktime[i], W(h, p + "bias"), f.kf[i], scratch, L, logn, 0, L, -1, st);
         } else {   // kf [256][S][N]: one launch per segment writes the strided slice through a temporary
             float2* tmp = nullptr;
             HIPCHK(h, hipMalloc((void**)&tmp, (size_t)D * N * sizeof(float2)));
             for (int j = 0; j < S; ++j) {
-                launch_filter_spectrum(f.ktime[i], W(h, p + "bias"), tmp, scratch, L, logn, j * SEG_LEN, SEG_LEN, st);
+                launch_filter_spectrum(f.ktime[i], W(h, p + "bias"), tmp, scratch, L, logn, j * SEG_LEN, SEG_LEN,
+                                       (j - 1) * SEG_LEN, st);
                 HIPCHK(h, hipMemcpy2DAsync(f.kf[i] + (size_t)j * N, (size_t)S * N * sizeof(float2), tmp,
                                            (size_t)N * sizeof(float2), (size_t)N * sizeof(float2), D,
                                            hipMemcpyDeviceToDevice, st));
@@ -411,8 +411,8 @@ int forward_chunk(clm_handle* h, const void* ids, int ids_dtype, int64_t row_str
                 launch_hyena_conv(prec, h->z, h->y, fs->kf[i], fs->tw, fs->ktime[i], lw.short_w, lw.short_b, Bc, L, Lp,
                                   fs->logn, idconv ? h->ids8 : nullptr, idconv ? h->ztab : nullptr, st);
             else
-                launch_hyena_conv_seg(prec, h->z, h->y, fs->kf[i], fs->tw, lw.short_w, lw.short_b, h->gscratch,
-                                      h->carry, Bc, L, Lp, fs->S, fs->krev[i], fs->krev_stride, st);
+                launch_hyena_conv_seg(prec, h->z, h->y, fs->kf[i], fs->tw, lw.short_w, lw.short_b, h->gscratch, Bc, L,
+                                      Lp, fs->S, fs->krev[i], fs->krev_stride, st);
         }
         if (stop_here(h, i, CLM_STAGE_CONV)) return CLM_OK;
         const bool stop_mid = stop_here(h, i, CLM_STAGE_OUTPROJ);

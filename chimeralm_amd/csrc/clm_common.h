@@ -173,7 +173,7 @@ size_t packed_weight_bytes(int prec, int n, int k);
 void launch_pack_weight(int prec, const float* w, void* out, int n, int k, hipStream_t st);
 
 // long convolution (hyena_conv.hip)
-constexpr int SEG_LEN = 8192;                     // tokens per segment of the overlap-add path (half a 16384 transform)
+constexpr int SEG_LEN = 8192;                     // tokens per segment of the long-read path (half a 16384 transform)
 int conv_logn_for(int L);                         // log2 of the single-shot FFT size for L tokens; <0 if L > 8193
 int conv_segments_for(int L);                     // 1 = single shot; >1 = number of 8192-token segments
 bool conv_lone_tail(int L);                       // long read of S*8192 + 1 tokens: the last output is a dot product (krev)
@@ -184,8 +184,9 @@ void launch_filter(const float* z /*[maxlen][5]*/, const float* t /*[maxlen]*/, 
                    const float* w6, const float* deltas, float* k_out /*[L][256]*/, int L, hipStream_t st);
 // spectrum of one layer's filter: kf [256][N] float2 = FFT_N(k[:, c]) / N (double precision inside);
 // scratch: 256*N double2
+// prev_off >= 0: taps [prev_off, prev_off + seg_len) additionally in the upper half of the block (long-read partitions)
 void launch_filter_spectrum(const float* k /*[L][256]*/, const float* dskip /*[256], folded into tap 0*/, float2* kf,
-                            double2* scratch, int L, int logn, int seg_off, int seg_len, hipStream_t st);
+                            double2* scratch, int L, int logn, int seg_off, int seg_len, int prev_off, hipStream_t st);
 void launch_twiddles(float2* tw, int logn, hipStream_t st);   // tw[m] = exp(-2 pi i m / N), m < N/2
 // y = ((causal_conv(v*x1, k) + D*(v*x1)) * x0)   with (x0,x1,v) = short_filter(z)    [B,256,Lp]; D lives in kf
 // ids8/ztab non-null (16-bit modes, block 0): x0|x1|v come from the 16-row table ztab[id][768] via the token ids
@@ -196,9 +197,10 @@ void launch_hyena_conv(int prec, const void* z, void* y, const float2* kf, const
 void launch_ztab(const float* emb, const float* g, const float* bta, const float* w, const float* bias, float* ztab,
                  float eps, hipStream_t st);
 
-// long reads (L > 8193): overlap-add over S segments; kf [256][S][N], gscratch [pairs][256][S][N], carry [pairs][256][8192]
+// long reads (L > 8193): partitioned convolution over S segments; kf [256][S][N] (segment j built with prev_off = (j-1)*SEG_LEN),
+// gscratch [pairs][256][S][N]
 void launch_hyena_conv_seg(int prec, const void* z, void* y, const float2* kf, const float2* tw, const float* short_w,
-                           const float* short_b, float2* gscratch, float2* carry, int B, int L, int Lp, int S,
+                           const float* short_b, float2* gscratch, int B, int L, int Lp, int S,
                            const float* krev /*null unless conv_lone_tail(L)*/, int krev_stride, hipStream_t st);
 
 // head (head.hip)

@@ -90,17 +90,19 @@ void launch_filter_reversed(const float* k, const float* dskip, float* krev, int
 // workgroup per channel (runs once per distinct L).
 // The skip term of fftconv, y += g * D[c], is a convolution with D[c]*delta: it is folded into tap 0 here, so the
 // convolution kernel needs neither D nor g after the transform.
-// Segment form (long reads): taps [seg_off, seg_off + seg_len) of the filter, zero-padded to N.
+// Segment form (long reads): taps [seg_off, seg_off + seg_len) of the filter in the lower half and, when prev_off >= 0, taps
+// [prev_off, prev_off + seg_len) in the upper half (overlap-save partition, see hyena_conv_seg_kernel); zero elsewhere.
 __global__ __launch_bounds__(256) void spectrum_kernel(const float* __restrict__ k, const float* __restrict__ dskip,
                                                        float2* __restrict__ kf, double2* __restrict__ scratch, int L,
-                                                       int logn, int seg_off, int seg_len) {
+                                                       int logn, int seg_off, int seg_len, int prev_off) {
     const int N = 1 << logn, c = blockIdx.x;
     double2* a = scratch + (size_t)c * N;
     for (int i = threadIdx.x; i < N; i += blockDim.x) {  // bit-reversed load
         int rv = __brev((unsigned)i) >> (32 - logn);
-        const int t = seg_off + i;
-        double v = (i < seg_len && t < L) ? (double)k[(size_t)t * D + c] : 0.0;
-        if (t == 0) v += (double)dskip[c];
+        const bool upper = prev_off >= 0 && i >= seg_len && i < 2 * seg_len;
+        const int t = upper ? prev_off + (i - seg_len) : seg_off + i;
+        double v = ((i < seg_len || upper) && t < L) ? (double)k[(size_t)t * D + c] : 0.0;
+        if (t == 0 && (i < seg_len || upper)) v += (double)dskip[c];
         a[rv] = make_double2(v, 0.0);
     }
     __syncthreads();
@@ -124,8 +126,9 @@ __global__ __launch_bounds__(256) void spectrum_kernel(const float* __restrict__
 }
 
 void launch_filter_spectrum(const float* k, const float* dskip, float2* kf, double2* scratch, int L, int logn,
-                            int seg_off, int seg_len, hipStream_t st) {
-    hipLaunchKernelGGL(spectrum_kernel, dim3(D), dim3(256), 0, st, k, dskip, kf, scratch, L, logn, seg_off, seg_len);
+                            int seg_off, int seg_len, int prev_off, hipStream_t st) {
+    hipLaunchKernelGGL(spectrum_kernel, dim3(D), dim3(256), 0, st, k, dskip, kf, scratch, L, logn, seg_off, seg_len,
+                       prev_off);
 }
 
 __global__ void twiddle_kernel(float2* tw, int logn) {
@@ -146,10 +149,10 @@ int conv_logn_for(int L) {
     if (L < 1) return -1;
     for (int logn = 8; logn <= 14; ++logn)
         if (2 * L - 2 <= (1 << logn)) return logn;
-    return -1;  // L > 8193: segmented overlap-add path (conv_segments_for)
+    return -1;  // L > 8193: partitioned path (conv_segments_for)
 }
 
-// Long reads: S segments of SEG_LEN tokens, each convolved through the 16384-point transform (overlap-add).
+// Long reads: S segments of SEG_LEN tokens, each through the 16384-point transform (hyena_conv_seg_kernel).
 // A read of S*SEG_LEN + 1 tokens (every read truncated at a multiple of 8192 bases + [SEP]: 16385, 24577, 32769 = the model
 // maximum) does not get a segment of its own for the lone last token: see conv_lone_tail.
 int conv_segments_for(int L) { return L <= SEG_LEN + 1 ? 1 : (L - 1 + SEG_LEN - 1) / SEG_LEN; }
@@ -599,12 +602,15 @@ __global__ __launch_bounds__(Plan<LOGN>::NT) void hyena_conv_kernel(
 
 
 // ================================================================================================ long reads
-// L > 8193 tokens does not fit one LDS-resident transform.  Overlap-add over S = ceil(L / 8192) segments:
-//     y[m*Ls + t] = p_m[t] + p_{m-1}[Ls + t],   p_m = IFFT( sum_{i+j=m} FFT(g_i) . FFT(k_j) ),   0 <= t < Ls
-// with g_i / k_j the i-th / j-th 8192-token segment of the gated signal / the filter (each product is a linear
-// convolution of two 8192-long pieces, 16383 <= N outputs: no wrap-around).  One workgroup walks the segments of
-// its (channel, read pair) in order; segment spectra G_i and the carried upper half p_{m-1}[Ls:] live in a global
-// scratch that each thread only ever re-reads where it wrote itself (no fences needed).
+// L > 8193 tokens does not fit one LDS-resident transform.  Uniformly partitioned convolution over S segments of Ls = 8192:
+//     y[m*Ls + t] = IFFT( sum_{i <= m} FFT(g_i) . K'_{m-i} )[t],   0 <= t < Ls
+// with g_i the i-th segment of the gated signal (zero-padded to N = 2 Ls) and K'_j the spectrum of the filter taps
+// [j Ls, (j+1) Ls) in the lower and [(j-1) Ls, j Ls) in the upper half of the transform (launch_filter_spectrum with prev_off):
+// the circular wrap of that upper half is exactly what plain overlap-add would carry over from the previous output segment
+// (K'_j = K_j + (-1)^k K_{j-1}), so nothing is carried in the time domain, only the lower half of each inverse transform is
+// needed (pruned last pass) and a segment moves 384 KB instead of 512 KB through HBM.  One workgroup walks the segments of
+// its (channel, read pair) in order; the segment spectra G_i live in a global scratch that each thread only ever re-reads
+// where it wrote itself (no fences needed); the last segment's spectrum is never stored.
 // LONE: L = S*SEG_LEN + 1.  The S segments produce the outputs t < L-1 (causal: they need neither g[L-1] nor the taps beyond
 // S*SEG_LEN); the one remaining output is the full-length dot product y[L-1] = x0[L-1] * sum_t g[t] krev[c][t], whose partial
 // sums ride along with phase A of every segment -- instead of a whole transform pipeline for a single token (S+1 segments:
@@ -613,8 +619,8 @@ template <typename T, bool LONE>
 __global__ __launch_bounds__(Plan<14>::NT) void hyena_conv_seg_kernel(
     const T* __restrict__ z, T* __restrict__ y, const float2* __restrict__ kf /*[256][S][N]*/,
     const float2* __restrict__ tw, const float* __restrict__ short_w, const float* __restrict__ short_b,
-    float2* __restrict__ gscratch /*[pairs][256][S][N]*/, float2* __restrict__ carry /*[pairs][256][SEG_LEN]*/, int B,
-    int L, int Lp, int S, const float* __restrict__ krev /*[256][krev_stride], LONE only*/, int krev_stride) {
+    float2* __restrict__ gscratch /*[pairs][256][S][N]*/, int B, int L, int Lp, int S,
+    const float* __restrict__ krev /*[256][krev_stride], LONE only*/, int krev_stride) {
     constexpr int LOGN = 14;
     using P = Plan<LOGN>;
     using TL = TwLayout<LOGN>;
@@ -634,7 +640,6 @@ __global__ __launch_bounds__(Plan<14>::NT) void hyena_conv_seg_kernel(
     T* yB = y + ((size_t)(hasB ? bB : bA) * D + c) * Lp;
     const float2* kfc = kf + (size_t)c * S * N;
     float2* gs = gscratch + ((size_t)pair * D + c) * S * N;
-    float2* cr = carry + ((size_t)pair * D + c) * SEG_LEN;
     const float* kr = LONE ? krev + (size_t)c * krev_stride : nullptr;
     float dotA = 0.f, dotB = 0.f;
 
@@ -784,8 +789,10 @@ __global__ __launch_bounds__(Plan<14>::NT) void hyena_conv_seg_kernel(
         for (int e = 0; e < 16; ++e) {            // keep G_m, start P_m = G_m K_0
             const int ba = stockham_in<LOGN, LAST>(G::jba(ltid, e / LAST), e % LAST);
             const int bb = stockham_in<LOGN, LAST>(G::jbb(ltid, e / LAST), e % LAST);
-            gs[(size_t)m * N + ba] = lane_a(v[e]);
-            gs[(size_t)m * N + bb] = lane_b(v[e]);
+            if (m + 1 < S) {                      // (uniform) the last segment's spectrum is never read again
+                gs[(size_t)m * N + ba] = lane_a(v[e]);
+                gs[(size_t)m * N + bb] = lane_b(v[e]);
+            }
             v[e] = Cx2::mul(v[e], pack2(kfc[ba], kfc[bb]));
         }
 #pragma unroll 1
@@ -816,14 +823,20 @@ __global__ __launch_bounds__(Plan<14>::NT) void hyena_conv_seg_kernel(
 #pragma unroll
             for (int p = 1; p <= P::NPASS - 1; ++p) {
                 pass_load<LOGN, 16>(bre, bim, v, ltid);
-                pass_compute_w<LOGN, 16, true>(v, ltid, true, wall + TL::inv(p));
-                __syncthreads();
-                pass_store<LOGN, 16>(bre, bim, v, ltid, Ns);
+                if (p == P::NPASS - 1) {   // only the lower half of the outputs is used: half-output butterfly, half the stores
+                    pass_compute_last_inverse_lower<LOGN>(v, ltid, wall + TL::inv(p));
+                    __syncthreads();
+                    pass_store_lower<LOGN>(bre, bim, v, ltid, false);
+                } else {
+                    pass_compute_w<LOGN, 16, true>(v, ltid, true, wall + TL::inv(p));
+                    __syncthreads();
+                    pass_store<LOGN, 16>(bre, bim, v, ltid, Ns);
+                }
                 __syncthreads();
                 Ns *= 16;
             }
         }
-        // ---- phase C: lower half + carried upper half of the previous segment -> y; keep this segment's upper half
+        // ---- phase C: the lower half is output segment m -> gate with x0 -> y
 #pragma unroll
         for (int ch = 0; ch < CH; ++ch) {
             const int tl = 8 * (ltid + ch * NT), t0 = seg0 + tl;
@@ -832,11 +845,6 @@ __global__ __launch_bounds__(Plan<14>::NT) void hyena_conv_seg_kernel(
             lds_load8(bim + pad_index(tl), oB);
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                if (m > 0) {
-                    const float2 cv = cr[tl + e];
-                    oA[e] += cv.x;
-                    oB[e] += cv.y;
-                }
                 const bool ok = t0 + e < L;
                 oA[e] = ok ? oA[e] * x0A[ch][e] : 0.f;
                 oB[e] = ok ? oB[e] * x0B[ch][e] : 0.f;
@@ -844,11 +852,6 @@ __global__ __launch_bounds__(Plan<14>::NT) void hyena_conv_seg_kernel(
             if (t0 < Lp) {
                 store8<T>(yA + t0, oA);
                 if (hasB) store8<T>(yB + t0, oB);
-            }
-            if (m + 1 < S) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e)
-                    cr[tl + e] = make_float2(bre[pad_index(HALF + tl + e)], bim[pad_index(HALF + tl + e)]);
             }
         }
         __syncthreads();   // the LDS buffer is refilled by the next segment
@@ -889,7 +892,7 @@ __global__ __launch_bounds__(Plan<14>::NT) void hyena_conv_seg_kernel(
 
 template <typename T, bool LONE>
 static void launch_conv_seg_inst(const void* z, void* y, const float2* kf, const float2* tw, const float* short_w,
-                              const float* short_b, float2* gscratch, float2* carry, int B, int L, int Lp, int S,
+                              const float* short_b, float2* gscratch, int B, int L, int Lp, int S,
                               const float* krev, int krev_stride, hipStream_t st) {
     using P = Plan<14>;
     constexpr size_t lds = (size_t)2 * padded_size(P::N) * sizeof(float);
@@ -902,25 +905,25 @@ static void launch_conv_seg_inst(const void* z, void* y, const float2* kf, const
     }
     dim3 grid((B + 1) / 2, D), block(P::NT);
     hipLaunchKernelGGL(kern, grid, block, lds, st, reinterpret_cast<const T*>(z), reinterpret_cast<T*>(y), kf, tw,
-                       short_w, short_b, gscratch, carry, B, L, Lp, S, krev, krev_stride);
+                       short_w, short_b, gscratch, B, L, Lp, S, krev, krev_stride);
 }
 template <typename T>
 static void launch_conv_seg_t(const void* z, void* y, const float2* kf, const float2* tw, const float* short_w,
-                              const float* short_b, float2* gscratch, float2* carry, int B, int L, int Lp, int S,
+                              const float* short_b, float2* gscratch, int B, int L, int Lp, int S,
                               const float* krev, int krev_stride, hipStream_t st) {
-    if (krev) launch_conv_seg_inst<T, true>(z, y, kf, tw, short_w, short_b, gscratch, carry, B, L, Lp, S, krev, krev_stride, st);
-    else launch_conv_seg_inst<T, false>(z, y, kf, tw, short_w, short_b, gscratch, carry, B, L, Lp, S, nullptr, 0, st);
+    if (krev) launch_conv_seg_inst<T, true>(z, y, kf, tw, short_w, short_b, gscratch, B, L, Lp, S, krev, krev_stride, st);
+    else launch_conv_seg_inst<T, false>(z, y, kf, tw, short_w, short_b, gscratch, B, L, Lp, S, nullptr, 0, st);
 }
 
 void launch_hyena_conv_seg(int prec, const void* z, void* y, const float2* kf, const float2* tw, const float* short_w,
-                           const float* short_b, float2* gscratch, float2* carry, int B, int L, int Lp, int S,
+                           const float* short_b, float2* gscratch, int B, int L, int Lp, int S,
                            const float* krev, int krev_stride, hipStream_t st) {
     if (prec == PREC_F32)
-        launch_conv_seg_t<float>(z, y, kf, tw, short_w, short_b, gscratch, carry, B, L, Lp, S, krev, krev_stride, st);
+        launch_conv_seg_t<float>(z, y, kf, tw, short_w, short_b, gscratch, B, L, Lp, S, krev, krev_stride, st);
     else if (prec == PREC_BF16)
-        launch_conv_seg_t<bf16_t>(z, y, kf, tw, short_w, short_b, gscratch, carry, B, L, Lp, S, krev, krev_stride, st);
+        launch_conv_seg_t<bf16_t>(z, y, kf, tw, short_w, short_b, gscratch, B, L, Lp, S, krev, krev_stride, st);
     else
-        launch_conv_seg_t<f16_t>(z, y, kf, tw, short_w, short_b, gscratch, carry, B, L, Lp, S, krev, krev_stride, st);
+        launch_conv_seg_t<f16_t>(z, y, kf, tw, short_w, short_b, gscratch, B, L, Lp, S, krev, krev_stride, st);
 }
 
 // ztab[id][n] = in_proj(LN1(embedding[id]))[n] of block 0, fp32: one workgroup per token id

@@ -147,9 +147,11 @@ def test_full_size_8k_reads(engines, sd, prec):
     _check(engines[prec], prec, ids, sd)
 
 
-@pytest.mark.parametrize("prec,B,L", [("fp32", 3, 8194), ("fp32", 2, 16385), ("fp16", 3, 20000)])
+@pytest.mark.parametrize("prec,B,L", [("fp32", 3, 8194), ("fp32", 2, 16385), ("fp16", 3, 20000), ("fp16", 3, 24577),
+                                      ("fp32", 1, 8200)])
 def test_long_reads_segmented_convolution(engines, sd, prec, B, L):
-    """L > 8193: overlap-add over 8192-token segments (2 and 3 segments, odd batch, segment with a single token)."""
+    """L > 8193: partitioned convolution over 8192-token segments (2 and 3 segments, odd batch, a last segment of 1, 2 and 8 tokens;
+    lengths S*8192 + 1 take the dot-product path for the lone last token: 16385 in fp32, 24577 in fp16 with an odd batch)."""
     _check(engines[prec], prec, _ids(B, L, seed=21, pads=5), sd)
 
 
