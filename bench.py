@@ -169,10 +169,13 @@ def main():
     from chimeralm_amd import distributed as cdist, lm
     from chimeralm_amd.engine import Engine
 
-    rank, local_rank, world = cdist.init_process_group("nccl")
+    # CLM_DIST_BACKEND=gloo is the rehearsal switch of tests/test_gpu_multirank.py: several ranks on ONE GPU (RCCL refuses two
+    # ranks per device), everything else -- sharding, gather, max-over-ranks timing, the JSON line -- as in the real run
+    backend = os.environ.get("CLM_DIST_BACKEND", "nccl")
+    rank, local_rank, world = cdist.init_process_group(backend)
     if world != a.gpus:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus}")
-    device = torch.device("cuda", local_rank)
+    device = torch.device("cuda", local_rank % torch.cuda.device_count() if backend != "nccl" else local_rank)
     torch.cuda.set_device(device)
     lo, hi = cdist.shard_bounds(a.batch, rank, world)
     L = a.bases + 1
