@@ -379,9 +379,9 @@ int forward_chunk(clm_handle* h, const void* ids, int ids_dtype, int64_t row_str
     if (rc) return rc;
     h->last_B = Bc; h->last_L = L; h->last_Lp = Lp;
     const bool tuned16 = prec != PREC_F32 && !h->force_generic;
-    // 16-bit modes, reads that fit one transform, no debug stop: block 0 never touches the fp32 embedding rows in HBM --
+    // 16-bit modes, no debug stop: block 0 never touches the fp32 embedding rows in HBM --
     // its in_proj is a 16-row table looked up by the convolution and its residual is gathered from the embedding table
-    const bool idpath = tuned16 && fs->S == 1 && !h->no_idconv && !h->split_tail && h->stop_stage < 0;
+    const bool idpath = tuned16 && !h->no_idconv && !h->split_tail && h->stop_stage < 0;
     // ... and every block's tail kernel goes on, on the tile it has just produced, with LayerNorm-1 + in_proj of the next
     // block (the last block: ln_f + attention scores + pooling partials): no separate in_proj / score launches
     const bool fuse_next = tuned16 && !h->split_tail && !h->no_fuse_next && h->stop_stage < 0;
@@ -397,8 +397,8 @@ int forward_chunk(clm_handle* h, const void* ids, int ids_dtype, int64_t row_str
     for (int i = 0; i < NLAYER; ++i) {
         const LayerW& lw = h->lw[i];
         // block 0 in the 16-bit modes: its in_proj output is a function of the token id alone, the convolution looks it
-        // up (ztab) -- unless a debug stop asks for z itself, the read needs the segmented kernel, or CLM_NO_IDCONV=1
-        const bool idconv = i == 0 && (idpath || (tuned16 && fs->S == 1 && !h->no_idconv && !stop_here(h, 0, CLM_STAGE_INPROJ)));
+        // up (ztab), single-shot and segmented kernel alike -- unless a debug stop asks for z itself or CLM_NO_IDCONV=1
+        const bool idconv = i == 0 && (idpath || (tuned16 && !h->no_idconv && !stop_here(h, 0, CLM_STAGE_INPROJ)));
         if (!idconv && !(fuse_next && i > 0)) {
             StageTimer t(h, st, CLM_STAGE_INPROJ);
             if (tuned16) launch_inproj16(prec, h->h, lw.ln1_g, lw.ln1_b, lw.w_in, lw.b_in, h->z, Bc, L, Lp, eps, st);
@@ -412,7 +412,8 @@ int forward_chunk(clm_handle* h, const void* ids, int ids_dtype, int64_t row_str
                                   fs->logn, idconv ? h->ids8 : nullptr, idconv ? h->ztab : nullptr, st);
             else
                 launch_hyena_conv_seg(prec, h->z, h->y, fs->kf[i], fs->tw, lw.short_w, lw.short_b, h->gscratch, Bc, L,
-                                      Lp, fs->S, fs->krev[i], fs->krev_stride, st);
+                                      Lp, fs->S, fs->krev[i], fs->krev_stride, idconv ? h->ids8 : nullptr,
+                                      idconv ? h->ztab : nullptr, st);
         }
         if (stop_here(h, i, CLM_STAGE_CONV)) return CLM_OK;
         const bool stop_mid = stop_here(h, i, CLM_STAGE_OUTPROJ);

@@ -201,7 +201,9 @@ void launch_ztab(const float* emb, const float* g, const float* bta, const float
 // gscratch [pairs][256][S][N]
 void launch_hyena_conv_seg(int prec, const void* z, void* y, const float2* kf, const float2* tw, const float* short_w,
                            const float* short_b, float2* gscratch, int B, int L, int Lp, int S,
-                           const float* krev /*null unless conv_lone_tail(L)*/, int krev_stride, hipStream_t st);
+                           const float* krev /*null unless conv_lone_tail(L)*/, int krev_stride,
+                           const unsigned char* ids8 /*16-bit modes, block 0: as launch_hyena_conv*/, const float* ztab,
+                           hipStream_t st);
 
 // head (head.hip)
 void launch_softmax_stats(const float* scores, float* stats /*[B][2] = max, sum*/, int B, int L, hipStream_t st);

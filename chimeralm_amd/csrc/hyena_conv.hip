@@ -300,6 +300,9 @@ __device__ __forceinline__ void raw_decode(const Raw<T>& r, int t0, bool valid, 
     }
 }
 // IDS source: x[a3][0..9] = table row a3 of the ten token ids t0-2 .. t0+7 (zero outside the read)
+// SELECT: load every entry and select afterwards (ids are always inside the 16-row table).  The segmented kernel needs that
+// form: there hipcc turns the conditional loads into one divergent branch per element (1,600 spilled registers).
+template <bool SELECT = false>
 __device__ __forceinline__ void ids_decode(uint2 d, unsigned short p, int t0, bool valid, const float* zt, float (*x)[10]) {
     const unsigned w[3] = {p, d.x, d.y};
 #pragma unroll
@@ -308,7 +311,14 @@ __device__ __forceinline__ void ids_decode(uint2 d, unsigned short p, int t0, bo
         const unsigned id = (w[j < 2 ? 0 : 1 + ((j - 2) >> 2)] >> sh) & 15u;
         const bool ok = j < 2 ? (valid && t0 > 0) : valid;
 #pragma unroll
-        for (int a3 = 0; a3 < 3; ++a3) x[a3][j] = ok ? zt[a3 * 16 + id] : 0.f;
+        for (int a3 = 0; a3 < 3; ++a3) {
+            if constexpr (SELECT) {
+                const float val = zt[a3 * 16 + id];
+                x[a3][j] = ok ? val : 0.f;
+            } else {
+                x[a3][j] = ok ? zt[a3 * 16 + id] : 0.f;
+            }
+        }
     }
 }
 __device__ __forceinline__ void fir3(const float* x /*[10]*/, float w0, float w1, float w2, float bias, float* out /*[8]*/) {
@@ -615,12 +625,14 @@ __global__ __launch_bounds__(Plan<LOGN>::NT) void hyena_conv_kernel(
 // S*SEG_LEN); the one remaining output is the full-length dot product y[L-1] = x0[L-1] * sum_t g[t] krev[c][t], whose partial
 // sums ride along with phase A of every segment -- instead of a whole transform pipeline for a single token (S+1 segments:
 // +25 % of the kernel at 32769 tokens, +50 % at 16385).
-template <typename T, bool LONE>
+// IDS (16-bit modes, block 0): x0 | x1 | v looked up in ztab by token id, as in hyena_conv_kernel.
+template <typename T, bool LONE, bool IDS>
 __global__ __launch_bounds__(Plan<14>::NT) void hyena_conv_seg_kernel(
     const T* __restrict__ z, T* __restrict__ y, const float2* __restrict__ kf /*[256][S][N]*/,
     const float2* __restrict__ tw, const float* __restrict__ short_w, const float* __restrict__ short_b,
     float2* __restrict__ gscratch /*[pairs][256][S][N]*/, int B, int L, int Lp, int S,
-    const float* __restrict__ krev /*[256][krev_stride], LONE only*/, int krev_stride) {
+    const float* __restrict__ krev /*[256][krev_stride], LONE only*/, int krev_stride,
+    const unsigned char* __restrict__ ids8 /*[B][Lp], IDS only*/, const float* __restrict__ ztab /*[16][768]*/) {
     constexpr int LOGN = 14;
     using P = Plan<LOGN>;
     using TL = TwLayout<LOGN>;
@@ -666,6 +678,13 @@ __global__ __launch_bounds__(Plan<14>::NT) void hyena_conv_seg_kernel(
         for (int e = 0; e < 3; ++e) sw[q][e] = short_w[(q * D + c) * 3 + e];
         sb[q] = short_b[q * D + c];
     }
+    float* zt = bim + padded_size(N) + 4;                    // IDS: [3][16] rows x0 | x1 | v of this channel
+    const unsigned char* irA = IDS ? ids8 + (size_t)bA * Lp : nullptr;
+    const unsigned char* irB = IDS ? ids8 + (size_t)(hasB ? bB : bA) * Lp : nullptr;
+    if constexpr (IDS) {
+        if (tid < 48) zt[tid] = ztab[(size_t)(tid & 15) * D3 + (tid >> 4) * D + c];
+        __syncthreads();
+    }
 
 #pragma unroll 1
     for (int m = 0; m < S; ++m) {
@@ -674,6 +693,11 @@ __global__ __launch_bounds__(Plan<14>::NT) void hyena_conv_seg_kernel(
         // passes out of this loop and ~1000 VGPRs spill.
         int ltid = tid;
         asm volatile("" : "+v"(ltid));
+        int lz = 0;                        // same for the id table and the id rows (IDS): an opaque zero added to their bases
+        asm volatile("" : "+v"(lz));
+        const float* ztm = zt + lz;
+        const unsigned char* irAm = IDS ? irA + lz : nullptr;
+        const unsigned char* irBm = IDS ? irB + lz : nullptr;
 #pragma unroll
         for (int i = 0; i < TL::TOTAL; ++i)                                                  // same for w^r trees
             asm volatile("" : "+v"(wall[i].re.x), "+v"(wall[i].re.y), "+v"(wall[i].im.x), "+v"(wall[i].im.y));
@@ -681,27 +705,46 @@ __global__ __launch_bounds__(Plan<14>::NT) void hyena_conv_seg_kernel(
         float x0A[CH][8], x0B[CH][8];
         if constexpr (!std::is_same<T, float>::value) {
             // all loads of the segment up front, no control flow in between (see Raw<T>): six serialized HBM round trips otherwise
-            Raw<T> raw[CH][2][3];
+            Raw<T> raw[IDS ? 1 : CH][2][IDS ? 1 : 3];
+            uint2 idd[CH][2];                                // IDS: 8 token ids of the chunk
+            unsigned short idp[CH][2];                       //      and the two before it
+            if constexpr (IDS) {
 #pragma unroll
-            for (int rd = 0; rd < 2; ++rd)
-#pragma unroll
-                for (int a3 = 0; a3 < 3; ++a3) {
-                    const T* row = (rd == 0 ? zA : zB) + (size_t)(a3 * D + c) * Lp;
+                for (int rd = 0; rd < 2; ++rd)
 #pragma unroll
                     for (int ch = 0; ch < CH; ++ch) {
                         const int t0 = seg0 + 8 * (ltid + ch * NT);
-                        raw_load(raw[ch][rd][a3], row, t0, t0 < L);
+                        const unsigned char* ir = rd == 0 ? irAm : irBm;
+                        idd[ch][rd] = *reinterpret_cast<const uint2*>(ir + (t0 < L ? t0 : 0));
+                        idp[ch][rd] = *reinterpret_cast<const unsigned short*>(ir + ((t0 < L && t0 > 0) ? t0 - 2 : 0));
                     }
-                }
+            } else {
+#pragma unroll
+                for (int rd = 0; rd < 2; ++rd)
+#pragma unroll
+                    for (int a3 = 0; a3 < 3; ++a3) {
+                        const T* row = (rd == 0 ? zA : zB) + (size_t)(a3 * D + c) * Lp;
+#pragma unroll
+                        for (int ch = 0; ch < CH; ++ch) {
+                            const int t0 = seg0 + 8 * (ltid + ch * NT);
+                            raw_load(raw[ch][rd][a3], row, t0, t0 < L);
+                        }
+                    }
+            }
 #pragma unroll
             for (int ch = 0; ch < CH; ++ch) {
                 const int tl = 8 * (ltid + ch * NT), t0 = seg0 + tl;
                 const bool valid = t0 < L;
                 float xa[3][10], xb[3][10], gA[8], gB[8], x1[8], v[8];
+                if constexpr (IDS) {
+                    ids_decode<true>(idd[ch][0], idp[ch][0], t0, valid, ztm, xa);
+                    ids_decode<true>(idd[ch][1], idp[ch][1], t0, valid && hasB, ztm, xb);
+                } else {
 #pragma unroll
-                for (int a3 = 0; a3 < 3; ++a3) {
-                    raw_decode(raw[ch][0][a3], t0, valid, xa[a3]);
-                    raw_decode(raw[ch][1][a3], t0, valid && hasB, xb[a3]);
+                    for (int a3 = 0; a3 < 3; ++a3) {
+                        raw_decode(raw[ch][0][a3], t0, valid, xa[a3]);
+                        raw_decode(raw[ch][1][a3], t0, valid && hasB, xb[a3]);
+                    }
                 }
                 fir3(xa[0], sw[0][0], sw[0][1], sw[0][2], sb[0], x0A[ch]);
                 fir3(xa[1], sw[1][0], sw[1][1], sw[1][2], sb[1], x1);
@@ -870,18 +913,19 @@ __global__ __launch_bounds__(Plan<14>::NT) void hyena_conv_seg_kernel(
 #pragma unroll
             for (int w = 0; w < NT / 64; ++w) sa += bre[w], sbb += bim[w];
             const float k0 = kr[t];                          // tap 0 (+ skip term)
-            {
-                const float x0 = short_filter1<T>(zA + (size_t)(0 * D + c) * Lp, t, sw[0][0], sw[0][1], sw[0][2], sb[0]);
-                const float x1 = short_filter1<T>(zA + (size_t)(1 * D + c) * Lp, t, sw[1][0], sw[1][1], sw[1][2], sb[1]);
-                const float vv = short_filter1<T>(zA + (size_t)(2 * D + c) * Lp, t, sw[2][0], sw[2][1], sw[2][2], sb[2]);
-                yA[t] = from_float<T>(fmaf(vv * x1, k0, sa) * x0);
-            }
-            if (hasB) {
-                const float x0 = short_filter1<T>(zB + (size_t)(0 * D + c) * Lp, t, sw[0][0], sw[0][1], sw[0][2], sb[0]);
-                const float x1 = short_filter1<T>(zB + (size_t)(1 * D + c) * Lp, t, sw[1][0], sw[1][1], sw[1][2], sb[1]);
-                const float vv = short_filter1<T>(zB + (size_t)(2 * D + c) * Lp, t, sw[2][0], sw[2][1], sw[2][2], sb[2]);
-                yB[t] = from_float<T>(fmaf(vv * x1, k0, sbb) * x0);
-            }
+            // short filter of the one token t (t >= 2 here) on row a3 of read rd: from z, or from the id table
+            auto filt = [&](int rd, int a3) {
+                if constexpr (IDS) {
+                    const unsigned char* ir = rd == 0 ? irA : irB;
+                    const float* r = zt + a3 * 16;
+                    return sb[a3] + sw[a3][0] * r[ir[t - 2] & 15] + sw[a3][1] * r[ir[t - 1] & 15] + sw[a3][2] * r[ir[t] & 15];
+                } else {
+                    return short_filter1<T>((rd == 0 ? zA : zB) + (size_t)(a3 * D + c) * Lp, t, sw[a3][0], sw[a3][1], sw[a3][2],
+                                            sb[a3]);
+                }
+            };
+            yA[t] = from_float<T>(fmaf(filt(0, 2) * filt(0, 1), k0, sa) * filt(0, 0));
+            if (hasB) yB[t] = from_float<T>(fmaf(filt(1, 2) * filt(1, 1), k0, sbb) * filt(1, 0));
         }
         for (int t = L + tid; t < Lp; t += NT) {             // padding columns stay zero
             yA[t] = from_float<T>(0.f);
@@ -890,13 +934,14 @@ __global__ __launch_bounds__(Plan<14>::NT) void hyena_conv_seg_kernel(
     }
 }
 
-template <typename T, bool LONE>
+template <typename T, bool LONE, bool IDS>
 static void launch_conv_seg_inst(const void* z, void* y, const float2* kf, const float2* tw, const float* short_w,
                               const float* short_b, float2* gscratch, int B, int L, int Lp, int S,
-                              const float* krev, int krev_stride, hipStream_t st) {
+                              const float* krev, int krev_stride, const unsigned char* ids8, const float* ztab,
+                              hipStream_t st) {
     using P = Plan<14>;
-    constexpr size_t lds = (size_t)2 * padded_size(P::N) * sizeof(float);
-    auto kern = hyena_conv_seg_kernel<T, LONE>;
+    constexpr size_t lds = (size_t)2 * padded_size(P::N) * sizeof(float) + 256;   // + the 3x16 id table
+    auto kern = hyena_conv_seg_kernel<T, LONE, IDS>;
     static bool attr_done = false;
     if (!attr_done) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -905,25 +950,36 @@ static void launch_conv_seg_inst(const void* z, void* y, const float2* kf, const
     }
     dim3 grid((B + 1) / 2, D), block(P::NT);
     hipLaunchKernelGGL(kern, grid, block, lds, st, reinterpret_cast<const T*>(z), reinterpret_cast<T*>(y), kf, tw,
-                       short_w, short_b, gscratch, B, L, Lp, S, krev, krev_stride);
+                       short_w, short_b, gscratch, B, L, Lp, S, krev, krev_stride, ids8, ztab);
 }
 template <typename T>
 static void launch_conv_seg_t(const void* z, void* y, const float2* kf, const float2* tw, const float* short_w,
-                              const float* short_b, float2* gscratch, int B, int L, int Lp, int S,
-                              const float* krev, int krev_stride, hipStream_t st) {
-    if (krev) launch_conv_seg_inst<T, true>(z, y, kf, tw, short_w, short_b, gscratch, B, L, Lp, S, krev, krev_stride, st);
-    else launch_conv_seg_inst<T, false>(z, y, kf, tw, short_w, short_b, gscratch, B, L, Lp, S, nullptr, 0, st);
+                              const float* short_b, float2* gscratch, int B, int L, int Lp, int S, const float* krev,
+                              int krev_stride, const unsigned char* ids8, const float* ztab, hipStream_t st) {
+#define CLM_SEG(LONE, IDS)                                                                                               \
+    launch_conv_seg_inst<T, LONE, IDS>(z, y, kf, tw, short_w, short_b, gscratch, B, L, Lp, S, krev, krev_stride, ids8, ztab, st)
+    if constexpr (std::is_same<T, float>::value) {           // fp32 mode never takes the id path
+        if (krev) CLM_SEG(true, false);
+        else CLM_SEG(false, false);
+    } else {
+        const bool ids = ids8 != nullptr && ztab != nullptr;
+        if (krev && ids) CLM_SEG(true, true);
+        else if (krev) CLM_SEG(true, false);
+        else if (ids) CLM_SEG(false, true);
+        else CLM_SEG(false, false);
+    }
+#undef CLM_SEG
 }
 
 void launch_hyena_conv_seg(int prec, const void* z, void* y, const float2* kf, const float2* tw, const float* short_w,
-                           const float* short_b, float2* gscratch, int B, int L, int Lp, int S,
-                           const float* krev, int krev_stride, hipStream_t st) {
+                           const float* short_b, float2* gscratch, int B, int L, int Lp, int S, const float* krev,
+                           int krev_stride, const unsigned char* ids8, const float* ztab, hipStream_t st) {
     if (prec == PREC_F32)
-        launch_conv_seg_t<float>(z, y, kf, tw, short_w, short_b, gscratch, B, L, Lp, S, krev, krev_stride, st);
+        launch_conv_seg_t<float>(z, y, kf, tw, short_w, short_b, gscratch, B, L, Lp, S, krev, krev_stride, nullptr, nullptr, st);
     else if (prec == PREC_BF16)
-        launch_conv_seg_t<bf16_t>(z, y, kf, tw, short_w, short_b, gscratch, B, L, Lp, S, krev, krev_stride, st);
+        launch_conv_seg_t<bf16_t>(z, y, kf, tw, short_w, short_b, gscratch, B, L, Lp, S, krev, krev_stride, ids8, ztab, st);
     else
-        launch_conv_seg_t<f16_t>(z, y, kf, tw, short_w, short_b, gscratch, B, L, Lp, S, krev, krev_stride, st);
+        launch_conv_seg_t<f16_t>(z, y, kf, tw, short_w, short_b, gscratch, B, L, Lp, S, krev, krev_stride, ids8, ztab, st);
 }
 
 // ztab[id][n] = in_proj(LN1(embedding[id]))[n] of block 0, fp32: one workgroup per token id

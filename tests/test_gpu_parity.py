@@ -117,6 +117,24 @@ def test_determinism_and_chunk_invariance(sd, built_lib):
     e1.close(), e2.close()
 
 
+@pytest.mark.parametrize("L", [9000, 16385])
+def test_block0_id_table_long_reads(sd, built_lib, monkeypatch, L):
+    """Same for the segmented kernel (L > 8193), incl. the dot-product path of the lone last token (16385)."""
+    from chimeralm_amd.engine import Engine
+
+    ids = _ids(3, L, seed=6, pads=3).astype(np.int64)
+    ids[0, 8190:8196] = [11, 0, 1, 2, 3, 15]                # specials across the first segment boundary
+    t = torch.from_numpy(ids).cuda()
+    e1 = Engine("cuda:0", precision="fp16", chunk_reads=4)
+    monkeypatch.setenv("CLM_NO_IDCONV", "1")
+    e2 = Engine("cuda:0", precision="fp16", chunk_reads=4)
+    monkeypatch.delenv("CLM_NO_IDCONV")
+    e1.load_state_dict(sd), e2.load_state_dict(sd)
+    a, b = e1.forward(t).cpu(), e2.forward(t).cpu()
+    assert (a - b).abs().max() < TOL["fp16"]
+    e1.close(), e2.close()
+
+
 @pytest.mark.parametrize("prec", ["fp16", "bf16"])
 def test_block0_id_table_convolution_matches_in_proj_path(sd, built_lib, monkeypatch, prec):
     """16-bit modes skip block 0's in_proj: the convolution looks x0|x1|v up by token id (ztab).  Same logits as the
