@@ -205,6 +205,34 @@ def test_baseline_batch_size_independent_properties(sd, built_lib):
     e.close()
 
 
+def test_shape_churn_filter_cache_and_workspace_regrowth(sd, built_lib):
+    """A stream of batches of changing shape through ONE engine: the per-length filter sets are an LRU of three (evicted and
+    rebuilt), the workspace grows on demand, short and long-read kernels alternate.  Every result must equal the one the
+    same shape gave the first time (bit-identical: no state leaks between calls), and the short ones the oracle's."""
+    from chimeralm_amd.engine import Engine
+
+    e = Engine("cuda:0", precision="fp16", chunk_reads=4)
+    e.load_state_dict(sd)
+    rng = np.random.default_rng(17)
+    shapes = [(2, 300), (5, 1000), (1, 9000), (3, 129), (2, 16385), (7, 2049), (1, 2), (4, 8193), (3, 8200)]
+    first = {}
+    order = list(range(len(shapes))) * 3
+    rng.shuffle(order)
+    for k in order:
+        B, L = shapes[k]
+        ids = _ids(B, L, seed=100 + k)
+        out = e.forward(torch.from_numpy(ids).cuda()).cpu()
+        assert torch.isfinite(out).all()
+        if k not in first:
+            first[k] = out
+            if L <= 2049:
+                ref = ho.forward(torch.from_numpy(ids.astype(np.int64)), sd)
+                assert (out - ref).abs().max() <= TOL["fp16"]
+        else:
+            assert torch.equal(out, first[k]), f"shape {shapes[k]} changed after other shapes ran"
+    e.close()
+
+
 def test_collated_bam_batch_against_oracle(engines, sd, golden_dir):
     """configs[0] plumbing: real reads -> tokenizer -> collator (left pad) -> engine == oracle on the same batch."""
     from chimeralm_amd import bam, tokenizer as T
