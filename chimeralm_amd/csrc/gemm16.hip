@@ -587,24 +587,27 @@ __global__ __launch_bounds__(512) void tail16_kernel(TailArgs m, unsigned long l
                 acc2[mt][4 * q + 3] += bb.w;
             }
         }
-        float* rs = reinterpret_cast<float*>(smem) + wave * (128 * 32);
+        // (the last block's output is consumed on chip by the score / pooling stage below and by nothing else: not stored)
+        if constexpr (NEXT != NEXT_SCORE) {
+            float* rs = reinterpret_cast<float*>(smem) + wave * (128 * 32);
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt) {
-            const int tok = mt * 32 + lrow;
+            for (int mt = 0; mt < 4; ++mt) {
+                const int tok = mt * 32 + lrow;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int chunk = (2 * q + lhalf) ^ (tok & 7);
-                *reinterpret_cast<float4*>(rs + tok * 32 + 4 * chunk) =
-                    make_float4(acc2[mt][4 * q + 0], acc2[mt][4 * q + 1], acc2[mt][4 * q + 2], acc2[mt][4 * q + 3]);
+                for (int q = 0; q < 4; ++q) {
+                    const int chunk = (2 * q + lhalf) ^ (tok & 7);
+                    *reinterpret_cast<float4*>(rs + tok * 32 + 4 * chunk) =
+                        make_float4(acc2[mt][4 * q + 0], acc2[mt][4 * q + 1], acc2[mt][4 * q + 2], acc2[mt][4 * q + 3]);
+                }
             }
-        }
-        const int c = lane & 7, rsub = lane >> 3;
-        float* hrow = m.h + ((size_t)b * L + t0) * D + wave * 32 + 4 * c;
+            const int c = lane & 7, rsub = lane >> 3;
+            float* hrow = m.h + ((size_t)b * L + t0) * D + wave * 32 + 4 * c;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int tr = i * 8 + rsub;
-            const float4 a = *reinterpret_cast<const float4*>(rs + tr * 32 + 4 * (c ^ (tr & 7)));
-            if (t0 + tr < L) *reinterpret_cast<float4*>(hrow + (size_t)tr * D) = a;
+            for (int i = 0; i < 16; ++i) {
+                const int tr = i * 8 + rsub;
+                const float4 a = *reinterpret_cast<const float4*>(rs + tr * 32 + 4 * (c ^ (tr & 7)));
+                if (t0 + tr < L) *reinterpret_cast<float4*>(hrow + (size_t)tr * D) = a;
+            }
         }
     }
     CLM_STAMP_AT(18);
