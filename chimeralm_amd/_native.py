@@ -35,7 +35,7 @@ class ClmConfig(C.Structure):
 class ClmFeederConfig(C.Structure):          # include/chimeralm_feed.h: struct clm_feeder_config
     _fields_ = [("struct_size", C.c_int32), ("batch_size", C.c_int32), ("max_tokens", C.c_int32), ("slots", C.c_int32),
                 ("rank", C.c_int32), ("world", C.c_int32), ("pad_left", C.c_int32), ("pinned", C.c_int32),
-                ("max_reads", C.c_int64)]
+                ("max_reads", C.c_int64), ("inflate_threads", C.c_int32), ("reserved", C.c_int32)]
 
 
 class ClmFeedBatch(C.Structure):              # include/chimeralm_feed.h: struct clm_feed_batch

@@ -52,7 +52,7 @@ struct Slot {
 struct clm_feeder {
     clm_feeder_config cfg{};
     std::string path, err;
-    clmbgzf::Reader rd;
+    clmbgzf::ParallelReader rd;
     std::vector<Slot> ring;
     uint8_t* slab_ids = nullptr;
     int8_t* slab_names = nullptr;
@@ -258,18 +258,26 @@ int clm_feeder_default_config(clm_feeder_config* cfg) {
     cfg->pad_left = 1;
     cfg->pinned = 1;
     cfg->max_reads = -1;
+    cfg->inflate_threads = 0;      // automatic
     return CLM_OK;
 }
 
 int clm_feeder_open(const char* bam_path, const clm_feeder_config* cfg, clm_feeder** out) {
     if (!bam_path || !cfg || !out) return fail_open(CLM_E_INVALID, "clm_feeder_open: null argument");
     if (cfg->struct_size != (int32_t)sizeof(clm_feeder_config)) return fail_open(CLM_E_INVALID, "clm_feeder_open: struct_size mismatch");
-    if (cfg->batch_size < 1 || cfg->max_tokens < 2 || cfg->slots < 2 || cfg->world < 1 || cfg->rank < 0 || cfg->rank >= cfg->world)
-        return fail_open(CLM_E_INVALID, "clm_feeder_open: bad batch_size / max_tokens / slots / rank / world");
+    if (cfg->batch_size < 1 || cfg->max_tokens < 2 || cfg->slots < 2 || cfg->world < 1 || cfg->rank < 0 || cfg->rank >= cfg->world ||
+        cfg->inflate_threads < 0 || cfg->inflate_threads > 256)
+        return fail_open(CLM_E_INVALID, "clm_feeder_open: bad batch_size / max_tokens / slots / rank / world / inflate_threads");
     clm_feeder* f = new clm_feeder();
     f->cfg = *cfg;
     f->path = bam_path;
-    if (!f->rd.open(bam_path)) {
+    int threads = cfg->inflate_threads;
+    if (threads <= 0) {   // every rank inflates the whole file (rank::world selection needs every record): share the cores
+        const int cores = (int)std::thread::hardware_concurrency();
+        threads = cores / cfg->world - 2;
+        threads = threads < 1 ? 1 : threads > 8 ? 8 : threads;
+    }
+    if (!f->rd.open(bam_path, threads)) {
         const std::string msg = f->rd.err;
         delete f;
         return fail_open(CLM_E_INVALID, msg);

@@ -5,13 +5,90 @@
 #pragma once
 #include <zlib.h>
 
+#include <condition_variable>
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <deque>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 namespace clmbgzf {
+
+// One member's framing: reads the gzip header, the BC subfield and the compressed bytes + trailer into `zin`.
+// 1 = ok (cdata bytes of deflate data, then CRC32 and ISIZE), 0 = clean end of file, -1 = error (err set)
+inline int read_member(FILE* fp, const std::string& path, std::vector<uint8_t>& zin, size_t& cdata, uint32_t& crc,
+                       uint32_t& isize, std::string& err) {
+    uint8_t head[12];
+    const size_t got = std::fread(head, 1, sizeof(head), fp);
+    if (got == 0) return 0;
+    if (got != sizeof(head) || head[0] != 31 || head[1] != 139 || head[2] != 8 || !(head[3] & 4)) {
+        err = path + ": not a BGZF block (bad gzip member header)";
+        return -1;
+    }
+    const unsigned xlen = head[10] | (head[11] << 8);
+    std::vector<uint8_t> extra(xlen);
+    if (std::fread(extra.data(), 1, xlen, fp) != xlen) {
+        err = path + ": truncated BGZF extra field";
+        return -1;
+    }
+    int bsize = -1;
+    for (size_t p = 0; p + 4 <= xlen;) {
+        const unsigned slen = extra[p + 2] | (extra[p + 3] << 8);
+        if (extra[p] == 'B' && extra[p + 1] == 'C' && slen == 2 && p + 6 <= xlen) bsize = extra[p + 4] | (extra[p + 5] << 8);
+        p += 4 + slen;
+    }
+    const long cd = (long)bsize + 1 - 12 - (long)xlen - 8;
+    if (bsize < 0 || cd < 0) {
+        err = path + ": BGZF block without a valid BC subfield";
+        return -1;
+    }
+    cdata = (size_t)cd;
+    zin.resize(cdata + 8);
+    if (std::fread(zin.data(), 1, zin.size(), fp) != zin.size()) {
+        err = path + ": truncated BGZF block";
+        return -1;
+    }
+    const uint8_t* tail = zin.data() + cdata;
+    crc = tail[0] | (tail[1] << 8) | (tail[2] << 16) | ((uint32_t)tail[3] << 24);
+    isize = tail[4] | (tail[5] << 8) | (tail[6] << 16) | ((uint32_t)tail[7] << 24);
+    if (isize > 65536) {
+        err = path + ": BGZF block claims more than 64 KiB of payload";
+        return -1;
+    }
+    return 1;
+}
+
+// Inflates one member's `cdata` bytes into out[0..isize) and checks the CRC; zs is (re)used across calls.
+inline bool inflate_member(z_stream& zs, bool& zs_ready, const std::string& path, const uint8_t* zin, size_t cdata, uint32_t crc,
+                           uint32_t isize, uint8_t* out, std::string& err) {
+    if (!zs_ready) {
+        std::memset(&zs, 0, sizeof(zs));
+        if (inflateInit2(&zs, -15) != Z_OK) {
+            err = "zlib inflateInit2 failed";
+            return false;
+        }
+        zs_ready = true;
+    } else {
+        inflateReset(&zs);
+    }
+    zs.next_in = const_cast<uint8_t*>(zin);
+    zs.avail_in = (uInt)cdata;
+    zs.next_out = out;
+    zs.avail_out = isize;
+    const int rc = inflate(&zs, Z_FINISH);
+    if (rc != Z_STREAM_END || zs.avail_out != 0) {
+        err = path + ": corrupt BGZF block (inflate failed)";
+        return false;
+    }
+    if ((uint32_t)crc32(crc32(0L, Z_NULL, 0), out, isize) != crc) {
+        err = path + ": corrupt BGZF block (CRC mismatch)";
+        return false;
+    }
+    return true;
+}
 
 struct Reader {
     std::string path, err;
@@ -36,53 +113,11 @@ struct Reader {
 
     // appends the payload of the next member to buf: 1 = ok, 0 = clean end of file, -1 = error (err set)
     int next_block() {
-        uint8_t head[12];
-        const size_t got = std::fread(head, 1, sizeof(head), fp);
-        if (got == 0) return 0;
-        if (got != sizeof(head) || head[0] != 31 || head[1] != 139 || head[2] != 8 || !(head[3] & 4)) {
-            err = path + ": not a BGZF block (bad gzip member header)";
-            return -1;
-        }
-        const unsigned xlen = head[10] | (head[11] << 8);
-        std::vector<uint8_t> extra(xlen);
-        if (std::fread(extra.data(), 1, xlen, fp) != xlen) {
-            err = path + ": truncated BGZF extra field";
-            return -1;
-        }
-        int bsize = -1;
-        for (size_t p = 0; p + 4 <= xlen;) {
-            const unsigned slen = extra[p + 2] | (extra[p + 3] << 8);
-            if (extra[p] == 'B' && extra[p + 1] == 'C' && slen == 2 && p + 6 <= xlen) bsize = extra[p + 4] | (extra[p + 5] << 8);
-            p += 4 + slen;
-        }
-        const long cdata = (long)bsize + 1 - 12 - (long)xlen - 8;
-        if (bsize < 0 || cdata < 0) {
-            err = path + ": BGZF block without a valid BC subfield";
-            return -1;
-        }
-        zin.resize((size_t)cdata + 8);
-        if (std::fread(zin.data(), 1, zin.size(), fp) != zin.size()) {
-            err = path + ": truncated BGZF block";
-            return -1;
-        }
-        const uint8_t* tail = zin.data() + cdata;
-        const uint32_t crc = tail[0] | (tail[1] << 8) | (tail[2] << 16) | ((uint32_t)tail[3] << 24);
-        const uint32_t isize = tail[4] | (tail[5] << 8) | (tail[6] << 16) | ((uint32_t)tail[7] << 24);
-        if (isize > 65536) {
-            err = path + ": BGZF block claims more than 64 KiB of payload";
-            return -1;
-        }
+        size_t cdata = 0;
+        uint32_t crc = 0, isize = 0;
+        const int rc = read_member(fp, path, zin, cdata, crc, isize, err);
+        if (rc <= 0) return rc;
         if (isize == 0) return 1;   // empty member (the EOF marker)
-        if (!zs_ready) {
-            std::memset(&zs, 0, sizeof(zs));
-            if (inflateInit2(&zs, -15) != Z_OK) {
-                err = "zlib inflateInit2 failed";
-                return -1;
-            }
-            zs_ready = true;
-        } else {
-            inflateReset(&zs);
-        }
         if (pos > 0 && pos == buf.size()) {                    // compact the consumed prefix before growing
             buf.clear();
             pos = 0;
@@ -92,20 +127,7 @@ struct Reader {
         }
         const size_t old = buf.size();
         buf.resize(old + isize);
-        zs.next_in = zin.data();
-        zs.avail_in = (uInt)cdata;
-        zs.next_out = buf.data() + old;
-        zs.avail_out = isize;
-        const int rc = inflate(&zs, Z_FINISH);
-        if (rc != Z_STREAM_END || zs.avail_out != 0) {
-            err = path + ": corrupt BGZF block (inflate failed)";
-            return -1;
-        }
-        if ((uint32_t)crc32(crc32(0L, Z_NULL, 0), buf.data() + old, isize) != crc) {
-            err = path + ": corrupt BGZF block (CRC mismatch)";
-            return -1;
-        }
-        return 1;
+        return inflate_member(zs, zs_ready, path, zin.data(), cdata, crc, isize, buf.data() + old, err) ? 1 : -1;
     }
 
     // makes n inflated bytes available at data(): 1 = ok, 0 = clean EOF before the first byte, -1 = error
@@ -121,6 +143,147 @@ struct Reader {
             }
         }
         return 1;
+    }
+};
+
+// The same stream interface with the inflate work spread over `threads` workers: BGZF members are independent deflate streams,
+// so an I/O thread frames them into a ring of jobs, the workers inflate and CRC-check them concurrently and need() appends
+// their payloads to buf in file order.  (One zlib inflate runs at 100-250 MB/s: a single decoder thread feeds about one GPU.)
+struct ParallelReader {
+    std::string path, err;
+    std::vector<uint8_t> buf;
+    size_t pos = 0;
+
+    bool open(const std::string& p, int threads) {
+        path = p;
+        fp = std::fopen(p.c_str(), "rb");
+        if (!fp) {
+            err = p + ": cannot open";
+            return false;
+        }
+        if (threads < 1) threads = 1;
+        jobs.resize((size_t)threads * 4);
+        io = std::thread([this] { io_loop(); });
+        for (int i = 0; i < threads; ++i) workers.emplace_back([this] { work_loop(); });
+        return true;
+    }
+    ~ParallelReader() {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            stop = true;
+        }
+        cv_io.notify_all();
+        cv_work.notify_all();
+        cv_cons.notify_all();
+        if (io.joinable()) io.join();
+        for (auto& w : workers)
+            if (w.joinable()) w.join();
+        if (fp) std::fclose(fp);
+    }
+    const uint8_t* data() const { return buf.data() + pos; }
+    void advance(size_t n) { pos += n; }
+
+    // makes n inflated bytes available at data(): 1 = ok, 0 = clean EOF before the first byte, -1 = error
+    int need(size_t n) {
+        while (buf.size() - pos < n) {
+            Job& j = jobs[next_take % jobs.size()];
+            int st;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv_cons.wait(lk, [&] { return j.state == DONE || j.state == FAILED || j.state == END; });
+                st = j.state;
+            }
+            if (st == END) {
+                if (buf.size() == pos) return 0;
+                err = path + ": BAM stream ends inside a record";
+                return -1;
+            }
+            if (st == FAILED) {
+                err = j.err;
+                return -1;
+            }
+            if (pos > 0 && pos == buf.size()) {                // compact the consumed prefix before growing
+                buf.clear();
+                pos = 0;
+            } else if (pos > (1u << 20)) {
+                buf.erase(buf.begin(), buf.begin() + (long)pos);
+                pos = 0;
+            }
+            buf.insert(buf.end(), j.out.begin(), j.out.begin() + j.isize);
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                j.state = EMPTY;
+            }
+            cv_io.notify_one();
+            ++next_take;
+        }
+        return 1;
+    }
+
+  private:
+    enum { EMPTY, QUEUED, DONE, FAILED, END };
+    struct Job {
+        std::vector<uint8_t> zin, out;
+        size_t cdata = 0;
+        uint32_t crc = 0, isize = 0;
+        int state = EMPTY;
+        std::string err;
+    };
+    FILE* fp = nullptr;
+    std::vector<Job> jobs;
+    std::mutex mu;
+    std::condition_variable cv_io, cv_work, cv_cons;
+    std::deque<size_t> work;
+    uint64_t next_take = 0;
+    bool stop = false;
+    std::thread io;
+    std::vector<std::thread> workers;
+
+    void io_loop() {
+        for (uint64_t seq = 0;; ++seq) {
+            Job& j = jobs[seq % jobs.size()];
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv_io.wait(lk, [&] { return stop || j.state == EMPTY; });
+                if (stop) return;
+            }
+            const int rc = read_member(fp, path, j.zin, j.cdata, j.crc, j.isize, j.err);   // the job is ours while EMPTY
+            std::lock_guard<std::mutex> lk(mu);
+            if (rc == 0) j.state = END;
+            else if (rc < 0) j.state = FAILED;
+            else if (j.isize == 0) j.state = DONE;             // empty member (the EOF marker): nothing to inflate
+            else {
+                j.state = QUEUED;
+                work.push_back(seq % jobs.size());
+                cv_work.notify_one();
+                continue;
+            }
+            cv_cons.notify_all();
+            if (rc <= 0) return;
+        }
+    }
+    void work_loop() {
+        z_stream zs;
+        bool zs_ready = false;
+        for (;;) {
+            size_t idx;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv_work.wait(lk, [&] { return stop || !work.empty(); });
+                if (stop) break;
+                idx = work.front();
+                work.pop_front();
+            }
+            Job& j = jobs[idx];
+            if (j.out.size() < j.isize) j.out.resize(65536);
+            const bool ok = inflate_member(zs, zs_ready, path, j.zin.data(), j.cdata, j.crc, j.isize, j.out.data(), j.err);
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                j.state = ok ? DONE : FAILED;
+            }
+            cv_cons.notify_all();
+        }
+        if (zs_ready) inflateEnd(&zs);
     }
 };
 

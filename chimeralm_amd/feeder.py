@@ -34,13 +34,15 @@ class FeedBatch:
 
 class BamFeeder:
     def __init__(self, bam_path: str | Path, batch_size: int = 12, *, max_tokens: int = 32769, slots: int = 4, rank: int = 0,
-                 world: int = 1, pad_left: bool = True, pinned: bool = True, max_reads: int | None = None):
+                 world: int = 1, pad_left: bool = True, pinned: bool = True, max_reads: int | None = None,
+                 inflate_threads: int = 0):
         self._lib = N.load()
         cfg = N.ClmFeederConfig()
         self._lib.clm_feeder_default_config(C.byref(cfg))
         cfg.batch_size, cfg.max_tokens, cfg.slots, cfg.rank, cfg.world = batch_size, max_tokens, slots, rank, world
         cfg.pad_left, cfg.pinned = int(pad_left), int(pinned)
         cfg.max_reads = -1 if max_reads is None else int(max_reads)
+        cfg.inflate_threads = int(inflate_threads)      # 0: chosen by the library from the core count and `world`
         self._h = C.c_void_p()
         rc = self._lib.clm_feeder_open(str(bam_path).encode(), C.byref(cfg), C.byref(self._h))
         if rc != 0:

@@ -10,8 +10,8 @@
  *                           tokenizer's padding side; id rows as int8 [B, 256]
  *   data/bam.py:142-174,287-299 batches of batch_size // world_size reads per device, rank r taking selected reads
  *                           r, r + world, r + 2 world, ... (the non-shuffling distributed sampler Lightning installs)
- * A decoder thread inflates BGZF blocks (zlib), decodes records, tokenises straight from the 4-bit base codes and fills
- * batches into a ring of (pinned) host slots; the consumer takes them in order and hands each slot back when its H2D copy
+ * Worker threads inflate the BGZF blocks (zlib; the members are independent deflate streams), a decoder thread takes them in
+ * file order, decodes records, tokenises straight from the 4-bit base codes and fills batches into a ring of (pinned) host slots; the consumer takes them in order and hands each slot back when its H2D copy
  * has been enqueued and completed (clm_stage_ids in chimeralm_hip.h does that copy on the engine's side stream).
  *
  * Every call returns 0 / a positive count on success and a negative CLM_E_* code on failure (chimeralm_hip.h);
@@ -40,6 +40,8 @@ typedef struct clm_feeder_config {
     int32_t pinned;           /* 1: slots in page-locked host memory (hipHostMalloc; needs a HIP device)         */
                               /* 0: plain host memory (CPU-side tests of the decoder)                           */
     int64_t max_reads;        /* stop after this many SELECTED reads of the file (all ranks together); < 0: all  */
+    int32_t inflate_threads;  /* BGZF members are inflated by this many worker threads, in file order for the     */
+    int32_t reserved;         /* decoder (0: chosen from the host's core count and `world`, at most 8)            */
 } clm_feeder_config;
 
 typedef struct clm_feed_batch {
@@ -53,7 +55,8 @@ typedef struct clm_feed_batch {
     int64_t first_index;      /* index, among this rank's reads, of row 0                                         */
 } clm_feed_batch;
 
-/* fills cfg with the reference's defaults: batch 12, 32769 tokens, 4 slots, rank 0 of 1, left padding, pinned */
+/* fills cfg with the reference's defaults: batch 12, 32769 tokens, 4 slots, rank 0 of 1, left padding, pinned, automatic
+ * number of inflate threads */
 int clm_feeder_default_config(clm_feeder_config* cfg);
 /* opens the file, checks the BAM magic, starts the decoder thread */
 int clm_feeder_open(const char* bam_path, const clm_feeder_config* cfg, clm_feeder** out);

@@ -247,6 +247,39 @@ def test_native_feeder_selection_and_errors(tmp_path, golden_dir):
         BamFeeder(path, pinned=False, batch_size=0)
 
 
+def test_native_feeder_parallel_inflate_is_order_preserving(tmp_path):
+    """BGZF members are inflated by worker threads: the stream the decoder sees, hence every batch, is the same for any number
+    of them (file order), and a member corrupted in the middle of the file fails the run whichever worker meets it."""
+    import sys
+
+    sys.path.insert(0, str(REPO / "tools"))
+    from feeder_bench import write_bam
+
+    from chimeralm_amd.feeder import BamFeeder, FeederError
+
+    path = tmp_path / "many_blocks.bam"
+    write_bam(path, 400, 3000, seed=3)                        # ~30 members, records straddle them
+    runs = {}
+    for threads in (1, 2, 5):
+        with BamFeeder(path, batch_size=7, pinned=False, inflate_threads=threads, slots=2) as f:
+            runs[threads] = [(ids.copy(), names.copy()) for ids, names in f]
+            assert f.stats()["selected"] == 400
+    assert len(runs[1]) == -(-400 // 7)
+    for threads in (2, 5):
+        assert len(runs[threads]) == len(runs[1])
+        for (a_ids, a_names), (b_ids, b_names) in zip(runs[1], runs[threads]):
+            assert np.array_equal(a_ids, b_ids) and np.array_equal(a_names, b_names)
+    raw = bytearray(path.read_bytes())
+    raw[len(raw) // 2] ^= 0x5A                                 # flip bits inside some member's deflate data
+    (tmp_path / "bad.bam").write_bytes(bytes(raw))
+    for threads in (1, 4):
+        with pytest.raises(FeederError, match="corrupt|BGZF|truncated"):
+            with BamFeeder(tmp_path / "bad.bam", batch_size=7, pinned=False, inflate_threads=threads) as f:
+                list(f)
+    with pytest.raises(FeederError, match="inflate_threads"):
+        BamFeeder(path, pinned=False, inflate_threads=-1)
+
+
 def test_native_feeder_ring_backpressure(golden_dir):
     """A consumer that holds slots stalls the decoder instead of being overwritten; releasing resumes it."""
     from chimeralm_amd.feeder import BamFeeder
