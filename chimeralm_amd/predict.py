@@ -6,6 +6,10 @@
         logits, labels = model.predict_step(batch)      # MI355X engine
         writer.write_on_batch_end(...)                  # {rank}_{batch}.txt, "name<TAB>label"
 
+Results leave the device one batch behind: the logits of batch i are copied to page-locked host memory right behind their
+forward, the forward of batch i+1 is enqueued, and only then does the host wait for copy i and write its file -- the GPU never
+idles while Python formats read names (the reference syncs on every batch, callbacks.py:107).
+
 `run_predict_native` is the same loop fed by the native BAM feeder (csrc/bam_feeder.cpp): a C++ thread decodes, selects,
 tokenises and collates into a ring of page-locked slots; each batch crosses PCIe as uint8 on the engine's copy stream
 (`clm_stage_ids`) while the previous batch is computing, and the slot goes back to the ring once its copy has landed.
@@ -30,6 +34,27 @@ def _to_device(batch: dict, device: torch.device, stream: torch.cuda.Stream) -> 
     return out
 
 
+class _Deferred:
+    """The logits of one batch on their way to the host (async copy + event), and what the writer needs with them."""
+
+    def __init__(self, logits: torch.Tensor, labels, batch: dict, batch_idx: int, gathered: torch.Tensor | None):
+        self.host = torch.empty(logits.shape, dtype=logits.dtype, pin_memory=True)   # caching host allocator: cheap after the first
+        self.host.copy_(logits, non_blocking=True)
+        self.gathered = None
+        if gathered is not None:
+            self.gathered = torch.empty(gathered.shape, dtype=gathered.dtype, pin_memory=True)
+            self.gathered.copy_(gathered, non_blocking=True)
+        self.event = torch.cuda.Event()
+        self.event.record()
+        self.labels, self.batch, self.batch_idx = labels, batch, batch_idx
+
+    def flush(self, writer, trainer, model, on_batch) -> None:
+        self.event.synchronize()
+        if self.gathered is not None and on_batch is not None:
+            on_batch(self.batch_idx, self.gathered)
+        writer.write_on_batch_end(trainer, model, (self.host, self.labels), None, self.batch, self.batch_idx, 0)
+
+
 def run_predict(model, datamodule, writer, device: torch.device, *, rank: int = 0, gather: bool = False,
                 on_batch=None) -> int:
     """Returns the number of reads this rank classified."""
@@ -41,6 +66,7 @@ def run_predict(model, datamodule, writer, device: torch.device, *, rank: int = 
     nxt = next(it, None)
     staged = _to_device(nxt, device, copy_stream) if nxt is not None else None
     n_reads, batch_idx = 0, 0
+    pending: _Deferred | None = None
     with torch.inference_mode():
         while staged is not None:
             compute.wait_stream(copy_stream)
@@ -48,13 +74,14 @@ def run_predict(model, datamodule, writer, device: torch.device, *, rank: int = 
             nxt = next(it, None)                              # host collation of batch i+1 ...
             staged = _to_device(nxt, device, copy_stream) if nxt is not None else None   # ... and its H2D overlap
             logits, labels = model.predict_step(cur, batch_idx)
-            if gather:
-                logits_all = gather_logits(logits)
-                if on_batch is not None:
-                    on_batch(batch_idx, logits_all)
-            writer.write_on_batch_end(trainer, model, (logits, labels), None, cur, batch_idx, 0)
+            now = _Deferred(logits, labels, cur, batch_idx, gather_logits(logits) if gather else None)
+            if pending is not None:
+                pending.flush(writer, trainer, model, on_batch)   # batch i-1: its copy finished while batch i was enqueued
+            pending = now
             n_reads += logits.shape[0]
             batch_idx += 1
+        if pending is not None:
+            pending.flush(writer, trainer, model, on_batch)
     return n_reads
 
 
@@ -67,6 +94,7 @@ def run_predict_native(model, feeder, writer, device: torch.device, *, rank: int
     eng = model.net.engine(device)
     trainer = SimpleNamespace(global_rank=rank)
     n_reads, batch_idx = 0, 0
+    pending: _Deferred | None = None
     cur = feeder.next()
     staged = eng.stage_host_ids(cur.ids_ptr, DT_U8, cur.row_stride, cur.n_reads, cur.n_tokens) if cur is not None else -1
     with torch.inference_mode():
@@ -79,12 +107,13 @@ def run_predict_native(model, feeder, writer, device: torch.device, *, rank: int
             feeder.release(cur)                               # ... which goes back to the decoder
             labels = torch.full((cur.n_reads,), -1, dtype=torch.int64)   # tokenizer.py:113: predict labels are all -1
             batch = {"id": torch.from_numpy(cur.names), "labels": labels}
-            if gather:
-                logits_all = gather_logits(logits)
-                if on_batch is not None:
-                    on_batch(batch_idx, logits_all)
-            writer.write_on_batch_end(trainer, model, (logits, labels), None, batch, batch_idx, 0)
+            now = _Deferred(logits, labels, batch, batch_idx, gather_logits(logits) if gather else None)
+            if pending is not None:
+                pending.flush(writer, trainer, model, on_batch)
+            pending = now
             n_reads += cur.n_reads
             batch_idx += 1
             cur, staged = nxt, nxt_staged
+        if pending is not None:
+            pending.flush(writer, trainer, model, on_batch)
     return n_reads
