@@ -13,6 +13,7 @@
 #include "chimeralm_hip.h"
 
 #include <algorithm>
+#include <cstdlib>
 #include <map>
 #include <numeric>
 #include <string>
@@ -33,6 +34,17 @@ int bam_fail(int code, const std::string& msg) {
     return code;
 }
 
+// worker threads for the BGZF members of input and output (independent deflate streams): the host's cores less two, at most 8;
+// CLM_BAM_THREADS overrides (tests compare 1 against several)
+int bam_threads() {
+    if (const char* e = std::getenv("CLM_BAM_THREADS")) {
+        const int v = std::atoi(e);
+        if (v >= 1 && v <= 256) return v;
+    }
+    const int t = (int)std::thread::hardware_concurrency() - 2;
+    return t < 1 ? 1 : t > 8 ? 8 : t;
+}
+
 // header bytes (magic .. last reference) as one blob; n_ref and the reference lengths on the side
 struct Header {
     std::vector<uint8_t> blob;
@@ -40,7 +52,7 @@ struct Header {
     size_t text_off = 0, text_len = 0;
 };
 
-int read_header(clmbgzf::Reader& rd, Header& h) {
+int read_header(clmbgzf::ParallelReader& rd, Header& h) {
     auto take = [&](size_t n) -> int {
         const int rc = rd.need(n);
         if (rc <= 0) return -1;
@@ -65,7 +77,7 @@ int read_header(clmbgzf::Reader& rd, Header& h) {
 }
 
 // next alignment record incl. its 4-byte length prefix: 1 = ok (ptr/len valid until the next call), 0 = end, -1 = error
-int next_record(clmbgzf::Reader& rd, const uint8_t*& ptr, size_t& len) {
+int next_record(clmbgzf::ParallelReader& rd, const uint8_t*& ptr, size_t& len) {
     int rc = rd.need(4);
     if (rc <= 0) return rc;
     const int32_t bs = le32(rd.data());
@@ -122,12 +134,12 @@ int clm_bam_filter(const char* in_bam, const char* out_bam, const char* const* d
     std::unordered_set<std::string> drop;
     drop.reserve((size_t)n_drop * 2 + 16);
     for (int64_t i = 0; i < n_drop; ++i) drop.insert(drop_names[i]);
-    clmbgzf::Reader rd;
-    if (!rd.open(in_bam)) return bam_fail(CLM_E_INVALID, rd.err);
+    clmbgzf::ParallelReader rd;
+    if (!rd.open(in_bam, bam_threads())) return bam_fail(CLM_E_INVALID, rd.err);
     Header hd;
     if (read_header(rd, hd)) return bam_fail(CLM_E_INVALID, rd.err.empty() ? std::string(in_bam) + ": not a BAM file" : rd.err);
-    clmbgzf::Writer wr;
-    if (!wr.open(out_bam)) return bam_fail(CLM_E_INVALID, wr.err);
+    clmbgzf::ParallelWriter wr;
+    if (!wr.open(out_bam, bam_threads())) return bam_fail(CLM_E_INVALID, wr.err);
     if (!wr.write(hd.blob.data(), hd.blob.size())) return bam_fail(CLM_E_INVALID, wr.err);
     int64_t nk = 0, nd = 0;
     const uint8_t* rec;
@@ -155,8 +167,8 @@ int clm_bam_filter(const char* in_bam, const char* out_bam, const char* const* d
 
 int clm_bam_sort_index(const char* in_bam, const char* out_sorted_bam, const char* out_bai, int64_t* n_records) {
     if (!in_bam || !out_sorted_bam) return bam_fail(CLM_E_INVALID, "clm_bam_sort_index: bad argument");
-    clmbgzf::Reader rd;
-    if (!rd.open(in_bam)) return bam_fail(CLM_E_INVALID, rd.err);
+    clmbgzf::ParallelReader rd;
+    if (!rd.open(in_bam, bam_threads())) return bam_fail(CLM_E_INVALID, rd.err);
     Header hd;
     if (read_header(rd, hd)) return bam_fail(CLM_E_INVALID, rd.err.empty() ? std::string(in_bam) + ": not a BAM file" : rd.err);
     // ---- all records in memory (the reference's samtools sort spills to disk; an external merge is future work)
@@ -200,8 +212,8 @@ int clm_bam_sort_index(const char* in_bam, const char* out_sorted_bam, const cha
     put32(nh, (uint32_t)text.size());
     nh.insert(nh.end(), text.begin(), text.end());
     nh.insert(nh.end(), hd.blob.begin() + (long)(hd.text_off + hd.text_len), hd.blob.end());
-    clmbgzf::Writer wr;
-    if (!wr.open(out_sorted_bam)) return bam_fail(CLM_E_INVALID, wr.err);
+    clmbgzf::ParallelWriter wr;                                // voffset() is logical until finish(): resolved below
+    if (!wr.open(out_sorted_bam, bam_threads())) return bam_fail(CLM_E_INVALID, wr.err);
     if (!wr.write(nh.data(), nh.size()) || !wr.flush_block()) return bam_fail(CLM_E_INVALID, wr.err);
     // ---- write in order, collecting the index
     struct RefIdx {
@@ -246,17 +258,17 @@ int clm_bam_sort_index(const char* in_bam, const char* out_sorted_bam, const cha
         for (auto& kv : x.bins) {
             put32(bai, kv.first);
             put32(bai, (uint32_t)kv.second.size());
-            for (auto& c : kv.second) put64(bai, c.first), put64(bai, c.second);
+            for (auto& c : kv.second) put64(bai, wr.resolve(c.first)), put64(bai, wr.resolve(c.second));
         }
         if (x.any) {                                            // metadata pseudo-bin
             put32(bai, 37450);
             put32(bai, 2);
-            put64(bai, x.beg), put64(bai, x.end), put64(bai, x.n_mapped), put64(bai, x.n_unmapped);
+            put64(bai, wr.resolve(x.beg)), put64(bai, wr.resolve(x.end)), put64(bai, x.n_mapped), put64(bai, x.n_unmapped);
         }
         for (size_t w = 1; w < x.lin.size(); ++w)
             if (x.lin[w] == 0) x.lin[w] = x.lin[w - 1];         // windows no read starts in inherit the previous offset
         put32(bai, (uint32_t)x.lin.size());
-        for (uint64_t v : x.lin) put64(bai, v);
+        for (uint64_t v : x.lin) put64(bai, wr.resolve(v));
     }
     put64(bai, n_no_coor);
     const std::string bai_path = out_bai ? std::string(out_bai) : std::string(out_sorted_bam) + ".bai";

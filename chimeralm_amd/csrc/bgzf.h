@@ -287,6 +287,37 @@ struct ParallelReader {
     }
 };
 
+// One complete BGZF member (header, deflate data at level 6, CRC32, ISIZE) for `n` <= 0xff00 payload bytes; returns its
+// length in zout or 0 on error.
+inline size_t deflate_member(const uint8_t* payload, size_t n, std::vector<uint8_t>& zout, const std::string& path,
+                             std::string& err) {
+    z_stream z;
+    std::memset(&z, 0, sizeof(z));
+    if (deflateInit2(&z, 6, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) {
+        err = "zlib deflateInit2 failed";
+        return 0;
+    }
+    zout.resize(deflateBound(&z, (uLong)n) + 64);
+    z.next_in = const_cast<uint8_t*>(payload);
+    z.avail_in = (uInt)n;
+    z.next_out = zout.data() + 18;
+    z.avail_out = (uInt)(zout.size() - 18);
+    const int rc = deflate(&z, Z_FINISH);
+    const size_t clen = z.total_out;
+    deflateEnd(&z);
+    if (rc != Z_STREAM_END || clen + 26 > 65536) {
+        err = path + ": BGZF block does not fit 64 KiB after deflate";
+        return 0;
+    }
+    const uint8_t head[18] = {31, 139, 8, 4, 0, 0, 0, 0, 0, 255, 6, 0, 'B', 'C', 2, 0,
+                              (uint8_t)((clen + 25) & 255), (uint8_t)((clen + 25) >> 8)};
+    std::memcpy(zout.data(), head, 18);
+    const uint32_t crc = (uint32_t)crc32(crc32(0L, Z_NULL, 0), payload, (uInt)n), isz = (uint32_t)n;
+    uint8_t* t = zout.data() + 18 + clen;
+    for (int i = 0; i < 4; ++i) t[i] = (uint8_t)(crc >> (8 * i)), t[4 + i] = (uint8_t)(isz >> (8 * i));
+    return clen + 26;
+}
+
 struct Writer {
     std::string path, err;
     FILE* fp = nullptr;
@@ -307,35 +338,13 @@ struct Writer {
     uint64_t voffset() const { return (file_off << 16) | (uint64_t)pend.size(); }   // of the next byte written
 
     bool flush_block() {
-        z_stream z;
-        std::memset(&z, 0, sizeof(z));
-        if (deflateInit2(&z, 6, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) {
-            err = "zlib deflateInit2 failed";
-            return false;
-        }
-        zout.resize(deflateBound(&z, (uLong)pend.size()) + 64);
-        z.next_in = pend.data();
-        z.avail_in = (uInt)pend.size();
-        z.next_out = zout.data() + 18;
-        z.avail_out = (uInt)(zout.size() - 18);
-        const int rc = deflate(&z, Z_FINISH);
-        const size_t clen = z.total_out;
-        deflateEnd(&z);
-        if (rc != Z_STREAM_END || clen + 26 > 65536) {
-            err = path + ": BGZF block does not fit 64 KiB after deflate";
-            return false;
-        }
-        const uint8_t head[18] = {31, 139, 8, 4, 0, 0, 0, 0, 0, 255, 6, 0, 'B', 'C', 2, 0,
-                                  (uint8_t)((clen + 25) & 255), (uint8_t)((clen + 25) >> 8)};
-        std::memcpy(zout.data(), head, 18);
-        const uint32_t crc = (uint32_t)crc32(crc32(0L, Z_NULL, 0), pend.data(), (uInt)pend.size()), isz = (uint32_t)pend.size();
-        uint8_t* t = zout.data() + 18 + clen;
-        for (int i = 0; i < 4; ++i) t[i] = (uint8_t)(crc >> (8 * i)), t[4 + i] = (uint8_t)(isz >> (8 * i));
-        if (std::fwrite(zout.data(), 1, clen + 26, fp) != clen + 26) {
+        const size_t mlen = deflate_member(pend.data(), pend.size(), zout, path, err);
+        if (!mlen) return false;
+        if (std::fwrite(zout.data(), 1, mlen, fp) != mlen) {
             err = path + ": write failed";
             return false;
         }
-        file_off += clen + 26;
+        file_off += mlen;
         pend.clear();
         return true;
     }
@@ -361,6 +370,168 @@ struct Writer {
         fp = nullptr;
         if (!ok) err = path + ": close failed";
         return ok;
+    }
+};
+
+// Writer with the deflate work spread over `threads` workers (the members are independent): write() fills a block, full blocks
+// go to a ring of jobs, workers compress them, an output thread writes them in order.  Compressed sizes are not known when a
+// record is written, so voffset() is LOGICAL -- (sequence number of the block << 16) | offset inside it -- and resolve() turns
+// it into the real virtual file offset once finish() has returned.  (One zlib deflate at level 6 runs at ~25 MB/s.)
+struct ParallelWriter {
+    std::string path, err;
+    static constexpr size_t BLOCK = 0xff00;
+
+    bool open(const std::string& p, int threads) {
+        path = p;
+        fp = std::fopen(p.c_str(), "wb");
+        if (!fp) {
+            err = p + ": cannot create";
+            return false;
+        }
+        if (threads < 1) threads = 1;
+        jobs.resize((size_t)threads * 4);
+        pend.reserve(BLOCK);
+        out = std::thread([this] { out_loop(); });
+        for (int i = 0; i < threads; ++i) workers.emplace_back([this] { work_loop(); });
+        return true;
+    }
+    ~ParallelWriter() { shutdown(); }
+
+    uint64_t voffset() const { return (seq << 16) | (uint64_t)pend.size(); }   // logical, of the next byte written
+    uint64_t resolve(uint64_t v) const { return (block_off[(size_t)(v >> 16)] << 16) | (v & 0xffff); }   // after finish()
+
+    bool flush_block() { return submit(); }
+    bool write(const uint8_t* p, size_t n) {
+        while (n) {
+            const size_t room = BLOCK - pend.size(), k = n < room ? n : room;
+            pend.insert(pend.end(), p, p + k);
+            p += k;
+            n -= k;
+            if (pend.size() == BLOCK && !submit()) return false;
+        }
+        return true;
+    }
+    bool align_block(size_t upcoming) {
+        if (!pend.empty() && pend.size() + upcoming > BLOCK) return submit();
+        return true;
+    }
+    bool finish() {                                            // last data block + the empty EOF member, then drain
+        if (!pend.empty() && !submit()) return false;
+        if (!submit()) return false;
+        {
+            std::unique_lock<std::mutex> lk(mu);
+            cv_main.wait(lk, [&] { return failed || written == seq; });
+        }
+        const bool bad = failed;
+        shutdown();
+        if (bad) return false;
+        block_off.push_back(file_off);                         // where a further block would start (voffsets taken at the end)
+        const bool ok = std::fclose(fp) == 0;
+        fp = nullptr;
+        if (!ok) err = path + ": close failed";
+        return ok;
+    }
+
+  private:
+    enum { EMPTY, QUEUED, DONE };
+    struct Job {
+        std::vector<uint8_t> in, zout;
+        size_t mlen = 0;
+        int state = EMPTY;
+    };
+    FILE* fp = nullptr;
+    std::vector<uint8_t> pend;
+    std::vector<Job> jobs;
+    std::vector<uint64_t> block_off;       // file offset of block i, filled by the output thread in order
+    uint64_t seq = 0, written = 0, file_off = 0;
+    std::mutex mu;
+    std::condition_variable cv_main, cv_work, cv_out;
+    std::deque<size_t> work;
+    bool stop = false, failed = false;
+    std::thread out;
+    std::vector<std::thread> workers;
+
+    bool submit() {                        // hands `pend` (possibly empty: the EOF member) to the workers as block `seq`
+        Job& j = jobs[seq % jobs.size()];
+        {
+            std::unique_lock<std::mutex> lk(mu);
+            cv_main.wait(lk, [&] { return failed || j.state == EMPTY; });
+            if (failed) return false;
+        }
+        j.in.swap(pend);
+        pend.clear();
+        pend.reserve(BLOCK);
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            j.state = QUEUED;
+            work.push_back(seq % jobs.size());
+        }
+        cv_work.notify_one();
+        ++seq;
+        return true;
+    }
+    void work_loop() {
+        for (;;) {
+            size_t idx;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv_work.wait(lk, [&] { return stop || !work.empty(); });
+                if (stop) return;
+                idx = work.front();
+                work.pop_front();
+            }
+            Job& j = jobs[idx];
+            std::string e;
+            j.mlen = deflate_member(j.in.data(), j.in.size(), j.zout, path, e);
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                if (!j.mlen) {
+                    failed = true;
+                    err = e;
+                }
+                j.state = DONE;
+            }
+            cv_out.notify_one();
+            cv_main.notify_all();
+        }
+    }
+    void out_loop() {
+        for (;;) {
+            Job& j = jobs[written % jobs.size()];
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv_out.wait(lk, [&] { return stop || failed || j.state == DONE; });
+                if (stop || failed) return;
+            }
+            const bool ok = std::fwrite(j.zout.data(), 1, j.mlen, fp) == j.mlen;
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                if (!ok) {
+                    failed = true;
+                    err = path + ": write failed";
+                } else {
+                    block_off.push_back(file_off);
+                    file_off += j.mlen;
+                    ++written;
+                }
+                j.state = EMPTY;
+            }
+            cv_main.notify_all();
+            if (!ok) return;
+        }
+    }
+    void shutdown() {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            stop = true;
+        }
+        cv_work.notify_all();
+        cv_out.notify_all();
+        cv_main.notify_all();
+        if (out.joinable()) out.join();
+        for (auto& w : workers)
+            if (w.joinable()) w.join();
+        workers.clear();
     }
 };
 

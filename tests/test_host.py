@@ -409,6 +409,35 @@ def _bam_records(path):
     return text, n_ref, recs
 
 
+def test_filter_outputs_do_not_depend_on_the_thread_count(tmp_path, monkeypatch):
+    """Filter / sort / index inflate and deflate their BGZF members on worker threads: filtered BAM, sorted BAM and BAI are
+    byte-identical for 1 and 5 workers (blocks are cut at the same payload offsets and written in order; the index's virtual
+    offsets are resolved after the compressed sizes are known)."""
+    import hashlib
+    import sys
+
+    sys.path.insert(0, str(REPO / "tools"))
+    from feeder_bench import write_bam
+
+    from chimeralm_amd import _native as N
+
+    lib = N.load()
+    src = tmp_path / "src.bam"
+    write_bam(src, 300, 2500, seed=9)
+    drop = [f"read_{i:08d}".encode() for i in range(0, 300, 4)]
+    arr = (ctypes.c_char_p * len(drop))(*drop)
+    digests = {}
+    for threads in ("1", "5"):
+        monkeypatch.setenv("CLM_BAM_THREADS", threads)
+        kept, dropped, n = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int64()
+        f, fs = tmp_path / f"f{threads}.bam", tmp_path / f"fs{threads}.bam"
+        assert lib.clm_bam_filter(str(src).encode(), str(f).encode(), arr, len(drop), ctypes.byref(kept), ctypes.byref(dropped)) == 0
+        assert (kept.value, dropped.value) == (225, 75)
+        assert lib.clm_bam_sort_index(str(f).encode(), str(fs).encode(), None, ctypes.byref(n)) == 0 and n.value == 225
+        digests[threads] = [hashlib.md5(p.read_bytes()).hexdigest() for p in (f, fs, Path(str(fs) + ".bai"))]
+    assert digests["1"] == digests["5"]
+
+
 def test_filter_drops_artifacts_sorts_and_indexes(tmp_path, golden_dir):
     """`filter` (reference __main__.py:99-153): reads labelled 1 disappear, the rest is copied bit for bit, then coordinate
     sort + BAI whose chunks / linear index / counts are consistent with the records' real virtual offsets."""
