@@ -24,14 +24,23 @@ struct Tensor {
     bool loaded = false;
 };
 
+// The filters of the four layers for one CLASS of lengths, built once and kept: the implicit filter's taps do not depend on L
+// (k[t] is a function of t and the weights), and the spectrum of the first N/2 + 1 taps serves every L that runs through the
+// N-point transform (L <= N/2 + 1: extra taps only reach outputs beyond L and nothing aliases, except the one product the
+// convolution kernel already removes at L = N/2 + 1).  key = log2 N for single-shot lengths; KEY_LONG for L > 8193: the
+// partition spectra K'_j of ALL taps (every long L uses a prefix of them).  Ragged real-world batches therefore never
+// rebuild a filter (a rebuild per batch cost 3x at the reference's default batch of 12).
+constexpr int KEY_LONG = 100;
+struct ReversedFilter {           // conv_lone_tail(L): [256][stride] per layer, one per such L (16385, 24577, 32769)
+    int L = 0, stride = 0;
+    float* p[NLAYER] = {};
+};
 struct FilterSet {
-    int L = 0, logn = 0, S = 1;   // S > 1: partitioned long convolution, kf holds S partition spectra per channel
+    int key = 0, Lf = 0, logn = 0, KS = 1;   // Lf taps; KS partition spectra per channel in kf ([256][KS][N])
     float* ktime[NLAYER] = {};
-    float* krev[NLAYER] = {};     // conv_lone_tail(L) only: [256][krev_stride]
-    int krev_stride = 0;
     float2* kf[NLAYER] = {};
     float2* tw = nullptr;
-    uint64_t stamp = 0;
+    std::vector<ReversedFilter> krev;
 };
 
 struct ProfRec {
@@ -202,11 +211,12 @@ void free_filter_set(FilterSet& f) {
     for (int i = 0; i < NLAYER; ++i) {
         if (f.ktime[i]) (void)hipFree(f.ktime[i]);
         if (f.kf[i]) (void)hipFree(f.kf[i]);
-        if (f.krev[i]) (void)hipFree(f.krev[i]);
+        for (auto& r : f.krev)
+            if (r.p[i]) (void)hipFree(r.p[i]);
         f.ktime[i] = nullptr;
         f.kf[i] = nullptr;
-        f.krev[i] = nullptr;
     }
+    f.krev.clear();
     if (f.tw) (void)hipFree(f.tw);
     f.tw = nullptr;
 }
@@ -272,71 +282,77 @@ int ensure_workspace(clm_handle* h, int Bc, int L, hipStream_t st) {
     return CLM_OK;
 }
 
-int ensure_filters(clm_handle* h, int L, hipStream_t st, FilterSet** out) {
-    for (auto& f : h->filters)
-        if (f.L == L) {
-            f.stamp = ++h->clock;
-            *out = &f;
-            return CLM_OK;
-        }
+int ensure_filters(clm_handle* h, int L, hipStream_t st, FilterSet** out, const ReversedFilter** krev_out) {
+    *krev_out = nullptr;
     const int S = conv_segments_for(L);
     const int logn = S > 1 ? 14 : conv_logn_for(L);
     if (logn < 0 || L > h->cfg.max_seq_len)
         return fail(h, CLM_E_UNSUPPORTED, "sequence length " + std::to_string(L) + " tokens exceeds max_seq_len " +
                                               std::to_string(h->cfg.max_seq_len));
-    HIPCHK(h, hipStreamSynchronize(st));
-    if (h->filters.size() >= 3) {  // drop the least recently used length
-        size_t lru = 0;
-        for (size_t i = 1; i < h->filters.size(); ++i)
-            if (h->filters[i].stamp < h->filters[lru].stamp) lru = i;
-        free_filter_set(h->filters[lru]);
-        h->filters.erase(h->filters.begin() + lru);
-    }
+    const int key = S > 1 ? KEY_LONG : logn;
+    FilterSet* fs = nullptr;
+    for (auto& f : h->filters)
+        if (f.key == key) fs = &f;
     const int N = 1 << logn;
-    FilterSet f;
-    f.L = L;
-    f.logn = logn;
-    f.S = S;
-    f.stamp = ++h->clock;
-    double2* scratch = nullptr;
-    HIPCHK(h, hipMalloc((void**)&scratch, (size_t)D * N * sizeof(double2)));
-    HIPCHK(h, hipMalloc((void**)&f.tw, (size_t)(N / 2) * sizeof(float2)));
-    launch_twiddles(f.tw, logn, st);
-    for (int i = 0; i < NLAYER; ++i) {
-        HIPCHK(h, hipMalloc((void**)&f.ktime[i], (size_t)L * D * 4));
-        HIPCHK(h, hipMalloc((void**)&f.kf[i], (size_t)D * S * N * sizeof(float2)));
-        std::string p = "bb.layers." + std::to_string(i) + ".mixer.filter_fn.";
-        launch_filter(W(h, p + "pos_emb.z"), W(h, p + "pos_emb.t"), W(h, p + "implicit_filter.0.weight"),
-                      W(h, p + "implicit_filter.0.bias"), W(h, p + "implicit_filter.1.freq"),
-                      W(h, p + "implicit_filter.2.weight"), W(h, p + "implicit_filter.2.bias"),
-                      W(h, p + "implicit_filter.4.weight"), W(h, p + "implicit_filter.4.bias"),
-                      W(h, p + "implicit_filter.6.weight"), W(h, p + "modulation.deltas"), f.ktime[i], L, st);
-        if (conv_lone_tail(L)) {
-            f.krev_stride = round_up(L, 8);
-            HIPCHK(h, hipMalloc((void**)&f.krev[i], (size_t)D * f.krev_stride * 4));
-            launch_filter_reversed(f.ktime[i], W(h, p + "bias"), f.krev[i], L, f.krev_stride, st);
-        }
-        if (S == 1) {
-            launch_filter_spectrum(f.ktime[i], W(h, p + "bias"), f.kf[i], scratch, L, logn, 0, L, -1, st);
-        } else {   // kf [256][S][N]: one launch per segment writes the strided slice through a temporary
-            float2* tmp = nullptr;
-            HIPCHK(h, hipMalloc((void**)&tmp, (size_t)D * N * sizeof(float2)));
-            for (int j = 0; j < S; ++j) {
-                launch_filter_spectrum(f.ktime[i], W(h, p + "bias"), tmp, scratch, L, logn, j * SEG_LEN, SEG_LEN,
-                                       (j - 1) * SEG_LEN, st);
-                HIPCHK(h, hipMemcpy2DAsync(f.kf[i] + (size_t)j * N, (size_t)S * N * sizeof(float2), tmp,
-                                           (size_t)N * sizeof(float2), (size_t)N * sizeof(float2), D,
-                                           hipMemcpyDeviceToDevice, st));
+    if (!fs) {
+        HIPCHK(h, hipStreamSynchronize(st));
+        FilterSet f;
+        f.key = key;
+        f.logn = logn;
+        f.Lf = S > 1 ? h->cfg.max_seq_len : std::min(N / 2 + 1, h->cfg.max_seq_len);
+        f.KS = S > 1 ? conv_segments_for(h->cfg.max_seq_len) : 1;
+        double2* scratch = nullptr;
+        HIPCHK(h, hipMalloc((void**)&scratch, (size_t)D * N * sizeof(double2)));
+        HIPCHK(h, hipMalloc((void**)&f.tw, (size_t)(N / 2) * sizeof(float2)));
+        launch_twiddles(f.tw, logn, st);
+        for (int i = 0; i < NLAYER; ++i) {
+            HIPCHK(h, hipMalloc((void**)&f.ktime[i], (size_t)f.Lf * D * 4));
+            HIPCHK(h, hipMalloc((void**)&f.kf[i], (size_t)D * f.KS * N * sizeof(float2)));
+            std::string p = "bb.layers." + std::to_string(i) + ".mixer.filter_fn.";
+            launch_filter(W(h, p + "pos_emb.z"), W(h, p + "pos_emb.t"), W(h, p + "implicit_filter.0.weight"),
+                          W(h, p + "implicit_filter.0.bias"), W(h, p + "implicit_filter.1.freq"),
+                          W(h, p + "implicit_filter.2.weight"), W(h, p + "implicit_filter.2.bias"),
+                          W(h, p + "implicit_filter.4.weight"), W(h, p + "implicit_filter.4.bias"),
+                          W(h, p + "implicit_filter.6.weight"), W(h, p + "modulation.deltas"), f.ktime[i], f.Lf, st);
+            if (S == 1) {
+                launch_filter_spectrum(f.ktime[i], W(h, p + "bias"), f.kf[i], scratch, f.Lf, logn, 0, f.Lf, -1, st);
+            } else {   // kf [256][KS][N]: one launch per partition writes the strided slice through a temporary
+                float2* tmp = nullptr;
+                HIPCHK(h, hipMalloc((void**)&tmp, (size_t)D * N * sizeof(float2)));
+                for (int j = 0; j < f.KS; ++j) {
+                    launch_filter_spectrum(f.ktime[i], W(h, p + "bias"), tmp, scratch, f.Lf, logn, j * SEG_LEN, SEG_LEN,
+                                           (j - 1) * SEG_LEN, st);
+                    HIPCHK(h, hipMemcpy2DAsync(f.kf[i] + (size_t)j * N, (size_t)f.KS * N * sizeof(float2), tmp,
+                                               (size_t)N * sizeof(float2), (size_t)N * sizeof(float2), D,
+                                               hipMemcpyDeviceToDevice, st));
+                }
+                HIPCHK(h, hipStreamSynchronize(st));
+                HIPCHK(h, hipFree(tmp));
             }
-            HIPCHK(h, hipStreamSynchronize(st));
-            HIPCHK(h, hipFree(tmp));
+        }
+        HIPCHK(h, hipGetLastError());
+        HIPCHK(h, hipStreamSynchronize(st));
+        HIPCHK(h, hipFree(scratch));
+        h->filters.push_back(f);
+        fs = &h->filters.back();
+    }
+    if (conv_lone_tail(L)) {               // the reversed taps [0, L) of the dot product for the lone last token
+        for (auto& r : fs->krev)
+            if (r.L == L) *krev_out = &r;
+        if (!*krev_out) {
+            ReversedFilter r;
+            r.L = L;
+            r.stride = round_up(L, 8);
+            for (int i = 0; i < NLAYER; ++i) {
+                std::string p = "bb.layers." + std::to_string(i) + ".mixer.filter_fn.";
+                HIPCHK(h, hipMalloc((void**)&r.p[i], (size_t)D * r.stride * 4));
+                launch_filter_reversed(fs->ktime[i], W(h, p + "bias"), r.p[i], L, r.stride, st);
+            }
+            fs->krev.push_back(r);
+            *krev_out = &fs->krev.back();
         }
     }
-    HIPCHK(h, hipGetLastError());
-    HIPCHK(h, hipStreamSynchronize(st));
-    HIPCHK(h, hipFree(scratch));
-    h->filters.push_back(f);
-    *out = &h->filters.back();
+    *out = fs;
     return CLM_OK;
 }
 
@@ -373,7 +389,9 @@ int forward_chunk(clm_handle* h, const void* ids, int ids_dtype, int64_t row_str
     const int prec = h->cfg.precision, Lp = round_up(L, 64);
     const float eps = h->cfg.ln_eps;
     FilterSet* fs = nullptr;
-    int rc = ensure_filters(h, L, st, &fs);
+    const ReversedFilter* kr = nullptr;
+    int rc = ensure_filters(h, L, st, &fs, &kr);
+    const int S = conv_segments_for(L);
     if (rc) return rc;
     rc = ensure_workspace(h, Bc, L, st);
     if (rc) return rc;
@@ -407,12 +425,12 @@ int forward_chunk(clm_handle* h, const void* ids, int ids_dtype, int64_t row_str
         if (stop_here(h, i, CLM_STAGE_INPROJ)) return CLM_OK;
         {
             StageTimer t(h, st, CLM_STAGE_CONV);
-            if (fs->S == 1)
+            if (S == 1)
                 launch_hyena_conv(prec, h->z, h->y, fs->kf[i], fs->tw, fs->ktime[i], lw.short_w, lw.short_b, Bc, L, Lp,
                                   fs->logn, idconv ? h->ids8 : nullptr, idconv ? h->ztab : nullptr, st);
             else
-                launch_hyena_conv_seg(prec, h->z, h->y, fs->kf[i], fs->tw, lw.short_w, lw.short_b, h->gscratch, Bc, L,
-                                      Lp, fs->S, fs->krev[i], fs->krev_stride, idconv ? h->ids8 : nullptr,
+                launch_hyena_conv_seg(prec, h->z, h->y, fs->kf[i], fs->KS, fs->tw, lw.short_w, lw.short_b, h->gscratch, Bc,
+                                      L, Lp, S, kr ? kr->p[i] : nullptr, kr ? kr->stride : 0, idconv ? h->ids8 : nullptr,
                                       idconv ? h->ztab : nullptr, st);
         }
         if (stop_here(h, i, CLM_STAGE_CONV)) return CLM_OK;
@@ -639,7 +657,8 @@ int clm_reserve(clm_handle* h, int B, int L) {
     if (!h->finalized) return fail(h, CLM_E_STATE, "clm_reserve before clm_finalize");
     HIPCHK(h, hipSetDevice(h->device));
     FilterSet* fs = nullptr;
-    int rc = ensure_filters(h, L, 0, &fs);
+    const ReversedFilter* kr = nullptr;
+    int rc = ensure_filters(h, L, 0, &fs, &kr);
     if (rc) return rc;
     int Bc = B < h->cfg.chunk_reads ? B : h->cfg.chunk_reads;
     return ensure_workspace(h, Bc, L, 0);
@@ -750,8 +769,9 @@ int clm_debug_fetch(clm_handle* h, const char* name, void* host_out, size_t byte
     else if (n == "pooled") { src = h->pooled; have = B * D * 4; }
     else if (n.rfind("filter.", 0) == 0) {
         int i = std::atoi(n.c_str() + 7);
-        for (auto& f : h->filters)
-            if (f.L == (int)L && i >= 0 && i < NLAYER) { src = f.ktime[i]; have = L * D * 4; }
+        const int key = conv_segments_for((int)L) > 1 ? KEY_LONG : conv_logn_for((int)L);
+        for (auto& f : h->filters)          // the first L taps of the class's filter (they do not depend on L)
+            if (f.key == key && i >= 0 && i < NLAYER && (int)L <= f.Lf) { src = f.ktime[i]; have = L * D * 4; }
     }
     if (!src) return fail(h, CLM_E_INVALID, "clm_debug_fetch: unknown or empty buffer " + n);
     if (bytes > have) return fail(h, CLM_E_INVALID, "clm_debug_fetch: " + n + " holds only " + std::to_string(have) + " bytes");

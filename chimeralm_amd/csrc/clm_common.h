@@ -197,9 +197,10 @@ void launch_hyena_conv(int prec, const void* z, void* y, const float2* kf, const
 void launch_ztab(const float* emb, const float* g, const float* bta, const float* w, const float* bias, float* ztab,
                  float eps, hipStream_t st);
 
-// long reads (L > 8193): partitioned convolution over S segments; kf [256][S][N] (segment j built with prev_off = (j-1)*SEG_LEN),
+// long reads (L > 8193): partitioned convolution over S segments; kf [256][KS][N] (partition j built with prev_off = (j-1)*SEG_LEN),
 // gscratch [pairs][256][S][N]
-void launch_hyena_conv_seg(int prec, const void* z, void* y, const float2* kf, const float2* tw, const float* short_w,
+void launch_hyena_conv_seg(int prec, const void* z, void* y, const float2* kf, int KS /*partitions stored per channel >= S*/,
+                           const float2* tw, const float* short_w,
                            const float* short_b, float2* gscratch, int B, int L, int Lp, int S,
                            const float* krev /*null unless conv_lone_tail(L)*/, int krev_stride,
                            const unsigned char* ids8 /*16-bit modes, block 0: as launch_hyena_conv*/, const float* ztab,

@@ -628,8 +628,8 @@ __global__ __launch_bounds__(Plan<LOGN>::NT) void hyena_conv_kernel(
 // IDS (16-bit modes, block 0): x0 | x1 | v looked up in ztab by token id, as in hyena_conv_kernel.
 template <typename T, bool LONE, bool IDS>
 __global__ __launch_bounds__(Plan<14>::NT) void hyena_conv_seg_kernel(
-    const T* __restrict__ z, T* __restrict__ y, const float2* __restrict__ kf /*[256][S][N]*/,
-    const float2* __restrict__ tw, const float* __restrict__ short_w, const float* __restrict__ short_b,
+    const T* __restrict__ z, T* __restrict__ y, const float2* __restrict__ kf /*[256][KS][N], KS >= S partitions stored*/,
+    int KS, const float2* __restrict__ tw, const float* __restrict__ short_w, const float* __restrict__ short_b,
     float2* __restrict__ gscratch /*[pairs][256][S][N]*/, int B, int L, int Lp, int S,
     const float* __restrict__ krev /*[256][krev_stride], LONE only*/, int krev_stride,
     const unsigned char* __restrict__ ids8 /*[B][Lp], IDS only*/, const float* __restrict__ ztab /*[16][768]*/) {
@@ -650,7 +650,7 @@ __global__ __launch_bounds__(Plan<14>::NT) void hyena_conv_seg_kernel(
     const T* zB = z + (size_t)(hasB ? bB : bA) * D3 * Lp;
     T* yA = y + ((size_t)bA * D + c) * Lp;
     T* yB = y + ((size_t)(hasB ? bB : bA) * D + c) * Lp;
-    const float2* kfc = kf + (size_t)c * S * N;
+    const float2* kfc = kf + (size_t)c * KS * N;
     float2* gs = gscratch + ((size_t)pair * D + c) * S * N;
     const float* kr = LONE ? krev + (size_t)c * krev_stride : nullptr;
     float dotA = 0.f, dotB = 0.f;
@@ -935,7 +935,7 @@ __global__ __launch_bounds__(Plan<14>::NT) void hyena_conv_seg_kernel(
 }
 
 template <typename T, bool LONE, bool IDS>
-static void launch_conv_seg_inst(const void* z, void* y, const float2* kf, const float2* tw, const float* short_w,
+static void launch_conv_seg_inst(const void* z, void* y, const float2* kf, int KS, const float2* tw, const float* short_w,
                               const float* short_b, float2* gscratch, int B, int L, int Lp, int S,
                               const float* krev, int krev_stride, const unsigned char* ids8, const float* ztab,
                               hipStream_t st) {
@@ -949,15 +949,15 @@ static void launch_conv_seg_inst(const void* z, void* y, const float2* kf, const
         attr_done = true;
     }
     dim3 grid((B + 1) / 2, D), block(P::NT);
-    hipLaunchKernelGGL(kern, grid, block, lds, st, reinterpret_cast<const T*>(z), reinterpret_cast<T*>(y), kf, tw,
+    hipLaunchKernelGGL(kern, grid, block, lds, st, reinterpret_cast<const T*>(z), reinterpret_cast<T*>(y), kf, KS, tw,
                        short_w, short_b, gscratch, B, L, Lp, S, krev, krev_stride, ids8, ztab);
 }
 template <typename T>
-static void launch_conv_seg_t(const void* z, void* y, const float2* kf, const float2* tw, const float* short_w,
+static void launch_conv_seg_t(const void* z, void* y, const float2* kf, int KS, const float2* tw, const float* short_w,
                               const float* short_b, float2* gscratch, int B, int L, int Lp, int S, const float* krev,
                               int krev_stride, const unsigned char* ids8, const float* ztab, hipStream_t st) {
 #define CLM_SEG(LONE, IDS)                                                                                               \
-    launch_conv_seg_inst<T, LONE, IDS>(z, y, kf, tw, short_w, short_b, gscratch, B, L, Lp, S, krev, krev_stride, ids8, ztab, st)
+    launch_conv_seg_inst<T, LONE, IDS>(z, y, kf, KS, tw, short_w, short_b, gscratch, B, L, Lp, S, krev, krev_stride, ids8, ztab, st)
     if constexpr (std::is_same<T, float>::value) {           // fp32 mode never takes the id path
         if (krev) CLM_SEG(true, false);
         else CLM_SEG(false, false);
@@ -971,15 +971,15 @@ static void launch_conv_seg_t(const void* z, void* y, const float2* kf, const fl
 #undef CLM_SEG
 }
 
-void launch_hyena_conv_seg(int prec, const void* z, void* y, const float2* kf, const float2* tw, const float* short_w,
+void launch_hyena_conv_seg(int prec, const void* z, void* y, const float2* kf, int KS, const float2* tw, const float* short_w,
                            const float* short_b, float2* gscratch, int B, int L, int Lp, int S, const float* krev,
                            int krev_stride, const unsigned char* ids8, const float* ztab, hipStream_t st) {
     if (prec == PREC_F32)
-        launch_conv_seg_t<float>(z, y, kf, tw, short_w, short_b, gscratch, B, L, Lp, S, krev, krev_stride, nullptr, nullptr, st);
+        launch_conv_seg_t<float>(z, y, kf, KS, tw, short_w, short_b, gscratch, B, L, Lp, S, krev, krev_stride, nullptr, nullptr, st);
     else if (prec == PREC_BF16)
-        launch_conv_seg_t<bf16_t>(z, y, kf, tw, short_w, short_b, gscratch, B, L, Lp, S, krev, krev_stride, ids8, ztab, st);
+        launch_conv_seg_t<bf16_t>(z, y, kf, KS, tw, short_w, short_b, gscratch, B, L, Lp, S, krev, krev_stride, ids8, ztab, st);
     else
-        launch_conv_seg_t<f16_t>(z, y, kf, tw, short_w, short_b, gscratch, B, L, Lp, S, krev, krev_stride, ids8, ztab, st);
+        launch_conv_seg_t<f16_t>(z, y, kf, KS, tw, short_w, short_b, gscratch, B, L, Lp, S, krev, krev_stride, ids8, ztab, st);
 }
 
 // ztab[id][n] = in_proj(LN1(embedding[id]))[n] of block 0, fp32: one workgroup per token id

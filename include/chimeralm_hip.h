@@ -88,7 +88,7 @@ int clm_create(const clm_config* cfg, int device, clm_handle** out);
 int clm_load_weight(clm_handle* h, const char* key, const void* data, int dtype, const int64_t* shape, int ndim);
 
 /* Packs weights for the kernels (MFMA fragment order, compute dtype) and checks completeness.
- * May be called again after further clm_load_weight calls; cached per-length filters are dropped. */
+ * May be called again after further clm_load_weight calls; the cached filter spectra are dropped. */
 int clm_finalize(clm_handle* h);
 
 /* Grow the workspace for batches up to B reads of L tokens (optional; clm_forward does it on demand). */

@@ -206,8 +206,8 @@ def test_baseline_batch_size_independent_properties(sd, built_lib):
 
 
 def test_shape_churn_filter_cache_and_workspace_regrowth(sd, built_lib):
-    """A stream of batches of changing shape through ONE engine: the per-length filter sets are an LRU of three (evicted and
-    rebuilt), the workspace grows on demand, short and long-read kernels alternate.  Every result must equal the one the
+    """A stream of batches of changing shape through ONE engine: the filter sets (one per transform size, one for long reads) are built on
+    first use, the workspace grows on demand, short and long-read kernels alternate.  Every result must equal the one the
     same shape gave the first time (bit-identical: no state leaks between calls), and the short ones the oracle's."""
     from chimeralm_amd.engine import Engine
 

@@ -25,6 +25,7 @@ def main():
     ap.add_argument("--bases", type=int, default=8192)
     ap.add_argument("--batch", type=int, default=256)
     ap.add_argument("--precision", default="fp16")
+    ap.add_argument("--min-bases", type=int, default=None, help="ragged file: read lengths uniform in [min-bases, bases]")
     a = ap.parse_args()
     from feeder_bench import write_bam
 
@@ -38,7 +39,7 @@ def main():
     model = lm.ChimeraLM.new(precision=a.precision)
     with tempfile.TemporaryDirectory() as td:
         path = Path(td) / "synthetic.bam"
-        write_bam(path, a.reads, a.bases)
+        write_bam(path, a.reads, a.bases, min_bases=a.min_bases)
         for label, n in (("warm-up", 2 * a.batch), ("timed", None)):
             out = Path(td) / f"pred_{label}"
             t0 = time.perf_counter()

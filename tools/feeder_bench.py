@@ -21,8 +21,10 @@ import numpy as np
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 
 
-def write_bam(path: Path, n_reads: int, n_bases: int, seed: int = 0) -> int:
+def write_bam(path: Path, n_reads: int, n_bases: int, seed: int = 0, min_bases: int | None = None) -> int:
+    """`n_reads` records of `n_bases` bases, or of lengths uniform in [min_bases, n_bases] (real long-read files are ragged)."""
     rng = np.random.default_rng(seed)
+    max_bases = n_bases
     sa = b"SAZchr1,100,+,50M,60,0;\0"
     header = b"BAM\1" + struct.pack("<i", 4) + b"@HD\n" + struct.pack("<i", 1) + struct.pack("<i", 5) + b"chr1\0" + struct.pack("<i", 1 << 28)
     codes = np.array([1, 2, 4, 8], dtype=np.uint8)                      # A C G T in the 4-bit alphabet
@@ -39,9 +41,11 @@ def write_bam(path: Path, n_reads: int, n_bases: int, seed: int = 0) -> int:
                 f.write(data + struct.pack("<II", zlib.crc32(chunk), len(chunk)))
                 total += len(chunk)
         for i in range(n_reads):
+            n_bases = max_bases if min_bases is None else int(rng.integers(min_bases, max_bases + 1))
             name = f"read_{i:08d}".encode()
             b = codes[rng.integers(0, 4, n_bases)]
-            packed = ((b[0::2] << 4) | b[1::2]).astype(np.uint8).tobytes()
+            bp = b if n_bases % 2 == 0 else np.append(b, np.uint8(0))
+            packed = ((bp[0::2] << 4) | bp[1::2]).astype(np.uint8).tobytes()
             qual = np.clip(rng.normal(25, 6, n_bases), 2, 40).astype(np.uint8).tobytes()
             body = struct.pack("<iiBBHHHiiii", 0, 1000 + i, len(name) + 1, 60, 4681, 1, 0, n_bases, -1, -1, 0) + name + b"\0"
             body += struct.pack("<I", n_bases << 4) + packed + qual + sa
