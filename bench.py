@@ -29,8 +29,15 @@ import torch
 sys.path.insert(0, str(Path(__file__).resolve().parent))
 
 D, DI, NLAYER = 256, 1024, 4
-PEAK_TFLOPS = {"fp32": 157.3, "bf16": 2500.0, "fp16": 2500.0}      # dense MFMA peaks, MI355X_MICROARCH.md
+PEAK_TFLOPS = {"fp32": 157.3, "bf16": 2500.0, "fp16": 2500.0, "fp16c": 2500.0}      # dense MFMA peaks, MI355X_MICROARCH.md
 SUSTAINED_MFMA16_TFLOPS = 1630.0   # measured, see roofline["peak_sustained_measured"]
+# MFMA instructions issued per algorithmic product: fp16c multiplies every activation fragment with the hi AND the lo half of
+# the weight pair (include/chimeralm_hip.h CLM_PREC_F16C)
+MFMA_ISSUE_FACTOR = {"fp32": 1.0, "bf16": 1.0, "fp16": 1.0, "fp16c": 2.0}
+# arithmetic behind each --precision, as the JSON line's "dtype" words it
+DTYPE_NOTE = {"fp32": "fp32 (v_mfma_f32_32x32x2_f32, exact)", "fp16": "fp16 MFMA inputs, fp32 accumulate (reduced precision: outside the 1e-3 gate)",
+              "bf16": "bf16 MFMA inputs, fp32 accumulate (reduced precision: outside the 1e-3 gate)",
+              "fp16c": "fp16 activations x (hi+lo) fp16 weight pairs, fp32 accumulate / LayerNorm / FFT / softmax; within 1e-3 of the fp32 reference"}
 PEAK_HBM_GBS = 8000.0
 # algorithmic FLOPs per token of each GEMM stage
 STAGE_FLOPS_PER_TOKEN = {"ln1_in_proj": 2 * D * 3 * D, "out_proj": 2 * D * D, "ln2_fc1_gelu": 2 * D * DI,
@@ -50,16 +57,31 @@ def stage_bytes_per_token(stage: str, es: int) -> float:
             "embed": 1 + D * 4, "softmax_pool": D * 4 + 8}.get(stage, 0.0)
 
 
+def kernel_sources_sha() -> str:
+    """Identity of the kernel sources a PMC digest belongs to: sha1 over chimeralm_amd/csrc/*.{hip,h} (names + contents)."""
+    import hashlib
+
+    h = hashlib.sha1()
+    csrc = Path(__file__).resolve().parent / "chimeralm_amd" / "csrc"
+    for f in sorted(list(csrc.glob("*.hip")) + list(csrc.glob("*.h"))):
+        h.update(f.name.encode())
+        h.update(f.read_bytes())
+    return h.hexdigest()[:16]
+
+
 def measured_traffic(stage: str, config: dict, dtype: str):
     """HBM bytes per launch of `stage` from the newest committed PMC digest (profiles/rNN_traffic.json, written by
     tools/profile_round.sh + tools/profile_digest.py from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes with the
-    gfx950 FETCH_SIZE x2 correction) -- only if it was collected on exactly this workload, else None."""
+    gfx950 FETCH_SIZE x2 correction) -- only if it was collected on exactly this workload AND on exactly these kernel
+    sources (the digest records kernel_sources_sha(); a kernel edited since makes it stale: then None, never an old number)."""
     for f in sorted(Path(__file__).resolve().parent.glob("profiles/r*_traffic.json"), reverse=True):
         try:
             d = json.loads(f.read_text())
         except (OSError, ValueError):
             continue
         if d.get("config") == config and d.get("dtype") == dtype and stage in d.get("stages", {}):
+            if d.get("kernel_sources_sha") != kernel_sources_sha():
+                return {"stale": f"profiles/{f.name} was collected on other kernel sources"}
             return {"hbm_bytes_per_launch": d["stages"][stage]["hbm_bytes_per_dispatch"], "source": f"profiles/{f.name}"}
     return None
 
@@ -157,9 +179,12 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=256, help="global batch (reads per step)")
     ap.add_argument("--bases", type=int, default=8192)
-    ap.add_argument("--precision", default=os.environ.get("CLM_PRECISION", "fp16"))
+    ap.add_argument("--precision", default=os.environ.get("CLM_PRECISION", "fp16c"),
+                    help="fp16c (default: the 16-bit-rate mode inside the reference's 1e-3 tolerance) | fp32 (exact) | "
+                         "fp16 | bf16 (reduced precision, outside the tolerance)")
     ap.add_argument("--chunk-reads", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-fp32-leg", action="store_true", help="skip the extra exact-fp32 timing (fp32_exact_reads_per_s)")
     ap.add_argument("--net", default="hyena", choices=["hyena", "transformer"],
                     help="hyena = the production predict path (the headline metric); transformer = SequenceCNNTransformer")
     a = ap.parse_args()
@@ -188,11 +213,14 @@ def main():
     eng.reserve(hi - lo, L)
     n_data = max(1, min(4, a.steps))                 # a few distinct resident batches, cycled
     batches = [torch.from_numpy(synthetic_ids(i, a.batch, a.bases)[lo:hi]).to(device) for i in range(n_data)]
-    logits = torch.empty((hi - lo, 2), dtype=torch.float32, device=device)
+    logits2 = [torch.empty((hi - lo, 2), dtype=torch.float32, device=device) for _ in range(2)]
+    logits = logits2[0]
+    gather = cdist.LogitsGather(device)      # N > 1: the all-gather runs on its own stream, behind the forward it belongs to
 
     def step(i):
-        eng.forward(batches[i % n_data], out=logits)
-        return cdist.gather_logits(logits) if world > 1 else logits
+        buf = logits2[i & 1]
+        eng.forward(batches[i % n_data], out=buf)
+        return gather.submit(buf)[0] if world > 1 else buf   # forward i + 1 is enqueued while gather i is in flight
 
     for i in range(a.warmup):
         step(i)
@@ -217,6 +245,11 @@ def main():
         elapsed = float(t.item())
     prof = eng.profile_read(reset=True)
     lat = sorted(e0.elapsed_time(e1) for e0, e1 in ev)
+    dev_names = [f"rank {rank}: cuda:{device.index} {torch.cuda.get_device_name(device)}"]
+    if world > 1:
+        allnames = [None] * world
+        torch.distributed.all_gather_object(allnames, dev_names[0])
+        dev_names = allnames
 
     # PCIe-inclusive rate (reported beside `value`, never as it): the same batches start in page-locked HOST memory, are
     # staged as uint8 on the engine's copy stream (clm_stage_ids) one batch ahead of the forward that consumes them
@@ -251,6 +284,7 @@ def main():
 
     if rank == 0:
         es = 4 if a.precision == "fp32" else 2
+        assert a.precision != "fp16c" or L >= 2048, "fp16c runs reads below 2048 tokens in fp32 kernels: use --precision fp32 to bench them"
         total_ms = sum(ms for ms, _ in prof.values()) or 1.0
         dom = max(prof, key=lambda k: prof[k][0])
         ms, launches = prof[dom]
@@ -281,20 +315,47 @@ def main():
                   "global_batch": a.batch, "tokens_per_read": L, "reads_per_gpu": hi - lo, "chunk_reads": a.chunk_reads,
                   "parallelism": f"read-sharded x{world}, logits all-gather" if world > 1 else "single GPU"}
         tr = measured_traffic(dom, config, a.precision)
-        if tr:
+        if tr and "stale" in tr:
+            roof["traffic_stale"] = tr["stale"]
+        elif tr:
             roof["traffic"], roof["traffic_unit"], roof["traffic_source"] = tr["hbm_bytes_per_launch"], "bytes/launch", tr["source"]
             alg = stage_bytes_per_token(dom, es) or TAIL_BYTES_PER_TOKEN.get(dom, {}).get(es, 0.0)
             if fused_next:   # + z of the next block (3 of 4 launches); block 0 reads ids instead of its residual rows
                 alg += 3 * D * es * (NLAYER - 1) / NLAYER - D * 4 / NLAYER
             roof["algorithmic_hbm_bytes_per_launch"] = alg * tokens_per_launch
+        if roof["bound"] == "mfma":
+            # MFMA work actually issued (fp16c: two instructions per product) against the same peaks: pipe occupancy
+            roof["mfma_issue_factor"] = MFMA_ISSUE_FACTOR[a.precision]
+            roof["issued_tflops"] = achieved * MFMA_ISSUE_FACTOR[a.precision]
+            roof["issued_frac"] = roof["issued_tflops"] / PEAK_TFLOPS[a.precision]
+        fp32_rate = None
+        if world == 1 and a.precision != "fp32" and not a.no_fp32_leg:
+            # the exact-fp32 engine on the same batches, so that the driver's run also times the mode that is bit-for-bit the
+            # reference's arithmetic (a few steps: it is ~5x slower)
+            e32 = Engine(device, precision="fp32", chunk_reads=a.chunk_reads)
+            e32.load_state_dict(lm.ChimeraLM.new(precision="fp32").state_dict())
+            e32.forward(batches[0], out=logits)
+            torch.cuda.synchronize(device)
+            k32 = max(2, min(3, a.steps))
+            t3 = time.perf_counter()
+            for i in range(k32):
+                e32.forward(batches[i % n_data], out=logits)
+            torch.cuda.synchronize(device)
+            fp32_rate = a.batch * k32 / (time.perf_counter() - t3)
+            e32.close()
         res = {
-            "metric": "reads/sec (whole node), 8k-bp reads batch=256", "value": a.batch * a.steps / elapsed,
+            "metric": f"reads/sec (whole node), {a.bases}-bp reads batch={a.batch}", "value": a.batch * a.steps / elapsed,
             "unit": "reads/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": elapsed / a.steps * 1e3, "p50_batch_latency_ms": lat[len(lat) // 2],
             "p50_host_visible_latency_ms": host_lat[len(host_lat) // 2],   # this rank's shard: enqueue -> logits on the host
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": a.precision,
+            "dtype_note": DTYPE_NOTE[a.precision],
             "data": "synthetic reads (seeded), seeded random-init weights of the production architecture",
             "config": config,
+            "distributed": {"backend": torch.distributed.get_backend() if world > 1 else None,
+                            "world_size": torch.distributed.get_world_size() if world > 1 else 1,
+                            "devices": dev_names, "gather": "side stream, one step behind" if world > 1 else None},
+            "fp32_exact_reads_per_s": fp32_rate,
             "pcie_inclusive_reads_per_s": host_rate,
             "dense_tflops_per_gpu": 6_423_040 * L * (hi - lo) * a.steps / elapsed / 1e12,
             "stage_ms_share": {k: round(v[0] / total_ms, 4) for k, v in prof.items() if v[1]},

@@ -36,7 +36,7 @@ def predict(
     num_workers: int = typer.Option(0, "--workers", "-w", help="Number of workers"),
     ckpt_path: Path | None = typer.Option(None, "--ckpt", "-c", hidden=True, help="Path to the checkpoint file"),
     weights: str = typer.Option("yangliz5/chimeralm", "--weights", help="Directory/file with model.safetensors"),
-    precision: str = typer.Option("fp32", "--precision", help="MFMA input type: fp32 | bf16 | fp16"),
+    precision: str = typer.Option("fp16c", "--precision", help="arithmetic of the dense projections: fp16c (fp16 x hi+lo weight pairs, within 1e-3 of the fp32 reference; default) | fp32 (exact) | fp16 | bf16 (reduced precision)"),
     feeder: str = typer.Option("native", "--feeder", help="BAM input: native (C++ decoder thread, pinned ring) | python"),
     random: bool = typer.Option(False, "--random", "-r", help="Make the prediction not deterministic"),
     verbose: bool = typer.Option(False, "--verbose", "-v", help="Enable verbose output"),

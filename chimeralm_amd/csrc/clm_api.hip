@@ -61,6 +61,11 @@ struct clm_handle {
     // packed / derived weights
     void* packed[NLAYER][4] = {};
     void* packed_score = nullptr;
+    // fp16c only: exact-fp32 packing of the same weights for reads shorter than f16c_min_len (see forward_chunk)
+    void* packed32[NLAYER][4] = {};
+    void* packed_score32 = nullptr;
+    LayerW lw32[NLAYER]{};
+    int f16c_min_len = 2048;
     // host batches: two device staging buffers fed by the handle's own copy stream
     struct Stage {
         void* buf = nullptr;
@@ -81,6 +86,7 @@ struct clm_handle {
     uint64_t clock = 0;
     // workspace (one chunk of reads)
     int ws_B = 0, ws_L = 0;
+    size_t ws_z_bytes = 0, ws_y_bytes = 0, ws_es = 0;   // ws_es: element size z / y were last written with
     float* h = nullptr;
     void *z = nullptr, *y = nullptr, *u = nullptr;
     float *scores = nullptr, *stats = nullptr, *partial = nullptr, *pooled = nullptr;
@@ -116,6 +122,11 @@ int fail(clm_handle* h, int code, const std::string& msg) {
     } while (0)
 
 size_t elem_size(int prec) { return prec == PREC_F32 ? 4 : 2; }
+// The arithmetic a chunk of L-token reads runs in.  fp16c keeps fp16 activation operands; their roundings are independent
+// from token to token and average out in the attention pooling like 1/sqrt(L) (measured max |dlogit| at 3x head scale:
+// 1.6e-4 at 8193 tokens, 5.6e-4 at 1000, 1.5e-3 at 100), so reads too short to average them take the exact-fp32 kernels --
+// they are cheap there -- and the mode stays within the reference's 1e-3 at every length.
+int effective_prec(const clm_handle* h, int L);
 int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
 // ---- expected weights -------------------------------------------------------------------------------
@@ -241,8 +252,12 @@ void free_workspace(clm_handle* h) {
 void free_packed(clm_handle* h) {
     for (int i = 0; i < NLAYER; ++i)
         for (int j = 0; j < 4; ++j)
+        {
             if (h->packed[i][j]) { (void)hipFree(h->packed[i][j]); h->packed[i][j] = nullptr; }
+            if (h->packed32[i][j]) { (void)hipFree(h->packed32[i][j]); h->packed32[i][j] = nullptr; }
+        }
     if (h->packed_score) { (void)hipFree(h->packed_score); h->packed_score = nullptr; }
+    if (h->packed_score32) { (void)hipFree(h->packed_score32); h->packed_score32 = nullptr; }
     if (h->ztab) { (void)hipFree(h->ztab); h->ztab = nullptr; }
     for (int j = 0; j < 5; ++j)
         if (h->head_t[j]) { (void)hipFree(h->head_t[j]); h->head_t[j] = nullptr; }
@@ -255,9 +270,16 @@ int ensure_workspace(clm_handle* h, int Bc, int L, hipStream_t st) {
     HIPCHK(h, hipStreamSynchronize(st));
     int nb = Bc > h->ws_B ? Bc : h->ws_B, nl = L > h->ws_L ? L : h->ws_L;
     free_workspace(h);
-    const size_t es = elem_size(h->cfg.precision), Lp = (size_t)round_up(nl, 64);
-    const size_t n_h = (size_t)nb * nl * D * 4, n_z = (size_t)nb * D3 * Lp * es, n_y = (size_t)nb * D * Lp * es,
-                 n_u = (size_t)nb * nl * DI * es;
+    // fp16c: 2-byte activations at nl tokens, or 4-byte ones for the reads below f16c_min_len that run in fp32
+    const size_t Lp = (size_t)round_up(nl, 64);
+    size_t es = elem_size(h->cfg.precision), nl_es = (size_t)nl * es, Lp_es = Lp * es;
+    if (h->cfg.precision == PREC_F16C) {
+        const size_t ls = (size_t)std::min(nl, h->f16c_min_len - 1);
+        nl_es = std::max(nl_es, ls * 4);
+        Lp_es = std::max(Lp_es, (size_t)round_up((int)ls, 64) * 4);
+    }
+    const size_t n_h = (size_t)nb * nl * D * 4, n_z = (size_t)nb * D3 * Lp_es, n_y = (size_t)nb * D * Lp_es,
+                 n_u = (size_t)nb * DI * nl_es;
     HIPCHK(h, hipMalloc((void**)&h->h, n_h));
     HIPCHK(h, hipMalloc(&h->z, n_z));
     HIPCHK(h, hipMalloc(&h->y, n_y));
@@ -277,6 +299,7 @@ int ensure_workspace(clm_handle* h, int Bc, int L, hipStream_t st) {
     }
     HIPCHK(h, hipMemset(h->z, 0, n_z));   // padding columns [L, Lp) must never hold NaN garbage
     HIPCHK(h, hipMemset(h->y, 0, n_y));
+    h->ws_z_bytes = n_z; h->ws_y_bytes = n_y; h->ws_es = 0;
     h->ws_B = nb;
     h->ws_L = nl;
     return CLM_OK;
@@ -382,11 +405,16 @@ struct StageTimer {
     }
 };
 
+int effective_prec(const clm_handle* h, int L) {
+    return (h->cfg.precision == PREC_F16C && L < h->f16c_min_len) ? (int)PREC_F32 : h->cfg.precision;
+}
+
 bool stop_here(clm_handle* h, int layer, int stage) { return h->stop_layer == layer && h->stop_stage == stage; }
 
 int forward_chunk(clm_handle* h, const void* ids, int ids_dtype, int64_t row_stride, int Bc, int L, float* logits,
                   hipStream_t st) {
-    const int prec = h->cfg.precision, Lp = round_up(L, 64);
+    const int prec = effective_prec(h, L), Lp = round_up(L, 64);
+    const bool alt32 = prec != h->cfg.precision;              // fp16c engine, short reads: exact-fp32 kernels and packing
     const float eps = h->cfg.ln_eps;
     FilterSet* fs = nullptr;
     const ReversedFilter* kr = nullptr;
@@ -396,14 +424,22 @@ int forward_chunk(clm_handle* h, const void* ids, int ids_dtype, int64_t row_str
     rc = ensure_workspace(h, Bc, L, st);
     if (rc) return rc;
     h->last_B = Bc; h->last_L = L; h->last_Lp = Lp;
-    const bool tuned16 = prec != PREC_F32 && !h->force_generic;
+    if (h->ws_es != elem_size(prec)) {   // fp16c: fp32 and fp16 chunks share z / y -- what one type left in the padding
+        if (h->ws_es) {                  // columns may read as NaN in the other
+            HIPCHK(h, hipMemsetAsync(h->z, 0, h->ws_z_bytes, st));
+            HIPCHK(h, hipMemsetAsync(h->y, 0, h->ws_y_bytes, st));
+        }
+        h->ws_es = elem_size(prec);
+    }
+    const bool tuned16 = prec != PREC_F32 && (!h->force_generic || prec == PREC_F16C);   // fp16c has no generic kernels
     // 16-bit modes, no debug stop: block 0 never touches the fp32 embedding rows in HBM --
     // its in_proj is a 16-row table looked up by the convolution and its residual is gathered from the embedding table
     const bool idpath = tuned16 && !h->no_idconv && !h->split_tail && h->stop_stage < 0;
     // ... and every block's tail kernel goes on, on the tile it has just produced, with LayerNorm-1 + in_proj of the next
     // block (the last block: ln_f + attention scores + pooling partials): no separate in_proj / score launches
     const bool fuse_next = tuned16 && !h->split_tail && !h->no_fuse_next && h->stop_stage < 0;
-    const ScorePoolArgs spa{h->h, W(h, "bb.ln_f.weight"), W(h, "bb.ln_f.bias"), h->packed_score,
+    const void* packed_score = alt32 ? h->packed_score32 : h->packed_score;
+    const ScorePoolArgs spa{h->h, W(h, "bb.ln_f.weight"), W(h, "bb.ln_f.bias"), packed_score,
                             W(h, "head.attention.0.bias"), W(h, "head.attention.2.weight"),
                             W(h, "head.attention.2.bias"), h->scores, h->partial, Bc, L, (L + 127) / 128, eps};
     {
@@ -413,7 +449,7 @@ int forward_chunk(clm_handle* h, const void* ids, int ids_dtype, int64_t row_str
     }
     if (stop_here(h, -1, CLM_STAGE_EMBED)) return CLM_OK;
     for (int i = 0; i < NLAYER; ++i) {
-        const LayerW& lw = h->lw[i];
+        const LayerW& lw = alt32 ? h->lw32[i] : h->lw[i];
         // block 0 in the 16-bit modes: its in_proj output is a function of the token id alone, the convolution looks it
         // up (ztab), single-shot and segmented kernel alike -- unless a debug stop asks for z itself or CLM_NO_IDCONV=1
         const bool idconv = i == 0 && (idpath || (tuned16 && !h->no_idconv && !stop_here(h, 0, CLM_STAGE_INPROJ)));
@@ -474,7 +510,7 @@ int forward_chunk(clm_handle* h, const void* ids, int ids_dtype, int64_t row_str
     if (tuned16) {   // score + pooling partials in one pass over h, merged by the classifier kernel
         if (!fuse_next) {
             StageTimer t(h, st, CLM_STAGE_SCORE);
-            launch_score_pool16(prec, h->h, W(h, "bb.ln_f.weight"), W(h, "bb.ln_f.bias"), h->packed_score,
+            launch_score_pool16(prec, h->h, W(h, "bb.ln_f.weight"), W(h, "bb.ln_f.bias"), packed_score,
                                 W(h, "head.attention.0.bias"), W(h, "head.attention.2.weight"),
                                 W(h, "head.attention.2.bias"), h->scores, h->partial, Bc, L, eps, st);
         }
@@ -483,7 +519,7 @@ int forward_chunk(clm_handle* h, const void* ids, int ids_dtype, int64_t row_str
     } else {
         {
             StageTimer t(h, st, CLM_STAGE_SCORE);
-            launch_score(prec, h->h, W(h, "bb.ln_f.weight"), W(h, "bb.ln_f.bias"), h->packed_score,
+            launch_score(prec, h->h, W(h, "bb.ln_f.weight"), W(h, "bb.ln_f.bias"), packed_score,
                          W(h, "head.attention.0.bias"), W(h, "head.attention.2.weight"), W(h, "head.attention.2.bias"),
                          h->scores, Bc, L, eps, st);
         }
@@ -526,7 +562,7 @@ int clm_create(const clm_config* cfg, int device, clm_handle** out) {
         cfg->filter_order != FORDER || cfg->emb_dim != EMB || cfg->head_hidden != HH || cfg->n_classes != NCLS)
         return fail(nullptr, CLM_E_UNSUPPORTED,
                     "only the HyenaDNA-small-32k + 512-wide attention-pooling head of chimeralm/models/lm.py is built");
-    if (cfg->precision < CLM_PREC_F32 || cfg->precision > CLM_PREC_F16 || cfg->chunk_reads < 1 ||
+    if (cfg->precision < CLM_PREC_F32 || cfg->precision > CLM_PREC_F16C || cfg->chunk_reads < 1 ||
         cfg->max_seq_len < 2)
         return fail(nullptr, CLM_E_INVALID, "clm_create: bad precision / chunk_reads / max_seq_len");
     int ndev = 0;
@@ -544,6 +580,7 @@ int clm_create(const clm_config* cfg, int device, clm_handle** out) {
     h->split_tail = std::getenv("CLM_SPLIT_TAIL") && std::getenv("CLM_SPLIT_TAIL")[0] == '1';
     h->cfg = *cfg;
     h->device = device;
+    if (const char* e = std::getenv("CLM_F16C_MIN_LEN")) h->f16c_min_len = std::max(1, std::atoi(e));   // developer knob (1 = never fp32)
     *out = h;
     return CLM_OK;
 }
@@ -604,11 +641,12 @@ int clm_finalize(clm_handle* h) {
     free_filters(h);
     const int prec = h->cfg.precision;
     hipStream_t st = 0;
-    auto pack = [&](const std::string& key, int n, int k, void** out) -> int {
-        HIPCHK(h, hipMalloc(out, packed_weight_bytes(prec, n, k)));
-        launch_pack_weight(prec, W(h, key), *out, n, k, st);
+    auto pack_as = [&](int pr, const std::string& key, int n, int k, void** out) -> int {
+        HIPCHK(h, hipMalloc(out, packed_weight_bytes(pr, n, k)));
+        launch_pack_weight(pr, W(h, key), *out, n, k, st);
         return CLM_OK;
     };
+    auto pack = [&](const std::string& key, int n, int k, void** out) -> int { return pack_as(prec, key, n, k, out); };
     for (int i = 0; i < NLAYER; ++i) {
         std::string p = "bb.layers." + std::to_string(i) + ".";
         int rc;
@@ -624,10 +662,20 @@ int clm_finalize(clm_handle* h) {
         lw.b_fc1 = W(h, p + "mlp.fc1.bias"); lw.b_fc2 = W(h, p + "mlp.fc2.bias");
         lw.short_w = W(h, p + "mixer.short_filter.weight"); lw.short_b = W(h, p + "mixer.short_filter.bias");
         lw.filt_bias = W(h, p + "mixer.filter_fn.bias");
+        if (prec == PREC_F16C) {
+            if ((rc = pack_as(PREC_F32, p + "mixer.in_proj.weight", D3, D, &h->packed32[i][0]))) return rc;
+            if ((rc = pack_as(PREC_F32, p + "mixer.out_proj.weight", D, D, &h->packed32[i][1]))) return rc;
+            if ((rc = pack_as(PREC_F32, p + "mlp.fc1.weight", DI, D, &h->packed32[i][2]))) return rc;
+            if ((rc = pack_as(PREC_F32, p + "mlp.fc2.weight", D, DI, &h->packed32[i][3]))) return rc;
+            h->lw32[i] = lw;
+            h->lw32[i].w_in = h->packed32[i][0]; h->lw32[i].w_out = h->packed32[i][1];
+            h->lw32[i].w_fc1 = h->packed32[i][2]; h->lw32[i].w_fc2 = h->packed32[i][3];
+        }
     }
     {
         int rc;
         if ((rc = pack("head.attention.0.weight", D, D, &h->packed_score))) return rc;
+        if (prec == PREC_F16C && (rc = pack_as(PREC_F32, "head.attention.0.weight", D, D, &h->packed_score32))) return rc;
     }
     HIPCHK(h, hipMalloc((void**)&h->ztab, (size_t)VOCAB * D3 * 4));
     launch_ztab(W(h, "bb.embeddings.word_embeddings.weight"), W(h, "bb.layers.0.norm1.weight"),
@@ -756,7 +804,7 @@ int clm_debug_fetch(clm_handle* h, const char* name, void* host_out, size_t byte
     if (!h || !name || !host_out) return fail(h, CLM_E_INVALID, "clm_debug_fetch: bad argument");
     HIPCHK(h, hipSetDevice(h->device));
     HIPCHK(h, hipDeviceSynchronize());
-    const size_t es = elem_size(h->cfg.precision);
+    const size_t es = elem_size(effective_prec(h, h->last_L));
     const size_t B = h->last_B, L = h->last_L, Lp = h->last_Lp;
     const void* src = nullptr;
     size_t have = 0;

@@ -43,7 +43,29 @@ __global__ void pack_weight_kernel(const float* __restrict__ w, typename CT<PREC
     out[i] = from_float<typename C::elem>(w[(size_t)row * k + col]);
 }
 
-size_t packed_weight_bytes(int prec, int n, int k) { return (size_t)n * k * (prec == PREC_F32 ? 4 : 2); }
+// compensated mode: every fragment twice, hi = fp16(w) then lo = fp16(w - hi):
+//   out[(((nt*(K/16) + ks)*2 + hl)*64 + lane)*8 + j]
+// (|lo| <= 2^-12 |w| is an fp16 subnormal for |w| < 0.25; v_mfma_f32_32x32x16_f16 keeps subnormal inputs --
+// tools/micro/mfma_denorm.cpp -- and the 2^-24 subnormal spacing still leaves the pair within 2^-19 of |w| = 0.06.)
+__global__ void pack_weight_split_kernel(const float* __restrict__ w, f16_t* __restrict__ out, int n, int k) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)n * k) return;
+    const int j = int(i % 8);
+    size_t q = i / 8;
+    const int lane = int(q % 64);
+    q /= 64;
+    const int ksteps = k / 16, ks = int(q % ksteps), nt = int(q / ksteps);
+    const float v = w[(size_t)(nt * 32 + (lane & 31)) * k + ks * 16 + 8 * (lane >> 5) + j];
+    const f16_t hi = from_float<f16_t>(v);
+    const f16_t lo = from_float<f16_t>(v - to_float(hi));
+    const size_t base = ((((size_t)nt * ksteps + ks) * 2) * 64 + lane) * 8 + j;
+    out[base] = hi;
+    out[base + 64 * 8] = lo;
+}
+
+size_t packed_weight_bytes(int prec, int n, int k) {
+    return (size_t)n * k * (prec == PREC_F32 ? 4 : prec == PREC_F16C ? 4 : 2);
+}
 
 void launch_pack_weight(int prec, const float* w, void* out, int n, int k, hipStream_t st) {
     size_t total = (size_t)n * k;
@@ -52,6 +74,8 @@ void launch_pack_weight(int prec, const float* w, void* out, int n, int k, hipSt
         hipLaunchKernelGGL(pack_weight_kernel<PREC_F32>, grid, block, 0, st, w, (float*)out, n, k);
     else if (prec == PREC_BF16)
         hipLaunchKernelGGL(pack_weight_kernel<PREC_BF16>, grid, block, 0, st, w, (bf16_t*)out, n, k);
+    else if (prec == PREC_F16C)
+        hipLaunchKernelGGL(pack_weight_split_kernel, grid, block, 0, st, w, (f16_t*)out, n, k);
     else
         hipLaunchKernelGGL(pack_weight_kernel<PREC_F16>, grid, block, 0, st, w, (f16_t*)out, n, k);
 }

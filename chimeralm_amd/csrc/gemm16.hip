@@ -75,9 +75,6 @@ __device__ __forceinline__ void resid_epilogue(float* h_out, const float* bias, 
 // `hook(step)`, step = 0..5, runs right after the weight request of each half-block: the caller may slip further global
 // loads in there (they queue BEHIND the weights the next MFMAs wait for -- vmcnt completes in order -- and have a whole
 // MFMA phase to land before the following weight request needs them out of the way).
-struct NoHook {
-    __device__ __forceinline__ void operator()(int) const {}
-};
 template <int PREC, typename Hook = NoHook>
 __device__ __forceinline__ void inproj_blocks(const typename CT<PREC>::elem* As, typename CT<PREC>::elem* Zs,
                                               const u16x8* wp, const float* __restrict__ bias_all, void* zout, int b,
@@ -90,16 +87,7 @@ __device__ __forceinline__ void inproj_blocks(const typename CT<PREC>::elem* As,
 #pragma unroll
     for (int nb = 0; nb < NBLOCKS; ++nb) {
         zero_acc(acc);
-        load_set<PREC, K, 1>(wp, nb, 0, 1, wave, lane, bs[1]);
-        hook(2 * nb);
-        __builtin_amdgcn_sched_barrier(0);
-        compute_tm<PREC, false>(As, 0, lrow, lhalf, bs[0], acc);
-        __builtin_amdgcn_sched_barrier(0);
-        load_set<PREC, K, 1>(wp, nb + 1 < NBLOCKS ? nb + 1 : 0, 0, 0, wave, lane, bs[0]);
-        hook(2 * nb + 1);
-        __builtin_amdgcn_sched_barrier(0);
-        compute_tm<PREC, false>(As, 1, lrow, lhalf, bs[1], acc);
-        __builtin_amdgcn_sched_barrier(0);
+        phase_tm<PREC, K, K, false>(As, wp, nb, 0, wp, nb + 1 < NBLOCKS ? nb + 1 : 0, 0, wave, lane, bs, acc, hook, 2 * nb);
         // epilogue: rows = tokens (register quads = 4 consecutive tokens), cols = feature (lane) -> zs[feature][token]
         const int nbase = nb * 256 + wave * 32;
         const float bias = bias_all[nbase + lrow];
@@ -177,9 +165,7 @@ __global__ __launch_bounds__(512) void out_proj16_kernel(GemmArgs a) {
     }
     __syncthreads();
     zero_acc(acc);
-    compute_km<PREC>(Ys, 0, lane, bs[0], acc);
-    compute_km<PREC>(Ys, 1, lane, bs[1], acc);
-    __builtin_amdgcn_sched_barrier(0);
+    phase_km<PREC, K, K>(Ys, wp, 0, 0, wp, 0, 0, wave, lane, bs, acc);
     __syncthreads();                                       // every wave is done reading Ys: reuse it as the staging tile
     resid_epilogue(a.h_out, a.bias, acc, b, t0, L, wave, lane, reinterpret_cast<float*>(smem));
 }
@@ -226,14 +212,7 @@ __global__ __launch_bounds__(512) void mlp16_kernel(MlpArgs m) {
     for (int j = 0; j < NCH; ++j) {
         // ---- fc1, hidden units [256 j, 256 j + 256): rows = hidden unit, cols = token
         zero_acc(acc1);
-        load_set<PREC, D, 1>(w1, j, 0, 1, wave, lane, bs[1]);
-        __builtin_amdgcn_sched_barrier(0);
-        compute_tm<PREC, true>(As, 0, lrow, lhalf, bs[0], acc1);
-        __builtin_amdgcn_sched_barrier(0);
-        load_set<PREC, DI, 1>(w2, 0, j, 0, wave, lane, bs[0]);
-        __builtin_amdgcn_sched_barrier(0);
-        compute_tm<PREC, true>(As, 1, lrow, lhalf, bs[1], acc1);
-        __builtin_amdgcn_sched_barrier(0);
+        phase_tm<PREC, D, DI, true>(As, w1, j, 0, w2, 0, j, wave, lane, bs, acc1);
         // ---- GELU -> Hs[token][hidden]: every wave must be done reading the previous chunk
         __syncthreads();
         {
@@ -252,14 +231,7 @@ __global__ __launch_bounds__(512) void mlp16_kernel(MlpArgs m) {
         }
         __syncthreads();
         // ---- fc2, reduction chunk j: rows = output feature, cols = token
-        load_set<PREC, DI, 1>(w2, 0, j, 1, wave, lane, bs[1]);
-        __builtin_amdgcn_sched_barrier(0);
-        compute_tm<PREC, true>(Hs, 0, lrow, lhalf, bs[0], acc2);
-        __builtin_amdgcn_sched_barrier(0);
-        load_set<PREC, D, 1>(w1, j + 1 < NCH ? j + 1 : 0, 0, 0, wave, lane, bs[0]);
-        __builtin_amdgcn_sched_barrier(0);
-        compute_tm<PREC, true>(Hs, 1, lrow, lhalf, bs[1], acc2);
-        __builtin_amdgcn_sched_barrier(0);
+        phase_tm<PREC, DI, D, true>(Hs, w2, 0, j, w1, j + 1 < NCH ? j + 1 : 0, 0, wave, lane, bs, acc2);
     }
     __syncthreads();                                       // As / Hs are dead: reuse them as the staging tiles
     resid_epilogue(m.h, m.b2, acc2, b, t0, L, wave, lane, reinterpret_cast<float*>(smem));
@@ -284,8 +256,10 @@ __device__ __forceinline__ void score_pool_tile(const ScorePoolArgs& m, const ty
     float* V = E + BM;
     const int lane = tid & 63, wave = tid >> 6, lrow = lane & 31, lhalf = lane >> 5, t0 = tile * BM, L = m.L;
     zero_acc(acc);
-    compute_tm<PREC, true>(As, 0, lrow, lhalf, bs[0], acc);   // rows = features (register quads), lane = token
-    compute_tm<PREC, true>(As, 1, lrow, lhalf, bs[1], acc);
+    {   // rows = features (register quads), lane = token; the last slot re-requests set 0 (unconditional prefetch, unused)
+        const u16x8* wsp = reinterpret_cast<const u16x8*>(m.w1);
+        phase_tm<PREC, D, D, true, true>(As, wsp, 0, 0, wsp, 0, 0, wave, lane, bs, acc);
+    }
     {
         float4 b1v[4], w2v[4];
 #pragma unroll
@@ -498,12 +472,7 @@ __global__ __launch_bounds__(512) void tail16_kernel(TailArgs m, unsigned long l
     CLM_STAMP_AT(1);
     // ---- 1. out_proj, then r = acc + h + b_out (kept in acc2)
     zero_acc(acc2);
-    compute_km<PREC>(Ys, 0, lane, bs[0], acc2);
-    __builtin_amdgcn_sched_barrier(0);
-    load_set<PREC, D, 1>(w1, 0, 0, 0, wave, lane, bs[0]);             // first fc1 set under the second half
-    __builtin_amdgcn_sched_barrier(0);
-    compute_km<PREC>(Ys, 1, lane, bs[1], acc2);
-    __builtin_amdgcn_sched_barrier(0);
+    phase_km<PREC, D, D>(Ys, wo, 0, 0, w1, 0, 0, wave, lane, bs, acc2);   // (first fc1 set requested under the last set)
     {
         const float* bo = Bt + BT_BOUT + wave * 32 + 4 * lhalf;
 #pragma unroll
@@ -527,14 +496,7 @@ __global__ __launch_bounds__(512) void tail16_kernel(TailArgs m, unsigned long l
 #pragma unroll 1
     for (int j = 0; j < NCH; ++j) {
         zero_acc(acc1);
-        load_set<PREC, D, 1>(w1, j, 0, 1, wave, lane, bs[1]);
-        __builtin_amdgcn_sched_barrier(0);
-        compute_tm<PREC, true>(As, 0, lrow, lhalf, bs[0], acc1);
-        __builtin_amdgcn_sched_barrier(0);
-        load_set<PREC, DI, 1>(w2, 0, j, 0, wave, lane, bs[0]);
-        __builtin_amdgcn_sched_barrier(0);
-        compute_tm<PREC, true>(As, 1, lrow, lhalf, bs[1], acc1);
-        __builtin_amdgcn_sched_barrier(0);
+        phase_tm<PREC, D, DI, true>(As, w1, j, 0, w2, 0, j, wave, lane, bs, acc1);
         // GELU biases first, then the second fc2 half-set: it streams in while the workgroup is in its VALU-only GELU
         // phase and the L2 -> CU path is otherwise idle (the MFMA phases are bound by exactly that path)
         float4 b1v[4];
@@ -562,13 +524,9 @@ __global__ __launch_bounds__(512) void tail16_kernel(TailArgs m, unsigned long l
         }
         __syncthreads();
         CLM_STAMP_AT(6 + 3 * j);
-        compute_tm<PREC, true>(Hs, 0, lrow, lhalf, bs[0], acc2);
-        __builtin_amdgcn_sched_barrier(0);
-        // next fc1 set; on the last trip the first set of what follows (wrap-around keeps the prefetch unconditional)
-        load_set<PREC, D, 1>((NEXT != NEXT_NONE && j + 1 == NCH) ? wn : w1, j + 1 < NCH ? j + 1 : 0, 0, 0, wave, lane, bs[0]);
-        __builtin_amdgcn_sched_barrier(0);
-        compute_tm<PREC, true>(Hs, 1, lrow, lhalf, bs[1], acc2);
-        __builtin_amdgcn_sched_barrier(0);
+        // last slot: next fc1 set; on the last trip the first set of what follows (wrap-around keeps the prefetch unconditional)
+        phase_tm<PREC, DI, D, true, true>(Hs, w2, 0, j, (NEXT != NEXT_NONE && j + 1 == NCH) ? wn : w1, j + 1 < NCH ? j + 1 : 0,
+                                          0, wave, lane, bs, acc2);
         CLM_STAMP_AT(7 + 3 * j);
     }
     __syncthreads();                                       // As / Hs are dead: reuse them as the staging tiles
@@ -653,6 +611,18 @@ template <typename Kern>
 static void set_lds(Kern kern, size_t lds) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
 }
+template <typename Kern, typename Args>
+static void launch16_inst(Kern kern, dim3 grid, dim3 block, size_t lds, hipStream_t st, const Args& args) {
+    set_lds(kern, lds);
+    hipLaunchKernelGGL(kern, grid, block, lds, st, args);
+}
+// one instantiation per 16-bit arithmetic mode (bf16, fp16, fp16 with hi + lo weights)
+#define CLM_LAUNCH16(prec, KERN, grid, block, lds, st, args)                                  \
+    do {                                                                                      \
+        if ((prec) == PREC_BF16) launch16_inst(KERN<PREC_BF16>, grid, block, lds, st, args);  \
+        else if ((prec) == PREC_F16C) launch16_inst(KERN<PREC_F16C>, grid, block, lds, st, args); \
+        else launch16_inst(KERN<PREC_F16>, grid, block, lds, st, args);                       \
+    } while (0)
 
 void launch_inproj16(int prec, const float* h, const float* g, const float* bta, const void* w, const float* bias,
                      void* z, int B, int L, int Lp, float eps, hipStream_t st) {
@@ -660,15 +630,7 @@ void launch_inproj16(int prec, const float* h, const float* g, const float* bta,
     a.h_in = h; a.ln_g = g; a.ln_b = bta; a.w = w; a.bias = bias; a.out = z; a.B = B; a.L = L; a.Lp = Lp; a.eps = eps;
     constexpr size_t lds = (size_t)(128 * RS16 + 8 * 32 * RSOUT) * 2;
     dim3 grid((L + 127) / 128, B), block(512);
-    if (prec == PREC_BF16) {
-        static bool once = (set_lds(in_proj16_kernel<PREC_BF16>, lds), true);
-        (void)once;
-        hipLaunchKernelGGL(in_proj16_kernel<PREC_BF16>, grid, block, lds, st, a);
-    } else {
-        static bool once = (set_lds(in_proj16_kernel<PREC_F16>, lds), true);
-        (void)once;
-        hipLaunchKernelGGL(in_proj16_kernel<PREC_F16>, grid, block, lds, st, a);
-    }
+    CLM_LAUNCH16(prec, in_proj16_kernel, grid, block, lds, st, a);
 }
 
 void launch_outproj16(int prec, const void* y, const void* w, const float* bias, float* h, int B, int L, int Lp,
@@ -678,15 +640,7 @@ void launch_outproj16(int prec, const void* y, const void* w, const float* bias,
     constexpr size_t lds = (size_t)8 * 128 * 32 * 4;       // staging tiles of the residual epilogue (>= 256*RSKM*2)
     static_assert(lds >= (size_t)D * RSKM * 2, "k-major tile must fit");
     dim3 grid((L + 127) / 128, B), block(512);
-    if (prec == PREC_BF16) {
-        static bool once = (set_lds(out_proj16_kernel<PREC_BF16>, lds), true);
-        (void)once;
-        hipLaunchKernelGGL(out_proj16_kernel<PREC_BF16>, grid, block, lds, st, a);
-    } else {
-        static bool once = (set_lds(out_proj16_kernel<PREC_F16>, lds), true);
-        (void)once;
-        hipLaunchKernelGGL(out_proj16_kernel<PREC_F16>, grid, block, lds, st, a);
-    }
+    CLM_LAUNCH16(prec, out_proj16_kernel, grid, block, lds, st, a);
 }
 
 void launch_mlp16(int prec, float* h, const float* g, const float* bta, const void* w1, const float* b1, const void* w2,
@@ -694,15 +648,7 @@ void launch_mlp16(int prec, float* h, const float* g, const float* bta, const vo
     MlpArgs m{h, g, bta, w1, w2, b1, b2, B, L, eps};
     constexpr size_t lds = (size_t)2 * 128 * RS16 * 2;
     dim3 grid((L + 127) / 128, B), block(512);
-    if (prec == PREC_BF16) {
-        static bool once = (set_lds(mlp16_kernel<PREC_BF16>, lds), true);
-        (void)once;
-        hipLaunchKernelGGL(mlp16_kernel<PREC_BF16>, grid, block, lds, st, m);
-    } else {
-        static bool once = (set_lds(mlp16_kernel<PREC_F16>, lds), true);
-        (void)once;
-        hipLaunchKernelGGL(mlp16_kernel<PREC_F16>, grid, block, lds, st, m);
-    }
+    CLM_LAUNCH16(prec, mlp16_kernel, grid, block, lds, st, m);
 }
 
 // developer stamps (CLM_STAMP=1): per-phase mean cycles of wave 0 over all workgroups, printed by clm_destroy
@@ -775,7 +721,7 @@ void launch_tail16(int prec, const TailArgs& m, int next, hipStream_t st) {
     }();
     dim3 grid(total < cus ? total : cus), block(512);          // persistent: one workgroup per CU (LDS-limited anyway)
     static const bool stamp = std::getenv("CLM_STAMP") && std::getenv("CLM_STAMP")[0] == '1';
-    if (stamp && prec == PREC_F16 && next == NEXT_INPROJ) {
+    if (stamp && (prec == PREC_F16 || prec == PREC_F16C) && next == NEXT_INPROJ) {
         const size_t wgs = (size_t)total;
         if (wgs > s_stamp_wgs) {
             if (s_stamp_buf) (void)hipFree(s_stamp_buf);
@@ -783,15 +729,25 @@ void launch_tail16(int prec, const TailArgs& m, int next, hipStream_t st) {
             s_stamp_wgs = wgs;
         }
         (void)hipMemsetAsync(s_stamp_buf, 0, wgs * TAIL_NSTAMP * 8, st);
-        static bool once = (set_lds(tail16_kernel<PREC_F16, true, NEXT_INPROJ>, lds), true);
-        (void)once;
-        hipLaunchKernelGGL((tail16_kernel<PREC_F16, true, NEXT_INPROJ>), grid, block, lds, st, m, s_stamp_buf);
+        if (prec == PREC_F16) {
+            static bool once = (set_lds(tail16_kernel<PREC_F16, true, NEXT_INPROJ>, lds), true);
+            (void)once;
+            hipLaunchKernelGGL((tail16_kernel<PREC_F16, true, NEXT_INPROJ>), grid, block, lds, st, m, s_stamp_buf);
+        } else {
+            static bool once = (set_lds(tail16_kernel<PREC_F16C, true, NEXT_INPROJ>, lds), true);
+            (void)once;
+            hipLaunchKernelGGL((tail16_kernel<PREC_F16C, true, NEXT_INPROJ>), grid, block, lds, st, m, s_stamp_buf);
+        }
         return;
     }
     if (prec == PREC_BF16) {
         if (next == NEXT_INPROJ) launch_tail_inst<PREC_BF16, NEXT_INPROJ>(m, grid, lds, st);
         else if (next == NEXT_SCORE) launch_tail_inst<PREC_BF16, NEXT_SCORE>(m, grid, lds, st);
         else launch_tail_inst<PREC_BF16, NEXT_NONE>(m, grid, lds, st);
+    } else if (prec == PREC_F16C) {
+        if (next == NEXT_INPROJ) launch_tail_inst<PREC_F16C, NEXT_INPROJ>(m, grid, lds, st);
+        else if (next == NEXT_SCORE) launch_tail_inst<PREC_F16C, NEXT_SCORE>(m, grid, lds, st);
+        else launch_tail_inst<PREC_F16C, NEXT_NONE>(m, grid, lds, st);
     } else {
         if (next == NEXT_INPROJ) launch_tail_inst<PREC_F16, NEXT_INPROJ>(m, grid, lds, st);
         else if (next == NEXT_SCORE) launch_tail_inst<PREC_F16, NEXT_SCORE>(m, grid, lds, st);
@@ -806,13 +762,7 @@ void launch_score_pool16(int prec, const float* h, const float* g, const float* 
     ScorePoolArgs m{h, g, bta, w1, b1, w2, b2, scores, partial, B, L, ntiles, eps};
     constexpr size_t lds = (size_t)128 * RS16 * 2 + (size_t)(8 * 128 + 128 + 4 * D) * 4;
     dim3 grid(ntiles, B), block(512);
-    if (prec == PREC_BF16) {
-        set_lds(score_pool16_kernel<PREC_BF16>, lds);
-        hipLaunchKernelGGL(score_pool16_kernel<PREC_BF16>, grid, block, lds, st, m);
-    } else {
-        set_lds(score_pool16_kernel<PREC_F16>, lds);
-        hipLaunchKernelGGL(score_pool16_kernel<PREC_F16>, grid, block, lds, st, m);
-    }
+    CLM_LAUNCH16(prec, score_pool16_kernel, grid, block, lds, st, m);
 }
 
 }  // namespace clm

@@ -19,16 +19,18 @@ __device__ __forceinline__ unsigned short to_bits(float v) {
     return from_float<typename CT<PREC>::elem>(v).bits;
 }
 
-// acc[mt][nt] += A-tile(token-major LDS) x weight set.  ROWS_N: accumulator rows are output features (lane = token).
+// acc[mt] += A-tile(token-major LDS) x weight set `part` (k-steps [part * KPS, (part + 1) * KPS) of the 256-deep chunk).
+// ROWS_N: accumulator rows are output features (lane = token).  Compensated mode: the set holds (hi, lo) pairs and every
+// A fragment feeds two MFMAs -- half the LDS bytes per MFMA of the plain modes.
 template <int PREC, bool ROWS_N, int AHEAD = 4>
 __device__ __forceinline__ void compute_tm(const typename CT<PREC>::elem* As, int part, int lrow, int lhalf,
                                            const u16x8 (&src)[1][SETK], f32x16 (&acc)[4]) {
-    // Explicitly software-pipelined over the 4*SETK (k-step, row tile) items: the A fragment of item i + AHEAD is requested
-    // before the MFMA of item i (ring of AHEAD + 1 fragments), and that order is pinned with sched_group_barrier.  Left to
+    // Explicitly software-pipelined over the 4*KPS (k-step, row tile) items: the A fragment of item i + AHEAD is requested
+    // before the MFMA(s) of item i (ring of AHEAD + 1 fragments), and that order is pinned with sched_group_barrier.  Left to
     // itself hipcc serialises `ds_read -> s_waitcnt lgkmcnt(0) -> mfma` wherever registers are tight (fc1: both accumulators
     // and two half-sets live), and every MFMA then pays a full LDS latency: fc1 ran at half the rate of fc2.
-    constexpr int NI = 4 * SETK, R = AHEAD + 1;
-    const typename CT<PREC>::elem* a0 = As + lrow * RS16 + part * SETK * 16 + lhalf * 8;
+    constexpr int FR = WFR<PREC>, KP = KPS<PREC>, NI = 4 * KP, R = AHEAD + 1;
+    const typename CT<PREC>::elem* a0 = As + lrow * RS16 + part * KP * 16 + lhalf * 8;
     u16x8 af[R];
 #pragma unroll
     for (int i = 0; i < AHEAD; ++i) af[i % R] = *reinterpret_cast<const u16x8*>(a0 + (i & 3) * 32 * RS16 + (i >> 2) * 16);
@@ -38,14 +40,17 @@ __device__ __forceinline__ void compute_tm(const typename CT<PREC>::elem* As, in
             const int n = i + AHEAD;
             af[n % R] = *reinterpret_cast<const u16x8*>(a0 + (n & 3) * 32 * RS16 + (n >> 2) * 16);
         }
-        if (ROWS_N) acc[i & 3] = mfma<PREC>(src[0][i >> 2], af[i % R], acc[i & 3]);
-        else acc[i & 3] = mfma<PREC>(af[i % R], src[0][i >> 2], acc[i & 3]);
+#pragma unroll
+        for (int f = 0; f < FR; ++f) {
+            if (ROWS_N) acc[i & 3] = mfma<PREC>(src[0][(i >> 2) * FR + f], af[i % R], acc[i & 3]);
+            else acc[i & 3] = mfma<PREC>(af[i % R], src[0][(i >> 2) * FR + f], acc[i & 3]);
+        }
     }
     __builtin_amdgcn_sched_group_barrier(0x100, AHEAD, 0);
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
         if (i + AHEAD < NI) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, FR, 0);
     }
 }
 
@@ -54,20 +59,70 @@ __device__ __forceinline__ void compute_tm(const typename CT<PREC>::elem* As, in
 template <int PREC>
 __device__ __forceinline__ void compute_km(const typename CT<PREC>::elem* Ys, int part, int lane,
                                            const u16x8 (&src)[1][SETK], f32x16 (&acc)[4]) {
+    constexpr int FR = WFR<PREC>, KP = KPS<PREC>;
     const int li = lane & 15, g1 = (lane >> 4) & 1, h = lane >> 5, q = li >> 2, p = li & 3;
     const typename CT<PREC>::elem* base = Ys + (8 * h + q) * RSKM + 16 * g1 + 4 * p;
 #pragma unroll
-    for (int ks = 0; ks < SETK; ++ks) {
+    for (int ks = 0; ks < KP; ++ks) {
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) {
-            const typename CT<PREC>::elem* p0 = base + ((part * SETK + ks) * 16) * RSKM + mt * 32;
+            const typename CT<PREC>::elem* p0 = base + ((part * KP + ks) * 16) * RSKM + mt * 32;
             v4i16 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4i16_ptr)(p0));
             v4i16 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4i16_ptr)(p0 + 4 * RSKM));
             u16x8 af = {(unsigned short)lo[0], (unsigned short)lo[1], (unsigned short)lo[2], (unsigned short)lo[3],
                         (unsigned short)hi[0], (unsigned short)hi[1], (unsigned short)hi[2], (unsigned short)hi[3]};
-            acc[mt] = mfma<PREC>(src[0][ks], af, acc[mt]);     // rows = output feature, cols = token
+#pragma unroll
+            for (int f = 0; f < FR; ++f) acc[mt] = mfma<PREC>(src[0][ks * FR + f], af, acc[mt]);   // rows = output feature, cols = token
         }
     }
+}
+
+// ---- one 256-deep reduction phase of a wave's 32 output columns over an LDS-resident tile ---------------------------
+// The weight sets of the phase ping-pong through bs[0] / bs[1]: on entry bs[0] holds (or has in flight) set 0 of
+// (wp, nb, kc) and, if P1_LOADED, bs[1] set 1; set p + 1 is requested before the MFMAs of set p, and the slot of the last
+// set requests set 0 of the FOLLOWING phase (wnext, nnb, nkc) -- unconditionally (a conditional prefetch makes hipcc's
+// waitcnt pass merge the "nothing pending" state and wait inside the set, see gemm.hip).  NPARTS is even, so every phase
+// ends with its successor's set 0 in bs[0] and bs[1] free.  `hook(hook0 + i)`, i = 0, 1, runs right after the weight request
+// of each half of the phase: the caller may slip further global loads in there (they queue BEHIND the weights the next
+// MFMAs wait for -- vmcnt completes in order -- and have a whole MFMA phase to land).
+struct NoHook {
+    __device__ __forceinline__ void operator()(int) const {}
+};
+template <int PREC, int K, int KN, bool ROWS_N, bool P1_LOADED = false, typename Hook = NoHook>
+__device__ __forceinline__ void phase_tm(const typename CT<PREC>::elem* As, const u16x8* wp, int nb, int kc,
+                                         const u16x8* wnext, int nnb, int nkc, int wave, int lane,
+                                         u16x8 (&bs)[2][1][SETK], f32x16 (&acc)[4], Hook hook = Hook(), int hook0 = 0) {
+    constexpr int NP = NPARTS<PREC>;
+    const int lrow = lane & 31, lhalf = lane >> 5;
+    static_for<0, NP>([&](auto pc) {
+        constexpr int p = decltype(pc)::value;
+        if constexpr (p + 1 < NP) {
+            if constexpr (!(P1_LOADED && p == 0)) load_set<PREC, K, 1>(wp, nb, kc, p + 1, wave, lane, bs[(p + 1) & 1]);
+        } else {
+            load_set<PREC, KN, 1>(wnext, nnb, nkc, 0, wave, lane, bs[0]);
+        }
+        if constexpr (p % (NP / 2) == 0) hook(hook0 + p / (NP / 2));
+        __builtin_amdgcn_sched_barrier(0);
+        compute_tm<PREC, ROWS_N>(As, p, lrow, lhalf, bs[p & 1], acc);
+        __builtin_amdgcn_sched_barrier(0);
+    });
+}
+// same over the k-major tile (out_proj); set 1 is always loaded by the caller
+template <int PREC, int K, int KN>
+__device__ __forceinline__ void phase_km(const typename CT<PREC>::elem* Ys, const u16x8* wp, int nb, int kc,
+                                         const u16x8* wnext, int nnb, int nkc, int wave, int lane,
+                                         u16x8 (&bs)[2][1][SETK], f32x16 (&acc)[4]) {
+    constexpr int NP = NPARTS<PREC>;
+    static_for<0, NP>([&](auto pc) {
+        constexpr int p = decltype(pc)::value;
+        if constexpr (p > 0) {
+            if constexpr (p + 1 < NP) load_set<PREC, K, 1>(wp, nb, kc, p + 1, wave, lane, bs[(p + 1) & 1]);
+            else load_set<PREC, KN, 1>(wnext, nnb, nkc, 0, wave, lane, bs[0]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        compute_km<PREC>(Ys, p, lane, bs[p & 1], acc);
+        __builtin_amdgcn_sched_barrier(0);
+    });
 }
 
 __device__ __forceinline__ void zero_acc(f32x16 (&acc)[4]) {

@@ -28,6 +28,16 @@ struct CT<PREC_F16> {
     static constexpr int MFMA_K = 16, BM = 128, RS = 264;
 };
 
+template <>
+struct CT<PREC_F16C> {
+    using elem = f16_t;
+    using frag = u16x8;
+    static constexpr int MFMA_K = 16, BM = 128, RS = 264;
+};
+// weight fragments per k-step in the packed stream: 1, or 2 (hi, lo) in the compensated mode
+template <int PREC>
+constexpr int WFR = PREC == PREC_F16C ? 2 : 1;
+
 template <int PREC>
 __device__ __forceinline__ f32x16 mfma(typename CT<PREC>::frag a, typename CT<PREC>::frag b, f32x16 c);
 template <>
@@ -41,6 +51,12 @@ __device__ __forceinline__ f32x16 mfma<PREC_BF16>(u16x8 a, u16x8 b, f32x16 c) {
 }
 template <>
 __device__ __forceinline__ f32x16 mfma<PREC_F16>(u16x8 a, u16x8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0,
+                                                  0);
+}
+
+template <>
+__device__ __forceinline__ f32x16 mfma<PREC_F16C>(u16x8 a, u16x8 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0,
                                                   0);
 }
@@ -267,16 +283,22 @@ __device__ __forceinline__ void epilogue(const GemmArgs& a, f32x16 (&acc)[CT<PRE
     }
 }
 
-// one "set" of weight fragments: both column tiles of a wave x SETK k-steps (16 bytes per lane each)
+// one "set" of weight fragments: both column tiles of a wave x SETK fragments (16 bytes per lane each) = SETK k-steps,
+// or SETK / 2 k-steps of (hi, lo) pairs in the compensated mode; a 256-deep reduction chunk is NPARTS sets
 constexpr int SETK = 8;
+template <int PREC>
+constexpr int KPS = SETK / WFR<PREC>;                       // k-steps per set
+template <int PREC>
+constexpr int NPARTS = (256 / 16) / KPS<PREC>;              // sets per 256-deep chunk (16-bit types): 2, or 4
 template <int PREC, int K, int NT = 2>
 __device__ __forceinline__ void load_set(const typename CT<PREC>::frag* wp, int nb, int kc, int part, int wave, int lane,
                                          typename CT<PREC>::frag (&dst)[NT][SETK]) {
     constexpr int KSTEPS = 256 / CT<PREC>::MFMA_K, KSTEPS_ALL = K / CT<PREC>::MFMA_K;
+    constexpr int FR = CT<PREC>::MFMA_K == 16 ? WFR<PREC> : 1, KP = SETK / FR;
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
         const typename CT<PREC>::frag* p =
-            wp + ((size_t)(nb * 8 + wave * NT + nt) * KSTEPS_ALL + kc * KSTEPS + part * SETK) * 64 + lane;
+            wp + ((size_t)(nb * 8 + wave * NT + nt) * KSTEPS_ALL + kc * KSTEPS + part * KP) * (FR * 64) + lane;
 #pragma unroll
         for (int ks = 0; ks < SETK; ++ks) dst[nt][ks] = p[(size_t)ks * 64];
     }

@@ -51,6 +51,51 @@ def gather_logits(local_logits: torch.Tensor, world: int | None = None) -> torch
     return out
 
 
+class LogitsGather:
+    """The per-batch all-gather of `[B/G, C]` logits, kept OFF the compute stream ("on a side
+    stream"): `submit` orders the collective after the forward that produced `local_logits` through an event and issues it on
+    this object's own stream, so the next batch's kernels are enqueued and run while the 2 KiB exchange is in flight; the
+    caller picks the result up one batch later (`done.synchronize()` / `wait`).  RCCL when the backend is "nccl"."""
+
+    def __init__(self, device: torch.device):
+        self.device = device
+        self.side = torch.cuda.Stream(device) if device.type == "cuda" else None
+
+    def submit(self, local_logits: torch.Tensor):
+        """-> (gathered [B, C] tensor, event that fires when it is complete)."""
+        if not dist.is_initialized() or dist.get_world_size() == 1:
+            return local_logits, None
+        world = dist.get_world_size()
+        out = torch.empty((world * local_logits.shape[0], local_logits.shape[1]), dtype=local_logits.dtype,
+                          device=local_logits.device)
+        if self.side is None:
+            dist.all_gather_into_tensor(out, local_logits.contiguous())
+            return out, None
+        ready = torch.cuda.Event()
+        ready.record(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(self.side):
+            self.side.wait_event(ready)
+            dist.all_gather_into_tensor(out, local_logits.contiguous())
+            done = torch.cuda.Event()
+            done.record(self.side)
+        local_logits.record_stream(self.side)
+        out.record_stream(self.side)
+        return out, done
+
+    def wait(self):
+        if self.side is not None:
+            self.side.synchronize()
+
+
+def free_port() -> int:
+    """A TCP port that is free right now on 127.0.0.1 (rendezvous of the ranks `predict -g N` spawns)."""
+    import socket
+
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
 def barrier():
     if dist.is_initialized() and dist.get_world_size() > 1:
         dist.barrier()

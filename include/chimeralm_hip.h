@@ -51,6 +51,10 @@ extern "C" {
 #define CLM_PREC_F32 0
 #define CLM_PREC_BF16 1
 #define CLM_PREC_F16 2
+/* F16C: fp16 activations x weights held as an fp16 pair hi + lo (two MFMAs per product, one fp32 accumulator).  The mode
+ * that runs at 16-bit MFMA rate AND stays within the reference's 1e-3 logit tolerance (weight rounding is the error
+ * that attention pooling cannot average out, tests/error_model.py); z / y are stored as fp16 like CLM_PREC_F16. */
+#define CLM_PREC_F16C 3
 
 typedef struct clm_handle clm_handle;
 

@@ -1,0 +1,117 @@
+"""CPU error model of the 16-bit engine modes (developer tool; test infrastructure: it imports the oracle).
+
+Runs the oracle's forward in float64 with selectable roundings to fp16 / bf16 / split (hi + lo) at exactly the places the
+HIP path rounds: GEMM activation operands (LN1, y, LN2, GELU output, ln_f), packed weights, and the z / y tensors stored
+between the tail kernel and the long convolution.  Prints the max |logit error| against the unrounded float64 forward for
+each ablation, so that the cheapest set of compensations meeting north_star's 1e-3 can be chosen before any kernel is
+written.       python tests/error_model.py [B L]
+"""
+import sys
+from pathlib import Path
+
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from oracle import hyena_oracle as ho
+
+DT = torch.float64
+
+
+def rnd(x, mode):
+    """mode: None exact | 'h' fp16 | 'b' bf16 | 'hh' fp16 hi + fp16 lo | 'h8' fp16 + e4m3-grade lo (4 significant bits)"""
+    if mode is None:
+        return x
+    if mode == "h":
+        return x.to(torch.float16).to(DT)
+    if mode == "b":
+        return x.to(torch.bfloat16).to(DT)
+    if mode == "hh":
+        hi = x.to(torch.float16).to(DT)
+        return hi + (x - hi).to(torch.float16).to(DT)
+    if mode == "h8":
+        hi = x.to(torch.float16).to(DT)
+        lo = x - hi
+        m, e = torch.frexp(lo)
+        return hi + torch.ldexp(torch.round(m * 16) / 16, e)
+    raise ValueError(mode)
+
+
+def lin(x, sd, key, am, wm):
+    if isinstance(wm, dict):
+        wm = next((v for k, v in wm.items() if k in key), None)
+    b = sd.get(key + ".bias")
+    return F.linear(rnd(x, am), rnd(sd[key + ".weight"].to(DT), wm), None if b is None else b.to(DT))
+
+
+def forward(ids, sd, cfg):
+    """cfg keys: a_ln1, a_y, a_ln2, a_gelu, a_lnf (activation operand modes), w (weights), z, y (storage), pool (pooled
+    vector taken from the rounded ln_f tile)"""
+    g = cfg.get
+    ids = torch.as_tensor(ids, dtype=torch.int64)
+    h = F.embedding(ids, sd[ho.BB + "embeddings.word_embeddings.weight"].to(DT))
+    L = h.shape[1]
+    for i in range(ho.N_LAYER):
+        p = f"{ho.BB}layers.{i}."
+        u = ho._ln(h, sd, p + "norm1", DT)
+        if i == 0 and g("block0_exact", True):       # the engine looks block 0's in_proj up in an fp32 table by token id
+            z = lin(u, sd, p + "mixer.in_proj", None, None).transpose(1, 2)
+        else:
+            z = rnd(lin(u, sd, p + "mixer.in_proj", g("a_ln1"), g("w")).transpose(1, 2), g("z"))
+        uc = ho.short_filter(z, sd, i, DT)
+        x0, x1, v = uc.split(ho.D_MODEL, dim=1)
+        k = ho.hyena_filter(sd, i, L, DT).transpose(0, 1)
+        v = ho.fftconv(v * x1, k, sd[p + "mixer.filter_fn.bias"].to(DT))
+        y = rnd(v * x0, g("y"))
+        r = lin(y.transpose(1, 2), sd, p + "mixer.out_proj", g("a_y"), g("w")) + h
+        m = lin(ho._ln(r, sd, p + "norm2", DT), sd, p + "mlp.fc1", g("a_ln2"), g("w"))
+        h = lin(F.gelu(m, approximate="tanh"), sd, p + "mlp.fc2", g("a_gelu"), g("w")) + r
+    hid = ho._ln(h, sd, ho.BB + "ln_f", DT)
+    s = ho._lin(F.gelu(lin(hid, sd, ho.HD + "attention.0", g("a_lnf"), g("w"))), sd, ho.HD + "attention.2", DT)
+    a = torch.softmax(s, dim=1)
+    pooled = (rnd(hid, g("pool")) * a).sum(dim=1)
+    x = F.gelu(ho._lin(pooled, sd, ho.HD + "classifier.0", DT))
+    x = F.gelu(ho._lin(x, sd, ho.HD + "classifier.3", DT))
+    x = ho._lin(F.gelu(ho._lin(x, sd, ho.HD + "classifier.6.layers.0", DT)), sd, ho.HD + "classifier.6.layers.3", DT) + x
+    return ho._lin(x, sd, ho.HD + "output_layer", DT)
+
+
+ACT = ("a_ln1", "a_y", "a_ln2", "a_gelu", "a_lnf")
+ALL16 = {**{k: "h" for k in ACT}, "w": "h", "z": "h", "y": "h", "pool": "h"}
+
+
+def main():
+    B, L = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (6, 1000)
+    wseed = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+    sd = ho.make_state_dict(wseed, head_scale=3.0)
+    rows = []
+    for seed in (99, 7):
+        ids, _ = ho.synthetic_batch(5, B, L - 1, seed=seed)
+        with torch.no_grad():
+            ref = forward(ids, sd, {})
+            W = lambda **kw: {"in_proj": "h", "out_proj": "h", "fc1": "h", "fc2": "h", "attention": "h", **kw}
+            cases = {
+                "all fp16 (the r01 fp16 mode)": ALL16,
+                "P: all weights split": {**ALL16, "w": "hh"},
+                "Q: in/out/att weights split": {**ALL16, "w": W(in_proj="hh", out_proj="hh", attention="hh")},
+                "Q2: in/out weights split": {**ALL16, "w": W(in_proj="hh", out_proj="hh")},
+                "R: Q + a_ln1 split": {**ALL16, "a_ln1": "hh", "w": W(in_proj="hh", out_proj="hh", attention="hh")},
+                "S: R + a_lnf split + pool exact": {**ALL16, "a_ln1": "hh", "a_lnf": "hh", "pool": None, "w": W(in_proj="hh", out_proj="hh", attention="hh")},
+                "T: S + y split (storage + operand)": {**ALL16, "a_ln1": "hh", "a_lnf": "hh", "pool": None, "y": "hh", "a_y": "hh", "w": W(in_proj="hh", out_proj="hh", attention="hh")},
+                "U: T + fc1/fc2 weights split": {**ALL16, "a_ln1": "hh", "a_lnf": "hh", "pool": None, "y": "hh", "a_y": "hh", "w": "hh"},
+                "V: U + z split": {**ALL16, "a_ln1": "hh", "a_lnf": "hh", "pool": None, "y": "hh", "a_y": "hh", "z": "hh", "w": "hh"},
+                "P2: all weights split + pool exact": {**ALL16, "w": "hh", "pool": None},
+                "P3: P2 + a_ln1 split": {**ALL16, "w": "hh", "pool": None, "a_ln1": "hh"},
+                "P4: P3 + a_lnf split": {**ALL16, "w": "hh", "pool": None, "a_ln1": "hh", "a_lnf": "hh"},
+                "x3: everything split": {**{k: "hh" for k in ACT}, "w": "hh", "y": "hh", "z": "hh"},
+                "h8: everything fp16 + 4-bit lo": {**{k: "h8" for k in ACT}, "w": "h8", "y": "h8", "z": "h8"},
+            }
+            for name, cfg in cases.items():
+                err = (forward(ids, sd, cfg) - ref).abs().max().item()
+                rows.append((seed, name, err))
+                print(f"seed {seed}  {B} x {L}  {name:44s} max |dlogit| {err:.2e}   (max |logit| {ref.abs().max():.2f})", flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -27,7 +27,7 @@ def test_bench_two_ranks_on_one_gpu(built_lib):
     env = dict(os.environ, CLM_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), str(REPO / "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
-           "--batch", "8", "--bases", "1500", "--no-cpu-baseline"]
+           "--batch", "8", "--bases", "2100", "--no-cpu-baseline"]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=REPO)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
@@ -38,3 +38,4 @@ def test_bench_two_ranks_on_one_gpu(built_lib):
     assert d["config"]["reads_per_gpu"] == 4 and "x2" in d["config"]["parallelism"]
     assert abs(d["value"] - 8 * 3 / (d["ms_per_step"] * 3e-3)) < 1e-6 * d["value"]   # whole-job reads / max-over-ranks time
     assert {"bound", "achieved", "peak", "unit", "frac", "traffic"} <= set(d["roofline"])
+    assert d["distributed"]["backend"] == "gloo" and d["distributed"]["world_size"] == 2 and len(d["distributed"]["devices"]) == 2

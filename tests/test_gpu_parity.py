@@ -1,9 +1,13 @@
 """GPU (MI355X): parity of the HIP engine, called through the C ABI, with the CPU oracle on the same seeded inputs.
 
-Tolerances (north_star: identical labels, logits within 1e-3 in fp32):
-  fp32 mode  |logit - oracle| <= 1e-3  (observed ~1e-5)        -- the parity gate
-  fp16 mode  |logit - oracle| <= 5e-3  (observed 0.5-1.5e-3), labels identical wherever the oracle margin > 2e-2
-  bf16 mode  |logit - oracle| <= 6e-2  (observed ~2e-2),       labels identical wherever the oracle margin > 2e-1
+The parity gate (north_star: identical labels, logits within 1e-3 of the fp32 reference) is GATE = 1e-3 and applies to the
+two modes that claim reference parity:
+  fp32   exact-fp32 MFMA                                   observed ~1e-5
+  fp16c  fp16 activations x (hi + lo) fp16 weight pairs    observed 2-6e-4   <- the throughput mode (bench.py default)
+Labels must be identical on every row whose oracle margin exceeds 2 x GATE.
+The plain 16-bit modes are REDUCED-PRECISION modes outside the gate; their bounds below only pin their rounding behaviour:
+  fp16   |logit - oracle| <= 5e-3  (observed 0.5-1.5e-3), labels identical wherever the oracle margin > 2e-2
+  bf16   |logit - oracle| <= 6e-2  (observed ~2e-2),       labels identical wherever the oracle margin > 2e-1
 """
 from __future__ import annotations
 
@@ -19,8 +23,9 @@ from oracle import hyena_oracle as ho
 pytestmark = pytest.mark.gpu
 REPO = Path(__file__).resolve().parent.parent
 
-TOL = {"fp32": 1e-3, "fp16": 5e-3, "bf16": 6e-2}
-MARGIN = {"fp32": 2e-3, "fp16": 2e-2, "bf16": 2e-1}
+GATE = 1e-3
+TOL = {"fp32": GATE, "fp16c": GATE, "fp16": 5e-3, "bf16": 6e-2}
+MARGIN = {"fp32": 2 * GATE, "fp16c": 2 * GATE, "fp16": 2e-2, "bf16": 2e-1}
 
 
 @pytest.fixture(scope="module")
@@ -33,7 +38,7 @@ def engines(sd, built_lib):
     from chimeralm_amd.engine import Engine
 
     out = {}
-    for prec in ("fp32", "fp16", "bf16"):
+    for prec in ("fp32", "fp16c", "fp16", "bf16"):
         e = Engine("cuda:0", precision=prec, chunk_reads=4)
         e.load_state_dict(sd)
         out[prec] = e
@@ -49,8 +54,9 @@ def _ids(B, L, seed=5, pads=0):
     return ids
 
 
-def _check(engine, prec, ids_np, sd, dtype=torch.int64):
-    ref = ho.forward(torch.from_numpy(ids_np.astype(np.int64)), sd).numpy()
+def _check(engine, prec, ids_np, sd, dtype=torch.int64, ref=None):
+    if ref is None:
+        ref = ho.forward(torch.from_numpy(ids_np.astype(np.int64)), sd).numpy()
     got = engine.forward(torch.from_numpy(ids_np).to(dtype).cuda()).cpu().numpy()
     assert np.isfinite(got).all()
     err = np.abs(got - ref).max()
@@ -66,10 +72,33 @@ def test_fp32_parity_shapes(engines, sd, B, L):
     _check(engines["fp32"], "fp32", _ids(B, L, pads=min(3, L - 1)), sd)
 
 
-@pytest.mark.parametrize("prec", ["fp16", "bf16"])
+@pytest.mark.parametrize("prec", ["fp16c", "fp16", "bf16"])
 @pytest.mark.parametrize("B,L", [(3, 129), (5, 300), (6, 1000)])
 def test_16bit_modes(engines, sd, prec, B, L):
     _check(engines[prec], prec, _ids(B, L, pads=2), sd)
+
+
+@pytest.mark.parametrize("B,L", [(1, 2), (1, 5), (2, 128), (4, 513), (3, 2047), (3, 2048), (7, 2049), (2, 4097)])
+def test_fp16c_parity_shapes(engines, sd, B, L):
+    """The throughput mode at the gate over the same shape classes as the fp32 mode.  Reads below 2048 tokens run through the
+    exact-fp32 kernels inside the fp16c engine (too few tokens for the pooling to average the fp16 activation roundings,
+    clm_api.hip effective_prec); 2047 / 2048 straddle that switch and alternate the element type of the shared z / y buffers."""
+    _check(engines["fp16c"], "fp16c", _ids(B, L, pads=min(3, L - 1)), sd)
+
+
+@pytest.mark.parametrize("wseed", [1, 2, 3])
+def test_fp16c_other_weight_draws(built_lib, wseed):
+    """The gate must not hinge on one weight draw: three more seeded state dicts, at the shortest length that still runs the
+    fp16 kernels (2048 tokens: the least averaging, i.e. the largest error of the mode) and at 100 tokens (fp32 kernels)."""
+    from chimeralm_amd.engine import Engine
+
+    sdw = ho.make_state_dict(wseed, head_scale=3.0)
+    e = Engine("cuda:0", precision="fp16c", chunk_reads=4)
+    e.load_state_dict(sdw)
+    err = _check(e, "fp16c", _ids(6, 2048, seed=50 + wseed, pads=1), sdw)
+    assert err <= 0.7 * GATE, f"fp16c at its shortest fp16 length: {err:.2e} leaves no margin under the gate"
+    _check(e, "fp16c", _ids(6, 100, seed=60 + wseed), sdw)
+    e.close()
 
 
 def test_intermediates_fp32(engines, sd):
@@ -158,7 +187,7 @@ def test_block0_id_table_convolution_matches_in_proj_path(sd, built_lib, monkeyp
     e1.close(), e2.close()
 
 
-@pytest.mark.parametrize("prec", ["fp32", "fp16"])
+@pytest.mark.parametrize("prec", ["fp32", "fp16c", "fp16"])
 def test_full_size_8k_reads(engines, sd, prec):
     """BASELINE config size (8192 bases + [SEP] = 8193 tokens, FFT size 16384 with the aliased tail)."""
     ids = _ids(3, 8193, seed=11)
@@ -166,7 +195,7 @@ def test_full_size_8k_reads(engines, sd, prec):
 
 
 @pytest.mark.parametrize("prec,B,L", [("fp32", 3, 8194), ("fp32", 2, 16385), ("fp16", 3, 20000), ("fp16", 3, 24577),
-                                      ("fp32", 1, 8200)])
+                                      ("fp32", 1, 8200), ("fp16c", 3, 20000), ("fp16c", 2, 16385)])
 def test_long_reads_segmented_convolution(engines, sd, prec, B, L):
     """L > 8193: partitioned convolution over 8192-token segments (2 and 3 segments, odd batch, a last segment of 1, 2 and 8 tokens;
     lengths S*8192 + 1 take the dot-product path for the lone last token: 16385 in fp32, 24577 in fp16 with an odd batch)."""
@@ -176,7 +205,10 @@ def test_long_reads_segmented_convolution(engines, sd, prec, B, L):
 def test_maximum_length_reads(engines, sd):
     """The longest input the reference can produce: tokenizer.max_len_single_sentence = 32769 tokens (bam.py:155-166), i.e.
     5 convolution segments, the last one holding a single token."""
-    _check(engines["fp16"], "fp16", _ids(2, 32769, seed=31), sd)
+    ids = _ids(2, 32769, seed=31)
+    ref = ho.forward(torch.from_numpy(ids.astype(np.int64)), sd).numpy()
+    _check(engines["fp16c"], "fp16c", ids, sd, ref=ref)
+    _check(engines["fp16"], "fp16", ids, sd, ref=ref)
 
 
 def test_baseline_batch_size_independent_properties(sd, built_lib):

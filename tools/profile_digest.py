@@ -52,7 +52,7 @@ def main(tag):
     if stats:
         shutil.copy(stats[0], dst / f"{tag}_kernel_stats.csv")
     lines, traffic = [], defaultdict(lambda: {"fetch_kb": None, "write_kb": None})
-    for sub in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_inst"):
+    for sub in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_inst", "pmc_icache"):
         acc, dur = counters(str(src / sub / "**" / "*counter_collection.csv"))
         if not acc:
             continue
@@ -79,8 +79,11 @@ def main(tag):
         if stage and (stage not in out or e["hbm_bytes_per_dispatch"] > out[stage]["hbm_bytes_per_dispatch"]):
             out[stage] = e
     cfg = json.loads(bench[-1])["config"] if bench else {}
+    sys.path.insert(0, str(ROOT))
+    from bench import kernel_sources_sha        # the digest is only valid for the kernel sources it was measured on
+
     (dst / f"{tag}_traffic.json").write_text(json.dumps({"config": cfg, "dtype": json.loads(bench[-1])["dtype"] if bench else None,
-                                                         "stages": out}, indent=1) + "\n")
+                                                         "kernel_sources_sha": kernel_sources_sha(), "stages": out}, indent=1) + "\n")
     # the bench line of this round carries the traffic of the previous digest (bench.py reads profiles/*_traffic.json at run
     # time): put the figure of THIS run's counter passes into the committed copy
     if bench:
