@@ -44,7 +44,19 @@ class ClassificationLit(_Base):
 
             sd = load_file(path)
         else:
-            obj = torch.load(path, map_location="cpu", weights_only=False)
+            # a Lightning .ckpt is a pickle: load tensors only.  Checkpoints that also pickle arbitrary objects (hyper-parameter
+            # partials, callbacks) need the full unpickler, which executes code from the file -- opt in explicitly.
+            import os
+            import pickle
+
+            try:
+                obj = torch.load(path, map_location="cpu", weights_only=True)
+            except (pickle.UnpicklingError, RuntimeError) as e:
+                if os.environ.get("CLM_TRUST_CHECKPOINT") != "1":
+                    raise RuntimeError(
+                        f"{path} holds pickled Python objects besides tensors; loading it would run code from the file. "
+                        "Re-run with CLM_TRUST_CHECKPOINT=1 if you trust its origin, or convert it to safetensors.") from e
+                obj = torch.load(path, map_location="cpu", weights_only=False)
             sd = obj.get("state_dict", obj)
         own = self.state_dict()
         # safetensors drops the aliases of the shared sine module; restore them from `.1.freq`

@@ -347,7 +347,7 @@ def test_hydra_style_configs_instantiate():
     cfg = yaml.safe_load((REPO / "configs" / "model" / "hyena.yaml").read_text())
     model = build(cfg)
     assert type(model).__name__ == "ClassificationLit" and model.net.number_of_classes == 2
-    assert model.net.precision == "fp16"
+    assert model.net.precision == "fp16c"
     tcfg = yaml.safe_load((REPO / "configs" / "model" / "transformer.yaml").read_text())   # reference transformer.yaml:3-12
     tmodel = build(tcfg)
     assert type(tmodel.net).__name__ == "SequenceCNNTransformer" and tmodel.net.number_of_classes == 2
@@ -356,6 +356,53 @@ def test_hydra_style_configs_instantiate():
     data = yaml.safe_load((REPO / "configs" / "data" / "bam.yaml").read_text())
     dm = build({**data, "predict_data_path": str(REPO / "tests/golden/test_chimric_reads.bam"), "batch_size": 4})
     assert dm.tokenizer.padding_side == "left"
+
+
+def test_eval_yaml_composes_like_hydra(tmp_path):
+    """The Hydra entry route (reference eval.py:87-101 + configs/eval.yaml): defaults list, group override, value / add
+    overrides, interpolations, mandatory ckpt_path -- composed by chimeralm_amd.config (hydra is not in the image)."""
+    from chimeralm_amd.config import ConfigError, compose, instantiate, instantiate_callbacks
+
+    with pytest.raises(ConfigError, match="ckpt_path"):
+        compose(REPO / "configs", "eval.yaml", [])
+    bam = str(REPO / "tests/golden/test_chimric_reads.bam")
+    cfg = compose(REPO / "configs", "eval.yaml", ["ckpt_path=/x/y.ckpt", f"+data.predict_data_path={bam}", "data.batch_size=12",
+                                                    "trainer=ddp", "model.net.precision=fp32"], output_dir=tmp_path)
+    assert cfg.ckpt_path == "/x/y.ckpt" and cfg.task_name == "eval"
+    assert cfg.trainer._target_ == "chimeralm_amd.trainer.Trainer" and cfg.trainer.devices == 4 and cfg.trainer.strategy == "ddp"
+    assert cfg.trainer.default_root_dir == str(tmp_path)                       # ${paths.output_dir} -> ${hydra:runtime.output_dir}
+    assert cfg.callbacks.write.output_dir == f"{tmp_path}/predicts"
+    assert cfg.model.net.precision == "fp32" and cfg.data.batch_size == 12
+    with pytest.raises(ConfigError, match=r"use \+"):
+        compose(REPO / "configs", "eval.yaml", ["ckpt_path=/x", "data.predict_data_path=/z"])   # new key needs '+', like hydra
+    dm = instantiate(cfg.data)
+    assert type(dm).__name__ == "BamDataModule" and dm.batch_size == 12 and dm.tokenizer.padding_side == "left"
+    cbs = instantiate_callbacks(cfg.get("callbacks"))
+    assert len(cbs) == 1 and type(cbs[0]).__name__ == "PredictionWriter"
+    model = instantiate(cfg.model)
+    assert type(model).__name__ == "ClassificationLit" and model.net.precision == "fp32"
+    gpu = compose(REPO / "configs", "eval.yaml", ["ckpt_path=/x"], output_dir=tmp_path)          # default trainer: gpu.yaml
+    assert gpu.trainer.devices == -1 and gpu.trainer.accelerator == "gpu"
+
+
+def test_untrusted_checkpoint_pickles_are_refused(tmp_path, monkeypatch):
+    """A .ckpt that pickles arbitrary objects is not unpickled unless CLM_TRUST_CHECKPOINT=1 (tensor-only ones load)."""
+    import torch
+
+    from chimeralm_amd import lm
+
+    class Evil:
+        def __reduce__(self):
+            return (print, ("code from the checkpoint ran",))
+
+    model = lm.ChimeraLM.new()
+    good, bad = tmp_path / "good.ckpt", tmp_path / "bad.ckpt"
+    torch.save({"state_dict": model.state_dict()}, good)
+    torch.save({"state_dict": model.state_dict(), "extra": Evil()}, bad)
+    lm.ChimeraLM.new().load_reference_checkpoint(good)
+    monkeypatch.delenv("CLM_TRUST_CHECKPOINT", raising=False)
+    with pytest.raises(RuntimeError, match="CLM_TRUST_CHECKPOINT"):
+        lm.ChimeraLM.new().load_reference_checkpoint(bad)
 
 
 def _bam_records(path):
