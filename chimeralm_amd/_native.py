@@ -16,6 +16,7 @@ LIB_PATH = Path(os.environ.get("CLM_LIB") or Path(__file__).resolve().parent / "
 OK, E_INVALID, E_HIP, E_MISSING, E_UNSUPPORTED, E_STATE = 0, -1, -2, -3, -4, -5
 DT_F32, DT_F64, DT_BF16, DT_F16, DT_U8, DT_I32, DT_I64 = range(7)
 PREC_F32, PREC_BF16, PREC_F16, PREC_F16C = 0, 1, 2, 3
+BAM_INPUT_SAM, BAM_KEEP_UNPLACED = 1, 2
 PRECISIONS = {"fp32": PREC_F32, "f32": PREC_F32, "bf16": PREC_BF16, "fp16": PREC_F16, "f16": PREC_F16, "fp16c": PREC_F16C}
 STAGES = ["embed", "ln1_in_proj", "short_long_conv", "out_proj", "ln2_fc1_gelu", "fc2", "lnf_pool_score",
           "softmax_pool", "head_mlp", "filter", "out_proj_ln2_mlp", "ln2_mlp"]
@@ -56,6 +57,7 @@ SYMBOLS = {
     "clm_stage_ids": (C.c_int, [_H, C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_int, C.POINTER(C.c_int)]),
     "clm_forward_staged": (C.c_int, [_H, C.c_int, C.c_void_p, C.c_void_p]),
     "clm_stage_wait": (C.c_int, [_H, C.c_int]),
+    "clm_check": (C.c_int, [_H, C.c_void_p]),
     "clm_attention_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "clm_tf_create": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(_H)]),
     "clm_tf_load_weight": (C.c_int, [_H, C.c_char_p, C.c_void_p, C.c_int, C.POINTER(C.c_int64), C.c_int]),
@@ -81,6 +83,8 @@ SYMBOLS = {
     "clm_feeder_close": (C.c_int, [_H]),
     "clm_bam_filter": (C.c_int, [C.c_char_p, C.c_char_p, C.POINTER(C.c_char_p), C.c_int64, C.POINTER(C.c_int64),
                                  C.POINTER(C.c_int64)]),
+    "clm_bam_filter2": (C.c_int, [C.c_char_p, C.c_char_p, C.POINTER(C.c_char_p), C.c_int64, C.c_int, C.POINTER(C.c_int64),
+                                  C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "clm_bam_sort_index": (C.c_int, [C.c_char_p, C.c_char_p, C.c_char_p, C.POINTER(C.c_int64)]),
     "clm_bam_last_error": (C.c_char_p, []),
 }

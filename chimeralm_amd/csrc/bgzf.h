@@ -290,10 +290,10 @@ struct ParallelReader {
 // One complete BGZF member (header, deflate data at level 6, CRC32, ISIZE) for `n` <= 0xff00 payload bytes; returns its
 // length in zout or 0 on error.
 inline size_t deflate_member(const uint8_t* payload, size_t n, std::vector<uint8_t>& zout, const std::string& path,
-                             std::string& err) {
+                             std::string& err, int level = 6) {
     z_stream z;
     std::memset(&z, 0, sizeof(z));
-    if (deflateInit2(&z, 6, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) {
+    if (deflateInit2(&z, level, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) {
         err = "zlib deflateInit2 failed";
         return 0;
     }
@@ -379,6 +379,7 @@ struct Writer {
 // it into the real virtual file offset once finish() has returned.  (One zlib deflate at level 6 runs at ~25 MB/s.)
 struct ParallelWriter {
     std::string path, err;
+    int level = 6;                  // zlib level of the members (set before open; 1 for temporary sort runs)
     static constexpr size_t BLOCK = 0xff00;
 
     bool open(const std::string& p, int threads) {
@@ -482,7 +483,7 @@ struct ParallelWriter {
             }
             Job& j = jobs[idx];
             std::string e;
-            j.mlen = deflate_member(j.in.data(), j.in.size(), j.zout, path, e);
+            j.mlen = deflate_member(j.in.data(), j.in.size(), j.zout, path, e, level);
             {
                 std::lock_guard<std::mutex> lk(mu);
                 if (!j.mlen) {

@@ -77,6 +77,7 @@ struct clm_handle {
     } stage[2];
     hipStream_t copy_stream = nullptr;
     int next_stage = 0;
+    int* bad_ids = nullptr;       // host-mapped flag the id kernels set for a token id outside [0, vocab_rows)
     float* ztab = nullptr;        // [16][768] block-0 in_proj rows per token id (16-bit modes)
     unsigned char* ids8 = nullptr;   // workspace: clamped ids [B][Lp]
     float* head_t[5] = {};
@@ -409,6 +410,17 @@ int effective_prec(const clm_handle* h, int L) {
     return (h->cfg.precision == PREC_F16C && L < h->f16c_min_len) ? (int)PREC_F32 : h->cfg.precision;
 }
 
+// Asynchronous error of an EARLIER forward (the call itself returned before its kernels ran): reported once, by the next
+// forward / stage_wait / profile_read / clm_check call.  The reference raises IndexError inside nn.Embedding for such ids.
+int check_bad_ids(clm_handle* h) {
+    if (h->bad_ids && *reinterpret_cast<volatile int*>(h->bad_ids)) {
+        *reinterpret_cast<volatile int*>(h->bad_ids) = 0;
+        return fail(h, CLM_E_INVALID, "an earlier batch held token ids outside [0, " + std::to_string(h->cfg.vocab_rows) +
+                                          ") (its logits were computed with those ids clamped; the reference raises IndexError)");
+    }
+    return CLM_OK;
+}
+
 bool stop_here(clm_handle* h, int layer, int stage) { return h->stop_layer == layer && h->stop_stage == stage; }
 
 int forward_chunk(clm_handle* h, const void* ids, int ids_dtype, int64_t row_stride, int Bc, int L, float* logits,
@@ -445,7 +457,7 @@ int forward_chunk(clm_handle* h, const void* ids, int ids_dtype, int64_t row_str
     {
         StageTimer t(h, st, CLM_STAGE_EMBED);
         launch_embed(ids, ids_dtype, row_stride, W(h, "bb.embeddings.word_embeddings.weight"), idpath ? nullptr : h->h,
-                     h->ids8, Bc, L, Lp, st);
+                     h->ids8, Bc, L, Lp, st, h->bad_ids);
     }
     if (stop_here(h, -1, CLM_STAGE_EMBED)) return CLM_OK;
     for (int i = 0; i < NLAYER; ++i) {
@@ -580,6 +592,8 @@ int clm_create(const clm_config* cfg, int device, clm_handle** out) {
     h->split_tail = std::getenv("CLM_SPLIT_TAIL") && std::getenv("CLM_SPLIT_TAIL")[0] == '1';
     h->cfg = *cfg;
     h->device = device;
+    if (hipHostMalloc((void**)&h->bad_ids, sizeof(int), hipHostMallocMapped) == hipSuccess) *h->bad_ids = 0;
+    else h->bad_ids = nullptr;
     if (const char* e = std::getenv("CLM_F16C_MIN_LEN")) h->f16c_min_len = std::max(1, std::atoi(e));   // developer knob (1 = never fp32)
     *out = h;
     return CLM_OK;
@@ -721,6 +735,7 @@ int clm_forward(clm_handle* h, const void* ids, int ids_dtype, int64_t ids_row_s
     if (ids_dtype != CLM_DT_I64 && ids_dtype != CLM_DT_I32 && ids_dtype != CLM_DT_U8)
         return fail(h, CLM_E_INVALID, "clm_forward: ids dtype must be i64, i32 or u8");
     HIPCHK(h, hipSetDevice(h->device));
+    if (int rc = check_bad_ids(h)) return rc;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const size_t ies = ids_dtype == CLM_DT_I64 ? 8 : (ids_dtype == CLM_DT_I32 ? 4 : 1);
     const int chunk = h->cfg.chunk_reads;
@@ -778,11 +793,11 @@ int clm_forward_staged(clm_handle* h, int staged, float* logits_out, void* strea
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     HIPCHK(h, hipStreamWaitEvent(st, s.copied, 0));
     const int rc = clm_forward(h, s.buf, s.dtype, s.stride, s.B, s.L, logits_out, stream);
-    if (rc) return rc;
-    HIPCHK(h, hipEventRecord(s.consumed, st));
+    // whatever happened, the buffer is no longer "staged and waiting": a failed forward must not wedge it for good
     s.pending = false;
     s.used = true;
-    return CLM_OK;
+    (void)hipEventRecord(s.consumed, st);
+    return rc;
 }
 
 int clm_stage_wait(clm_handle* h, int staged) {
@@ -790,7 +805,14 @@ int clm_stage_wait(clm_handle* h, int staged) {
     if (staged < 0 || staged > 1 || !h->stage[staged].copied) return fail(h, CLM_E_STATE, "clm_stage_wait: nothing was staged there");
     HIPCHK(h, hipSetDevice(h->device));
     HIPCHK(h, hipEventSynchronize(h->stage[staged].copied));
-    return CLM_OK;
+    return check_bad_ids(h);
+}
+
+int clm_check(clm_handle* h, void* stream) {
+    if (!h) return CLM_E_INVALID;
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipStreamSynchronize(reinterpret_cast<hipStream_t>(stream)));
+    return check_bad_ids(h);
 }
 
 int clm_debug_stop_after(clm_handle* h, int layer, int stage) {
@@ -880,6 +902,7 @@ int clm_destroy(clm_handle* h) {
         if (sg.consumed) (void)hipEventDestroy(sg.consumed);
     }
     if (h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
+    if (h->bad_ids) (void)hipHostFree(h->bad_ids);
     for (auto& kv : h->w)
         if (kv.second.d) (void)hipFree(kv.second.d);
     delete h;

@@ -114,7 +114,8 @@ struct LayerW {            // device pointers, fp32 unless noted
 
 // embedding gather: ids [B, L] (dtype code CLM_DT_*) -> h fp32 [B, L, 256]
 void launch_embed(const void* ids, int ids_dtype, int64_t row_stride, const float* table, float* h,
-                  unsigned char* ids8 /*[B][Lp] clamped ids, may be null*/, int B, int L, int Lp, hipStream_t st);
+                  unsigned char* ids8 /*[B][Lp] clamped ids, may be null*/, int B, int L, int Lp, hipStream_t st,
+                  int* bad_ids = nullptr /*device-visible flag set when an id is outside [0, 16)*/);
 
 // GEMM family (gemm.hip).  `prec` selects compute dtype; T16 activations are bf16/f16 (or fp32 for PREC_F32).
 // z  = in_proj(LN1(h))      -> channel-major [B, 768, Lp]

@@ -14,13 +14,17 @@ namespace clm {
 template <typename IdT>
 __global__ __launch_bounds__(256) void embed_kernel(const IdT* __restrict__ ids, int64_t row_stride,
                                                     const float* __restrict__ table, float* __restrict__ h,
-                                                    unsigned char* __restrict__ ids8, int B, int L, int Lp) {
+                                                    unsigned char* __restrict__ ids8, int B, int L, int Lp,
+                                                    int* __restrict__ bad_ids) {
     // one wave per token row: 64 lanes x float4 = 1 KiB
     const int lane = threadIdx.x & 63;
     const size_t tok = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (tok >= (size_t)B * L) return;
     const int b = int(tok / L), t = int(tok % L);
     int id = (int)ids[(size_t)b * row_stride + t];
+    // the reference's nn.Embedding(16, 256) raises IndexError for ids outside [0, 16); a kernel cannot raise: the id is
+    // clamped (no wild read) and the handle's flag makes the NEXT API call fail with the message (clm_api.hip)
+    if ((id < 0 || id >= VOCAB) && lane == 0 && bad_ids) *bad_ids = 1;
     id = id < 0 ? 0 : (id >= VOCAB ? VOCAB - 1 : id);
     if (ids8 && lane == 0) ids8[(size_t)b * Lp + t] = (unsigned char)id;   // compact copy for the block-0 conv
     if (h) {
@@ -32,33 +36,35 @@ __global__ __launch_bounds__(256) void embed_kernel(const IdT* __restrict__ ids,
 // ids only (16-bit modes, block 0 reads the embedding through the id tables): one thread per token
 template <typename IdT>
 __global__ __launch_bounds__(256) void ids8_kernel(const IdT* __restrict__ ids, int64_t row_stride,
-                                                   unsigned char* __restrict__ ids8, int B, int L, int Lp) {
+                                                   unsigned char* __restrict__ ids8, int B, int L, int Lp,
+                                                   int* __restrict__ bad_ids) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= (size_t)B * Lp) return;
     const int b = int(i / Lp), t = int(i % Lp);
     int id = t < L ? (int)ids[(size_t)b * row_stride + t] : 0;
+    if ((id < 0 || id >= VOCAB) && bad_ids) *bad_ids = 1;      // see embed_kernel
     ids8[i] = (unsigned char)(id < 0 ? 0 : (id >= VOCAB ? VOCAB - 1 : id));
 }
 
 void launch_embed(const void* ids, int ids_dtype, int64_t row_stride, const float* table, float* h,
-                  unsigned char* ids8, int B, int L, int Lp, hipStream_t st) {
+                  unsigned char* ids8, int B, int L, int Lp, hipStream_t st, int* bad_ids) {
     if (!h) {
         dim3 g1((unsigned)(((size_t)B * Lp + 255) / 256)), b1(256);
         if (ids_dtype == CLM_DT_I64)
-            hipLaunchKernelGGL(ids8_kernel<int64_t>, g1, b1, 0, st, (const int64_t*)ids, row_stride, ids8, B, L, Lp);
+            hipLaunchKernelGGL(ids8_kernel<int64_t>, g1, b1, 0, st, (const int64_t*)ids, row_stride, ids8, B, L, Lp, bad_ids);
         else if (ids_dtype == CLM_DT_I32)
-            hipLaunchKernelGGL(ids8_kernel<int32_t>, g1, b1, 0, st, (const int32_t*)ids, row_stride, ids8, B, L, Lp);
+            hipLaunchKernelGGL(ids8_kernel<int32_t>, g1, b1, 0, st, (const int32_t*)ids, row_stride, ids8, B, L, Lp, bad_ids);
         else
-            hipLaunchKernelGGL(ids8_kernel<uint8_t>, g1, b1, 0, st, (const uint8_t*)ids, row_stride, ids8, B, L, Lp);
+            hipLaunchKernelGGL(ids8_kernel<uint8_t>, g1, b1, 0, st, (const uint8_t*)ids, row_stride, ids8, B, L, Lp, bad_ids);
         return;
     }
     dim3 grid((unsigned)(((size_t)B * L + 3) / 4)), block(256);
     if (ids_dtype == CLM_DT_I64)
-        hipLaunchKernelGGL(embed_kernel<int64_t>, grid, block, 0, st, (const int64_t*)ids, row_stride, table, h, ids8, B, L, Lp);
+        hipLaunchKernelGGL(embed_kernel<int64_t>, grid, block, 0, st, (const int64_t*)ids, row_stride, table, h, ids8, B, L, Lp, bad_ids);
     else if (ids_dtype == CLM_DT_I32)
-        hipLaunchKernelGGL(embed_kernel<int32_t>, grid, block, 0, st, (const int32_t*)ids, row_stride, table, h, ids8, B, L, Lp);
+        hipLaunchKernelGGL(embed_kernel<int32_t>, grid, block, 0, st, (const int32_t*)ids, row_stride, table, h, ids8, B, L, Lp, bad_ids);
     else
-        hipLaunchKernelGGL(embed_kernel<uint8_t>, grid, block, 0, st, (const uint8_t*)ids, row_stride, table, h, ids8, B, L, Lp);
+        hipLaunchKernelGGL(embed_kernel<uint8_t>, grid, block, 0, st, (const uint8_t*)ids, row_stride, table, h, ids8, B, L, Lp, bad_ids);
 }
 
 // ---------------------------------------------------------------------------------------- softmax statistics

@@ -124,6 +124,12 @@ class Engine:
         self._check(self._lib.clm_forward_staged(self._h, int(staged), C.c_void_p(out.data_ptr()), C.c_void_p(stream)))
         return out
 
+    def check(self):
+        """Wait for the current stream and raise for errors only the device can see (token ids outside the embedding table:
+        the reference raises IndexError there)."""
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        self._check(self._lib.clm_check(self._h, C.c_void_p(stream)))
+
     def stage_wait(self, staged: int):
         self._check(self._lib.clm_stage_wait(self._h, int(staged)))
 

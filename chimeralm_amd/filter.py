@@ -3,8 +3,10 @@
 `load_predicts` / `load_predictions_from_folder` read the per-batch `name<TAB>label` files the prediction writer produced;
 `filter_bam_by_predcition` (the reference's spelling is kept) drops every record of the reads labelled 1 (chimera artifact),
 writes `<bam>.filtered.bam`, then -- with `index=True` -- `<bam>.filtered.sorted.bam` + its `.bai`.  The BAM work (BGZF
-inflate/deflate, record copy, coordinate sort, BAI binning index) is native C++ (csrc/bam_filter.cpp) behind
-`clm_bam_filter` / `clm_bam_sort_index`; the reference does it through pysam / samtools.
+inflate/deflate, SAM text parsing, record copy, coordinate sort with spill-to-disk runs, BAI binning index) is native C++
+(csrc/bam_filter.cpp) behind `clm_bam_filter2` / `clm_bam_sort_index`; the reference does it through pysam / samtools.
+As there (`file_mode = "rb" if suffix == ".bam" else "r"`, :127) any other suffix is read as SAM text.  Records of a BAM
+that have no reference placement are left out, as the reference's index walk (`bam_file.fetch()`, :131) never yields them.
 """
 from __future__ import annotations
 
@@ -67,15 +69,17 @@ def filter_bam_by_predcition(bam_path: Path, prediction_path: Path, *, index: bo
     counter = Counter(predictions.values())
     log.info(f"Biological: {counter.get(0, 0)} ({counter.get(0, 0) / len(predictions) * 100:.1f}%), "
              f"Chimera artifact: {counter.get(1, 0)} ({counter.get(1, 0) / len(predictions) * 100:.1f}%)")
-    if bam_path.suffix != ".bam":
-        raise NotImplementedError("the native filter reads BAM (the reference also accepts SAM text through pysam)")
+    flags = 0 if bam_path.suffix == ".bam" else N.BAM_INPUT_SAM          # __main__.py:127
     lib = N.load()
     drop = [n.encode() for n, label in predictions.items() if label == 1]
     arr = (C.c_char_p * max(1, len(drop)))(*drop)
-    kept, dropped = C.c_int64(), C.c_int64()
+    kept, dropped, unplaced = C.c_int64(), C.c_int64(), C.c_int64()
     output_path = bam_path.with_suffix(".filtered.bam")
-    _check(lib.clm_bam_filter(str(bam_path).encode(), str(output_path).encode(), arr, len(drop), C.byref(kept), C.byref(dropped)))
-    result = {"kept": kept.value, "dropped": dropped.value, "filtered": output_path, "sorted": None}
+    _check(lib.clm_bam_filter2(str(bam_path).encode(), str(output_path).encode(), arr, len(drop), flags, C.byref(kept),
+                               C.byref(dropped), C.byref(unplaced)))
+    if unplaced.value:
+        log.info(f"{unplaced.value} records without a reference placement left out (an index walk does not reach them)")
+    result = {"kept": kept.value, "dropped": dropped.value, "unplaced": unplaced.value, "filtered": output_path, "sorted": None}
     if index:
         log.info(f"Sorting {output_path}")
         sorted_output_path = output_path.with_suffix(".sorted.bam")

@@ -118,6 +118,12 @@ int clm_stage_ids(clm_handle* h, const void* host_ids, int ids_dtype, int64_t id
 int clm_forward_staged(clm_handle* h, int staged, float* logits_out, void* stream);
 int clm_stage_wait(clm_handle* h, int staged);
 
+/* Errors a forward can only detect on the device after the call has returned: a token id outside [0, vocab_rows), for
+ * which the reference's nn.Embedding raises IndexError inside HyenaDna.forward (hyena.py:249).  The id kernels clamp such an
+ * id (no wild read) and flag the handle; the flag is reported ONCE, as CLM_E_INVALID with the message in clm_last_error,
+ * by the next clm_forward / clm_forward_staged / clm_stage_wait, or by clm_check, which first waits for `stream`. */
+int clm_check(clm_handle* h, void* stream);
+
 /* ---- SequenceCNNTransformer -----------------------------------------------------------
  * Multi-head self-attention of nn.TransformerEncoderLayer as the reference builds it
  * (/root/reference/chimeralm/models/components/transformer.py:64-68,98: d_model 256, 8 heads of 32, no masks):

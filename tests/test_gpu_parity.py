@@ -168,12 +168,12 @@ def test_block0_id_table_long_reads(sd, built_lib, monkeypatch, L):
 def test_block0_id_table_convolution_matches_in_proj_path(sd, built_lib, monkeypatch, prec):
     """16-bit modes skip block 0's in_proj: the convolution looks x0|x1|v up by token id (ztab).  Same logits as the
     explicit in_proj path (CLM_NO_IDCONV=1) up to the 16-bit rounding of z that the table path does not have; covers every
-    token id (specials, N, out-of-vocabulary ids clamp) and both read parities of a pair."""
+    row of the 16-row embedding table (specials, N, the padding rows 12-15) and both read parities of a pair."""
     from chimeralm_amd.engine import Engine
 
     ids = _ids(5, 1000, seed=5).astype(np.int64)
     ids[0, :16] = np.arange(16)
-    ids[1, -3:] = [40, 200, 15]                 # clamped to the last row like the reference's 16-row table allows
+    ids[1, -3:] = [12, 13, 15]                  # rows of the 16-row table beyond the 12-token vocabulary
     t = torch.from_numpy(ids).cuda()
     e1 = Engine("cuda:0", precision=prec, chunk_reads=8)
     monkeypatch.setenv("CLM_NO_IDCONV", "1")
@@ -368,6 +368,30 @@ def test_error_behaviour(engines):
         e.load_weight("net.head.output_layer.bias", torch.zeros(3))
     with pytest.raises(EngineError, match="unknown"):
         e.load_weight("net.nope", torch.zeros(3))
+
+
+@pytest.mark.parametrize("prec", ["fp32", "fp16c"])
+def test_token_ids_outside_the_embedding_table_are_reported(engines, prec):
+    """The reference raises IndexError inside nn.Embedding(16, 256) for such ids (hyena.py:249).  A kernel cannot raise: the id
+    is clamped and the handle is flagged; clm_check (or the next forward) reports it once, then the engine is usable again."""
+    from chimeralm_amd.engine import EngineError
+
+    e = engines[prec]
+    ids = _ids(2, 2100).astype(np.int64)
+    good = e.forward(torch.from_numpy(ids).cuda()).cpu()
+    e.check()
+    bad = ids.copy()
+    bad[1, 7] = 16
+    e.forward(torch.from_numpy(bad).cuda())
+    with pytest.raises(EngineError, match="token ids outside"):
+        e.check()
+    e.check()                                                           # reported once
+    bad[1, 7] = -3
+    e.forward(torch.from_numpy(bad).cuda())
+    torch.cuda.synchronize()
+    with pytest.raises(EngineError, match="token ids outside"):
+        e.forward(torch.from_numpy(ids).cuda())                         # ... or by the next forward
+    assert torch.equal(e.forward(torch.from_numpy(ids).cuda()).cpu(), good)
 
 
 def test_cli_predict_then_filter_end_to_end(sd, tmp_path, golden_dir, built_lib):

@@ -572,3 +572,206 @@ def test_filter_drops_artifacts_sorts_and_indexes(tmp_path, golden_dir):
     assert flt.filter_bam_by_predcition(bam, empty) is None
     with pytest.raises(RuntimeError, match="cannot open"):
         flt.filter_bam_by_predcition(tmp_path / "missing.bam", pred)
+
+
+# ---------------------------------------------------------------------------------------------- filter: SAM, spill, unplaced
+def _bam_body(name, tid, pos, flag, n_bases, rng, tags=b"SAZchr1,100,+,50M,60,0;\0"):
+    import struct
+
+    b = rng.integers(0, 4, n_bases)
+    codes = np.array([1, 2, 4, 8], dtype=np.uint8)[b]
+    bp = codes if n_bases % 2 == 0 else np.append(codes, np.uint8(0))
+    packed = ((bp[0::2] << 4) | bp[1::2]).astype(np.uint8).tobytes()
+    qual = rng.integers(2, 41, n_bases).astype(np.uint8).tobytes()
+    nm = name.encode() + b"\0"
+    cigar = struct.pack("<I", n_bases << 4) if not flag & 4 else b""
+    body = struct.pack("<iiBBHHHiiii", tid, pos, len(nm), 60, 4680, 1 if cigar else 0, flag, n_bases, -1, -1, 0) + nm
+    return body + cigar + packed + qual + tags
+
+
+def _write_bam(path, text, refs, bodies):
+    import struct
+    import zlib
+
+    hdr = b"BAM\1" + struct.pack("<i", len(text)) + text.encode() + struct.pack("<i", len(refs))
+    for n, ln in refs:
+        hdr += struct.pack("<i", len(n) + 1) + n.encode() + b"\0" + struct.pack("<i", ln)
+    stream = hdr + b"".join(struct.pack("<i", len(b)) + b for b in bodies)
+    with open(path, "wb") as f:
+        for i in range(0, len(stream), 0xff00):
+            chunk = stream[i: i + 0xff00]
+            c = zlib.compressobj(6, 8, -15)
+            data = c.compress(chunk) + c.flush()
+            f.write(struct.pack("<BBBBIBBHBBHH", 31, 139, 8, 4, 0, 0, 255, 6, 66, 67, 2, len(data) + 25))
+            f.write(data + struct.pack("<II", zlib.crc32(chunk), len(chunk)))
+        f.write(bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000"))
+
+
+def test_sort_spills_runs_and_merges_to_the_same_bytes(tmp_path, monkeypatch):
+    """`pysam.sort` spills to disk beyond its memory budget (reference __main__.py:148-151): so does clm_bam_sort_index.  A BAM
+    of ~9 MB of records, many equal keys, three references and unplaced reads, sorted with a 1 MiB budget (about ten runs on
+    disk, k-way merged) must give the byte-identical sorted BAM and BAI as the in-memory sort, leave no temporary file, and
+    keep input order among equal keys (stability across runs)."""
+    import hashlib
+
+    from chimeralm_amd import _native as N
+
+    lib = N.load()
+    rng = np.random.default_rng(3)
+    refs = [("chr1", 1 << 27), ("chr2", 1 << 26), ("chrM", 16569)]
+    bodies = []
+    for i in range(3000):
+        unplaced = i % 97 == 0
+        tid = -1 if unplaced else int(rng.integers(0, 3))
+        pos = -1 if unplaced else int(rng.integers(0, 40)) * 1000          # 40 distinct positions: thousands of ties
+        flag = 4 if unplaced else (16 if rng.random() < 0.5 else 0)
+        bodies.append(_bam_body(f"r{i:05d}", tid, pos, flag, 2000 + int(rng.integers(0, 1500)), rng))
+    src = tmp_path / "src.bam"
+    _write_bam(src, "@HD\tVN:1.6\tSO:unsorted\n@SQ\tSN:chr1\tLN:134217728\n", refs, bodies)
+    out = {}
+    for tag, mb in (("mem", "4096"), ("spill", "1")):
+        monkeypatch.setenv("CLM_SORT_MEM_MB", mb)
+        dst = tmp_path / f"{tag}.sorted.bam"
+        n = ctypes.c_int64()
+        assert lib.clm_bam_sort_index(str(src).encode(), str(dst).encode(), None, ctypes.byref(n)) == 0, lib.clm_bam_last_error()
+        assert n.value == 3000
+        out[tag] = [hashlib.md5(p.read_bytes()).hexdigest() for p in (dst, Path(str(dst) + ".bai"))]
+        assert not list(tmp_path.glob("*.run")), "temporary sort runs left behind"
+    assert out["mem"] == out["spill"]
+    text, _, recs = _bam_records(tmp_path / "spill.sorted.bam")
+    assert "SO:coordinate" in text.split("\n")[0]
+    key = lambda r: (r[1] if r[1] >= 0 else 1 << 31, r[2], (r[3] >> 4) & 1)   # noqa: E731
+    keys = [key(r) for r in recs]
+    assert keys == sorted(keys) and len(recs) == 3000
+    for a, b in zip(recs, recs[1:]):                                          # stable: equal keys keep the input order
+        if key(a) == key(b):
+            assert a[4] < b[4], (a[4], b[4])
+
+
+def _bam_to_sam(path) -> str:
+    """Independent BAM -> SAM text decoder (SAM specification 4.2), used to feed the SAM input of `filter`."""
+    import struct
+
+    text, n_ref, recs = _bam_records(path)
+    raw_refs = []
+    # reference names from the header blob
+    import zlib
+
+    raw = Path(path).read_bytes()
+    stream, off = b"", 0
+    while off < len(raw):
+        xlen = struct.unpack_from("<H", raw, off + 10)[0]
+        bsize = struct.unpack_from("<H", raw, off + 16)[0] + 1
+        if bsize - xlen - 20 > 0:
+            stream += zlib.decompress(raw[off + 12 + xlen: off + bsize - 8], -15)
+        off += bsize
+    l_text = struct.unpack_from("<i", stream, 4)[0]
+    p = 8 + l_text + 4
+    for _ in range(n_ref):
+        ln = struct.unpack_from("<i", stream, p)[0]
+        raw_refs.append(stream[p + 4: p + 4 + ln - 1].decode())
+        p += 8 + ln
+    lines = [text.rstrip("\n")] if text.strip() else []
+    for _, tid, pos, flag, name, rec in recs:
+        b = rec[4:]
+        l_name, mapq, _bin, n_cig, _flag, l_seq, ntid, npos, tlen = struct.unpack_from("<BBHHHiiii", b, 8)
+        q = 32 + l_name
+        cig = "".join(f"{v >> 4}{'MIDNSHP=X'[v & 15]}" for v in struct.unpack_from(f"<{n_cig}I", b, q)) or "*"
+        q += 4 * n_cig
+        sq = b[q: q + (l_seq + 1) // 2]
+        seq = "".join("=ACMGRSVTWYHKDBN"[(sq[i >> 1] >> (4 if i % 2 == 0 else 0)) & 15] for i in range(l_seq)) or "*"
+        q += (l_seq + 1) // 2
+        ql = b[q: q + l_seq]
+        qual = "*" if (l_seq == 0 or ql[0] == 0xFF) else "".join(chr(c + 33) for c in ql)
+        q += l_seq
+        tags = []
+        while q < len(b):
+            tag, typ = b[q: q + 2].decode(), chr(b[q + 2])
+            q += 3
+            if typ == "A":
+                tags.append(f"{tag}:A:{chr(b[q])}"); q += 1
+            elif typ in "cCsSiI":
+                fmt = {"c": "<b", "C": "<B", "s": "<h", "S": "<H", "i": "<i", "I": "<I"}[typ]
+                tags.append(f"{tag}:i:{struct.unpack_from(fmt, b, q)[0]}"); q += struct.calcsize(fmt)
+            elif typ == "f":
+                tags.append(f"{tag}:f:{struct.unpack_from('<f', b, q)[0]:.9g}"); q += 4
+            elif typ in "ZH":
+                e = b.index(b"\0", q)
+                tags.append(f"{tag}:{typ}:{b[q:e].decode()}"); q = e + 1
+            elif typ == "B":
+                sub, cnt = chr(b[q]), struct.unpack_from("<i", b, q + 1)[0]
+                fmt = {"c": "b", "C": "B", "s": "h", "S": "H", "i": "i", "I": "I", "f": "f"}[sub]
+                vals = struct.unpack_from(f"<{cnt}{fmt}", b, q + 5)
+                tags.append(f"{tag}:B:{sub}," + ",".join(f"{v:.9g}" if sub == "f" else str(v) for v in vals))
+                q += 5 + cnt * struct.calcsize(fmt)
+            else:
+                raise ValueError(typ)
+        rn = raw_refs[tid] if tid >= 0 else "*"
+        rnext = "*" if ntid < 0 else ("=" if ntid == tid else raw_refs[ntid])
+        lines.append("\t".join([name, str(flag), rn, str(pos + 1), str(mapq), cig, rnext, str(npos + 1), str(tlen), seq, qual] + tags))
+    return "\n".join(lines) + "\n"
+
+
+def test_filter_reads_sam_text_like_the_reference(tmp_path, golden_dir):
+    """The reference opens any path whose suffix is not .bam as SAM text (__main__.py:127).  The reference's test BAM, written
+    out as SAM by an independent decoder, must filter to the same records as the BAM itself -- byte for byte where the
+    encoding is canonical (bin, smallest integer tag types: what htslib writes), and semantically everywhere."""
+    import shutil
+
+    from chimeralm_amd import filter as flt
+
+    bam = tmp_path / "reads.bam"
+    shutil.copyfile(golden_dir / "test_chimric_reads.bam", bam)
+    sam = tmp_path / "reads.sam"
+    sam.write_text(_bam_to_sam(bam))
+    _, _, recs_in = _bam_records(bam)
+    names = list(dict.fromkeys(r[4] for r in recs_in))
+    pred = tmp_path / "pred"
+    pred.mkdir()
+    (pred / "0_0.txt").write_text("".join(f"{n}\t{i % 2}\n" for i, n in enumerate(names)))
+    res_s = flt.filter_bam_by_predcition(sam, pred, index=True)
+    assert res_s["filtered"].name == "reads.filtered.bam" and res_s["sorted"].exists()   # same output names for both inputs:
+    ts, ns, rs = _bam_records(res_s["filtered"])                                          # read one back before the other runs
+    res_b = flt.filter_bam_by_predcition(bam, pred, index=False)
+    assert (res_s["kept"], res_s["dropped"]) == (res_b["kept"], res_b["dropped"]) and res_s["dropped"] > 0
+    tb, nb, rb = _bam_records(res_b["filtered"])
+    assert ns == nb and ts.split("\n")[1:] == tb.split("\n")[1:]            # same references and header lines
+    assert [(r[1], r[2], r[3], r[4]) for r in rs] == [(r[1], r[2], r[3], r[4]) for r in rb]
+    same = sum(a[5] == b[5] for a, b in zip(rs, rb))
+    assert same == len(rb), f"only {same} of {len(rb)} records re-encode to the original bytes"
+    # every optional-field type and the corner encodings
+    text = ("@HD\tVN:1.6\n@SQ\tSN:c1\tLN:5000\n@SQ\tSN:c2\tLN:900\n"
+            "q1\t0\tc1\t101\t60\t3S10M2D5M1I4M\t=\t301\t200\tACGTNACGTNACGTNACGTNACG\t" + "I" * 23 +
+            "\tXA:A:k\tXi:i:-70000\tXj:i:-5\tXk:i:300\tXl:i:70000\tXf:f:1.5\tXz:Z:hello world\tXh:H:1AE301\tXb:B:s,-3,4,5\tXc:B:f,0.5,2\n"
+            "q2\t4\t*\t0\t0\t*\t*\t0\t0\t*\t*\n"
+            "q3\t16\tc2\t1\t0\t4M\tc1\t7\t-9\tACGT\t*\n")
+    sam2 = tmp_path / "t.sam"
+    sam2.write_text(text)
+    (pred / "0_0.txt").write_text("q3\t1\nq1\t0\n")
+    res = flt.filter_bam_by_predcition(sam2, pred, index=True)
+    assert (res["kept"], res["dropped"], res["unplaced"]) == (2, 1, 0)       # SAM text: the unplaced q2 is iterated and kept
+    assert _bam_to_sam(res["filtered"]) == "\n".join(text.split("\n")[:5]) + "\n"
+    sam2.write_text(text.replace("3S10M", "3S10Q"))
+    with pytest.raises(RuntimeError, match="line 4: bad CIGAR"):
+        flt.filter_bam_by_predcition(sam2, pred)
+    assert not (tmp_path / "t.filtered.bam").exists()                         # no partial output left behind (:140-144)
+
+
+def test_filter_leaves_out_unplaced_records_of_a_bam(tmp_path):
+    """`bam_file.fetch()` on a BAM walks the index reference by reference (reference __main__.py:131): records without a
+    reference placement never reach the output.  CLM_BAM_KEEP_UNPLACED keeps them."""
+    from chimeralm_amd import _native as N
+
+    lib = N.load()
+    rng = np.random.default_rng(5)
+    bodies = [_bam_body(f"r{i}", -1 if i % 4 == 3 else 0, -1 if i % 4 == 3 else 100 * i, 4 if i % 4 == 3 else 0, 50, rng) for i in range(20)]
+    src = tmp_path / "u.bam"
+    _write_bam(src, "@HD\tVN:1.6\tSO:coordinate\n", [("chr1", 100000)], bodies)
+    drop = (ctypes.c_char_p * 1)(b"r0")
+    k, d, u = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int64()
+    assert lib.clm_bam_filter2(str(src).encode(), str(tmp_path / "a.bam").encode(), drop, 1, 0, ctypes.byref(k), ctypes.byref(d), ctypes.byref(u)) == 0
+    assert (k.value, d.value, u.value) == (14, 1, 5)
+    assert all(r[1] >= 0 for r in _bam_records(tmp_path / "a.bam")[2])
+    assert lib.clm_bam_filter2(str(src).encode(), str(tmp_path / "b.bam").encode(), drop, 1, N.BAM_KEEP_UNPLACED, ctypes.byref(k),
+                               ctypes.byref(d), ctypes.byref(u)) == 0
+    assert (k.value, d.value, u.value) == (19, 1, 0)
