@@ -83,7 +83,7 @@ SYMBOLS = {
     "clm_feeder_close": (C.c_int, [_H]),
     "clm_bam_filter": (C.c_int, [C.c_char_p, C.c_char_p, C.POINTER(C.c_char_p), C.c_int64, C.POINTER(C.c_int64),
                                  C.POINTER(C.c_int64)]),
-    "clm_bam_filter2": (C.c_int, [C.c_char_p, C.c_char_p, C.POINTER(C.c_char_p), C.c_int64, C.c_int, C.POINTER(C.c_int64),
+    "clm_bam_filter_ex": (C.c_int, [C.c_char_p, C.c_char_p, C.POINTER(C.c_char_p), C.c_int64, C.c_int, C.POINTER(C.c_int64),
                                   C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "clm_bam_sort_index": (C.c_int, [C.c_char_p, C.c_char_p, C.c_char_p, C.POINTER(C.c_int64)]),
     "clm_bam_last_error": (C.c_char_p, []),

@@ -476,7 +476,7 @@ extern "C" {
 
 const char* clm_bam_last_error(void) { return g_err.c_str(); }
 
-int clm_bam_filter2(const char* in_path, const char* out_bam, const char* const* drop_names, int64_t n_drop, int flags,
+int clm_bam_filter_ex(const char* in_path, const char* out_bam, const char* const* drop_names, int64_t n_drop, int flags,
                     int64_t* kept, int64_t* dropped, int64_t* unplaced) {
     if (!in_path || !out_bam || (n_drop > 0 && !drop_names) || n_drop < 0) return bam_fail(CLM_E_INVALID, "clm_bam_filter: bad argument");
     const bool sam = (flags & CLM_BAM_INPUT_SAM) != 0;
@@ -537,7 +537,7 @@ int clm_bam_filter2(const char* in_path, const char* out_bam, const char* const*
 
 int clm_bam_filter(const char* in_bam, const char* out_bam, const char* const* drop_names, int64_t n_drop, int64_t* kept,
                    int64_t* dropped) {
-    return clm_bam_filter2(in_bam, out_bam, drop_names, n_drop, 0, kept, dropped, nullptr);
+    return clm_bam_filter_ex(in_bam, out_bam, drop_names, n_drop, 0, kept, dropped, nullptr);
 }
 
 int clm_bam_sort_index(const char* in_bam, const char* out_sorted_bam, const char* out_bai, int64_t* n_records) {

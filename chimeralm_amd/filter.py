@@ -4,7 +4,7 @@
 `filter_bam_by_predcition` (the reference's spelling is kept) drops every record of the reads labelled 1 (chimera artifact),
 writes `<bam>.filtered.bam`, then -- with `index=True` -- `<bam>.filtered.sorted.bam` + its `.bai`.  The BAM work (BGZF
 inflate/deflate, SAM text parsing, record copy, coordinate sort with spill-to-disk runs, BAI binning index) is native C++
-(csrc/bam_filter.cpp) behind `clm_bam_filter2` / `clm_bam_sort_index`; the reference does it through pysam / samtools.
+(csrc/bam_filter.cpp) behind `clm_bam_filter_ex` / `clm_bam_sort_index`; the reference does it through pysam / samtools.
 As there (`file_mode = "rb" if suffix == ".bam" else "r"`, :127) any other suffix is read as SAM text.  Records of a BAM
 that have no reference placement are left out, as the reference's index walk (`bam_file.fetch()`, :131) never yields them.
 """
@@ -75,7 +75,7 @@ def filter_bam_by_predcition(bam_path: Path, prediction_path: Path, *, index: bo
     arr = (C.c_char_p * max(1, len(drop)))(*drop)
     kept, dropped, unplaced = C.c_int64(), C.c_int64(), C.c_int64()
     output_path = bam_path.with_suffix(".filtered.bam")
-    _check(lib.clm_bam_filter2(str(bam_path).encode(), str(output_path).encode(), arr, len(drop), flags, C.byref(kept),
+    _check(lib.clm_bam_filter_ex(str(bam_path).encode(), str(output_path).encode(), arr, len(drop), flags, C.byref(kept),
                                C.byref(dropped), C.byref(unplaced)))
     if unplaced.value:
         log.info(f"{unplaced.value} records without a reference placement left out (an index walk does not reach them)")

@@ -77,16 +77,16 @@ int clm_feeder_close(clm_feeder* f);                       /* stops the thread, 
  * The sort works in memory up to a budget (CLM_SORT_MEM_MB; default a quarter of the host's RAM, 256 MiB .. 16 GiB) and beyond
  * it spills sorted runs to `<out>.tmp.N.run` files and merges them (same stable order whatever the budget), like `samtools
  * sort -m`.  Errors: negative CLM_E_* code, text from clm_bam_last_error() (per thread).
- * clm_bam_filter2 adds: `flags` -- CLM_BAM_INPUT_SAM: `in_path` is SAM text (the reference opens any suffix but .bam in mode
+ * clm_bam_filter_ex adds: `flags` -- CLM_BAM_INPUT_SAM: `in_path` is SAM text (the reference opens any suffix but .bam in mode
  * "r", :127); CLM_BAM_KEEP_UNPLACED: also copy records without a reference placement (refID < 0).  By default those are left
  * out of a BAM's output and counted in `unplaced`: the reference walks the input with `bam_file.fetch()` (:131), which for a BAM
  * goes through the index reference by reference and never yields them; for SAM text it yields every record, so
- * CLM_BAM_INPUT_SAM implies keeping them.  clm_bam_filter is clm_bam_filter2 with flags = 0. */
+ * CLM_BAM_INPUT_SAM implies keeping them.  clm_bam_filter is clm_bam_filter_ex with flags = 0. */
 #define CLM_BAM_INPUT_SAM 1
 #define CLM_BAM_KEEP_UNPLACED 2
 int clm_bam_filter(const char* in_bam, const char* out_bam, const char* const* drop_names, int64_t n_drop, int64_t* kept,
                    int64_t* dropped);
-int clm_bam_filter2(const char* in_path, const char* out_bam, const char* const* drop_names, int64_t n_drop, int flags,
+int clm_bam_filter_ex(const char* in_path, const char* out_bam, const char* const* drop_names, int64_t n_drop, int flags,
                     int64_t* kept, int64_t* dropped, int64_t* unplaced);
 int clm_bam_sort_index(const char* in_bam, const char* out_sorted_bam, const char* out_bai, int64_t* n_records);
 const char* clm_bam_last_error(void);

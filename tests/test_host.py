@@ -769,9 +769,9 @@ def test_filter_leaves_out_unplaced_records_of_a_bam(tmp_path):
     _write_bam(src, "@HD\tVN:1.6\tSO:coordinate\n", [("chr1", 100000)], bodies)
     drop = (ctypes.c_char_p * 1)(b"r0")
     k, d, u = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int64()
-    assert lib.clm_bam_filter2(str(src).encode(), str(tmp_path / "a.bam").encode(), drop, 1, 0, ctypes.byref(k), ctypes.byref(d), ctypes.byref(u)) == 0
+    assert lib.clm_bam_filter_ex(str(src).encode(), str(tmp_path / "a.bam").encode(), drop, 1, 0, ctypes.byref(k), ctypes.byref(d), ctypes.byref(u)) == 0
     assert (k.value, d.value, u.value) == (14, 1, 5)
     assert all(r[1] >= 0 for r in _bam_records(tmp_path / "a.bam")[2])
-    assert lib.clm_bam_filter2(str(src).encode(), str(tmp_path / "b.bam").encode(), drop, 1, N.BAM_KEEP_UNPLACED, ctypes.byref(k),
+    assert lib.clm_bam_filter_ex(str(src).encode(), str(tmp_path / "b.bam").encode(), drop, 1, N.BAM_KEEP_UNPLACED, ctypes.byref(k),
                                ctypes.byref(d), ctypes.byref(u)) == 0
     assert (k.value, d.value, u.value) == (19, 1, 0)
