@@ -102,6 +102,12 @@ def load() -> C.CDLL:
             f"{LIB_PATH} not found: the ChimeraLM MI355X engine has no CPU or PyTorch fallback. "
             "Build it with `python -m chimeralm_amd.build` (needs hipcc, targets gfx950)."
         )
+    # The process must hold ONE HIP runtime.  PyTorch-ROCm ships its own libamdhip64; if this library were opened first it
+    # would pull in /opt/rocm's copy and device enumeration then fails in whichever runtime comes second
+    # ("no such HIP device 0").  Importing torch first makes the dynamic loader resolve our dependency to the copy torch
+    # has already mapped, whatever order the caller imports things in.
+    import torch  # noqa: F401
+
     lib = C.CDLL(str(LIB_PATH))
     for name, (res, args) in SYMBOLS.items():
         try:

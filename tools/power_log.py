@@ -45,15 +45,26 @@ class Sampler:
     def sample(self) -> dict:
         row = {"t": time.perf_counter()}
         if self.src == "sysfs":
-            h = self.hw[0]
-            p = _read(f"{h}/power1_average") or _read(f"{h}/power1_input")
-            row["power_w"] = float(p) / 1e6 if p else None
-            f = _read(f"{h}/freq1_input")
-            row["sclk_mhz"] = float(f) / 1e6 if f else None
-            t = _read(f"{h}/temp1_input")
-            row["temp_c"] = float(t) / 1e3 if t else None
-            cap = _read(f"{h}/power1_cap")
-            row["cap_w"] = float(cap) / 1e6 if cap else None
+            # the box's sysfs shows every GPU of the host, the process sees one of them: sample all, report the busiest
+            best = None
+            for h in self.hw:
+                p = _read(f"{h}/power1_average") or _read(f"{h}/power1_input")
+                if not p:
+                    continue
+                card = h.split("/")[4]
+                row[f"power_w_{card}"] = float(p) / 1e6
+                if best is None or float(p) > best[0]:
+                    best = (float(p), h)
+            if best:
+                h = best[1]
+                row["card"] = h.split("/")[4]
+                row["power_w"] = best[0] / 1e6
+                f = _read(f"{h}/freq1_input")
+                row["sclk_mhz"] = float(f) / 1e6 if f else None
+                t = _read(f"{h}/temp2_input") or _read(f"{h}/temp1_input")
+                row["temp_c"] = float(t) / 1e3 if t else None
+                cap = _read(f"{h}/power1_cap")
+                row["cap_w"] = float(cap) / 1e6 if cap else None
         elif self.src == "amd-smi":
             r = subprocess.run(["amd-smi", "metric", "-g", "0", "--power", "--clock", "--temperature", "--json"],
                                capture_output=True, text=True)
@@ -108,6 +119,10 @@ def summarize(name, rows):
         v = [r[k] for r in rows if r.get(k) is not None]
         if v:
             out.append(f"   {k:9s} mean {sum(v) / len(v):8.1f}   min {min(v):8.1f}   max {max(v):8.1f}")
+    cards = sorted({k for r in rows for k in r if k.startswith("power_w_")})
+    if cards:
+        out.append("   mean W per card: " + "  ".join(f"{c[8:]} {sum(r.get(c, 0) for r in rows) / len(rows):.0f}" for c in cards)
+                   + f"   (busiest card sampled for clock/temperature: {rows[len(rows) // 2].get('card')})")
     errs = [r["err"] for r in rows if "err" in r]
     if errs:
         out.append(f"   {len(errs)} failed samples, first: {errs[0]}")
