@@ -40,6 +40,8 @@ def predict(
     feeder: str = typer.Option("native", "--feeder", help="BAM input: native (C++ decoder thread, pinned ring) | python"),
     random: bool = typer.Option(False, "--random", "-r", help="Make the prediction not deterministic"),
     verbose: bool = typer.Option(False, "--verbose", "-v", help="Enable verbose output"),
+    gather_logits: bool = typer.Option(False, "--gather-logits", help="multi-GPU: all-gather every batch's logits (RCCL, side "
+                                       "stream) and let rank 0 also write them to logits.tsv (batch, rank, row, logit0, logit1)"),
 ):
     """Predict the given dataset using ChimeraLM."""
     logging.basicConfig(level=logging.DEBUG if verbose else logging.INFO, format="%(message)s")
@@ -49,17 +51,22 @@ def predict(
         output_path = data_path.with_suffix(".predictions")
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if gpus > 1 and world == 1:                   # one process per GPU, launched before anything touches HIP
+        from .distributed import free_port
+
+        port = os.environ.get("MASTER_PORT") or str(free_port())      # a port that is free now, not a fixed one
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}",
-               "--master-addr", "127.0.0.1", "--master-port", os.environ.get("MASTER_PORT", "29511"),
-               "-m", "chimeralm_amd", *sys.argv[1:]]
+               "--master-addr", "127.0.0.1", "--master-port", port, "-m", "chimeralm_amd", *sys.argv[1:]]
         raise typer.Exit(subprocess.call(cmd))
 
     from . import bam, callbacks, distributed, lm, predict as loop, tokenizer
 
-    rank, local_rank, world = distributed.init_process_group()
+    # CLM_DIST_BACKEND=gloo with CLM_RANKS_SHARE_GPU=1 is the one-GPU rehearsal of a multi-GPU run (tests/test_gpu_multirank.py):
+    # RCCL refuses two ranks per device, everything else is the real path
+    backend = os.environ.get("CLM_DIST_BACKEND")
+    rank, local_rank, world = distributed.init_process_group(backend)
     if not random:
         torch.manual_seed(42)
-    device = torch.device("cuda", local_rank)
+    device = torch.device("cuda", local_rank % torch.cuda.device_count() if os.environ.get("CLM_RANKS_SHARE_GPU") == "1" else local_rank)
     torch.cuda.set_device(device)
     tok = tokenizer.load_tokenizer_from_hyena_model("hyenadna-small-32k-seqlen")
     if feeder not in ("native", "python"):
@@ -79,15 +86,33 @@ def predict(
 
         with BamFeeder(data_path, batch_size=batch_size // world, max_tokens=tok.max_len_single_sentence, rank=rank,
                        world=world, pad_left=tok.padding_side == "left") as fd:
-            n = loop.run_predict_native(model, fd, writer, device, rank=rank)
+            n = loop.run_predict_native(model, fd, writer, device, rank=rank, gather=world > 1 and gather_logits,
+                                        on_batch=_gathered_sink(output_path, rank) if gather_logits else None)
             log.info(f"[rank {rank}] feeder: {fd.stats()}")
     else:
         dm = bam.BamDataModule(tokenizer=tok, train_data_path=Path("dummy.bam"), predict_data_path=data_path,
                                batch_size=batch_size, num_workers=num_workers)
         dm.setup("predict", world_size=world, rank=rank)
-        n = loop.run_predict(model, dm, writer, device, rank=rank)
+        n = loop.run_predict(model, dm, writer, device, rank=rank, gather=world > 1 and gather_logits,
+                             on_batch=_gathered_sink(output_path, rank) if gather_logits else None)
     distributed.barrier()
     log.info(f"[rank {rank}] {n} reads; predictions saved to {output_path}")
+
+
+def _gathered_sink(output_path: Path, rank: int):
+    """Rank 0 appends the gathered [B, 2] logits of every batch to <output>/logits.tsv; rows are in rank order (rank r's
+    shard of batch b are rows r*B/G .. (r+1)*B/G - 1)."""
+    if rank != 0:
+        return lambda batch_idx, gathered: None
+    f = (output_path / "logits.tsv").open("w")
+
+    def sink(batch_idx: int, gathered):
+        rows = gathered.shape[0] // max(1, int(os.environ.get("WORLD_SIZE", "1")))
+        for i, row in enumerate(gathered.tolist()):
+            if row[2] > 0:                                    # rows of short / empty batches are padding
+                f.write(f"{batch_idx}\t{i // rows}\t{i % rows}\t{row[0]:.7g}\t{row[1]:.7g}\n")
+        f.flush()
+    return sink
 
 
 @app.command()

@@ -20,7 +20,7 @@ from types import SimpleNamespace
 
 import torch
 
-from .distributed import gather_logits
+from .distributed import LogitsGather
 
 
 def _to_device(batch: dict, device: torch.device, stream: torch.cuda.Stream) -> dict:
@@ -35,33 +35,81 @@ def _to_device(batch: dict, device: torch.device, stream: torch.cuda.Stream) -> 
 
 
 class _Deferred:
-    """The logits of one batch on their way to the host (async copy + event), and what the writer needs with them."""
+    """The logits of one batch on their way to the host (async copy + event), and what the writer needs with them.
 
-    def __init__(self, logits: torch.Tensor, labels, batch: dict, batch_idx: int, gathered: torch.Tensor | None):
-        self.host = torch.empty(logits.shape, dtype=logits.dtype, pin_memory=True)   # caching host allocator: cheap after the first
-        self.host.copy_(logits, non_blocking=True)
-        self.gathered = None
-        if gathered is not None:
-            self.gathered = torch.empty(gathered.shape, dtype=gathered.dtype, pin_memory=True)
-            self.gathered.copy_(gathered, non_blocking=True)
-        self.event = torch.cuda.Event()
-        self.event.record()
+    With a `LogitsGather` the batch also takes part in the all-gather of this round: every rank contributes a
+    `[rows, 3]` tensor (logit0, logit1, valid) -- short or empty batches are padded with valid = 0 -- on the gather's own stream,
+    behind this forward only; the gathered `[world * rows, 3]` tensor follows to page-locked host memory on that stream."""
+
+    def __init__(self, logits: torch.Tensor | None, labels, batch: dict | None, batch_idx: int,
+                 gather: LogitsGather | None = None, rows: int = 0, device: torch.device | None = None):
+        self.host, self.event = None, None
+        if logits is not None and logits.is_cuda:
+            self.host = torch.empty(logits.shape, dtype=logits.dtype, pin_memory=True)   # caching host allocator: cheap after the first
+            self.host.copy_(logits, non_blocking=True)
+            self.event = torch.cuda.Event()
+            self.event.record()
+        elif logits is not None:                               # host tensors: the CPU rehearsal of the multi-rank protocol (tests)
+            self.host = logits
+        self.gathered, self.gathered_done = None, None
+        if gather is not None:
+            mine = torch.zeros((rows, 3), dtype=torch.float32, device=device if logits is None else logits.device)
+            if logits is not None:
+                mine[: logits.shape[0], :2] = logits
+                mine[: logits.shape[0], 2] = 1.0
+            full, done = gather.submit(mine)
+            if done is not None:
+                with torch.cuda.stream(gather.side):
+                    self.gathered = torch.empty(full.shape, dtype=full.dtype, pin_memory=True)
+                    self.gathered.copy_(full, non_blocking=True)
+                    full.record_stream(gather.side)
+                    self.gathered_done = torch.cuda.Event()
+                    self.gathered_done.record(gather.side)
+            else:
+                self.gathered = full.cpu()
         self.labels, self.batch, self.batch_idx = labels, batch, batch_idx
 
-    def flush(self, writer, trainer, model, on_batch) -> None:
-        self.event.synchronize()
-        if self.gathered is not None and on_batch is not None:
-            on_batch(self.batch_idx, self.gathered)
-        writer.write_on_batch_end(trainer, model, (self.host, self.labels), None, self.batch, self.batch_idx, 0)
+    def flush(self, writer, trainer, model, on_batch) -> bool:
+        """Write this batch's file; hand the gathered round to `on_batch`.  Returns whether ANY rank had reads in this round."""
+        alive = self.host is not None
+        if self.gathered is not None:
+            if self.gathered_done is not None:
+                self.gathered_done.synchronize()
+            alive = bool((self.gathered[:, 2] > 0).any())
+            if on_batch is not None and alive:
+                on_batch(self.batch_idx, self.gathered)
+        if self.host is not None:
+            if self.event is not None:
+                self.event.synchronize()
+            writer.write_on_batch_end(trainer, model, (self.host, self.labels), None, self.batch, self.batch_idx, 0)
+        return alive
+
+
+def _drain_gather(pending, gatherer, rows, device, batch_idx, writer, trainer, model, on_batch):
+    """Ranks run out of reads at different times, but a collective needs every rank: a rank that is done keeps contributing
+    empty rounds until one round has come back with no valid row from anybody.  All ranks see the same gathered tensors one
+    round behind, so all of them leave this loop after the same number of rounds."""
+    while True:
+        now = _Deferred(None, None, None, batch_idx, gatherer, rows, device)
+        alive = pending.flush(writer, trainer, model, on_batch) if pending is not None else True
+        pending = now
+        batch_idx += 1
+        if not alive:
+            break
+    pending.flush(writer, trainer, model, on_batch)
 
 
 def run_predict(model, datamodule, writer, device: torch.device, *, rank: int = 0, gather: bool = False,
                 on_batch=None) -> int:
-    """Returns the number of reads this rank classified."""
+    """Returns the number of reads this rank classified.  `gather`: every batch's logits are also all-gathered over the process
+    group (RCCL over xGMI when the backend is "nccl"), off the compute stream, and handed to `on_batch(batch_idx, tensor)` one
+    batch behind as a `[world * rows, 3]` host tensor (logit0, logit1, valid), rank r's rows at [r * rows, (r + 1) * rows)."""
     model.eval()
     copy_stream = torch.cuda.Stream(device)
     compute = torch.cuda.current_stream(device)
     trainer = SimpleNamespace(global_rank=rank)
+    gatherer = LogitsGather(device) if gather else None
+    rows = getattr(datamodule, "batch_size_per_device", 0)
     it = iter(datamodule.predict_dataloader())
     nxt = next(it, None)
     staged = _to_device(nxt, device, copy_stream) if nxt is not None else None
@@ -74,13 +122,15 @@ def run_predict(model, datamodule, writer, device: torch.device, *, rank: int = 
             nxt = next(it, None)                              # host collation of batch i+1 ...
             staged = _to_device(nxt, device, copy_stream) if nxt is not None else None   # ... and its H2D overlap
             logits, labels = model.predict_step(cur, batch_idx)
-            now = _Deferred(logits, labels, cur, batch_idx, gather_logits(logits) if gather else None)
+            now = _Deferred(logits, labels, cur, batch_idx, gatherer, rows)
             if pending is not None:
                 pending.flush(writer, trainer, model, on_batch)   # batch i-1: its copy finished while batch i was enqueued
             pending = now
             n_reads += logits.shape[0]
             batch_idx += 1
-        if pending is not None:
+        if gatherer is not None:
+            _drain_gather(pending, gatherer, rows, device, batch_idx, writer, trainer, model, on_batch)
+        elif pending is not None:
             pending.flush(writer, trainer, model, on_batch)
     return n_reads
 
@@ -93,6 +143,8 @@ def run_predict_native(model, feeder, writer, device: torch.device, *, rank: int
     model.eval()
     eng = model.net.engine(device)
     trainer = SimpleNamespace(global_rank=rank)
+    gatherer = LogitsGather(device) if gather else None
+    rows = feeder.batch_size
     n_reads, batch_idx = 0, 0
     pending: _Deferred | None = None
     cur = feeder.next()
@@ -107,13 +159,15 @@ def run_predict_native(model, feeder, writer, device: torch.device, *, rank: int
             feeder.release(cur)                               # ... which goes back to the decoder
             labels = torch.full((cur.n_reads,), -1, dtype=torch.int64)   # tokenizer.py:113: predict labels are all -1
             batch = {"id": torch.from_numpy(cur.names), "labels": labels}
-            now = _Deferred(logits, labels, batch, batch_idx, gather_logits(logits) if gather else None)
+            now = _Deferred(logits, labels, batch, batch_idx, gatherer, rows)
             if pending is not None:
                 pending.flush(writer, trainer, model, on_batch)
             pending = now
             n_reads += cur.n_reads
             batch_idx += 1
             cur, staged = nxt, nxt_staged
-        if pending is not None:
+        if gatherer is not None:
+            _drain_gather(pending, gatherer, rows, device, batch_idx, writer, trainer, model, on_batch)
+        elif pending is not None:
             pending.flush(writer, trainer, model, on_batch)
     return n_reads

@@ -39,3 +39,64 @@ def test_bench_two_ranks_on_one_gpu(built_lib):
     assert abs(d["value"] - 8 * 3 / (d["ms_per_step"] * 3e-3)) < 1e-6 * d["value"]   # whole-job reads / max-over-ranks time
     assert {"bound", "achieved", "peak", "unit", "frac", "traffic"} <= set(d["roofline"])
     assert d["distributed"]["backend"] == "gloo" and d["distributed"]["world_size"] == 2 and len(d["distributed"]["devices"]) == 2
+
+
+def test_predict_two_ranks_on_one_gpu_union_equals_single_rank(tmp_path, golden_dir, built_lib):
+    """`python -m chimeralm_amd predict BAM -g 2` (one process per rank through torchrun, a free rendezvous port) with both
+    ranks on this box's one GPU over gloo: rank r classifies reads r, r+2, ... (the non-shuffling distributed sampler of the
+    reference's Lightning run) and writes `{rank}_{batch}.txt`; `--gather-logits` exercises the side-stream all-gather and its
+    drain protocol for real.  Every read must appear exactly once in the union of the files, and a single-rank run fed the same
+    per-rank batches must give the same labels (batches are compared like for like: logits depend on the batch's padding)."""
+    import shutil
+
+    from safetensors.torch import save_file
+
+    from oracle import hyena_oracle as ho
+
+    sd = ho.make_state_dict(0, head_scale=3.0)
+    wdir = tmp_path / "weights"
+    wdir.mkdir()
+    save_file({k: v.contiguous() for k, v in sd.items() if not (k.endswith(".3.freq") or k.endswith(".5.freq"))},
+              str(wdir / "model.safetensors"))
+    bam = tmp_path / "reads.bam"
+    shutil.copyfile(golden_dir / "test_chimric_reads.bam", bam)
+    env = dict(os.environ, PYTHONPATH=str(REPO), CLM_DIST_BACKEND="gloo", CLM_RANKS_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("MASTER_PORT", None)
+    out2 = tmp_path / "two"
+    r = subprocess.run([sys.executable, "-m", "chimeralm_amd", "predict", str(bam), "-g", "2", "-b", "24", "-o", str(out2),
+                        "--weights", str(wdir), "--precision", "fp32", "--gather-logits"],
+                       capture_output=True, text=True, env=env, cwd=str(REPO), timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    files = sorted(p.name for p in out2.glob("*_*.txt"))
+    # 100 selected reads, 12 per rank and batch: 50 reads per rank = 5 batches each (12, 12, 12, 12, 2)
+    assert files == sorted(f"{rk}_{b}.txt" for rk in (0, 1) for b in range(5)), files
+    two = {}
+    for rk in (0, 1):
+        for b in range(5):
+            for ln in (out2 / f"{rk}_{b}.txt").read_text().splitlines():
+                name, label = ln.split("\t")
+                assert name not in two, f"{name} classified twice"
+                two[name] = (rk, b, int(label))
+    assert len(two) == 100
+    # gathered logits: rank 0 wrote one row per read, rows of rank r in [r*12, (r+1)*12)
+    rows = [ln.split("\t") for ln in (out2 / "logits.tsv").read_text().splitlines()]
+    assert len(rows) == 100 and {int(x[1]) for x in rows} == {0, 1}
+    # same batches through one process: the Python data module with world_size 2 yields exactly the per-rank batches
+    import torch
+
+    from chimeralm_amd import bam as bam_mod, lm, tokenizer as T
+    from oracle import data_oracle as do
+
+    model = lm.ChimeraLM.new(precision="fp32")
+    model.load_state_dict(sd, strict=True)
+    tok = T.load_tokenizer_from_hyena_model("hyenadna-small-32k-seqlen")
+    for rk in (0, 1):
+        dm = bam_mod.BamDataModule(tokenizer=tok, predict_data_path=bam, batch_size=24)
+        dm.setup("predict", world_size=2, rank=rk)
+        for b, batch in enumerate(dm.predict_dataloader()):
+            logits, _ = model.predict_step({**batch, "input_ids": batch["input_ids"].cuda()}, b)
+            want = "".join(do.prediction_lines(logits.cpu().numpy(), batch["id"].numpy()))
+            assert (out2 / f"{rk}_{b}.txt").read_text() == want, f"rank {rk} batch {b}"
+            mine = [x for x in rows if int(x[0]) == b and int(x[1]) == rk]
+            got = torch.tensor([[float(x[3]), float(x[4])] for x in mine])
+            assert got.shape == logits.shape and (got - logits.cpu()).abs().max() < 1e-5
