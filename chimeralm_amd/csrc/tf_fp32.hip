@@ -1,0 +1,234 @@
+// tf_fp32.hip -- SequenceCNNTransformer forward in the REFERENCE'S OWN PRECISION (fp32), the parity mode of the encoder net.
+//
+// Reference: /root/reference/chimeralm/models/components/transformer.py:28-104 (modules and forward; no masks anywhere).
+// The 16-bit path (tf_model.hip, attention.hip) is the throughput path; its fp16 MFMA inputs leave 0.6-2.2e-2 on logits of
+// magnitude 3-9, far from north_star's 1e-3.  This path computes every product exactly as fp32 x fp32 with fp32 accumulation:
+//   * dense layers and the k = 3 convolutions: v_mfma_f32_32x32x2_f32 (the convolution as a K = 768 GEMM whose A rows are
+//     gathered on the fly: x[t-1] | x[t] | x[t+1], zero outside the read -- Conv1d(padding=1));
+//   * attention: one thread per query row, K / V tiles of 64 keys staged in LDS (read as broadcasts), online softmax,
+//     fp32 throughout (8 heads of 32; scores scaled by 1/sqrt(32) like nn.MultiheadAttention);
+//   * LayerNorm (post-norm: LN(x + sublayer(x))), positional encoding, ReLU / MaxPool1d(2) as plain fp32 kernels.
+// It is a correctness reference on the GPU, not tuned: stages are separate kernels and activations live in HBM as fp32.
+#include <string>
+
+#include "clm_common.h"
+
+namespace clm {
+namespace tf32 {
+
+constexpr int TVOC = 12;
+
+// x[b, t, :] = emb[id]   (ids8 already clamped to [0, 16); rows >= 12 do not exist in nn.Embedding(12, 256): clamp to 11)
+__global__ __launch_bounds__(256) void embed_kernel(const unsigned char* __restrict__ ids8, int ids_stride,
+                                                    const float* __restrict__ emb, float* __restrict__ x, int B, int L) {
+    const size_t tok = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (tok >= (size_t)B * L) return;
+    const int b = int(tok / L), t = int(tok % L), lane = threadIdx.x & 63;
+    const int id = ids8[(size_t)b * ids_stride + t];
+    const float4 v = *reinterpret_cast<const float4*>(emb + (size_t)(id < TVOC ? id : TVOC - 1) * D + lane * 4);
+    *reinterpret_cast<float4*>(x + tok * D + lane * 4) = v;
+}
+
+// C[m, n] = act(sum_k A(m, k) W(n, k) + bias[n]) (+ R[m, n]).  Tile 64 x 64 per workgroup, 4 waves of one 32 x 32 MFMA tile.
+//   CONV3 = false: A(m, k) = A[m * lda + k],  W(n, k) = W[n * K + k]
+//   CONV3 = true : rows are (read, position t) with Lrow positions per read, K = 3 * 256:
+//                  A(m, dk * 256 + ci) = x[b, t + dk - 1, ci] (0 outside),  W(n, dk * 256 + ci) = w[n][ci][dk]  (Conv1d weight)
+template <bool RELU, bool CONV3>
+__global__ __launch_bounds__(256) void gemm_kernel(const float* __restrict__ A, int lda, const float* __restrict__ W,
+                                                   const float* __restrict__ bias, const float* __restrict__ R,
+                                                   float* __restrict__ C, int ldc, size_t M, int N, int K, int Lrow) {
+    constexpr int KC = 32, LS = KC + 1;
+    __shared__ float As[64 * LS], Ws[64 * LS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, mt = wave >> 1, nt = wave & 1;
+    const size_t m0 = (size_t)blockIdx.x * 64;
+    const int n0 = blockIdx.y * 64;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    for (int k0 = 0; k0 < K; k0 += KC) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int e = tid + i * 256, row = e >> 5, kk = e & 31, k = k0 + kk;
+            const size_t m = m0 + row;
+            float a = 0.f;
+            if (m < M) {
+                if (CONV3) {
+                    const int dk = k >> 8, ci = k & 255;
+                    const long t = (long)(m % (size_t)Lrow) + dk - 1;
+                    if (t >= 0 && t < Lrow) a = A[(m + dk - 1) * (size_t)lda + ci];
+                } else {
+                    a = A[m * (size_t)lda + k];
+                }
+            }
+            As[row * LS + kk] = a;
+            const int n = n0 + row;
+            float w = 0.f;
+            if (n < N) w = CONV3 ? W[((size_t)n * D + (k & 255)) * 3 + (k >> 8)] : W[(size_t)n * K + k];
+            Ws[row * LS + kk] = w;
+        }
+        __syncthreads();
+        const float* ap = As + (mt * 32 + (lane & 31)) * LS + (lane >> 5);
+        const float* wp = Ws + (nt * 32 + (lane & 31)) * LS + (lane >> 5);
+#pragma unroll
+        for (int ks = 0; ks < KC / 2; ++ks) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[2 * ks], wp[2 * ks], acc, 0, 0, 0);
+        __syncthreads();
+    }
+    // C/D map: column = lane & 31 (output feature), row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5) (token)
+    const int n = n0 + nt * 32 + (lane & 31);
+    if (n < N) {
+        const float bv = bias ? bias[n] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const size_t m = m0 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            if (m < M) {
+                float v = acc[r] + bv;
+                if (RELU) v = fmaxf(v, 0.f);
+                if (R) v += R[m * (size_t)ldc + n];
+                C[m * (size_t)ldc + n] = v;
+            }
+        }
+    }
+}
+
+// MaxPool1d(2, 2) over positions (the ReLU before it was applied by the GEMM): out[b, p, :] = max(in[b, 2p, :], in[b, 2p + 1, :])
+__global__ __launch_bounds__(256) void maxpool2_kernel(const float* __restrict__ in, float* __restrict__ out, int B, int Lin, int Lout) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;               // one float4 of an output row
+    if (i >= (size_t)B * Lout * (D / 4)) return;
+    const size_t row = i / (D / 4);
+    const int c4 = int(i % (D / 4)), b = int(row / Lout), p = int(row % Lout);
+    const float4 a = *reinterpret_cast<const float4*>(in + ((size_t)b * Lin + 2 * p) * D + c4 * 4);
+    const float4 c = *reinterpret_cast<const float4*>(in + ((size_t)b * Lin + 2 * p + 1) * D + c4 * 4);
+    *reinterpret_cast<float4*>(out + row * D + c4 * 4) = make_float4(fmaxf(a.x, c.x), fmaxf(a.y, c.y), fmaxf(a.z, c.z), fmaxf(a.w, c.w));
+}
+
+// out[m, :] = LayerNorm(in[m, :] (+ pe[m % Lpos, :])) * g + b; one wave per row, two-pass variance
+__global__ __launch_bounds__(256) void ln_kernel(const float* __restrict__ in, const float* __restrict__ pe, const float* __restrict__ g,
+                                                 const float* __restrict__ bta, float* __restrict__ out, size_t M, int Lpos, float eps) {
+    const size_t m = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (m >= M) return;
+    const int lane = threadIdx.x & 63;
+    float4 x = *reinterpret_cast<const float4*>(in + m * D + lane * 4);
+    if (pe) {
+        const float4 p = *reinterpret_cast<const float4*>(pe + (m % (size_t)Lpos) * D + lane * 4);
+        x = make_float4(x.x + p.x, x.y + p.y, x.z + p.z, x.w + p.w);
+    }
+    const float mean = wave_sum((x.x + x.y) + (x.z + x.w)) * (1.0f / D);
+    const float d0 = x.x - mean, d1 = x.y - mean, d2 = x.z - mean, d3 = x.w - mean;
+    const float var = wave_sum((d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3)) * (1.0f / D);
+    const float rstd = 1.0f / sqrtf(var + eps);
+    const float4 g4 = *reinterpret_cast<const float4*>(g + lane * 4), b4 = *reinterpret_cast<const float4*>(bta + lane * 4);
+    *reinterpret_cast<float4*>(out + m * D + lane * 4) =
+        make_float4(d0 * rstd * g4.x + b4.x, d1 * rstd * g4.y + b4.y, d2 * rstd * g4.z + b4.z, d3 * rstd * g4.w + b4.w);
+}
+
+// softmax(q k^T / sqrt(32)) v per (read, head): thread = query position; keys in LDS tiles of 64
+__global__ __launch_bounds__(256) void attention_kernel(const float* __restrict__ qkv, float* __restrict__ out, int L3) {
+    __shared__ float Ks[64 * 32], Vs[64 * 32];
+    const int tid = threadIdx.x, head = blockIdx.y, b = blockIdx.z;
+    const int qpos = blockIdx.x * 256 + tid;
+    const bool active = qpos < L3;
+    const float* base = qkv + (size_t)b * L3 * 768;
+    float q[32], o[32];
+    const float scale = 0.17677669529663687f;                              // 1 / sqrt(32)
+    {
+        const float* qp = base + (size_t)(active ? qpos : 0) * 768 + head * 32;
+#pragma unroll
+        for (int d = 0; d < 32; d += 4) {
+            const float4 v = *reinterpret_cast<const float4*>(qp + d);
+            q[d] = v.x * scale; q[d + 1] = v.y * scale; q[d + 2] = v.z * scale; q[d + 3] = v.w * scale;
+        }
+    }
+#pragma unroll
+    for (int d = 0; d < 32; ++d) o[d] = 0.f;
+    float mx = -INFINITY, sum = 0.f;
+    for (int k0 = 0; k0 < L3; k0 += 64) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {                                      // 64 keys x 8 float4 of K and of V
+            const int e = tid + i * 256, j = e >> 3, d4 = e & 7;
+            const int kp = k0 + j < L3 ? k0 + j : L3 - 1;
+            const float* rowp = base + (size_t)kp * 768 + head * 32 + d4 * 4;
+            *reinterpret_cast<float4*>(Ks + j * 32 + d4 * 4) = *reinterpret_cast<const float4*>(rowp + 256);
+            *reinterpret_cast<float4*>(Vs + j * 32 + d4 * 4) = *reinterpret_cast<const float4*>(rowp + 512);
+        }
+        __syncthreads();
+        const int nk = L3 - k0 < 64 ? L3 - k0 : 64;
+        for (int j = 0; j < nk; ++j) {
+            float s = 0.f;
+#pragma unroll
+            for (int d = 0; d < 32; ++d) s = fmaf(q[d], Ks[j * 32 + d], s);
+            const float nm = fmaxf(mx, s), corr = expf(mx - nm), p = expf(s - nm);   // exp(-inf) = 0 on the first key
+            sum = sum * corr + p;
+#pragma unroll
+            for (int d = 0; d < 32; ++d) o[d] = fmaf(p, Vs[j * 32 + d], o[d] * corr);
+            mx = nm;
+        }
+    }
+    if (active) {
+        const float inv = 1.0f / sum;
+        float* op = out + ((size_t)b * L3 + qpos) * D + head * 32;
+#pragma unroll
+        for (int d = 0; d < 32; d += 4)
+            *reinterpret_cast<float4*>(op + d) = make_float4(o[d] * inv, o[d + 1] * inv, o[d + 2] * inv, o[d + 3] * inv);
+    }
+}
+
+template <bool RELU, bool CONV3>
+static void gemm(const float* A, int lda, const float* W, const float* bias, const float* R, float* C, int ldc, size_t M, int N,
+                 int K, int Lrow, hipStream_t st) {
+    dim3 grid((unsigned)((M + 63) / 64), (unsigned)((N + 63) / 64));
+    hipLaunchKernelGGL((gemm_kernel<RELU, CONV3>), grid, dim3(256), 0, st, A, lda, W, bias, R, C, ldc, M, N, K, Lrow);
+}
+
+}  // namespace tf32
+
+// Workspace (floats): x [B*L*256] | y [B*L*256] | qkv [M*768] | att [M*256] | u [M*1024] | t [M*256]
+size_t tf32_workspace_floats(int B, int L) {
+    const size_t M = (size_t)B * (L / 8);
+    return (size_t)2 * B * L * D + M * (768 + 256 + 1024 + 256);
+}
+
+// `get(key)`: fp32 device pointer of a reference state-dict tensor.  h [M][256] receives the encoder output (the residual stream
+// the pooling head reads), exactly where the 16-bit path leaves it.
+int tf32_forward(const unsigned char* ids8, int ids_stride, int B, int L, int n_layers, float* ws, float* h,
+                 const float* (*get)(void*, const std::string&), void* ctx, hipStream_t st) {
+    using namespace tf32;
+    const int L1 = L / 2, L2 = L1 / 2, L3 = L2 / 2;
+    const size_t M = (size_t)B * L3;
+    float* x = ws;
+    float* y = x + (size_t)B * L * D;
+    float* qkv = y + (size_t)B * L * D;
+    float* att = qkv + M * 768;
+    float* u = att + M * D;
+    float* t = u + M * 1024;
+    auto Wt = [&](const std::string& k) { return get(ctx, k); };
+    hipLaunchKernelGGL(embed_kernel, dim3((unsigned)(((size_t)B * L + 3) / 4)), dim3(256), 0, st, ids8, ids_stride, Wt("embedding.weight"),
+                       x, B, L);
+    // 3 x [Conv1d(k = 3, padding = 1) -> ReLU -> MaxPool1d(2)]; a trailing odd position is dropped by the pooling, as in torch
+    int Lin = L;
+    for (int i : {0, 3, 6}) {
+        const std::string n = "cnn." + std::to_string(i);
+        gemm<true, true>(x, D, Wt(n + ".weight"), Wt(n + ".bias"), nullptr, y, D, (size_t)B * Lin, D, 3 * D, Lin, st);
+        const int Lout = Lin / 2;
+        hipLaunchKernelGGL(maxpool2_kernel, dim3((unsigned)(((size_t)B * Lout * (D / 4) + 255) / 256)), dim3(256), 0, st, y, x, B, Lin, Lout);
+        Lin = Lout;
+    }
+    // + positional encoding, LayerNorm -> residual stream
+    hipLaunchKernelGGL(ln_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, st, x, Wt("pos_encoder.pe"), Wt("norm.weight"),
+                       Wt("norm.bias"), h, M, L3, 1e-5f);
+    for (int i = 0; i < n_layers; ++i) {
+        const std::string p = "transformer_encoder.layers." + std::to_string(i) + ".";
+        gemm<false, false>(h, D, Wt(p + "self_attn.in_proj_weight"), Wt(p + "self_attn.in_proj_bias"), nullptr, qkv, 768, M, 768, D, 0, st);
+        hipLaunchKernelGGL(attention_kernel, dim3((unsigned)((L3 + 255) / 256), 8, (unsigned)B), dim3(256), 0, st, qkv, att, L3);
+        gemm<false, false>(att, D, Wt(p + "self_attn.out_proj.weight"), Wt(p + "self_attn.out_proj.bias"), h, t, D, M, D, D, 0, st);
+        hipLaunchKernelGGL(ln_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, st, t, (const float*)nullptr, Wt(p + "norm1.weight"),
+                           Wt(p + "norm1.bias"), h, M, 1, 1e-5f);
+        gemm<true, false>(h, D, Wt(p + "linear1.weight"), Wt(p + "linear1.bias"), nullptr, u, 1024, M, 1024, D, 0, st);
+        gemm<false, false>(u, 1024, Wt(p + "linear2.weight"), Wt(p + "linear2.bias"), h, t, D, M, D, 1024, 0, st);
+        hipLaunchKernelGGL(ln_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, st, t, (const float*)nullptr, Wt(p + "norm2.weight"),
+                           Wt(p + "norm2.bias"), h, M, 1, 1e-5f);
+    }
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+}  // namespace clm

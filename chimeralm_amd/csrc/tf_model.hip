@@ -491,6 +491,10 @@ __global__ __launch_bounds__(256) void pool_head_kernel(const float* __restrict_
 }  // namespace tf
 
 void launch_attention_fwd(int prec, const void* qkv, void* out, int B, int L, hipStream_t st);   // attention.hip
+// tf_fp32.hip: the same forward with exact-fp32 products (the reference's precision), up to the encoder output h
+size_t tf32_workspace_floats(int B, int L);
+int tf32_forward(const unsigned char* ids8, int ids_stride, int B, int L, int n_layers, float* ws, float* h,
+                 const float* (*get)(void*, const std::string&), void* ctx, hipStream_t st);
 
 }  // namespace clm
 
@@ -509,6 +513,8 @@ struct clm_tf_handle {
     unsigned char* ids8 = nullptr;
     void *x1 = nullptr, *x2 = nullptr, *x3 = nullptr, *hx = nullptr, *qkv = nullptr, *att = nullptr, *u = nullptr;
     float *h = nullptr, *scores = nullptr, *pooled = nullptr;
+    float* ws32 = nullptr;                        // fp32 mode: activations of tf_fp32.hip
+    size_t cap_ws32 = 0;
     int last_B = 0, last_L3 = 0;
 };
 
@@ -556,11 +562,11 @@ std::map<std::string, std::vector<int64_t>> tf_expected(int n_layers) {
 
 void tf_free_ws(clm_tf_handle* h) {
     for (void* p : {(void*)h->ids8, h->x1, h->x2, h->x3, h->hx, h->qkv, h->att, h->u, (void*)h->h, (void*)h->scores,
-                    (void*)h->pooled})
+                    (void*)h->pooled, (void*)h->ws32})
         if (p) (void)hipFree(p);
     h->ids8 = nullptr; h->x1 = h->x2 = h->x3 = h->hx = h->qkv = h->att = h->u = nullptr;
-    h->h = h->scores = h->pooled = nullptr;
-    h->cap_rows = h->cap_tok = 0;
+    h->h = h->scores = h->pooled = h->ws32 = nullptr;
+    h->cap_rows = h->cap_tok = h->cap_ws32 = 0;
 }
 
 template <int PREC, int EPI, int K, int N>
@@ -647,15 +653,15 @@ extern "C" {
 
 int clm_tf_create(int device, int precision, int n_layers, clm_tf_handle** out) {
     if (!out || n_layers < 1 || n_layers > 64) return tf_fail(nullptr, CLM_E_INVALID, "clm_tf_create: bad argument");
-    if (precision != CLM_PREC_F16 && precision != CLM_PREC_BF16)
-        return tf_fail(nullptr, CLM_E_UNSUPPORTED, "clm_tf_create: the encoder path runs with 16-bit MFMA inputs (fp16 or bf16)");
+    if (precision != CLM_PREC_F16 && precision != CLM_PREC_BF16 && precision != CLM_PREC_F32)
+        return tf_fail(nullptr, CLM_E_UNSUPPORTED, "clm_tf_create: precision must be fp32 (exact, the reference's arithmetic), fp16 or bf16");
     if (hipSetDevice(device) != hipSuccess) return tf_fail(nullptr, CLM_E_HIP, "clm_tf_create: hipSetDevice failed");
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) != hipSuccess || std::string(prop.gcnArchName).rfind("gfx950", 0) != 0)
         return tf_fail(nullptr, CLM_E_UNSUPPORTED, "clm_tf_create: this engine is built for gfx950 (MI355X) only");
     clm_tf_handle* h = new clm_tf_handle();
     h->device = device;
-    h->prec = precision == CLM_PREC_BF16 ? PREC_BF16 : PREC_F16;
+    h->prec = precision == CLM_PREC_BF16 ? PREC_BF16 : precision == CLM_PREC_F32 ? PREC_F32 : PREC_F16;
     h->n_layers = n_layers;
     *out = h;
     return CLM_OK;
@@ -695,6 +701,10 @@ int clm_tf_finalize(clm_tf_handle* h) {
     if (!h->w.count("pos_encoder.pe")) return tf_fail(h, CLM_E_MISSING, "clm_tf_finalize: missing buffer pos_encoder.pe");
     for (auto& kv : h->packed) (void)hipFree(kv.second);
     h->packed.clear();
+    if (h->prec == PREC_F32) {                                 // tf_fp32.hip reads the fp32 tensors as they are
+        h->finalized = true;
+        return CLM_OK;
+    }
     auto pack = [&](const std::string& name, const float* w, int n, int k) -> int {
         void* p = nullptr;
         TFCHK(h, hipMalloc(&p, packed_weight_bytes(h->prec, n, k)));
@@ -740,6 +750,31 @@ int clm_tf_forward(clm_tf_handle* h, const void* ids, int ids_dtype, int64_t ids
         return tf_fail(h, CLM_E_INVALID, "clm_tf_forward: Sequence too long (" + std::to_string(L3) + " > max_len of pos_encoder.pe)");
     TFCHK(h, hipSetDevice(h->device));
     const size_t M = (size_t)B * L3, tok = (size_t)B * ((L + 63) / 64 * 64);
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (h->prec == PREC_F32) {
+        const size_t need = tf32_workspace_floats(B, L);
+        if (M > h->cap_rows || tok > h->cap_tok || need > h->cap_ws32) {
+            TFCHK(h, hipDeviceSynchronize());
+            tf_free_ws(h);
+            TFCHK(h, hipMalloc((void**)&h->ids8, tok));
+            TFCHK(h, hipMalloc((void**)&h->ws32, need * 4));
+            TFCHK(h, hipMalloc((void**)&h->h, M * D * 4));
+            TFCHK(h, hipMalloc((void**)&h->scores, M * 4));
+            TFCHK(h, hipMalloc((void**)&h->pooled, (size_t)B * D * 4));
+            h->cap_rows = M; h->cap_tok = tok; h->cap_ws32 = need;
+        }
+        const int Lp = (L + 63) / 64 * 64;
+        launch_embed(ids, ids_dtype, ids_row_stride, nullptr, nullptr, h->ids8, B, L, Lp, st);
+        auto get = [](void* ctx, const std::string& k) -> const float* { return static_cast<clm_tf_handle*>(ctx)->w.at(k); };
+        if (tf32_forward(h->ids8, Lp, B, L, h->n_layers, h->ws32, h->h, get, h, st))
+            return tf_fail(h, CLM_E_HIP, std::string("clm_tf_forward (fp32): ") + hipGetErrorString(hipGetLastError()));
+        auto W = [&](const std::string& k) { return h->w.at(k); };
+        hipLaunchKernelGGL(tf::pool_head_kernel, dim3(B), dim3(256), 0, st, h->h, W("attn_pool.weight"), W("attn_pool.bias"),
+                           W("classifier.0.weight"), W("classifier.0.bias"), W("classifier.3.weight"), W("classifier.3.bias"),
+                           h->scores, h->pooled, logits_out, L3);
+        h->last_B = B; h->last_L3 = L3;
+        return hipGetLastError() == hipSuccess ? CLM_OK : tf_fail(h, CLM_E_HIP, "clm_tf_forward (fp32): launch failed");
+    }
     if (M > h->cap_rows || tok > h->cap_tok) {
         TFCHK(h, hipDeviceSynchronize());
         tf_free_ws(h);
@@ -756,7 +791,6 @@ int clm_tf_forward(clm_tf_handle* h, const void* ids, int ids_dtype, int64_t ids
         TFCHK(h, hipMalloc((void**)&h->pooled, (size_t)B * D * 4));
         h->cap_rows = M; h->cap_tok = tok;
     }
-    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const int rc = h->prec == PREC_BF16 ? tf_forward_t<PREC_BF16>(h, ids, ids_dtype, ids_row_stride, B, L, logits_out, st)
                                         : tf_forward_t<PREC_F16>(h, ids, ids_dtype, ids_row_stride, B, L, logits_out, st);
     if (rc) return tf_fail(h, rc, std::string("clm_tf_forward: ") + hipGetErrorString(hipGetLastError()));

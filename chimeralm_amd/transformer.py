@@ -5,7 +5,7 @@ Same constructor arguments, same `state_dict()` keys (torch's own modules are us
 `transformer_encoder.layers.{i}.self_attn.in_proj_weight` etc. come out exactly as in the reference, and `pos_encoder.pe` is a
 buffer of the same shape), same `forward(input_ids, input_quals=None) -> logits [B, 2]`, same `number_of_classes` attribute that
 `ClassificationLit` reads.  The arithmetic runs in csrc/tf_model.hip + csrc/attention.hip behind the `clm_tf_*` C ABI; there is no
-CPU path.  Engine knob absent in the reference: `precision` in {"fp16", "bf16"}.
+CPU path.  Engine knob absent in the reference: `precision` in {"fp32", "fp16", "bf16"} (fp32 = the reference's arithmetic).
 """
 from __future__ import annotations
 
@@ -42,8 +42,9 @@ class SequenceCNNTransformer(nn.Module):
         if (vocab_size, d_model, cnn_kernel_size, nhead, dim_feedforward, number_of_classes) != (12, 256, 3, 8, 1024, 2):
             raise NotImplementedError("the MI355X encoder implements the production shape: vocab 12, d_model 256, kernel 3, "
                                       "8 heads, feed-forward 1024, 2 classes (configs/model/transformer.yaml)")
-        if precision not in ("fp16", "bf16"):
-            raise ValueError("precision must be fp16 or bf16 (16-bit MFMA inputs, fp32 accumulation and statistics)")
+        if precision not in ("fp32", "fp16", "bf16"):
+            raise ValueError("precision must be fp32 (exact fp32 products: the reference's arithmetic, the parity mode) or "
+                             "fp16 / bf16 (16-bit MFMA inputs, fp32 accumulation and statistics: the throughput modes)")
         self.number_of_classes, self.precision, self.num_encoder_layers = number_of_classes, precision, num_encoder_layers
         self.embedding = nn.Embedding(vocab_size, d_model, padding_idx=padding_idx)
         self.pos_encoder = _PosEnc(d_model, max_len)
@@ -69,7 +70,7 @@ class SequenceCNNTransformer(nn.Module):
         if self._h is None or self._dev != device:
             self.close()
             h = C.c_void_p()
-            rc = lib.clm_tf_create(device.index or 0, N.PRECISIONS[self.precision], self.num_encoder_layers, C.byref(h))
+            rc = lib.clm_tf_create(device.index if device.index is not None else torch.cuda.current_device(), N.PRECISIONS[self.precision], self.num_encoder_layers, C.byref(h))
             if rc != 0:
                 raise TransformerEngineError(lib.clm_tf_last_error(None).decode())
             self._h, self._dev, self._sig = h, device, None

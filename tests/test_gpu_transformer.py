@@ -8,10 +8,13 @@ from oracle import transformer_oracle as to
 
 pytestmark = pytest.mark.gpu
 
-# logits of the seeded classifier (scale 3) are 3..9 in magnitude: tolerances are ~0.5 % / 4 % of that, and the encoder output
-# (O(1) LayerNorm values) is checked separately
-TOL = {"fp16": 4e-2, "bf16": 4e-1}
-TOL_HIDDEN = {"fp16": 1e-2, "bf16": 1e-1}
+# fp32 = the reference's arithmetic (exact-fp32 MFMA, csrc/tf_fp32.hip): held to north_star's gate, 1e-3 on the logits.
+# fp16 / bf16 are the throughput modes of this net, REDUCED precision outside the gate: logits of the seeded classifier
+# (scale 3) are 3..9 in magnitude, their bounds are ~0.5 % / 4 % of that; the encoder output (O(1) LayerNorm values) is
+# checked separately.
+GATE = 1e-3
+TOL = {"fp32": GATE, "fp16": 4e-2, "bf16": 4e-1}
+TOL_HIDDEN = {"fp32": 2e-4, "fp16": 1e-2, "bf16": 1e-1}
 
 
 def _model(sd, prec, layers=12):
@@ -23,7 +26,9 @@ def _model(sd, prec, layers=12):
     return net
 
 
-@pytest.mark.parametrize("prec,seed,B,L,pads", [("fp16", 0, 2, 1000, 0), ("fp16", 1, 3, 777, 40), ("fp16", 2, 1, 8, 0),
+@pytest.mark.parametrize("prec,seed,B,L,pads", [("fp32", 0, 2, 1000, 0), ("fp32", 1, 3, 777, 40), ("fp32", 2, 1, 8, 0),
+                                                ("fp32", 3, 2, 2055, 0), ("fp32", 4, 3, 4101, 7),
+                                                ("fp16", 0, 2, 1000, 0), ("fp16", 1, 3, 777, 40), ("fp16", 2, 1, 8, 0),
                                                 ("fp16", 3, 2, 2055, 0), ("bf16", 0, 2, 1000, 0)])
 def test_forward_matches_oracle(built_lib, golden_dir, prec, seed, B, L, pads):
     sd = to.make_state_dict(seed, to.PRODUCTION, scale=3.0)
@@ -43,7 +48,7 @@ def test_forward_matches_oracle(built_lib, golden_dir, prec, seed, B, L, pads):
     err = np.abs(got - ref).max()
     print(f"{prec} B={B} L={L}: |logits - oracle| = {err:.2e}, |hidden - oracle| = {err_h:.2e}")
     assert err < TOL[prec] and err_h < TOL_HIDDEN[prec], f"{prec}: |logits - oracle| = {err:.2e} (hidden {err_h:.2e})"
-    decided = np.abs(ref[:, 0] - ref[:, 1]) > 4 * TOL[prec]
+    decided = np.abs(ref[:, 0] - ref[:, 1]) > (2 if prec == "fp32" else 4) * TOL[prec]
     assert (got.argmax(1)[decided] == ref.argmax(1)[decided]).all()
     pooled = net.debug_fetch("pooled", (B, 256))
     assert np.abs(pooled - trace["pooled"].numpy()).max() < TOL_HIDDEN[prec]
