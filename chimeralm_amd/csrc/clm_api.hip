@@ -40,6 +40,8 @@ struct FilterSet {
     float* ktime[NLAYER] = {};
     float2* kf[NLAYER] = {};
     float2* tw = nullptr;
+    float2* kf2[NLAYER] = {};     // 16384-point class only: even | odd bins of kf (split-transform kernel)
+    float2* twM = nullptr;        //                          twiddles of the 8192-point passes
     std::vector<ReversedFilter> krev;
 };
 
@@ -99,6 +101,7 @@ struct clm_handle {
     bool split_tail = false;      // CLM_SPLIT_TAIL=1: separate out_proj16 + mlp16 kernels instead of the fused tail (A/B runs)
     bool no_fuse_next = false;    // CLM_NO_FUSE_NEXT=1: separate in_proj / score kernels instead of fusing them into the tail
     bool no_idconv = false;       // CLM_NO_IDCONV=1: run block 0's in_proj instead of the id-table convolution (A/B runs)
+    bool split_conv = false;      // CLM_SPLIT_CONV=1: 8k reads through hyena_conv_eo_kernel (two 8192-point problems; measured slower, kept for A/B)
     bool force_generic = false;   // CLM_GENERIC_GEMM=1: route 16-bit modes through the generic kernels (A/B runs)
     bool prof = false;
     std::vector<ProfRec> recs;
@@ -223,6 +226,8 @@ void free_filter_set(FilterSet& f) {
     for (int i = 0; i < NLAYER; ++i) {
         if (f.ktime[i]) (void)hipFree(f.ktime[i]);
         if (f.kf[i]) (void)hipFree(f.kf[i]);
+        if (f.kf2[i]) (void)hipFree(f.kf2[i]);
+        f.kf2[i] = nullptr;
         for (auto& r : f.krev)
             if (r.p[i]) (void)hipFree(r.p[i]);
         f.ktime[i] = nullptr;
@@ -230,7 +235,9 @@ void free_filter_set(FilterSet& f) {
     }
     f.krev.clear();
     if (f.tw) (void)hipFree(f.tw);
+    if (f.twM) (void)hipFree(f.twM);
     f.tw = nullptr;
+    f.twM = nullptr;
 }
 
 void free_filters(clm_handle* h) {
@@ -329,6 +336,10 @@ int ensure_filters(clm_handle* h, int L, hipStream_t st, FilterSet** out, const 
         HIPCHK(h, hipMalloc((void**)&scratch, (size_t)D * N * sizeof(double2)));
         HIPCHK(h, hipMalloc((void**)&f.tw, (size_t)(N / 2) * sizeof(float2)));
         launch_twiddles(f.tw, logn, st);
+        if (S == 1 && logn == 14 && h->split_conv) {
+            HIPCHK(h, hipMalloc((void**)&f.twM, (size_t)(N / 4) * sizeof(float2)));
+            launch_twiddles(f.twM, logn - 1, st);
+        }
         for (int i = 0; i < NLAYER; ++i) {
             HIPCHK(h, hipMalloc((void**)&f.ktime[i], (size_t)f.Lf * D * 4));
             HIPCHK(h, hipMalloc((void**)&f.kf[i], (size_t)D * f.KS * N * sizeof(float2)));
@@ -340,6 +351,10 @@ int ensure_filters(clm_handle* h, int L, hipStream_t st, FilterSet** out, const 
                           W(h, p + "implicit_filter.6.weight"), W(h, p + "modulation.deltas"), f.ktime[i], f.Lf, st);
             if (S == 1) {
                 launch_filter_spectrum(f.ktime[i], W(h, p + "bias"), f.kf[i], scratch, f.Lf, logn, 0, f.Lf, -1, st);
+                if (logn == 14 && h->split_conv) {
+                    HIPCHK(h, hipMalloc((void**)&f.kf2[i], (size_t)D * N * sizeof(float2)));
+                    launch_spectrum_split(f.kf[i], f.kf2[i], logn, st);
+                }
             } else {   // kf [256][KS][N]: one launch per partition writes the strided slice through a temporary
                 float2* tmp = nullptr;
                 HIPCHK(h, hipMalloc((void**)&tmp, (size_t)D * N * sizeof(float2)));
@@ -473,7 +488,10 @@ int forward_chunk(clm_handle* h, const void* ids, int ids_dtype, int64_t row_str
         if (stop_here(h, i, CLM_STAGE_INPROJ)) return CLM_OK;
         {
             StageTimer t(h, st, CLM_STAGE_CONV);
-            if (S == 1)
+            if (S == 1 && fs->logn == 14 && fs->kf2[i] && h->split_conv)
+                launch_hyena_conv_dif(prec, h->z, h->y, fs->kf2[i], fs->twM, fs->tw, fs->ktime[i], lw.short_w, lw.short_b, Bc, L,
+                                      Lp, idconv ? h->ids8 : nullptr, idconv ? h->ztab : nullptr, st);
+            else if (S == 1)
                 launch_hyena_conv(prec, h->z, h->y, fs->kf[i], fs->tw, fs->ktime[i], lw.short_w, lw.short_b, Bc, L, Lp,
                                   fs->logn, idconv ? h->ids8 : nullptr, idconv ? h->ztab : nullptr, st);
             else
@@ -590,6 +608,7 @@ int clm_create(const clm_config* cfg, int device, clm_handle** out) {
     h->no_fuse_next = std::getenv("CLM_NO_FUSE_NEXT") && std::getenv("CLM_NO_FUSE_NEXT")[0] == '1';
     h->no_idconv = std::getenv("CLM_NO_IDCONV") && std::getenv("CLM_NO_IDCONV")[0] == '1';
     h->split_tail = std::getenv("CLM_SPLIT_TAIL") && std::getenv("CLM_SPLIT_TAIL")[0] == '1';
+    h->split_conv = std::getenv("CLM_SPLIT_CONV") && std::getenv("CLM_SPLIT_CONV")[0] == '1';
     h->cfg = *cfg;
     h->device = device;
     if (hipHostMalloc((void**)&h->bad_ids, sizeof(int), hipHostMallocMapped) == hipSuccess) *h->bad_ids = 0;

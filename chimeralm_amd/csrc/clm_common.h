@@ -4,6 +4,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 namespace clm {
 
 // model constants fixed by the reference (chimeralm/models/lm.py:19-31)
@@ -22,6 +24,15 @@ using bf16x8 = __bf16 __attribute__((ext_vector_type(8)));
 using f16x8 = _Float16 __attribute__((ext_vector_type(8)));
 using u16x8 = unsigned short __attribute__((ext_vector_type(8)));
 using u16x4 = unsigned short __attribute__((ext_vector_type(4)));
+
+// compile-time loop: f(std::integral_constant<int, I>) for I in [0, N) -- guarantees static register indexing
+template <int I, int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
 
 // ---- storage element types of the 16-bit activations -------------------------------------------------
 struct bf16_t {
@@ -199,6 +210,12 @@ void launch_twiddles(float2* tw, int logn, hipStream_t st);   // tw[m] = exp(-2 
 void launch_hyena_conv(int prec, const void* z, void* y, const float2* kf, const float2* tw, const float* ktime,
                        const float* short_w, const float* short_b, int B, int L, int Lp, int logn,
                        const unsigned char* ids8, const float* ztab, hipStream_t st);
+// 8k reads (4098 .. 8193 tokens): the 16384-point convolution as two 8192-point problems (even / odd bins), two workgroups per CU.
+// kf2 [256][2][8192] from launch_spectrum_split(kf of the 16384-point class); twM = the 8192-point twiddle table, twN the 16384 one
+void launch_spectrum_split(const float2* kf, float2* kf2, int logn, hipStream_t st);
+void launch_hyena_conv_dif(int prec, const void* z, void* y, const float2* kf2, const float2* twM, const float2* twN,
+                           const float* ktime, const float* short_w, const float* short_b, int B, int L, int Lp,
+                           const unsigned char* ids8, const float* ztab, hipStream_t st);
 void launch_ztab(const float* emb, const float* g, const float* bta, const float* w, const float* bias, float* ztab,
                  float eps, hipStream_t st);
 

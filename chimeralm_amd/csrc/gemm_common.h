@@ -1,8 +1,6 @@
 // gemm_common.h -- shared pieces of the MFMA GEMM kernels (gemm.hip: generic/fp32 + score; gemm16.hip: the tuned
 // 16-bit kernels).  See gemm.hip for the design notes and the MFMA register maps.
 #pragma once
-#include <type_traits>
-
 #include "clm_common.h"
 
 namespace clm {
@@ -59,15 +57,6 @@ template <>
 __device__ __forceinline__ f32x16 mfma<PREC_F16C>(u16x8 a, u16x8 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0,
                                                   0);
-}
-
-// compile-time loop: f(std::integral_constant<int, I>) for I in [0, N) -- guarantees static register indexing
-template <int I, int N, typename F>
-__device__ __forceinline__ void static_for(F&& f) {
-    if constexpr (I < N) {
-        f(std::integral_constant<int, I>{});
-        static_for<I + 1, N>(f);
-    }
 }
 
 // ---------------------------------------------------------------------------------------- the kernel

@@ -611,6 +611,265 @@ __global__ __launch_bounds__(Plan<LOGN>::NT) void hyena_conv_kernel(
 }
 
 
+// ================================================================================================ 8k reads: split transform
+// Reads of 4098 .. 8193 tokens need the 16384-point transform, whose LDS buffer (147 KiB) leaves ONE workgroup per CU, and in
+// hyena_conv_kernel all eight waves move through the passes together: the LDS-bound exchange (store) phases and the
+// VALU-bound load + butterfly phases run strictly one after the other (stamps: eight exchanges of 4-5.7k cycles, of which
+// ~2k are LDS time and ~2.2k VALU time).
+// The transform of a half-zero input, of which only half the output is wanted, is two INDEPENDENT half-size problems
+// (decimation in frequency into the even and the odd bins; fft_core_test.cpp test_conv_split13 emulates this kernel's passes):
+//     X[2j]   = DFT_M(x_lo + x_hi)[j]                     y[n] = IDFT_M(X_e K_e)[n] + w_N^-n IDFT_M(X_o K_o)[n],  n < M
+//     X[2j+1] = DFT_M((x_lo - x_hi) w_N^n)[j]             y[M] = IDFT_M(X_e K_e)[0] - IDFT_M(X_o K_o)[0]
+// with M = N/2 = 8192 and x_hi = the one element at index M (L == M + 1) or nothing.  The two problems live side by side in
+// the same 147 KiB and are run by the two HALVES of the workgroup (waves 0-3: even bins, waves 4-7: odd bins; one wave of each
+// on every SIMD), the odd half one phase BEHIND the even half: in every barrier interval one half is in a load + butterfly
+// phase and the other in a store phase, so the VALU and the LDS pipe of the CU work at the same time instead of in turn.  The
+// zero padding is never transformed (no pruned first / last passes needed), and phase A / C stay those of the one-shot kernel.
+// MEASURED SLOWER than hyena_conv_kernel and therefore OFF by default (CLM_SPLIT_CONV=1 selects it; tests keep it correct):
+// same box, 8k x 256, convolution stage of a step: 13.5 ms one-shot kernel, 15.4 ms this kernel.  A SIMD needs TWO waves in
+// VALU code to reach its packed-fp32 issue rate (a lone wave issues every 4 cycles); with one half of the workgroup storing
+// while the other computes, every butterfly phase runs at half rate and takes as long as the one-shot kernel's (which moves
+// twice the data with two waves per SIMD), and the store intervals come on top.  Two earlier forms were dropped for the same
+// reason plus register pressure (convolution stage 13.0 ms one-shot on that box): the two problems one after the other in
+// 256-thread workgroups, two per CU, even result held in registers: 14.1 ms unrolled (57 KB of code, 25-36 spilled dwords),
+// 18.2 ms with the two trips rolled (85 spilled dwords).  Overlapping the LDS and VALU phases needs four waves per SIMD, i.e.
+// 16 points per thread instead of 32 -- a different pass geometry, not built.
+// exp(-2 pi i e / 16384), e = 0..7: the within-chunk factors of w_N^n (literals: folded into the unrolled code)
+#define CLM_DIF_WC                                                                                                          \
+    {{1.0f, -0.0f}, {0.99999992646f, -3.8349518757e-4f}, {0.99999970586f, -7.6699031874e-4f}, {0.99999933819f, -1.1504853371e-3f}, \
+     {0.99999882345f, -1.5339801863e-3f}, {0.99999816164f, -1.9174748099e-3f}, {0.99999735277f, -2.3009691514e-3f},          \
+     {0.99999639683f, -2.6844631547e-3f}}
+
+template <typename T, bool IDS>
+__global__ __launch_bounds__(512) void hyena_conv_eo_kernel(
+    const T* __restrict__ z, T* __restrict__ y, const float2* __restrict__ kf2 /*[256][2][M]: even | odd bins of kf*/,
+    const float2* __restrict__ twM /*exp(-2 pi i m / M), m < M/2*/, const float2* __restrict__ twN /*exp(-2 pi i n / 2M), n < M*/,
+    const float* __restrict__ ktime, const float* __restrict__ short_w, const float* __restrict__ short_b, int B, int L, int Lp,
+    const unsigned char* __restrict__ ids8, const float* __restrict__ ztab) {
+    constexpr int M = 8192, NT = 512, CH = M / 8 / NT;          // 2 chunks of 8 tokens per thread in phases A and C
+    static_assert(Plan<Split13::LOGM>::N == M && Plan<Split13::LOGM>::NT == NT / 2 && CH == 2, "two 256-thread halves");
+    constexpr float DIF_WC[8][2] = CLM_DIF_WC;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float* ere = reinterpret_cast<float*>(smem);              // even problem: read A of the pair = real parts, read B = imaginary
+    float* eim = ere + padded_size(M);
+    float* ore = eim + padded_size(M);                        // odd problem
+    float* oim = ore + padded_size(M);
+    float* gtail = oim + padded_size(M);                      // g[M], x0[M] of both reads (L == M + 1)
+    float* zt = gtail + 4;                                    // IDS: [3][16] rows x0 | x1 | v of this channel
+
+    const int tid = threadIdx.x;
+    const int c = blockIdx.y, pair = blockIdx.x;
+    const int bA = 2 * pair, bB = 2 * pair + 1;
+    const bool hasB = bB < B;
+    const T* zA = z + (size_t)bA * D3 * Lp;
+    const T* zB = z + (size_t)(hasB ? bB : bA) * D3 * Lp;
+    const bool tail = (L == M + 1);
+    float sw[3][3], sb[3];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+#pragma unroll
+        for (int e = 0; e < 3; ++e) sw[q][e] = short_w[(q * D + c) * 3 + e];
+        sb[q] = short_b[q * D + c];
+    }
+    float2 wb[CH];                                            // w_N^t0 of this thread's chunks
+#pragma unroll
+    for (int ch = 0; ch < CH; ++ch) wb[ch] = twN[8 * (tid + ch * NT)];
+
+    // ---------------------------------------------------------------- phase A: load, short filter, gate (as hyena_conv_kernel)
+    constexpr int TAIL_TID = M / 8 - 1 - (CH - 1) * NT;       // owner of tokens [M-8, M): also computes token M
+    Raw<T> raw[IDS ? 1 : CH][2][IDS ? 1 : 3];
+    T ztail[2][3];
+    uint2 idd[CH][2];
+    unsigned short idp[CH][2];
+    unsigned char idt[2] = {0, 0};
+    if constexpr (IDS) {
+        if (tid < 48) zt[tid] = ztab[(size_t)(tid & 15) * D3 + (tid >> 4) * D + c];
+#pragma unroll
+        for (int rd = 0; rd < 2; ++rd) {
+            const unsigned char* ir = ids8 + (size_t)(rd == 0 ? bA : (hasB ? bB : bA)) * Lp;
+#pragma unroll
+            for (int ch = 0; ch < CH; ++ch) {
+                const int t0 = 8 * (tid + ch * NT);
+                const bool valid = t0 < L;
+                idd[ch][rd] = *reinterpret_cast<const uint2*>(ir + (valid ? t0 : 0));
+                idp[ch][rd] = *reinterpret_cast<const unsigned short*>(ir + ((valid && t0 > 0) ? t0 - 2 : 0));
+            }
+            idt[rd] = ir[(tail && tid == TAIL_TID) ? M : 0];
+        }
+        __syncthreads();                                      // zt visible
+    } else {
+#pragma unroll
+        for (int rd = 0; rd < 2; ++rd) {
+            const T* zr = rd == 0 ? zA : zB;
+#pragma unroll
+            for (int a3 = 0; a3 < 3; ++a3) {
+                const T* row = zr + (size_t)(a3 * D + c) * Lp;
+#pragma unroll
+                for (int ch = 0; ch < CH; ++ch) {
+                    const int t0 = 8 * (tid + ch * NT);
+                    raw_load(raw[ch][rd][a3], row, t0, t0 < L);
+                }
+                ztail[rd][a3] = row[(tail && tid == TAIL_TID) ? M : 0];
+            }
+        }
+    }
+    float x0A[CH][8], x0B[CH][8];
+#pragma unroll
+    for (int ch = 0; ch < CH; ++ch) {
+        const int t0 = 8 * (tid + ch * NT);
+        const bool valid = t0 < L;
+        float xa[3][10], xb[3][10], gA[8], gB[8], x1[8], v[8], x1b[8], vb[8];
+        if constexpr (IDS) {
+            ids_decode<true>(idd[ch][0], idp[ch][0], t0, valid, zt, xa);
+            ids_decode<true>(idd[ch][1], idp[ch][1], t0, valid && hasB, zt, xb);
+        } else {
+#pragma unroll
+            for (int a3 = 0; a3 < 3; ++a3) {
+                raw_decode(raw[ch][0][a3], t0, valid, xa[a3]);
+                raw_decode(raw[ch][1][a3], t0, valid && hasB, xb[a3]);
+            }
+        }
+        fir3_pair(xa[0], xb[0], sw[0][0], sw[0][1], sw[0][2], sb[0], x0A[ch], x0B[ch]);
+        fir3_pair(xa[1], xb[1], sw[1][0], sw[1][1], sw[1][2], sb[1], x1, x1b);
+        fir3_pair(xa[2], xb[2], sw[2][0], sw[2][1], sw[2][2], sb[2], v, vb);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            gA[e] = (t0 + e < L) ? v[e] * x1[e] : 0.f;
+            gB[e] = (hasB && t0 + e < L) ? vb[e] * x1b[e] : 0.f;
+        }
+        lds_store8(ere + pad_index(t0), gA);                  // even problem: x_lo as it is
+        lds_store8(eim + pad_index(t0), gB);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {                         // odd problem: x_lo w_N^n
+            const float wr = wb[ch].x * DIF_WC[e][0] - wb[ch].y * DIF_WC[e][1];
+            const float wi = wb[ch].x * DIF_WC[e][1] + wb[ch].y * DIF_WC[e][0];
+            const float xr = gA[e] * wr - gB[e] * wi, xi = gA[e] * wi + gB[e] * wr;
+            gA[e] = xr, gB[e] = xi;
+        }
+        lds_store8(ore + pad_index(t0), gA);
+        lds_store8(oim + pad_index(t0), gB);
+        if (ch == CH - 1 && tail && tid == TAIL_TID) {        // token M: taps are x[8], x[9] of this chunk and z[M]
+            float ta[3], tb[3];
+#pragma unroll
+            for (int a3 = 0; a3 < 3; ++a3) {
+                const float za = IDS ? zt[a3 * 16 + (idt[0] & 15)] : to_float(ztail[0][a3]);
+                const float zb = IDS ? zt[a3 * 16 + (idt[1] & 15)] : to_float(ztail[1][a3]);
+                ta[a3] = sb[a3] + sw[a3][0] * xa[a3][8] + sw[a3][1] * xa[a3][9] + sw[a3][2] * za;
+                tb[a3] = sb[a3] + sw[a3][0] * xb[a3][8] + sw[a3][1] * xb[a3][9] + sw[a3][2] * zb;
+            }
+            gtail[0] = ta[1] * ta[2];
+            gtail[1] = hasB ? tb[1] * tb[2] : 0.f;
+            gtail[2] = ta[0];
+            gtail[3] = hasB ? tb[0] : 0.f;
+        }
+    }
+    __syncthreads();
+    if (tail && tid == 0) {             // x_hi = the element at index M joins element 0 of both problems, with opposite signs
+        ere[0] += gtail[0], eim[0] += gtail[1];               // (w_N^0 = 1)
+        ore[0] -= gtail[0], oim[0] -= gtail[1];
+    }
+    __syncthreads();
+
+    // ---------------------------------------------------------------- the two 8192-point problems, one phase apart
+    {
+        const int half = tid >> 8, gtid = tid & 255;          // wave-uniform: waves 0-3 even bins, waves 4-7 odd bins
+        float* bre = half ? ore : ere;
+        float* bim = half ? oim : eim;
+        const float2* kfs = kf2 + ((size_t)c * 2 + half) * M;
+        Cx2 v[16];
+        static_for<0, 2 * Split13::NPASS + 1>([&](auto kc) {
+            constexpr int k = decltype(kc)::value;
+            if (half == 0) {
+                if constexpr (k < 2 * Split13::NPASS) {
+                    if constexpr (k % 2 == 0) split13_compute<k / 2>(bre, bim, v, gtid, twM, kfs);
+                    else split13_store<k / 2>(bre, bim, v, gtid);
+                }
+            } else {
+                if constexpr (k >= 1) {
+                    if constexpr ((k - 1) % 2 == 0) split13_compute<(k - 1) / 2>(bre, bim, v, gtid, twM, kfs);
+                    else split13_store<(k - 1) / 2>(bre, bim, v, gtid);
+                }
+            }
+            __syncthreads();
+        });
+    }
+
+    // ---------------------------------------------------------------- phase C: combine, gate with x0, store
+    T* yA = y + ((size_t)bA * D + c) * Lp;
+    T* yB = y + ((size_t)(hasB ? bB : bA) * D + c) * Lp;
+#pragma unroll
+    for (int ch = 0; ch < CH; ++ch) {
+        const int t0 = 8 * (tid + ch * NT);
+        if (t0 < Lp) {
+            float eA[8], eB[8], oA[8], oB[8];
+            lds_load8(ere + pad_index(t0), eA);
+            lds_load8(eim + pad_index(t0), eB);
+            lds_load8(ore + pad_index(t0), oA);
+            lds_load8(oim + pad_index(t0), oB);
+            if (tail && t0 == 0) {      // token M: y[M] = (r_e[0] - r_o[0]) x0[M]; the one wrapped product k[L-1] g[L-1] on output 0
+                yA[M] = from_float<T>((eA[0] - oA[0]) * gtail[2]);
+                if (hasB) yB[M] = from_float<T>((eB[0] - oB[0]) * gtail[3]);
+                const float kl = ktime[(size_t)(L - 1) * D + c];
+                eA[0] -= kl * gtail[0];
+                eB[0] -= kl * gtail[1];
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {                     // r_e + conj(w_N^n) r_o, then the gate
+                const float wr = wb[ch].x * DIF_WC[e][0] - wb[ch].y * DIF_WC[e][1];
+                const float wi = wb[ch].x * DIF_WC[e][1] + wb[ch].y * DIF_WC[e][0];
+                const bool ok = t0 + e < L;
+                const float a = eA[e] + (oA[e] * wr + oB[e] * wi), b = eB[e] + (oB[e] * wr - oA[e] * wi);
+                eA[e] = ok ? a * x0A[ch][e] : 0.f;
+                eB[e] = ok ? b * x0B[ch][e] : 0.f;
+            }
+            store8<T>(yA + t0, eA);
+            if (hasB) store8<T>(yB + t0, eB);
+        }
+    }
+}
+
+// kf2[c][s][j] = kf[c][2 j + s]: the even and the odd bins of the N-point filter spectrum as two contiguous M-point spectra
+__global__ __launch_bounds__(256) void spectrum_split_kernel(const float2* __restrict__ kf, float2* __restrict__ kf2, int N) {
+    const int i = blockIdx.x * 256 + threadIdx.x, c = blockIdx.y;
+    if (i < N) kf2[(size_t)c * N + (size_t)(i & 1) * (N / 2) + (i >> 1)] = kf[(size_t)c * N + i];
+}
+void launch_spectrum_split(const float2* kf, float2* kf2, int logn, hipStream_t st) {
+    const int N = 1 << logn;
+    hipLaunchKernelGGL(spectrum_split_kernel, dim3((N + 255) / 256, D), dim3(256), 0, st, kf, kf2, N);
+}
+
+template <typename T, bool IDS>
+static void launch_conv_eo_inst(const void* z, void* y, const float2* kf2, const float2* twM, const float2* twN, const float* ktime,
+                                 const float* short_w, const float* short_b, int B, int L, int Lp, const unsigned char* ids8,
+                                 const float* ztab, hipStream_t st) {
+    constexpr size_t lds = (size_t)4 * padded_size(8192) * sizeof(float) + 256;     // both problems + tail slots + the 3x16 id table
+    static_assert(lds <= 160 * 1024, "LDS");
+    auto kern = hyena_conv_eo_kernel<T, IDS>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_done = true;
+    }
+    dim3 grid((B + 1) / 2, D), block(512);
+    hipLaunchKernelGGL(kern, grid, block, lds, st, reinterpret_cast<const T*>(z), reinterpret_cast<T*>(y), kf2, twM, twN, ktime,
+                       short_w, short_b, B, L, Lp, ids8, ztab);
+}
+
+void launch_hyena_conv_dif(int prec, const void* z, void* y, const float2* kf2, const float2* twM, const float2* twN,
+                           const float* ktime, const float* short_w, const float* short_b, int B, int L, int Lp,
+                           const unsigned char* ids8, const float* ztab, hipStream_t st) {
+    const bool ids = ids8 != nullptr && ztab != nullptr;
+    if (prec == PREC_F32)
+        launch_conv_eo_inst<float, false>(z, y, kf2, twM, twN, ktime, short_w, short_b, B, L, Lp, nullptr, nullptr, st);
+    else if (prec == PREC_BF16) {
+        if (ids) launch_conv_eo_inst<bf16_t, true>(z, y, kf2, twM, twN, ktime, short_w, short_b, B, L, Lp, ids8, ztab, st);
+        else launch_conv_eo_inst<bf16_t, false>(z, y, kf2, twM, twN, ktime, short_w, short_b, B, L, Lp, nullptr, nullptr, st);
+    } else {
+        if (ids) launch_conv_eo_inst<f16_t, true>(z, y, kf2, twM, twN, ktime, short_w, short_b, B, L, Lp, ids8, ztab, st);
+        else launch_conv_eo_inst<f16_t, false>(z, y, kf2, twM, twN, ktime, short_w, short_b, B, L, Lp, nullptr, nullptr, st);
+    }
+}
+
 // ================================================================================================ long reads
 // L > 8193 tokens does not fit one LDS-resident transform.  Uniformly partitioned convolution over S segments of Ls = 8192:
 //     y[m*Ls + t] = IFFT( sum_{i <= m} FFT(g_i) . K'_{m-i} )[t],   0 <= t < Ls
