@@ -140,6 +140,9 @@ def bench_transformer(a):
         step(i)
     cdist.barrier()
     torch.cuda.synchronize(device)
+    if a.precision != "fp32":
+        net.profile_read(reset=True)
+        net.profile_enable(True)
     t0 = time.perf_counter()
     for i in range(a.steps):
         out = step(i)
@@ -151,6 +154,7 @@ def bench_transformer(a):
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t.item())
     assert out.shape[0] == a.batch and bool(torch.isfinite(out).all())
+    prof = net.profile_read(reset=True) if a.precision != "fp32" else {}
     if rank == 0:
         L3 = L // 8
         # dense FLOPs per read: conv stack (K = 768 GEMMs at L, L/2, L/4 positions) + 12 x (QKV, out, FFN) + attention products
@@ -168,6 +172,40 @@ def bench_transformer(a):
                "roofline": {"bound": "mfma", "kernel": "whole forward (conv stack + encoder + attention)", "achieved": flops,
                             "peak": PEAK_TFLOPS[a.precision], "unit": "TFLOP/s", "frac": flops / PEAK_TFLOPS[a.precision],
                             "traffic": None}}
+        if prof:
+            # per-kernel rooflines from the engine's HIP-event taps (launch stream), averaged over the timed launches:
+            # algorithmic dense FLOPs of the stage for this rank's reads / its accumulated time
+            reads = (hi - lo) * a.steps
+            per = {"conv_stack_pe_ln": conv, "attention": att, "encoder_layer": enc}
+            kr = {}
+            for k, fl in per.items():
+                ms, n = prof[k]
+                if n:
+                    ach = fl * reads / (ms * 1e-3) / 1e12
+                    kr[k] = {"bound": "mfma", "achieved": ach, "peak": PEAK_TFLOPS[a.precision], "unit": "TFLOP/s",
+                             "frac": ach / PEAK_TFLOPS[a.precision], "avg_launch_ms": ms / n, "launches": n,
+                             "share_of_device_time": ms / max(1e-9, sum(v[0] for v in prof.values()))}
+            tr = None
+            for f in sorted(Path(__file__).resolve().parent.glob("profiles/r*_tf_traffic.json"), reverse=True):
+                try:
+                    tj = json.loads(f.read_text())
+                except (OSError, ValueError):
+                    continue
+                if tj.get("config") == res["config"] and tj.get("dtype") == a.precision:
+                    tr = (tj, f.name)
+                    break
+            if tr:
+                fresh = tr[0].get("kernel_sources_sha") == kernel_sources_sha()
+                for k, stg in (("attention", "attention"), ("encoder_layer", "encoder_layer")):
+                    e = tr[0].get("stages", {}).get(stg)
+                    if e and k in kr:
+                        kr[k]["traffic" if fresh else "traffic_stale"] = e["hbm_bytes_per_dispatch"] if fresh else f"profiles/{tr[1]} is of other kernel sources"
+            res["roofline_kernels"] = kr
+            dom = max(kr, key=lambda k: kr[k]["share_of_device_time"]) if kr else None
+            if dom:
+                res["roofline"] = {"bound": "mfma", "kernel": dom, **{k: v for k, v in kr[dom].items()}, "traffic": kr[dom].get("traffic")}
+                res["roofline_whole_forward"] = {"achieved": flops, "peak": PEAK_TFLOPS[a.precision], "unit": "TFLOP/s",
+                                                 "frac": flops / PEAK_TFLOPS[a.precision]}
         print(json.dumps(res), flush=True)
     cdist.barrier()
     if world > 1:

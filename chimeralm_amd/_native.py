@@ -64,6 +64,8 @@ SYMBOLS = {
     "clm_tf_finalize": (C.c_int, [_H]),
     "clm_tf_forward": (C.c_int, [_H, C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "clm_tf_debug_fetch": (C.c_int, [_H, C.c_char_p, C.c_void_p, C.c_size_t]),
+    "clm_tf_profile_enable": (C.c_int, [_H, C.c_int]),
+    "clm_tf_profile_read": (C.c_int, [_H, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.c_int]),
     "clm_tf_last_error": (C.c_char_p, [_H]),
     "clm_tf_destroy": (C.c_int, [_H]),
     "clm_debug_fetch": (C.c_int, [_H, C.c_char_p, C.c_void_p, C.c_size_t]),

@@ -516,11 +516,35 @@ struct clm_tf_handle {
     float* ws32 = nullptr;                        // fp32 mode: activations of tf_fp32.hip
     size_t cap_ws32 = 0;
     int last_B = 0, last_L3 = 0;
+    // profiling taps (clm_tf_profile_*): HIP events on the launch stream around each stage, stages: 0 conv stack + pe/LN,
+    // 1 attention, 2 encoder layer kernel (out_proj + LN1 + FFN + LN2 + next QKV; the unfused pieces count here too), 3 pooling head
+    bool prof = false;
+    std::vector<std::pair<int, std::pair<hipEvent_t, hipEvent_t>>> recs;
+    double prof_ms[4] = {};
+    int64_t prof_n[4] = {};
 };
 
 namespace {
 
 std::string g_tf_create_error;
+
+struct TfTimer {                                   // RAII: one event pair per stage span when profiling is on
+    clm_tf_handle* h;
+    hipStream_t st;
+    int stage;
+    hipEvent_t e0{}, e1{};
+    bool on;
+    TfTimer(clm_tf_handle* h_, hipStream_t st_, int stage_) : h(h_), st(st_), stage(stage_), on(h_->prof && h_->recs.size() < 100000) {
+        if (!on) return;
+        if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) { on = false; return; }
+        (void)hipEventRecord(e0, st);
+    }
+    ~TfTimer() {
+        if (!on) return;
+        (void)hipEventRecord(e1, st);
+        h->recs.push_back({stage, {e0, e1}});
+    }
+};
 
 int tf_fail(clm_tf_handle* h, int code, const std::string& msg) {
     if (h) h->err = msg; else g_tf_create_error = msg;
@@ -585,6 +609,7 @@ int tf_forward_t(clm_tf_handle* h, const void* ids, int ids_dtype, int64_t strid
     const int L1 = L / 2, L2 = L1 / 2, L3 = L2 / 2, Lp = (L + 63) / 64 * 64;
     const size_t M = (size_t)B * L3;
     auto W = [&](const std::string& k) { return h->w.at(k); };
+    TfTimer* tconv = new TfTimer(h, st, 0);
     launch_embed(ids, ids_dtype, stride, nullptr, nullptr, h->ids8, B, L, Lp, st);      // ids of any dtype -> clamped uint8
     constexpr size_t conv_lds = (size_t)(130 * RS16 + 8 * 64 * tf::ZRS) * 2;
     {
@@ -602,16 +627,22 @@ int tf_forward_t(clm_tf_handle* h, const void* ids, int ids_dtype, int64_t strid
     }
     hipLaunchKernelGGL(tf::pe_ln_kernel<PREC>, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, st, (const elem*)h->x3,
                        W("pos_encoder.pe"), W("norm.weight"), W("norm.bias"), h->h, (elem*)h->hx, M, L3, 1e-5f);
+    delete tconv;
     for (int i = 0; i < h->n_layers; ++i) {
         const std::string p = "transformer_encoder.layers." + std::to_string(i) + ".";
         tf::LinArgs a{};
         a.M = M; a.eps = 1e-5f;
         static const bool unfused_ffn = std::getenv("CLM_TF_UNFUSED_FFN") && std::getenv("CLM_TF_UNFUSED_FFN")[0] == '1';
         if (i == 0 || unfused_ffn) {   // later layers: computed at the end of the previous layer's feed-forward kernel
+            TfTimer t(h, st, 2);
             a.a = h->hx; a.w = h->packed.at(p + "in"); a.bias = W(p + "self_attn.in_proj_bias"); a.out16 = h->qkv; a.relu = 0;
             tf_launch_linear<PREC, tf::E_ACT, D, tf::TQKV>(a, st);
         }
-        launch_attention_fwd(PREC, h->qkv, h->att, B, L3, st);
+        {
+            TfTimer t(h, st, 1);
+            launch_attention_fwd(PREC, h->qkv, h->att, B, L3, st);
+        }
+        TfTimer tl(h, st, 2);
         static const bool unfused_layer = std::getenv("CLM_TF_UNFUSED_LAYER") && std::getenv("CLM_TF_UNFUSED_LAYER")[0] == '1';
         const bool whole_layer = !unfused_layer && !unfused_ffn;   // out_proj + LN1 at the head of the feed-forward kernel
         if (!whole_layer) {
@@ -640,9 +671,12 @@ int tf_forward_t(clm_tf_handle* h, const void* ids, int ids_dtype, int64_t strid
             tf_launch_linear<PREC, tf::E_RES_LN, tf::TFF, D>(a, st);
         }
     }
-    hipLaunchKernelGGL(tf::pool_head_kernel, dim3(B), dim3(256), 0, st, h->h, W("attn_pool.weight"), W("attn_pool.bias"),
-                       W("classifier.0.weight"), W("classifier.0.bias"), W("classifier.3.weight"), W("classifier.3.bias"),
-                       h->scores, h->pooled, logits, L3);
+    {
+        TfTimer t(h, st, 3);
+        hipLaunchKernelGGL(tf::pool_head_kernel, dim3(B), dim3(256), 0, st, h->h, W("attn_pool.weight"), W("attn_pool.bias"),
+                           W("classifier.0.weight"), W("classifier.0.bias"), W("classifier.3.weight"), W("classifier.3.bias"),
+                           h->scores, h->pooled, logits, L3);
+    }
     h->last_B = B; h->last_L3 = L3;
     return hipGetLastError() == hipSuccess ? CLM_OK : CLM_E_HIP;
 }
@@ -814,6 +848,34 @@ int clm_tf_debug_fetch(clm_tf_handle* h, const char* name, void* host_out, size_
     return CLM_OK;
 }
 
+int clm_tf_profile_enable(clm_tf_handle* h, int on) {
+    if (!h) return CLM_E_INVALID;
+    h->prof = on != 0;
+    return CLM_OK;
+}
+
+int clm_tf_profile_read(clm_tf_handle* h, double* ms_out /*[4]*/, int64_t* spans_out /*[4]*/, int reset) {
+    if (!h) return CLM_E_INVALID;
+    TFCHK(h, hipSetDevice(h->device));
+    TFCHK(h, hipDeviceSynchronize());
+    for (auto& r : h->recs) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, r.second.first, r.second.second) == hipSuccess) {
+            h->prof_ms[r.first] += ms;
+            h->prof_n[r.first] += 1;
+        }
+        (void)hipEventDestroy(r.second.first);
+        (void)hipEventDestroy(r.second.second);
+    }
+    h->recs.clear();
+    for (int i = 0; i < 4; ++i) {
+        if (ms_out) ms_out[i] = h->prof_ms[i];
+        if (spans_out) spans_out[i] = h->prof_n[i];
+        if (reset) h->prof_ms[i] = 0, h->prof_n[i] = 0;
+    }
+    return CLM_OK;
+}
+
 const char* clm_tf_last_error(const clm_tf_handle* h) { return h ? h->err.c_str() : g_tf_create_error.c_str(); }
 
 int clm_tf_destroy(clm_tf_handle* h) {
@@ -821,6 +883,7 @@ int clm_tf_destroy(clm_tf_handle* h) {
     (void)hipSetDevice(h->device);
     (void)hipDeviceSynchronize();
     tf_free_ws(h);
+    for (auto& r : h->recs) { (void)hipEventDestroy(r.second.first); (void)hipEventDestroy(r.second.second); }
     for (auto& kv : h->w) (void)hipFree(kv.second);
     for (auto& kv : h->packed) (void)hipFree(kv.second);
     delete h;

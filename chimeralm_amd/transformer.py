@@ -101,6 +101,16 @@ class SequenceCNNTransformer(nn.Module):
                                        C.c_void_p(torch.cuda.current_stream(input_ids.device).cuda_stream)))
         return out
 
+    TF_STAGES = ("conv_stack_pe_ln", "attention", "encoder_layer", "pool_head")
+
+    def profile_enable(self, on: bool = True):
+        self._check(N.load().clm_tf_profile_enable(self._h, int(on)))
+
+    def profile_read(self, reset: bool = True) -> dict[str, tuple[float, int]]:
+        ms, n = (C.c_double * 4)(), (C.c_int64 * 4)()
+        self._check(N.load().clm_tf_profile_read(self._h, ms, n, int(reset)))
+        return {self.TF_STAGES[i]: (ms[i], n[i]) for i in range(4)}
+
     def debug_fetch(self, name: str, shape) -> np.ndarray:
         arr = np.empty(shape, dtype=np.float32)
         self._check(N.load().clm_tf_debug_fetch(self._h, name.encode(), arr.ctypes.data_as(C.c_void_p), arr.nbytes))

@@ -139,12 +139,18 @@ int clm_attention_fwd(const void* qkv, void* out, int B, int L, int precision, v
  * asserts the same, transformer.py:21).  clm_tf_debug_fetch names: "hidden" fp32 [B, L/8, 256] (encoder output),
  * "scores" fp32 [B, L/8] (pooling scores before the softmax), "pooled" fp32 [B, 256]. */
 typedef struct clm_tf_handle clm_tf_handle;
-int clm_tf_create(int device, int precision /* CLM_PREC_F16 | CLM_PREC_BF16 */, int n_layers, clm_tf_handle** out);
+int clm_tf_create(int device, int precision /* CLM_PREC_F32 (exact, parity mode) | CLM_PREC_F16 | CLM_PREC_BF16 */, int n_layers,
+                  clm_tf_handle** out);
 int clm_tf_load_weight(clm_tf_handle* h, const char* key, const void* data, int dtype, const int64_t* shape, int ndim);
 int clm_tf_finalize(clm_tf_handle* h);
 int clm_tf_forward(clm_tf_handle* h, const void* ids, int ids_dtype, int64_t ids_row_stride, int B, int L, float* logits_out,
                    void* stream);
 int clm_tf_debug_fetch(clm_tf_handle* h, const char* name, void* host_out, size_t bytes);
+/* Profiling taps of the 16-bit path (bench.py --net transformer): accumulated HIP-event time on the launch stream and number of
+ * spans per stage -- 0 conv stack + positional encoding / LayerNorm, 1 attention, 2 encoder layer kernel (out_proj + LayerNorm-1
+ * + feed-forward + LayerNorm-2 + next layer's QKV), 3 pooling head.  clm_tf_profile_read synchronises the device. */
+int clm_tf_profile_enable(clm_tf_handle* h, int on);
+int clm_tf_profile_read(clm_tf_handle* h, double* ms_out /*[4]*/, int64_t* spans_out /*[4]*/, int reset);
 const char* clm_tf_last_error(const clm_tf_handle* h);
 int clm_tf_destroy(clm_tf_handle* h);
 

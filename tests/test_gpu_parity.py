@@ -457,10 +457,10 @@ def test_integration_md_ctypes_stub_runs_as_documented(sd, built_lib):
     block = block.replace('C.CDLL("libchimeralm_hip.so")', f'C.CDLL("{built_lib}")')
     ns: dict = {}
     exec(compile(block, "INTEGRATION.md", "exec"), ns)  # noqa: S102
-    model = lm.ChimeraLM.new(precision="fp16")
+    model = lm.ChimeraLM.new(precision="fp16c")
     model.load_state_dict(sd, strict=True)
-    stub = ns["HyenaDnaHip"](model.net, device=0, precision=2)
-    ids = torch.from_numpy(_ids(3, 500).astype(np.int64)).cuda()
+    stub = ns["HyenaDnaHip"](model.net, device=0)              # the stub's default: 3 = CLM_PREC_F16C
+    ids = torch.from_numpy(_ids(3, 2500).astype(np.int64)).cuda()
     got = stub(ids)
     torch.cuda.synchronize()
     want = model.net(ids)

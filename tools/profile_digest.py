@@ -22,7 +22,8 @@ STAGE_OF = {"tail16_kernel": "out_proj_ln2_mlp", "mlp16_kernel": "ln2_mlp", "in_
             "out_proj16_kernel": "out_proj", "hyena_conv_kernel": "short_long_conv", "hyena_conv_seg_kernel": "short_long_conv",
             "embed_kernel": "embed", "gemm_kernel": "lnf_pool_score", "softmax_stats_kernel": "softmax_pool", "pool_kernel": "softmax_pool",
             "head_mlp_kernel": "head_mlp", "head_tiles_kernel": "head_mlp", "ids8_kernel": "embed",
-            "score_pool16_kernel": "lnf_pool_score"}
+            "score_pool16_kernel": "lnf_pool_score", "attention_fwd_kernel": "attention", "enc_ffn16_kernel": "encoder_layer",
+            "conv3_relu_pool_kernel": "conv_stack_pe_ln"}
 
 
 def short(name: str) -> str:
@@ -73,7 +74,7 @@ def main(tag):
     for n, t in traffic.items():
         if t["fetch_kb"] is None or t["write_kb"] is None:
             continue
-        stage = next((s for k, s in STAGE_OF.items() if n.startswith(k) or k in n), None)
+        stage = next((s for k, s in sorted(STAGE_OF.items(), key=lambda kv: -len(kv[0])) if k in n), None)   # longest name first
         e = {"kernel": n, "fetch_size_kb": t["fetch_kb"], "write_size_kb": t["write_kb"],
              "hbm_bytes_per_dispatch": (2.0 * t["fetch_kb"] + t["write_kb"]) * 1024.0}
         if stage and (stage not in out or e["hbm_bytes_per_dispatch"] > out[stage]["hbm_bytes_per_dispatch"]):
@@ -93,6 +94,7 @@ def main(tag):
             b["roofline"]["traffic"] = st["hbm_bytes_per_dispatch"]
             b["roofline"]["traffic_unit"] = "bytes/launch"
             b["roofline"]["traffic_source"] = f"profiles/{tag}_traffic.json"
+            b["roofline"].pop("traffic_stale", None)      # the line was printed before this round's digest existed
             (dst / f"{tag}_bench.json").write_text(json.dumps(b) + "\n")
     print("\n".join(lines[:60]))
 
