@@ -1,6 +1,6 @@
 """End-to-end `predict` throughput on a synthetic BAM: native feeder -> staged H2D -> engine -> prediction files, one GPU.
 
-    python tools/e2e_bench.py [--reads 6000] [--bases 8192] [--batch 256] [--precision fp16]
+    python tools/e2e_bench.py [--reads 6000] [--bases 8192] [--batch 256] [--precision fp16c]
 
 Same loop as `python -m chimeralm_amd predict` (chimeralm_amd.predict.run_predict_native) with seeded random weights; the
 clock starts after the first batch (filters / workspace for the length are built on it) and stops when the last prediction
@@ -24,7 +24,7 @@ def main():
     ap.add_argument("--reads", type=int, default=6000)
     ap.add_argument("--bases", type=int, default=8192)
     ap.add_argument("--batch", type=int, default=256)
-    ap.add_argument("--precision", default="fp16")
+    ap.add_argument("--precision", default="fp16c")
     ap.add_argument("--min-bases", type=int, default=None, help="ragged file: read lengths uniform in [min-bases, bases]")
     a = ap.parse_args()
     from feeder_bench import write_bam
