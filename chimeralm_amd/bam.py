@@ -88,7 +88,7 @@ class BamDataModule:
         self.max_predict_samples, self.pin_memory, self.num_workers = max_predict_samples, pin_memory, num_workers
         self.batch_size_per_device = batch_size
         self.data_collator = DataCollator(tokenizer)
-        self.data_predict: list[dict] | None = None
+        self.data_predict = False
         self.world_size, self.rank = 1, 0
 
     @property
@@ -104,18 +104,27 @@ class BamDataModule:
             raise RuntimeError(f"Batch size ({self.batch_size}) is not divisible by the number of devices ({world_size}).")
         self.world_size, self.rank = world_size, rank
         self.batch_size_per_device = self.batch_size // world_size
-        max_length = self.tokenizer.max_len_single_sentence
-        feats = []
-        for i, rec in enumerate(parse_bam_file(self.predict_data_path)):
-            if self.max_predict_samples is not None and i >= self.max_predict_samples:
-                break
-            feats.append(tokenize_and_align_labels_and_quals_ids(rec, self.tokenizer, max_length))
-        self.data_predict = feats
+        if not Path(self.predict_data_path).exists():
+            raise FileNotFoundError(f"File not found: {self.predict_data_path}")
+        self.data_predict = True               # set up; the file itself is streamed by predict_dataloader
 
     def predict_dataloader(self) -> Iterator[dict]:
         """Batches in file order; with world_size > 1 rank r takes samples r, r+G, r+2G, ... (the non-shuffling
-        distributed sampler Lightning installs -- SURVEY.md Appendix B)."""
-        assert self.data_predict is not None, "call setup('predict') first"
-        mine = self.data_predict[self.rank:: self.world_size] if self.world_size > 1 else self.data_predict
-        for i in range(0, len(mine), self.batch_size_per_device):
-            yield self.data_collator.torch_call(mine[i: i + self.batch_size_per_device])
+        distributed sampler Lightning installs -- SURVEY.md Appendix B).  The reference tokenises the whole file into an Arrow
+        cache before the first batch (bam.py:153-172); here records are parsed, tokenised and collated as they are consumed,
+        so memory holds one batch whatever the size of the BAM (the native feeder, the default of `predict`, does the same
+        in C++)."""
+        assert self.data_predict, "call setup('predict') first"
+        max_length = self.tokenizer.max_len_single_sentence
+        batch: list[dict] = []
+        for i, rec in enumerate(parse_bam_file(self.predict_data_path)):
+            if self.max_predict_samples is not None and i >= self.max_predict_samples:
+                break
+            if self.world_size > 1 and i % self.world_size != self.rank:
+                continue
+            batch.append(tokenize_and_align_labels_and_quals_ids(rec, self.tokenizer, max_length))
+            if len(batch) == self.batch_size_per_device:
+                yield self.data_collator.torch_call(batch)
+                batch = []
+        if batch:
+            yield self.data_collator.torch_call(batch)

@@ -174,13 +174,14 @@ _HEAD_KEYS = ("attention.0.weight", "attention.0.bias", "attention.2.weight", "a
 class HyenaDna(nn.Module):
     """Drop-in for the reference's `HyenaDna` net: same signature, same state_dict keys, MI355X forward.
 
-    Extra keyword-only arguments (engine knobs, absent in the reference): `precision` in
-    {"fp32", "bf16", "fp16"} selects the MFMA input type of the dense projections, `chunk_reads` the number
-    of reads pushed through all layers together.
+    Extra keyword-only arguments (engine knobs, absent in the reference): `precision` selects the arithmetic of the dense
+    projections -- "fp32" (exact, the reference's), "fp16c" (fp16 activations x hi + lo fp16 weight pairs: 16-bit MFMA rate
+    within the reference's 1e-3 logit tolerance; reads below 2,048 tokens run in fp32 kernels), "fp16" / "bf16" (reduced
+    precision, outside that tolerance) -- and `chunk_reads` the number of reads pushed through all layers together.
     """
 
     def __init__(self, number_of_classes: int, head: nn.Module, backbone_name: str = "hyenadna-small-32k-seqlen", *,
-                 freeze_backbone: bool = False, precision: str = "fp32", chunk_reads: int = 64):
+                 freeze_backbone: bool = False, precision: str = "fp16c", chunk_reads: int = 64):
         super().__init__()
         if number_of_classes != 2:
             raise NotImplementedError("the engine implements the binary (2-class) head only")

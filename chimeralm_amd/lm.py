@@ -13,7 +13,7 @@ from .hyena import BinarySequenceClassifier, HyenaDna
 
 class ChimeraLM:
     @classmethod
-    def new(cls, *, save_attention: bool = False, precision: str = "fp32", chunk_reads: int = 64) -> ClassificationLit:
+    def new(cls, *, save_attention: bool = False, precision: str = "fp16c", chunk_reads: int = 64) -> ClassificationLit:
         """Randomly initialised model of the production architecture (lm.py:39-61)."""
         return ClassificationLit(
             net=HyenaDna(
@@ -32,7 +32,7 @@ class ChimeraLM:
 
     @classmethod
     def from_pretrained(cls, model_name: str = "yangliz5/chimeralm", *, save_attention: bool = False,
-                        precision: str = "fp32", chunk_reads: int = 64) -> ClassificationLit:
+                        precision: str = "fp16c", chunk_reads: int = 64) -> ClassificationLit:
         """Released weights (lm.py:12-37).  `model_name` is a local directory / file holding `model.safetensors`
         or a Lightning `.ckpt`; a Hub repo id is resolved through the local HF cache only (no network here)."""
         model = cls.new(save_attention=save_attention, precision=precision, chunk_reads=chunk_reads)

@@ -25,7 +25,7 @@ from oracle import hyena_oracle as ho  # noqa: E402
 def decode(raw: np.ndarray, precision: str) -> np.ndarray:
     if precision == "fp32":
         return raw.view(np.float32)
-    if precision == "fp16":
+    if precision in ("fp16", "fp16c"):
         return raw.view(np.float16).astype(np.float32)
     return (raw.view(np.uint16).astype(np.uint32) << 16).view(np.float32)
 
