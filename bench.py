@@ -324,7 +324,8 @@ def main():
 
     if rank == 0:
         es = 4 if a.precision == "fp32" else 2
-        assert a.precision != "fp16c" or L >= 2048, "fp16c runs reads below 2048 tokens in fp32 kernels: use --precision fp32 to bench them"
+        if a.precision == "fp16c" and L < 2048:
+            raise SystemExit("fp16c runs reads below 2,048 tokens through its fp32 kernels: bench them with --precision fp32")
         total_ms = sum(ms for ms, _ in prof.values()) or 1.0
         dom = max(prof, key=lambda k: prof[k][0])
         ms, launches = prof[dom]

@@ -217,9 +217,9 @@ struct SamInput {
         return true;
     }
 
-    bool fail(const std::string& what) {
+    int fail(const std::string& what) {                     // malformed line: message with its number, -1 for next()
         err = path + ": line " + std::to_string(line_no) + ": " + what;
-        return false;
+        return -1;
     }
 
     // one alignment line -> BAM record with its length prefix in `out`; 1 = ok, 0 = end of file, -1 = error
@@ -242,7 +242,7 @@ struct SamInput {
             f.emplace_back(line.data() + b, e - b);
             b = e + 1;
         }
-        if (f.size() < 11) return fail("fewer than 11 fields") ? 1 : -1;
+        if (f.size() < 11) return fail("fewer than 11 fields");
         auto str = [&](int i) { return std::string(f[(size_t)i].first, f[(size_t)i].second); };
         auto refid = [&](const std::string& n, int32_t same, int32_t& o) -> bool {
             if (n == "*") { o = -1; return true; }
@@ -256,9 +256,9 @@ struct SamInput {
         const long flag = std::atol(str(1).c_str()), pos = std::atol(str(3).c_str()) - 1, mapq = std::atol(str(4).c_str()),
                    pnext = std::atol(str(7).c_str()) - 1, tlen = std::atol(str(8).c_str());
         int32_t tid = -1, ntid = -1;
-        if (!refid(rname, -1, tid)) return fail("unknown reference " + rname) ? 1 : -1;
-        if (!refid(rnext, tid, ntid)) return fail("unknown mate reference " + rnext) ? 1 : -1;
-        if (qname.size() > 254) return fail("read name longer than 254") ? 1 : -1;
+        if (!refid(rname, -1, tid)) return fail("unknown reference " + rname);
+        if (!refid(rnext, tid, ntid)) return fail("unknown mate reference " + rnext);
+        if (qname.size() > 254) return fail("read name longer than 254");
         std::vector<uint32_t> cg;
         if (cigar != "*") {
             static const char* OPS = "MIDNSHP=X";
@@ -268,13 +268,13 @@ struct SamInput {
                 size_t j = i;
                 while (j < cigar.size() && cigar[j] >= '0' && cigar[j] <= '9') n = n * 10 + (uint64_t)(cigar[j++] - '0');
                 const char* op = j < cigar.size() ? std::strchr(OPS, cigar[j]) : nullptr;
-                if (j == i || !op || !*op || n >= (1u << 28)) return fail("bad CIGAR " + cigar) ? 1 : -1;
+                if (j == i || !op || !*op || n >= (1u << 28)) return fail("bad CIGAR " + cigar);
                 cg.push_back((uint32_t)(n << 4) | (uint32_t)(op - OPS));
                 i = j + 1;
             }
         }
         const size_t l_seq = seq == "*" ? 0 : seq.size();
-        if (qual != "*" && qual.size() != l_seq) return fail("SEQ and QUAL differ in length") ? 1 : -1;
+        if (qual != "*" && qual.size() != l_seq) return fail("SEQ and QUAL differ in length");
         std::vector<uint8_t> body;
         put32(body, (uint32_t)tid);
         put32(body, (uint32_t)(int32_t)pos);
@@ -309,7 +309,7 @@ struct SamInput {
             const char* t = f[k].first;
             const size_t n = f[k].second;
             if (n == 0) continue;
-            if (n < 5 || t[2] != ':' || t[4] != ':') return fail("bad optional field") ? 1 : -1;
+            if (n < 5 || t[2] != ':' || t[4] != ':') return fail("bad optional field");
             const std::string val(t + 5, n - 5);
             body.push_back((uint8_t)t[0]);
             body.push_back((uint8_t)t[1]);
@@ -342,7 +342,7 @@ struct SamInput {
                     body.push_back(0);
                     break;
                 case 'B': {
-                    if (val.empty()) return fail("empty B array") ? 1 : -1;
+                    if (val.empty()) return fail("empty B array");
                     const char sub = val[0];
                     std::vector<std::string> items;
                     for (size_t b = 1; b < val.size();) {
@@ -366,12 +366,12 @@ struct SamInput {
                             if (sub == 'c' || sub == 'C') body.push_back((uint8_t)x);
                             else if (sub == 's' || sub == 'S') put16(body, (uint32_t)x);
                             else if (sub == 'i' || sub == 'I') put32(body, (uint32_t)x);
-                            else return fail("bad B array subtype") ? 1 : -1;
+                            else return fail("bad B array subtype");
                         }
                     }
                     break;
                 }
-                default: return fail(std::string("unknown optional field type ") + t[3]) ? 1 : -1;
+                default: return fail(std::string("unknown optional field type ") + t[3]);
             }
         }
         out.clear();
