@@ -13,7 +13,7 @@ from pathlib import Path
 CSRC = Path(__file__).resolve().parent / "csrc"
 INCLUDE = Path(__file__).resolve().parent.parent / "include"
 LIB = CSRC / "libchimeralm_hip.so"
-SOURCES = ["clm_api.hip", "gemm.hip", "gemm16.hip", "hyena_conv.hip", "head.hip", "attention.hip", "tf_model.hip", "tf_fp32.hip", "bam_feeder.cpp", "bam_filter.cpp"]
+SOURCES = ["clm_api.hip", "gemm.hip", "gemm16.hip", "hyena_conv.hip", "head.hip", "lone_token.hip", "attention.hip", "tf_model.hip", "tf_fp32.hip", "bam_feeder.cpp", "bam_filter.cpp"]
 HEADERS = ["clm_common.h", "gemm_common.h", "gemm16_common.h", "fft_core.h", "fft_passes.h", "bgzf.h"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast", "-Wall", "-Wno-unused-function",
          "-Wno-pass-failed"]

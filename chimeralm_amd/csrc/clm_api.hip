@@ -92,7 +92,7 @@ struct clm_handle {
     size_t ws_z_bytes = 0, ws_y_bytes = 0, ws_es = 0;   // ws_es: element size z / y were last written with
     float* h = nullptr;
     void *z = nullptr, *y = nullptr, *u = nullptr;
-    float *scores = nullptr, *stats = nullptr, *partial = nullptr, *pooled = nullptr;
+    float *scores = nullptr, *stats = nullptr, *partial = nullptr, *pooled = nullptr, *lone_ws = nullptr;
     float2* gscratch = nullptr;                     // segment spectra of the long-read convolution
     size_t gscratch_elems = 0;
     int last_B = 0, last_L = 0, last_Lp = 0;
@@ -101,6 +101,7 @@ struct clm_handle {
     bool split_tail = false;      // CLM_SPLIT_TAIL=1: separate out_proj16 + mlp16 kernels instead of the fused tail (A/B runs)
     bool no_fuse_next = false;    // CLM_NO_FUSE_NEXT=1: separate in_proj / score kernels instead of fusing them into the tail
     bool no_idconv = false;       // CLM_NO_IDCONV=1: run block 0's in_proj instead of the id-table convolution (A/B runs)
+    bool no_lone_peel = false;    // CLM_NO_LONE_PEEL=1: keep the lone last token of 128 k + 1-token reads in a tile of its own (A/B runs)
     bool split_conv = false;      // CLM_SPLIT_CONV=1: 8k reads through hyena_conv_eo_kernel (two 8192-point problems; measured slower, kept for A/B)
     bool force_generic = false;   // CLM_GENERIC_GEMM=1: route 16-bit modes through the generic kernels (A/B runs)
     bool prof = false;
@@ -247,12 +248,12 @@ void free_filters(clm_handle* h) {
 
 void free_workspace(clm_handle* h) {
     for (void* p : {(void*)h->h, h->z, h->y, h->u, (void*)h->scores, (void*)h->stats, (void*)h->partial,
-                    (void*)h->pooled, (void*)h->gscratch, (void*)h->ids8})
+                    (void*)h->pooled, (void*)h->gscratch, (void*)h->ids8, (void*)h->lone_ws})
         if (p) (void)hipFree(p);
     h->gscratch = nullptr;
     h->gscratch_elems = 0;
     h->h = nullptr; h->z = h->y = h->u = nullptr;
-    h->scores = h->stats = h->partial = h->pooled = nullptr;
+    h->scores = h->stats = h->partial = h->pooled = h->lone_ws = nullptr;
     h->ids8 = nullptr;
     h->ws_B = h->ws_L = 0;
 }
@@ -299,6 +300,7 @@ int ensure_workspace(clm_handle* h, int Bc, int L, hipStream_t st) {
         HIPCHK(h, hipMalloc((void**)&h->partial, (size_t)nb * per_read * 4));
     }
     HIPCHK(h, hipMalloc((void**)&h->pooled, (size_t)nb * D * 4));
+    HIPCHK(h, hipMalloc((void**)&h->lone_ws, lone_token_ws_floats(nb) * 4));
     HIPCHK(h, hipMalloc((void**)&h->ids8, (size_t)nb * Lp));
     if (conv_segments_for(nl) > 1) {
         const size_t pairs = (size_t)(nb + 1) / 2, S = (size_t)conv_segments_for(nl);
@@ -465,6 +467,9 @@ int forward_chunk(clm_handle* h, const void* ids, int ids_dtype, int64_t row_str
     // ... and every block's tail kernel goes on, on the tile it has just produced, with LayerNorm-1 + in_proj of the next
     // block (the last block: ln_f + attention scores + pooling partials): no separate in_proj / score launches
     const bool fuse_next = tuned16 && !h->split_tail && !h->no_fuse_next && h->stop_stage < 0;
+    // reads of 128 k + 1 tokens (every 8k-bp read: 8192 bases + [SEP]): the last token would be a tile of its own, a whole extra
+    // round of the tail kernel for one token per read; it is causally isolated, so a per-read matrix-vector kernel takes it
+    const bool peel = fuse_next && !h->no_lone_peel && L > 128 && L % 128 == 1;
     const void* packed_score = alt32 ? h->packed_score32 : h->packed_score;
     const ScorePoolArgs spa{h->h, W(h, "bb.ln_f.weight"), W(h, "bb.ln_f.bias"), packed_score,
                             W(h, "head.attention.0.bias"), W(h, "head.attention.2.weight"),
@@ -504,7 +509,7 @@ int forward_chunk(clm_handle* h, const void* ids, int ids_dtype, int64_t row_str
         if (tuned16 && !h->split_tail && !stop_mid) {   // out_proj + LN2 + fc1 + GELU + fc2 + both residuals: one kernel
             StageTimer t(h, st, CLM_STAGE_TAIL);
             TailArgs ta{h->y, h->h, lw.w_out, lw.w_fc1, lw.w_fc2, lw.b_out, lw.ln2_g, lw.ln2_b, lw.b_fc1, lw.b_fc2, Bc, L, Lp,
-                        eps, (idpath && i == 0) ? h->ids8 : nullptr, W(h, "bb.embeddings.word_embeddings.weight"),
+                        eps, peel ? L - 1 : L, (idpath && i == 0) ? h->ids8 : nullptr, W(h, "bb.embeddings.word_embeddings.weight"),
                         nullptr, nullptr, nullptr, nullptr, nullptr, spa};
             int next = NEXT_NONE;
             if (fuse_next && i + 1 < NLAYER) {
@@ -515,6 +520,27 @@ int forward_chunk(clm_handle* h, const void* ids, int ids_dtype, int64_t row_str
                 next = NEXT_SCORE;
             }
             launch_tail16(prec, ta, next, st);
+            if (peel) {
+                const std::string p = "bb.layers." + std::to_string(i) + ".", pn = "bb.layers." + std::to_string(i + 1) + ".";
+                const bool last = i + 1 == NLAYER;
+                LoneTokenArgs la{};
+                la.y = h->y; la.h = h->h; la.ids8 = ta.ids8; la.emb = ta.emb;
+                la.w_out = W(h, p + "mixer.out_proj.weight"); la.b_out = lw.b_out; la.ln2_g = lw.ln2_g; la.ln2_b = lw.ln2_b;
+                la.w_fc1 = W(h, p + "mlp.fc1.weight"); la.b_fc1 = lw.b_fc1; la.w_fc2 = W(h, p + "mlp.fc2.weight"); la.b_fc2 = lw.b_fc2;
+                la.last = last;
+                if (last) {
+                    la.n_g = W(h, "bb.ln_f.weight"); la.n_b = W(h, "bb.ln_f.bias");
+                    la.att_w1 = W(h, "head.attention.0.weight"); la.att_b1 = W(h, "head.attention.0.bias");
+                    la.att_w2 = W(h, "head.attention.2.weight"); la.att_b2 = W(h, "head.attention.2.bias");
+                    la.scores = h->scores; la.partial = h->partial;
+                } else {
+                    const LayerW& nx = h->lw[i + 1];
+                    la.n_g = nx.ln1_g; la.n_b = nx.ln1_b; la.n_w = W(h, pn + "mixer.in_proj.weight"); la.n_bias = nx.b_in; la.n_z = h->z;
+                }
+                la.ws = h->lone_ws;
+                la.B = Bc; la.L = L; la.Lp = Lp; la.ntiles = (L + 127) / 128; la.eps = eps;
+                launch_lone_token(prec, la, st);
+            }
         } else {
             {
                 StageTimer t(h, st, CLM_STAGE_OUTPROJ);
@@ -608,6 +634,7 @@ int clm_create(const clm_config* cfg, int device, clm_handle** out) {
     h->no_fuse_next = std::getenv("CLM_NO_FUSE_NEXT") && std::getenv("CLM_NO_FUSE_NEXT")[0] == '1';
     h->no_idconv = std::getenv("CLM_NO_IDCONV") && std::getenv("CLM_NO_IDCONV")[0] == '1';
     h->split_tail = std::getenv("CLM_SPLIT_TAIL") && std::getenv("CLM_SPLIT_TAIL")[0] == '1';
+    h->no_lone_peel = std::getenv("CLM_NO_LONE_PEEL") && std::getenv("CLM_NO_LONE_PEEL")[0] == '1';
     h->split_conv = std::getenv("CLM_SPLIT_CONV") && std::getenv("CLM_SPLIT_CONV")[0] == '1';
     h->cfg = *cfg;
     h->device = device;

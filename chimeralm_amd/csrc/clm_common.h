@@ -170,6 +170,7 @@ struct TailArgs {
     const float *b_out, *ln_g, *ln_b, *b1, *b2;
     int B, L, Lp;
     float eps;
+    int Lmain;                   // tokens covered by tiles: L, or L - 1 when the lone last token is peeled off (lone_token.hip)
     const unsigned char* ids8;   // block 0 only (else null): the incoming residual row of token t is emb[ids8[b][t]],
     const float* emb;            // read from the 16-row table instead of h (the embedding kernel then never writes h)
     // NEXT_INPROJ: LayerNorm-1 + in_proj of the FOLLOWING block on the tile just produced (z written for its convolution)
@@ -180,6 +181,25 @@ struct TailArgs {
     ScorePoolArgs sp;
 };
 constexpr int NEXT_NONE = 0, NEXT_INPROJ = 1, NEXT_SCORE = 2;
+// The last token of a read of 128 k + 1 tokens, through the second half of a block (and what follows) as fp32 matrix-vector
+// products: see lone_token.hip.  All weights are the fp32 originals [out][in].
+struct LoneTokenArgs {
+    const void* y;               // [B, 256, Lp] channel-major, 16-bit: the convolution's output (this token's column is read)
+    float* h;                    // residual stream [B, L, 256]: row L-1 read (unless ids8) and, if !last, written
+    const unsigned char* ids8;   // block 0 of the id path: the incoming residual is emb[ids8[b][L-1]]
+    const float* emb;
+    const float *w_out, *b_out, *ln2_g, *ln2_b, *w_fc1, *b_fc1, *w_fc2, *b_fc2;
+    int last;                    // 0: n_* = LayerNorm-1 + in_proj of the next block, z column written; 1: n_g / n_b = ln_f, score + partial
+    const float *n_g, *n_b, *n_w, *n_bias;
+    void* n_z;                   // [B, 768, Lp] 16-bit
+    const float *att_w1, *att_b1, *att_w2, *att_b2;
+    float *scores, *partial;     // [B, L]; [B, ntiles, POOL_PSTRIDE]
+    float* ws;                   // fp32 scratch, lone_token_ws_floats(B) floats: vectors handed from stage to stage
+    int B, L, Lp, ntiles;
+    float eps;
+};
+size_t lone_token_ws_floats(int B);
+void launch_lone_token(int prec, const LoneTokenArgs& a, hipStream_t st);
 // out_proj + LN2 + MLP (+ what follows on the same tile: NEXT_*), 16-bit modes (gemm16.hip)
 void launch_tail16(int prec, const TailArgs& m, int next, hipStream_t st);
 void tail16_dump_stamps();   // developer build only (CLM_STAMP=1)

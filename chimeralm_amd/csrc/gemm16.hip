@@ -426,7 +426,7 @@ __global__ __launch_bounds__(512) void tail16_kernel(TailArgs m, unsigned long l
     for (int i = threadIdx.x; i < BT_SIZE; i += 512)
         Bt[i] = i < BT_B2 ? m.b1[i] : i < BT_BOUT ? m.b2[i - BT_B2] : i < BT_NB ? m.b_out[i - BT_BOUT]
                 : (NEXT == NEXT_INPROJ ? m.n_bias[i - BT_NB] : 0.f);
-    const int L = m.L, Lp = m.Lp, tiles_x = (L + BM - 1) / BM, total = tiles_x * m.B;
+    const int L = m.L, Lp = m.Lp, tiles_x = (m.Lmain + BM - 1) / BM, total = tiles_x * m.B;
     const frag* wo = reinterpret_cast<const frag*>(m.w_out);
     const frag* w1 = reinterpret_cast<const frag*>(m.w1);
     const frag* w2 = reinterpret_cast<const frag*>(m.w2);
@@ -713,7 +713,7 @@ void launch_tail16(int prec, const TailArgs& m, int next, hipStream_t st) {
     static_assert((size_t)D * RSKM * 2 <= (size_t)2 * 128 * RS16 * 2, "y tile must fit under the partial tables");
     static_assert((size_t)8 * 32 * RSOUT * 2 <= (size_t)128 * RS16 * 2 + (size_t)2 * 16 * 128 * 4,
                   "in_proj staging tiles must fit in the Hs region + the (by then dead) LayerNorm tables");
-    const int total = ((m.L + 127) / 128) * m.B;
+    const int total = ((m.Lmain + 127) / 128) * m.B;
     static const int cus = [] {
         int dev = 0, n = 256;
         if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);

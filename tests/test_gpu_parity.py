@@ -194,6 +194,31 @@ def test_full_size_8k_reads(engines, sd, prec):
     _check(engines[prec], prec, ids, sd)
 
 
+@pytest.mark.parametrize("prec,B,L", [("fp16", 3, 129), ("fp16", 4, 385), ("bf16", 2, 1025), ("fp16c", 3, 2049), ("fp16c", 5, 8193),
+                                      ("fp16c", 2, 16385)])
+def test_lone_last_token_is_peeled_off_the_tile_kernels(sd, built_lib, monkeypatch, prec, B, L):
+    """Reads of 128 k + 1 tokens: the last token (the [SEP] of every 8k-bp read) is causally isolated in the backbone and runs
+    through fp32 matrix-vector kernels instead of a 128-token tile of its own (csrc/lone_token.hip).  Same logits as with the
+    token kept in the tile kernels (CLM_NO_LONE_PEEL=1) up to that one token's 16-bit roundings, both within the mode's bound
+    of the oracle -- incl. a batch in which that token dominates the attention pooling (its score pushed up through a large
+    attention.2 weight would need other weights; here: left-padded reads, where it is the only non-pad token of a short read)."""
+    from chimeralm_amd.engine import Engine
+
+    ids = _ids(B, L, seed=83, pads=3)
+    ids[0, : L - 1] = 4                                         # read 0: pads only, then [SEP]
+    t = torch.from_numpy(ids).cuda()
+    e0 = Engine("cuda:0", precision=prec, chunk_reads=4)
+    monkeypatch.setenv("CLM_NO_LONE_PEEL", "1")
+    e1 = Engine("cuda:0", precision=prec, chunk_reads=4)
+    monkeypatch.delenv("CLM_NO_LONE_PEEL")
+    e0.load_state_dict(sd), e1.load_state_dict(sd)
+    a, b = e0.forward(t).cpu(), e1.forward(t).cpu()
+    assert torch.equal(a, e0.forward(t).cpu())                  # deterministic
+    assert (a - b).abs().max() < TOL[prec]
+    _check(e0, prec, ids, sd)
+    e0.close(), e1.close()
+
+
 @pytest.mark.parametrize("prec,B,L", [("fp32", 3, 8193), ("fp16c", 3, 8193), ("fp16", 5, 6000), ("fp16c", 2, 4098)])
 def test_split_transform_convolution_kernel(sd, built_lib, monkeypatch, prec, B, L):
     """CLM_SPLIT_CONV=1: reads of 4098..8193 tokens through hyena_conv_eo_kernel (the 16384-point convolution as two 8192-point
