@@ -200,8 +200,7 @@ def test_lone_last_token_is_peeled_off_the_tile_kernels(sd, built_lib, monkeypat
     """Reads of 128 k + 1 tokens: the last token (the [SEP] of every 8k-bp read) is causally isolated in the backbone and runs
     through fp32 matrix-vector kernels instead of a 128-token tile of its own (csrc/lone_token.hip).  Same logits as with the
     token kept in the tile kernels (CLM_NO_LONE_PEEL=1) up to that one token's 16-bit roundings, both within the mode's bound
-    of the oracle -- incl. a batch in which that token dominates the attention pooling (its score pushed up through a large
-    attention.2 weight would need other weights; here: left-padded reads, where it is the only non-pad token of a short read)."""
+    of the oracle; read 0 of the batch is all [PAD] but for its [SEP] (left padding to the extreme)."""
     from chimeralm_amd.engine import Engine
 
     ids = _ids(B, L, seed=83, pads=3)
