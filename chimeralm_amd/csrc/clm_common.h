@@ -12,6 +12,7 @@ namespace clm {
 constexpr int D = 256;          // d_model
 constexpr int D3 = 768;         // in_proj width (x0 | x1 | v)
 constexpr int DI = 1024;        // MLP inner width
+constexpr int XCDS = 8;          // MI355X: 8 XCDs, each with its own L2; workgroup id % 8 picks the XCD (round-robin dispatch)
 constexpr int NLAYER = 4;
 constexpr int VOCAB = 16;
 constexpr int FORDER = 64;      // implicit filter MLP width

@@ -611,6 +611,323 @@ __global__ __launch_bounds__(Plan<LOGN>::NT) void hyena_conv_kernel(
 }
 
 
+// ================================================================================================ 8k reads: persistent units
+// hyena_conv_kernel has one workgroup per CU (LDS) and starts every unit with an HBM round trip for its z rows that nothing
+// overlaps (stamps: phase A 19 % of a unit).  Round 1 tried a persistent loop that prefetched the next unit's six rows into
+// registers: 40-66 spilled registers and slower.  This variant changes WHAT is held across the transform instead:
+//   * x0 (needed only by the output gate) is no longer computed in phase A and carried through the passes (32 registers):
+//     its two rows are requested just before the last inverse pass and filtered in phase C;
+//   * the x1 / v rows of the NEXT unit of this workgroup are requested at the same point (40 registers, live only across the
+//     last pass, phase C and the next phase A -- where the transform's 64 data registers are dead);
+//   * the pass twiddles are loaded once per workgroup instead of once per unit.
+// Units are taken round-robin by gridDim.x = #CUs workgroups; LOGN = 14 (reads of 4098 .. 8193 tokens) only.
+template <typename T, bool IDS>
+struct ConvGateRaw {                                   // x1 / v rows of one unit, both reads (IDS: the token ids instead)
+    Raw<T> r[2][2][2];                                 // [chunk][read][x1, v]
+    T ztail[2][2];
+    uint2 idd[2][2];
+    unsigned short idp[2][2];
+    unsigned char idt[2];
+};
+
+template <typename T, bool IDS>
+__global__ __launch_bounds__(Plan<14>::NT) void hyena_conv_pers_kernel(
+    const T* __restrict__ z, T* __restrict__ y, const float2* __restrict__ kf, const float2* __restrict__ tw,
+    const float* __restrict__ ktime, const float* __restrict__ short_w, const float* __restrict__ short_b, int B, int L,
+    int Lp, const unsigned char* __restrict__ ids8, const float* __restrict__ ztab) {
+    constexpr int LOGN = 14;
+    using P = Plan<LOGN>;
+    using TL = TwLayout<LOGN>;
+    constexpr int N = P::N, NT = P::NT, LAST = P::LAST, HALF = N / 2, CH = 2;
+    static_assert(HALF / 8 / NT == CH, "two 8-token chunks per thread");
+    constexpr int TAIL_TID = HALF / 8 - 1 - (CH - 1) * NT;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float* bre = reinterpret_cast<float*>(smem);
+    float* bim = bre + padded_size(N);
+    float* gtail = bim + padded_size(N);
+    float* zt = gtail + 4;
+
+    const int tid = threadIdx.x;
+    const int pairs = (B + 1) / 2, n_units = pairs * D;
+    const bool tail = (L == HALF + 1);
+    // Unit order.  Workgroups go round-robin to the 8 XCDs (id % 8), each with its own L2; a channel's spectrum (128 KB) is
+    // shared by all read pairs of the channel.  XCD x therefore takes the channels c = x (mod 8), and its workgroups walk
+    // (channel, pair) channel-major: a spectrum is fetched from HBM by one XCD, once, instead of by all eight.
+    const bool xcd_order = (gridDim.x % XCDS) == 0;
+    const int xcd = blockIdx.x % XCDS, wg_in_xcd = blockIdx.x / XCDS, wgs_per_xcd = gridDim.x / XCDS;
+    const int first = xcd_order ? wg_in_xcd : (int)blockIdx.x, stride = xcd_order ? wgs_per_xcd : (int)gridDim.x;
+    const int n_mine = xcd_order ? n_units / XCDS : n_units;            // D is a multiple of XCDS
+    auto unit_of = [&](int q, int& c, int& pair) {
+        c = xcd_order ? XCDS * (q / pairs) + xcd : q / pairs;
+        pair = q % pairs;
+    };
+
+    Cx2 wall[TL::TOTAL];                                // twiddles of every pass: unit-independent
+    {
+        int ns = 16;
+#pragma unroll
+        for (int p = 1; p <= P::NPASS - 2; ++p) {
+            pass_twiddles<LOGN, 16, false>(wall + TL::fwd(p), tid, ns, tw);
+            ns *= 16;
+        }
+        pass_twiddles<LOGN, LAST, false>(wall + TL::fwd_last(), tid, ns, tw);
+        ns = LAST;
+#pragma unroll
+        for (int p = 1; p <= P::NPASS - 1; ++p) {
+            pass_twiddles<LOGN, 16, true>(wall + TL::inv(p), tid, ns, tw);
+            ns *= 16;
+        }
+    }
+    // requests of the gate rows (x1, v) of unit u: no control flow between the loads (all in flight together)
+    auto request_gate = [&](int q, ConvGateRaw<T, IDS>& g, int ltid) {
+        int c, pair;
+        unit_of(q, c, pair);
+        const int bA = 2 * pair, bB = (2 * pair + 1 < B) ? 2 * pair + 1 : bA;
+        if constexpr (IDS) {
+#pragma unroll
+            for (int rd = 0; rd < 2; ++rd) {
+                const unsigned char* ir = ids8 + (size_t)(rd == 0 ? bA : bB) * Lp;
+#pragma unroll
+                for (int ch = 0; ch < CH; ++ch) {
+                    const int t0 = 8 * (ltid + ch * NT);
+                    const bool valid = t0 < L;
+                    g.idd[ch][rd] = *reinterpret_cast<const uint2*>(ir + (valid ? t0 : 0));
+                    g.idp[ch][rd] = *reinterpret_cast<const unsigned short*>(ir + ((valid && t0 > 0) ? t0 - 2 : 0));
+                }
+                g.idt[rd] = ir[(tail && ltid == TAIL_TID) ? HALF : 0];
+            }
+        } else {
+#pragma unroll
+            for (int rd = 0; rd < 2; ++rd) {
+                const T* zr = z + (size_t)(rd == 0 ? bA : bB) * D3 * Lp;
+#pragma unroll
+                for (int a3 = 1; a3 < 3; ++a3) {
+                    const T* row = zr + (size_t)(a3 * D + c) * Lp;
+#pragma unroll
+                    for (int ch = 0; ch < CH; ++ch) {
+                        const int t0 = 8 * (ltid + ch * NT);
+                        raw_load(g.r[ch][rd][a3 - 1], row, t0, t0 < L);
+                    }
+                    g.ztail[rd][a3 - 1] = row[(tail && ltid == TAIL_TID) ? HALF : 0];
+                }
+            }
+        }
+    };
+
+    ConvGateRaw<T, IDS> cur;
+    request_gate(first < n_mine ? first : 0, cur, tid);
+
+#pragma unroll 1
+    for (int u = first; u < n_mine; u += stride) {
+        int ltid = tid;                                  // opaque per trip: keeps the pass addresses from being hoisted and held
+        asm volatile("" : "+v"(ltid));
+#pragma unroll
+        for (int i = 0; i < TL::TOTAL; ++i)
+            asm volatile("" : "+v"(wall[i].re.x), "+v"(wall[i].re.y), "+v"(wall[i].im.x), "+v"(wall[i].im.y));
+        int c, pair;
+        unit_of(u, c, pair);
+        const int bA = 2 * pair, bB = 2 * pair + 1;
+        const bool hasB = bB < B;
+        const float2* kfc = kf + (size_t)c * N;
+        float sw[3][3], sb[3];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+#pragma unroll
+            for (int e = 0; e < 3; ++e) sw[q][e] = short_w[(q * D + c) * 3 + e];
+            sb[q] = short_b[q * D + c];
+        }
+        if constexpr (IDS) {
+            if (ltid < 48) zt[ltid] = ztab[(size_t)(ltid & 15) * D3 + (ltid >> 4) * D + c];
+            __syncthreads();
+        }
+        // ---------------------------------------------------------------- phase A: gate from the rows requested a unit ago
+        float gAt = 0.f, gBt = 0.f;
+#pragma unroll
+        for (int ch = 0; ch < CH; ++ch) {
+            const int t0 = 8 * (ltid + ch * NT);
+            const bool valid = t0 < L;
+            float xa[3][10], xb[3][10], gA[8], gB[8], x1[8], v[8], x1b[8], vb[8];
+            if constexpr (IDS) {
+                ids_decode<true>(cur.idd[ch][0], cur.idp[ch][0], t0, valid, zt, xa);
+                ids_decode<true>(cur.idd[ch][1], cur.idp[ch][1], t0, valid && hasB, zt, xb);
+            } else {
+#pragma unroll
+                for (int a3 = 1; a3 < 3; ++a3) {
+                    raw_decode(cur.r[ch][0][a3 - 1], t0, valid, xa[a3]);
+                    raw_decode(cur.r[ch][1][a3 - 1], t0, valid && hasB, xb[a3]);
+                }
+            }
+            fir3_pair(xa[1], xb[1], sw[1][0], sw[1][1], sw[1][2], sb[1], x1, x1b);
+            fir3_pair(xa[2], xb[2], sw[2][0], sw[2][1], sw[2][2], sb[2], v, vb);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                gA[e] = (t0 + e < L) ? v[e] * x1[e] : 0.f;
+                gB[e] = (hasB && t0 + e < L) ? vb[e] * x1b[e] : 0.f;
+            }
+            lds_store8(bre + pad_index(t0), gA);
+            lds_store8(bim + pad_index(t0), gB);
+            if (ch == CH - 1 && tail && ltid == TAIL_TID) {   // token HALF: taps are x[8], x[9] of this chunk and z[HALF]
+                float ta[3] = {0.f, 0.f, 0.f}, tb[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+                for (int a3 = 1; a3 < 3; ++a3) {
+                    const float za = IDS ? zt[a3 * 16 + (cur.idt[0] & 15)] : to_float(cur.ztail[0][a3 - 1]);
+                    const float zb = IDS ? zt[a3 * 16 + (cur.idt[1] & 15)] : to_float(cur.ztail[1][a3 - 1]);
+                    ta[a3] = sb[a3] + sw[a3][0] * xa[a3][8] + sw[a3][1] * xa[a3][9] + sw[a3][2] * za;
+                    tb[a3] = sb[a3] + sw[a3][0] * xb[a3][8] + sw[a3][1] * xb[a3][9] + sw[a3][2] * zb;
+                }
+                gAt = ta[1] * ta[2];
+                gBt = hasB ? tb[1] * tb[2] : 0.f;
+            }
+        }
+        __syncthreads();
+        if (tail && ltid == TAIL_TID) {
+            gtail[0] = gAt;
+            gtail[1] = gBt;
+        }
+        __syncthreads();
+
+        // ---------------------------------------------------------------- phase B: FFT, spectrum product, inverse FFT
+        Cx2 v[16];
+        {
+            int Ns = 1;
+#pragma unroll
+            for (int p = 0; p < P::NPASS - 1; ++p) {
+                if (p == 0) {
+                    pass_first_lower<LOGN>(bre, bim, v, ltid);
+                } else {
+                    pass_load<LOGN, 16>(bre, bim, v, ltid);
+                    pass_compute_w<LOGN, 16, false>(v, ltid, true, wall + TL::fwd(p));
+                }
+                __syncthreads();
+                pass_store<LOGN, 16>(bre, bim, v, ltid, Ns);
+                __syncthreads();
+                Ns *= 16;
+            }
+        }
+        {
+            Cx2 kv[16];
+            spectrum_fetch<LOGN, LAST>(kv, ltid, kfc);
+            pass_load<LOGN, LAST>(bre, bim, v, ltid);
+            pass_compute_w<LOGN, LAST, false>(v, ltid, true, wall + TL::fwd_last());
+            spectrum_multiply_and_first_inverse_v<LOGN, LAST>(v, ltid, kv, tail ? gtail[0] : 0.f, tail ? gtail[1] : 0.f);
+        }
+        __syncthreads();
+        pass_store<LOGN, LAST>(bre, bim, v, ltid, 1);
+        __syncthreads();
+        {
+            int Ns = LAST;
+#pragma unroll
+            for (int p = 1; p < P::NPASS - 1; ++p) {
+                pass_load<LOGN, 16>(bre, bim, v, ltid);
+                pass_compute_w<LOGN, 16, true>(v, ltid, true, wall + TL::inv(p));
+                __syncthreads();
+                pass_store<LOGN, 16>(bre, bim, v, ltid, Ns);
+                __syncthreads();
+                Ns *= 16;
+            }
+        }
+        // ---- requests that have the last pass to land: x0 rows of this unit, gate rows of this workgroup's next unit
+        Raw<T> x0r[CH][2];
+        T x0tail[2];
+        const T* zA = z + (size_t)bA * D3 * Lp;
+        const T* zB = z + (size_t)(hasB ? bB : bA) * D3 * Lp;
+        if constexpr (!IDS) {
+#pragma unroll
+            for (int rd = 0; rd < 2; ++rd) {
+                const T* row = (rd == 0 ? zA : zB) + (size_t)c * Lp;
+#pragma unroll
+                for (int ch = 0; ch < CH; ++ch) {
+                    const int t0 = 8 * (ltid + ch * NT);
+                    raw_load(x0r[ch][rd], row, t0, t0 < L);
+                }
+                x0tail[rd] = row[(tail && ltid == TAIL_TID) ? HALF : 0];
+            }
+        }
+        ConvGateRaw<T, IDS> nxt;
+        {
+            const int un = u + stride;
+            request_gate(un < n_mine ? un : u, nxt, ltid);       // clamped: unconditional loads
+        }
+        pass_load<LOGN, 16>(bre, bim, v, ltid);
+        pass_compute_last_inverse_lower<LOGN>(v, ltid, wall + TL::inv(P::NPASS - 1));
+        __syncthreads();
+        pass_store_lower<LOGN>(bre, bim, v, ltid, tail);
+        __syncthreads();
+
+        // ---------------------------------------------------------------- phase C: x0 through the short filter, gate, store
+        T* yA = y + ((size_t)bA * D + c) * Lp;
+        T* yB = y + ((size_t)(hasB ? bB : bA) * D + c) * Lp;
+#pragma unroll
+        for (int ch = 0; ch < CH; ++ch) {
+            const int t0 = 8 * (ltid + ch * NT);
+            const bool valid = t0 < L;
+            float xa[10], xb[10], x0a[8], x0b[8];
+            if constexpr (IDS) {
+                float xa3[3][10], xb3[3][10];
+                ids_decode<true>(cur.idd[ch][0], cur.idp[ch][0], t0, valid, zt, xa3);
+                ids_decode<true>(cur.idd[ch][1], cur.idp[ch][1], t0, valid && hasB, zt, xb3);
+#pragma unroll
+                for (int e = 0; e < 10; ++e) xa[e] = xa3[0][e], xb[e] = xb3[0][e];
+            } else {
+                raw_decode(x0r[ch][0], t0, valid, xa);
+                raw_decode(x0r[ch][1], t0, valid && hasB, xb);
+            }
+            fir3_pair(xa, xb, sw[0][0], sw[0][1], sw[0][2], sb[0], x0a, x0b);
+            if (t0 < Lp) {
+                float oA[8], oB[8];
+                lds_load8(bre + pad_index(t0), oA);
+                lds_load8(bim + pad_index(t0), oB);
+                if (tail && t0 == 0) {  // remove the one wrapped product k[L-1]*g[L-1] from output 0
+                    const float kl = ktime[(size_t)(L - 1) * D + c];
+                    oA[0] -= kl * gtail[0];
+                    oB[0] -= kl * gtail[1];
+                }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const bool ok = t0 + e < L;
+                    oA[e] = ok ? oA[e] * x0a[e] : 0.f;
+                    oB[e] = ok ? oB[e] * x0b[e] : 0.f;
+                }
+                store8<T>(yA + t0, oA);
+                if (hasB) store8<T>(yB + t0, oB);
+            }
+            if (ch == CH - 1 && tail && ltid == TAIL_TID) {     // token HALF: x0 from x[8], x[9] of this chunk and z[HALF]
+                const float za = IDS ? zt[cur.idt[0] & 15] : to_float(x0tail[0]);
+                const float zb = IDS ? zt[cur.idt[1] & 15] : to_float(x0tail[1]);
+                const float x0At = sb[0] + sw[0][0] * xa[8] + sw[0][1] * xa[9] + sw[0][2] * za;
+                const float x0Bt = sb[0] + sw[0][0] * xb[8] + sw[0][1] * xb[9] + sw[0][2] * zb;
+                yA[HALF] = from_float<T>(bre[pad_index(HALF)] * x0At);
+                if (hasB) yB[HALF] = from_float<T>(bim[pad_index(HALF)] * x0Bt);
+            }
+        }
+        cur = nxt;
+        __syncthreads();                                  // the buffer (and zt / gtail) are rewritten by the next unit
+    }
+}
+
+template <typename T, bool IDS>
+static void launch_conv_pers_inst(const void* z, void* y, const float2* kf, const float2* tw, const float* ktime,
+                                  const float* short_w, const float* short_b, int B, int L, int Lp, const unsigned char* ids8,
+                                  const float* ztab, hipStream_t st) {
+    using P = Plan<14>;
+    constexpr size_t lds = (size_t)2 * padded_size(P::N) * sizeof(float) + 256;
+    auto kern = hyena_conv_pers_kernel<T, IDS>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_done = true;
+    }
+    static const int cus = [] {
+        int dev = 0, n = 256;
+        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+        return n > 0 ? n : 256;
+    }();
+    const int n_units = ((B + 1) / 2) * D;
+    dim3 grid(n_units < cus ? n_units : cus), block(P::NT);
+    hipLaunchKernelGGL(kern, grid, block, lds, st, reinterpret_cast<const T*>(z), reinterpret_cast<T*>(y), kf, tw, ktime, short_w,
+                       short_b, B, L, Lp, ids8, ztab);
+}
+
 // ================================================================================================ 8k reads: split transform
 // Reads of 4098 .. 8193 tokens need the 16384-point transform, whose LDS buffer (147 KiB) leaves ONE workgroup per CU, and in
 // hyena_conv_kernel all eight waves move through the passes together: the LDS-bound exchange (store) phases and the
@@ -902,7 +1219,10 @@ __global__ __launch_bounds__(Plan<14>::NT) void hyena_conv_seg_kernel(
     float* bim = bre + padded_size(N);                       // read B            = imaginary parts
 
     const int tid = threadIdx.x;
-    const int c = blockIdx.y, pair = blockIdx.x;
+    // XCD-aware order (see hyena_conv_pers_kernel): all read pairs of a channel on one XCD, so that its S partition spectra
+    // (S x 128 KB, read (S+1)S/2 times per unit) are served by that XCD's L2 instead of being fetched by all eight
+    const int pairs = (B + 1) / 2, xcd = blockIdx.x % XCDS, slot = blockIdx.x / XCDS;
+    const int c = XCDS * (slot / pairs) + xcd, pair = slot % pairs;
     const int bA = 2 * pair, bB = 2 * pair + 1;
     const bool hasB = bB < B;
     const T* zA = z + (size_t)bA * D3 * Lp;
@@ -961,12 +1281,13 @@ __global__ __launch_bounds__(Plan<14>::NT) void hyena_conv_seg_kernel(
         for (int i = 0; i < TL::TOTAL; ++i)                                                  // same for w^r trees
             asm volatile("" : "+v"(wall[i].re.x), "+v"(wall[i].re.y), "+v"(wall[i].im.x), "+v"(wall[i].im.y));
         // ---- phase A: segment m of the gated signal into the lower half, zeros above
-        float x0A[CH][8], x0B[CH][8];
+        // (x0 only gates the output: its rows are requested before the last inverse pass and filtered in phase C -- held from
+        //  here, its 32 registers were the bulk of 80-135 spilled registers per thread, i.e. scratch traffic per segment)
+        uint2 idd[CH][2];                                    // IDS: 8 token ids of the chunk
+        unsigned short idp[CH][2];                           //      and the two before it
         if constexpr (!std::is_same<T, float>::value) {
-            // all loads of the segment up front, no control flow in between (see Raw<T>): six serialized HBM round trips otherwise
+            // all loads of the segment up front, no control flow in between (see Raw<T>): four serialized HBM round trips otherwise
             Raw<T> raw[IDS ? 1 : CH][2][IDS ? 1 : 3];
-            uint2 idd[CH][2];                                // IDS: 8 token ids of the chunk
-            unsigned short idp[CH][2];                       //      and the two before it
             if constexpr (IDS) {
 #pragma unroll
                 for (int rd = 0; rd < 2; ++rd)
@@ -981,7 +1302,7 @@ __global__ __launch_bounds__(Plan<14>::NT) void hyena_conv_seg_kernel(
 #pragma unroll
                 for (int rd = 0; rd < 2; ++rd)
 #pragma unroll
-                    for (int a3 = 0; a3 < 3; ++a3) {
+                    for (int a3 = 1; a3 < 3; ++a3) {
                         const T* row = (rd == 0 ? zA : zB) + (size_t)(a3 * D + c) * Lp;
 #pragma unroll
                         for (int ch = 0; ch < CH; ++ch) {
@@ -1000,21 +1321,19 @@ __global__ __launch_bounds__(Plan<14>::NT) void hyena_conv_seg_kernel(
                     ids_decode<true>(idd[ch][1], idp[ch][1], t0, valid && hasB, ztm, xb);
                 } else {
 #pragma unroll
-                    for (int a3 = 0; a3 < 3; ++a3) {
+                    for (int a3 = 1; a3 < 3; ++a3) {
                         raw_decode(raw[ch][0][a3], t0, valid, xa[a3]);
                         raw_decode(raw[ch][1][a3], t0, valid && hasB, xb[a3]);
                     }
                 }
-                fir3(xa[0], sw[0][0], sw[0][1], sw[0][2], sb[0], x0A[ch]);
-                fir3(xa[1], sw[1][0], sw[1][1], sw[1][2], sb[1], x1);
-                fir3(xa[2], sw[2][0], sw[2][1], sw[2][2], sb[2], v);
+                float x1b[8], vb[8];
+                fir3_pair(xa[1], xb[1], sw[1][0], sw[1][1], sw[1][2], sb[1], x1, x1b);
+                fir3_pair(xa[2], xb[2], sw[2][0], sw[2][1], sw[2][2], sb[2], v, vb);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) gA[e] = (t0 + e < L) ? v[e] * x1[e] : 0.f;
-                fir3(xb[0], sw[0][0], sw[0][1], sw[0][2], sb[0], x0B[ch]);
-                fir3(xb[1], sw[1][0], sw[1][1], sw[1][2], sb[1], x1);
-                fir3(xb[2], sw[2][0], sw[2][1], sw[2][2], sb[2], v);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) gB[e] = (hasB && t0 + e < L) ? v[e] * x1[e] : 0.f;
+                for (int e = 0; e < 8; ++e) {
+                    gA[e] = (t0 + e < L) ? v[e] * x1[e] : 0.f;
+                    gB[e] = (hasB && t0 + e < L) ? vb[e] * x1b[e] : 0.f;
+                }
                 lds_store8(bre + pad_index(tl), gA);
                 lds_store8(bim + pad_index(tl), gB);
             }
@@ -1025,24 +1344,22 @@ __global__ __launch_bounds__(Plan<14>::NT) void hyena_conv_seg_kernel(
                 float gA[8], gB[8];
                 if (t0 < L) {
                     float x1[8], v[8];
-                    short_filter8<T>(zA + (size_t)(0 * D + c) * Lp, t0, sw[0][0], sw[0][1], sw[0][2], sb[0], x0A[ch]);
                     short_filter8<T>(zA + (size_t)(1 * D + c) * Lp, t0, sw[1][0], sw[1][1], sw[1][2], sb[1], x1);
                     short_filter8<T>(zA + (size_t)(2 * D + c) * Lp, t0, sw[2][0], sw[2][1], sw[2][2], sb[2], v);
     #pragma unroll
                     for (int e = 0; e < 8; ++e) gA[e] = (t0 + e < L) ? v[e] * x1[e] : 0.f;
                     if (hasB) {
-                        short_filter8<T>(zB + (size_t)(0 * D + c) * Lp, t0, sw[0][0], sw[0][1], sw[0][2], sb[0], x0B[ch]);
                         short_filter8<T>(zB + (size_t)(1 * D + c) * Lp, t0, sw[1][0], sw[1][1], sw[1][2], sb[1], x1);
                         short_filter8<T>(zB + (size_t)(2 * D + c) * Lp, t0, sw[2][0], sw[2][1], sw[2][2], sb[2], v);
     #pragma unroll
                         for (int e = 0; e < 8; ++e) gB[e] = (t0 + e < L) ? v[e] * x1[e] : 0.f;
                     } else {
     #pragma unroll
-                        for (int e = 0; e < 8; ++e) gB[e] = 0.f, x0B[ch][e] = 0.f;
+                        for (int e = 0; e < 8; ++e) gB[e] = 0.f;
                     }
                 } else {
     #pragma unroll
-                    for (int e = 0; e < 8; ++e) gA[e] = 0.f, gB[e] = 0.f, x0A[ch][e] = 0.f, x0B[ch][e] = 0.f;
+                    for (int e = 0; e < 8; ++e) gA[e] = 0.f, gB[e] = 0.f;
                 }
                 lds_store8(bre + pad_index(tl), gA);
                 lds_store8(bim + pad_index(tl), gB);
@@ -1087,32 +1404,42 @@ __global__ __launch_bounds__(Plan<14>::NT) void hyena_conv_seg_kernel(
         // ---- spectrum bookkeeping: keep G_m, form P_m = sum_i G_i K_{m-i}, first inverse butterfly
         using G = PassGeom<LOGN, LAST>;
         static_assert(G::NP * LAST == 16 && G::IT == 2 * G::NP, "16 full pairs per thread");
+        // A thread's 32 bins are ltid + 512 k, k = 0 .. 31 (pair e: k = 2p + 8r and 2p + 1 + 8r, p = e / LAST, r = e % LAST).
+        // Addressed as (uniform base + 512 k) + one 32-bit lane offset: scalar base arithmetic, ONE address register -- as
+        // 32 per-bin 64-bit addresses the compiler kept them live around the whole product loop (80-135 spilled registers).
+        static_assert(NT == 512 && (N / LAST) % NT == 0, "bin = ltid + 512 k");
+        const unsigned loff = (unsigned)ltid * (unsigned)sizeof(float2);
+        auto bin = [&](const float2* ubase, int kk) -> const float2& {
+            return *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(ubase + NT * kk) + loff);
+        };
+        auto bin_w = [&](float2* ubase, int kk) -> float2& {
+            return *reinterpret_cast<float2*>(reinterpret_cast<char*>(ubase + NT * kk) + loff);
+        };
+        constexpr int KR = N / LAST / NT;                    // k step per radix input r
 #pragma unroll
         for (int e = 0; e < 16; ++e) {            // keep G_m, start P_m = G_m K_0
-            const int ba = stockham_in<LOGN, LAST>(G::jba(ltid, e / LAST), e % LAST);
-            const int bb = stockham_in<LOGN, LAST>(G::jbb(ltid, e / LAST), e % LAST);
+            const int ka = 2 * (e / LAST) + KR * (e % LAST), kb = ka + 1;
             if (m + 1 < S) {                      // (uniform) the last segment's spectrum is never read again
-                gs[(size_t)m * N + ba] = lane_a(v[e]);
-                gs[(size_t)m * N + bb] = lane_b(v[e]);
+                bin_w(gs + (size_t)m * N, ka) = lane_a(v[e]);
+                bin_w(gs + (size_t)m * N, kb) = lane_b(v[e]);
             }
-            v[e] = Cx2::mul(v[e], pack2(kfc[ba], kfc[bb]));
+            v[e] = Cx2::mul(v[e], pack2(bin(kfc, ka), bin(kfc, kb)));
         }
 #pragma unroll 1
         for (int i = 0; i < m; ++i) {             // P_m += G_i K_{m-i}; each thread re-reads only bins it wrote
             const float2* gi = gs + (size_t)i * N;
             const float2* kj = kfc + (size_t)(m - i) * N;
 #pragma unroll
-            for (int e0 = 0; e0 < 16; e0 += 4) {
-                Cx2 a[4], b[4];
+            for (int e0 = 0; e0 < 16; e0 += 8) {
+                Cx2 a[8], b[8];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int ba = stockham_in<LOGN, LAST>(G::jba(ltid, (e0 + e) / LAST), (e0 + e) % LAST);
-                    const int bb = stockham_in<LOGN, LAST>(G::jbb(ltid, (e0 + e) / LAST), (e0 + e) % LAST);
-                    a[e] = pack2(gi[ba], gi[bb]);
-                    b[e] = pack2(kj[ba], kj[bb]);
+                for (int e = 0; e < 8; ++e) {
+                    const int ka = 2 * ((e0 + e) / LAST) + KR * ((e0 + e) % LAST), kb = ka + 1;
+                    a[e] = pack2(bin(gi, ka), bin(gi, kb));
+                    b[e] = pack2(bin(kj, ka), bin(kj, kb));
                 }
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e0 + e] = Cx2::add(v[e0 + e], Cx2::mul(a[e], b[e]));
+                for (int e = 0; e < 8; ++e) v[e0 + e] = Cx2::add(v[e0 + e], Cx2::mul(a[e], b[e]));
             }
         }
 #pragma unroll
@@ -1120,10 +1447,24 @@ __global__ __launch_bounds__(Plan<14>::NT) void hyena_conv_seg_kernel(
         __syncthreads();
         pass_store<LOGN, LAST>(bre, bim, v, ltid, 1);
         __syncthreads();
+        Raw<T> x0r[CH][2];
         {
             int Ns = LAST;
 #pragma unroll
             for (int p = 1; p <= P::NPASS - 1; ++p) {
+                if (p == P::NPASS - 1) {   // x0 rows of this segment: the last pass to land
+                    if constexpr (!IDS && !std::is_same<T, float>::value) {
+#pragma unroll
+                        for (int rd = 0; rd < 2; ++rd) {
+                            const T* row = (rd == 0 ? zA : zB) + (size_t)c * Lp;
+#pragma unroll
+                            for (int ch = 0; ch < CH; ++ch) {
+                                const int t0 = seg0 + 8 * (ltid + ch * NT);
+                                raw_load(x0r[ch][rd], row, t0, t0 < L);
+                            }
+                        }
+                    }
+                }
                 pass_load<LOGN, 16>(bre, bim, v, ltid);
                 if (p == P::NPASS - 1) {   // only the lower half of the outputs is used: half-output butterfly, half the stores
                     pass_compute_last_inverse_lower<LOGN>(v, ltid, wall + TL::inv(p));
@@ -1142,14 +1483,37 @@ __global__ __launch_bounds__(Plan<14>::NT) void hyena_conv_seg_kernel(
 #pragma unroll
         for (int ch = 0; ch < CH; ++ch) {
             const int tl = 8 * (ltid + ch * NT), t0 = seg0 + tl;
+            const bool valid = t0 < L;
+            float x0A[8], x0B[8];
+            if constexpr (std::is_same<T, float>::value) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) x0A[e] = 0.f, x0B[e] = 0.f;
+                if (valid) {
+                    short_filter8<T>(zA + (size_t)c * Lp, t0, sw[0][0], sw[0][1], sw[0][2], sb[0], x0A);
+                    if (hasB) short_filter8<T>(zB + (size_t)c * Lp, t0, sw[0][0], sw[0][1], sw[0][2], sb[0], x0B);
+                }
+            } else {
+                float xa[10], xb[10];
+                if constexpr (IDS) {
+                    float xa3[3][10], xb3[3][10];
+                    ids_decode<true>(idd[ch][0], idp[ch][0], t0, valid, ztm, xa3);
+                    ids_decode<true>(idd[ch][1], idp[ch][1], t0, valid && hasB, ztm, xb3);
+#pragma unroll
+                    for (int e = 0; e < 10; ++e) xa[e] = xa3[0][e], xb[e] = xb3[0][e];
+                } else {
+                    raw_decode(x0r[ch][0], t0, valid, xa);
+                    raw_decode(x0r[ch][1], t0, valid && hasB, xb);
+                }
+                fir3_pair(xa, xb, sw[0][0], sw[0][1], sw[0][2], sb[0], x0A, x0B);
+            }
             float oA[8], oB[8];
             lds_load8(bre + pad_index(tl), oA);
             lds_load8(bim + pad_index(tl), oB);
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 const bool ok = t0 + e < L;
-                oA[e] = ok ? oA[e] * x0A[ch][e] : 0.f;
-                oB[e] = ok ? oB[e] * x0B[ch][e] : 0.f;
+                oA[e] = ok ? oA[e] * x0A[e] : 0.f;
+                oB[e] = ok ? oB[e] * x0B[e] : 0.f;
             }
             if (t0 < Lp) {
                 store8<T>(yA + t0, oA);
@@ -1207,7 +1571,8 @@ static void launch_conv_seg_inst(const void* z, void* y, const float2* kf, int K
                                   (int)lds);
         attr_done = true;
     }
-    dim3 grid((B + 1) / 2, D), block(P::NT);
+    static_assert(D % XCDS == 0, "channels split evenly over the XCDs");
+    dim3 grid(((B + 1) / 2) * D), block(P::NT);
     hipLaunchKernelGGL(kern, grid, block, lds, st, reinterpret_cast<const T*>(z), reinterpret_cast<T*>(y), kf, KS, tw,
                        short_w, short_b, gscratch, B, L, Lp, S, krev, krev_stride, ids8, ztab);
 }
@@ -1382,6 +1747,16 @@ static void launch_conv_p(int prec, const void* z, void* y, const float2* kf, co
 void launch_hyena_conv(int prec, const void* z, void* y, const float2* kf, const float2* tw, const float* ktime,
                        const float* short_w, const float* short_b, int B, int L, int Lp, int logn,
                        const unsigned char* ids8, const float* ztab, hipStream_t st) {
+    // 16384-point class, 16-bit activations: persistent workgroups with next-unit requests (CLM_CONV_ONESHOT=1: one workgroup
+    // per unit, for A/B runs and the developer stamps)
+    static const bool oneshot = (std::getenv("CLM_CONV_ONESHOT") && std::getenv("CLM_CONV_ONESHOT")[0] == '1') ||
+                                (std::getenv("CLM_STAMP") && std::getenv("CLM_STAMP")[0] == '1');
+    // (block 0's id-decoding variant keeps the one-shot kernel: with the id words held across the transform it spills)
+    if (logn == 14 && prec != PREC_F32 && !oneshot && !(ids8 != nullptr && ztab != nullptr)) {
+        if (prec == PREC_BF16) launch_conv_pers_inst<bf16_t, false>(z, y, kf, tw, ktime, short_w, short_b, B, L, Lp, nullptr, nullptr, st);
+        else launch_conv_pers_inst<f16_t, false>(z, y, kf, tw, ktime, short_w, short_b, B, L, Lp, nullptr, nullptr, st);
+        return;
+    }
 #define CLM_CONV_CASE(n) \
     case n: launch_conv_p<n>(prec, z, y, kf, tw, ktime, short_w, short_b, B, L, Lp, ids8, ztab, st); break;
     switch (logn) {
