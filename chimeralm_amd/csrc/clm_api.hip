@@ -357,15 +357,13 @@ int ensure_filters(clm_handle* h, int L, hipStream_t st, FilterSet** out, const 
                     HIPCHK(h, hipMalloc((void**)&f.kf2[i], (size_t)D * N * sizeof(float2)));
                     launch_spectrum_split(f.kf[i], f.kf2[i], logn, st);
                 }
-            } else {   // kf [256][KS][N]: one launch per partition writes the strided slice through a temporary
+            } else {   // kf [256][KS][N], lane-packed for the segmented kernel: one launch per partition, through a temporary
                 float2* tmp = nullptr;
                 HIPCHK(h, hipMalloc((void**)&tmp, (size_t)D * N * sizeof(float2)));
                 for (int j = 0; j < f.KS; ++j) {
                     launch_filter_spectrum(f.ktime[i], W(h, p + "bias"), tmp, scratch, f.Lf, logn, j * SEG_LEN, SEG_LEN,
                                            (j - 1) * SEG_LEN, st);
-                    HIPCHK(h, hipMemcpy2DAsync(f.kf[i] + (size_t)j * N, (size_t)f.KS * N * sizeof(float2), tmp,
-                                               (size_t)N * sizeof(float2), (size_t)N * sizeof(float2), D,
-                                               hipMemcpyDeviceToDevice, st));
+                    launch_spectrum_lanepack(tmp, f.kf[i], f.KS, j, st);
                 }
                 HIPCHK(h, hipStreamSynchronize(st));
                 HIPCHK(h, hipFree(tmp));

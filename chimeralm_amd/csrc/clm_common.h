@@ -234,6 +234,9 @@ void launch_hyena_conv(int prec, const void* z, void* y, const float2* kf, const
 // 8k reads (4098 .. 8193 tokens): the 16384-point convolution as two 8192-point problems (even / odd bins), two workgroups per CU.
 // kf2 [256][2][8192] from launch_spectrum_split(kf of the 16384-point class); twM = the 8192-point twiddle table, twN the 16384 one
 void launch_spectrum_split(const float2* kf, float2* kf2, int logn, hipStream_t st);
+// partition spectrum j (natural order, src [256][16384]) -> slice j of the lane-packed [256][KS][16][512] quads of the
+// segmented kernel (hyena_conv_seg_kernel)
+void launch_spectrum_lanepack(const float2* src, float2* dst, int KS, int j, hipStream_t st);
 void launch_hyena_conv_dif(int prec, const void* z, void* y, const float2* kf2, const float2* twM, const float2* twN,
                            const float* ktime, const float* short_w, const float* short_b, int B, int L, int Lp,
                            const unsigned char* ids8, const float* ztab, hipStream_t st);

@@ -1187,6 +1187,35 @@ void launch_hyena_conv_dif(int prec, const void* z, void* y, const float2* kf2, 
     }
 }
 
+typedef unsigned v4u32 __attribute__((vector_size(16)));   // the type the buffer builtins take and return
+// buffer descriptor over [p, p + bytes): every input wave-uniform, made provably so with readfirstlane
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, size_t bytes) {
+    const unsigned long long a = reinterpret_cast<unsigned long long>(p);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+    void* q = reinterpret_cast<void*>(((unsigned long long)hi << 32) | lo);
+    return __builtin_amdgcn_make_buffer_rsrc(q, 0, __builtin_amdgcn_readfirstlane((int)bytes), 0x00020000);
+}
+
+// Partition spectrum j of every channel from natural bin order (src [256][N]) into the lane-packed layout the segmented kernel
+// reads (dst [256][KS][16][512] quads): quad (e, t) = (re, re, im, im) of bins t + 512 ka and t + 512 (ka + 1),
+// ka = 2 (e / 4) + 8 (e % 4) -- the two butterflies thread t holds in pair e of the last forward pass (radix 4, 512 threads).
+__global__ __launch_bounds__(512) void spectrum_lanepack_kernel(const float2* __restrict__ src, float4* __restrict__ dst, int KS, int j) {
+    constexpr int N = 16384, NT = 512, LAST = Plan<14>::LAST;
+    static_assert(LAST == 4 && Plan<14>::NT == NT, "pair geometry of the 16384-point plan");
+    const int c = blockIdx.x, t = threadIdx.x;
+    const float2* s = src + (size_t)c * N;
+    float4* d = dst + ((size_t)c * KS + j) * (N / 2);
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const int ka = 2 * (e / LAST) + (N / LAST / NT) * (e % LAST);
+        const float2 a = s[t + NT * ka], b = s[t + NT * (ka + 1)];
+        d[e * NT + t] = make_float4(a.x, b.x, a.y, b.y);
+    }
+}
+void launch_spectrum_lanepack(const float2* src, float2* dst, int KS, int j, hipStream_t st) {
+    hipLaunchKernelGGL(spectrum_lanepack_kernel, dim3(D), dim3(512), 0, st, src, reinterpret_cast<float4*>(dst), KS, j);
+}
+
 // ================================================================================================ long reads
 // L > 8193 tokens does not fit one LDS-resident transform.  Uniformly partitioned convolution over S segments of Ls = 8192:
 //     y[m*Ls + t] = IFFT( sum_{i <= m} FFT(g_i) . K'_{m-i} )[t],   0 <= t < Ls
@@ -1204,7 +1233,7 @@ void launch_hyena_conv_dif(int prec, const void* z, void* y, const float2* kf2, 
 // IDS (16-bit modes, block 0): x0 | x1 | v looked up in ztab by token id, as in hyena_conv_kernel.
 template <typename T, bool LONE, bool IDS>
 __global__ __launch_bounds__(Plan<14>::NT) void hyena_conv_seg_kernel(
-    const T* __restrict__ z, T* __restrict__ y, const float2* __restrict__ kf /*[256][KS][N], KS >= S partitions stored*/,
+    const T* __restrict__ z, T* __restrict__ y, const float2* __restrict__ kf /*[256][KS][N] lane-packed (launch_spectrum_lanepack), KS >= S partitions stored*/,
     int KS, const float2* __restrict__ tw, const float* __restrict__ short_w, const float* __restrict__ short_b,
     float2* __restrict__ gscratch /*[pairs][256][S][N]*/, int B, int L, int Lp, int S,
     const float* __restrict__ krev /*[256][krev_stride], LONE only*/, int krev_stride,
@@ -1234,22 +1263,6 @@ __global__ __launch_bounds__(Plan<14>::NT) void hyena_conv_seg_kernel(
     const float* kr = LONE ? krev + (size_t)c * krev_stride : nullptr;
     float dotA = 0.f, dotB = 0.f;
 
-    Cx2 wall[TL::TOTAL];
-    {
-        int ns = 16;
-#pragma unroll
-        for (int p = 1; p <= P::NPASS - 2; ++p) {
-            pass_twiddles<LOGN, 16, false>(wall + TL::fwd(p), tid, ns, tw);
-            ns *= 16;
-        }
-        pass_twiddles<LOGN, LAST, false>(wall + TL::fwd_last(), tid, ns, tw);
-        ns = LAST;
-#pragma unroll
-        for (int p = 1; p <= P::NPASS - 1; ++p) {
-            pass_twiddles<LOGN, 16, true>(wall + TL::inv(p), tid, ns, tw);
-            ns *= 16;
-        }
-    }
     float sw[3][3], sb[3];
 #pragma unroll
     for (int q = 0; q < 3; ++q) {
@@ -1265,6 +1278,9 @@ __global__ __launch_bounds__(Plan<14>::NT) void hyena_conv_seg_kernel(
         __syncthreads();
     }
 
+    // buffer descriptors of this unit's spectrum scratch and this channel's partition spectra (uniform: blockIdx + arguments)
+    const __amdgpu_buffer_rsrc_t g_rs = make_rsrc(gs, (size_t)S * N * sizeof(float2));
+    const __amdgpu_buffer_rsrc_t k_rs = make_rsrc(kfc, (size_t)KS * N * sizeof(float2));
 #pragma unroll 1
     for (int m = 0; m < S; ++m) {
         const int seg0 = m * SEG_LEN;
@@ -1277,9 +1293,6 @@ __global__ __launch_bounds__(Plan<14>::NT) void hyena_conv_seg_kernel(
         const float* ztm = zt + lz;
         const unsigned char* irAm = IDS ? irA + lz : nullptr;
         const unsigned char* irBm = IDS ? irB + lz : nullptr;
-#pragma unroll
-        for (int i = 0; i < TL::TOTAL; ++i)                                                  // same for w^r trees
-            asm volatile("" : "+v"(wall[i].re.x), "+v"(wall[i].re.y), "+v"(wall[i].im.x), "+v"(wall[i].im.y));
         // ---- phase A: segment m of the gated signal into the lower half, zeros above
         // (x0 only gates the output: its rows are requested before the last inverse pass and filtered in phase C -- held from
         //  here, its 32 registers were the bulk of 80-135 spilled registers per thread, i.e. scratch traffic per segment)
@@ -1365,6 +1378,19 @@ __global__ __launch_bounds__(Plan<14>::NT) void hyena_conv_seg_kernel(
                 lds_store8(bim + pad_index(tl), gB);
             }
         }
+        // Pass twiddles: NOT held across the segment (88 registers that the spectrum product loop needs for its load buffers):
+        // the forward ones are requested once phase A has used its row registers (the last token's dot product and the barrier
+        // cover the L2 round trip); the inverse ones after the product loop.
+        Cx2 wall[TL::TOTAL];
+        {
+            int ns = 16;
+#pragma unroll
+            for (int p = 1; p <= P::NPASS - 2; ++p) {
+                pass_twiddles<LOGN, 16, false>(wall + TL::fwd(p), ltid, ns, tw);
+                ns *= 16;
+            }
+            pass_twiddles<LOGN, LAST, false>(wall + TL::fwd_last(), ltid, ns, tw);
+        }
         if constexpr (LONE) {
             // this segment's share of the last output's dot product: each thread re-reads the 16 gated samples it has just
             // written (own data: no barrier needed) -- in phase A itself the 16 extra registers doubled the spills
@@ -1399,47 +1425,86 @@ __global__ __launch_bounds__(Plan<14>::NT) void hyena_conv_seg_kernel(
                 Ns *= 16;
             }
         }
-        pass_load<LOGN, LAST>(bre, bim, v, ltid);
-        pass_compute_w<LOGN, LAST, false>(v, ltid, true, wall + TL::fwd_last());
         // ---- spectrum bookkeeping: keep G_m, form P_m = sum_i G_i K_{m-i}, first inverse butterfly
         using G = PassGeom<LOGN, LAST>;
         static_assert(G::NP * LAST == 16 && G::IT == 2 * G::NP, "16 full pairs per thread");
-        // A thread's 32 bins are ltid + 512 k, k = 0 .. 31 (pair e: k = 2p + 8r and 2p + 1 + 8r, p = e / LAST, r = e % LAST).
-        // Addressed as (uniform base + 512 k) + one 32-bit lane offset: scalar base arithmetic, ONE address register -- as
-        // 32 per-bin 64-bit addresses the compiler kept them live around the whole product loop (80-135 spilled registers).
-        static_assert(NT == 512 && (N / LAST) % NT == 0, "bin = ltid + 512 k");
-        const unsigned loff = (unsigned)ltid * (unsigned)sizeof(float2);
-        auto bin = [&](const float2* ubase, int kk) -> const float2& {
-            return *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(ubase + NT * kk) + loff);
+        // A thread's 32 bins are ltid + 512 k, k = 0 .. 31; pair e (one Cx2) holds k = 2p + 8r and 2p + 1 + 8r, p = e / LAST,
+        // r = e % LAST.  Both the unit's scratch (G) and the channel's partition spectra (K', launch_spectrum_lanepack) are laid
+        // out LANE-PACKED: [segment][e][ltid] quads (re_a, re_b, im_a, im_b) = a Cx2 as the butterflies hold it -- one 16-byte
+        // load per pair, no register shuffles between a load and its use.
+        // Buffer addressing: descriptor (scalar) + ONE lane offset register + the row (segment, e) in the scalar offset.  As 32
+        // per-bin 64-bit flat addresses the compiler kept them live around the whole product loop: 80-135 spilled registers.
+        static_assert(NT == 512 && (N / LAST) % NT == 0 && sizeof(Cx2) == 16, "pair row = 512 quads");
+        const int loff = ltid * (int)sizeof(Cx2);
+        auto quad = [&](const __amdgpu_buffer_rsrc_t& rs, int seg, int e) -> Cx2 {
+            const v4u32 r = __builtin_amdgcn_raw_buffer_load_b128(rs, loff, (seg * (N / 2) + NT * e) * (int)sizeof(Cx2), 0);
+            const unsigned r0 = r[0], r1 = r[1], r2 = r[2], r3 = r[3];   // (__builtin_bit_cast straight from a vector element
+            return Cx2{make_v2(__uint_as_float(r0), __uint_as_float(r1)),       //  reads element 0 with hipcc 7.2)
+                       make_v2(__uint_as_float(r2), __uint_as_float(r3))};
         };
-        auto bin_w = [&](float2* ubase, int kk) -> float2& {
-            return *reinterpret_cast<float2*>(reinterpret_cast<char*>(ubase + NT * kk) + loff);
+        auto quad_w = [&](const __amdgpu_buffer_rsrc_t& rs, int seg, int e, Cx2 val) {
+            v4u32 r;
+            r[0] = __float_as_uint(val.re.x), r[1] = __float_as_uint(val.re.y);
+            r[2] = __float_as_uint(val.im.x), r[3] = __float_as_uint(val.im.y);
+            __builtin_amdgcn_raw_buffer_store_b128(r, rs, loff, (seg * (N / 2) + NT * e) * (int)sizeof(Cx2), 0);
         };
-        constexpr int KR = N / LAST / NT;                    // k step per radix input r
+        Cx2 kv[16];                                // K'_0: requested ahead of the last forward pass
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {            // keep G_m, start P_m = G_m K_0
-            const int ka = 2 * (e / LAST) + KR * (e % LAST), kb = ka + 1;
-            if (m + 1 < S) {                      // (uniform) the last segment's spectrum is never read again
-                bin_w(gs + (size_t)m * N, ka) = lane_a(v[e]);
-                bin_w(gs + (size_t)m * N, kb) = lane_b(v[e]);
+        for (int e = 0; e < 16; ++e) kv[e] = quad(k_rs, 0, e);
+        pass_load<LOGN, LAST>(bre, bim, v, ltid);
+        pass_compute_w<LOGN, LAST, false>(v, ltid, true, wall + TL::fwd_last());
+        // P_m = G_m K'_0 + sum_{i < m} G_i K'_{m-i}, a quarter of the thread's pairs (4 of G, 4 of K') per step, the loads of a
+        // step issued one step ahead of its multiply-adds (two 32-register buffers; in-order return: vmcnt(8)).
+        // sched_barrier + the empty asm on the accumulators pin that order (the asm keeps the IR passes from sinking the
+        // multiply-adds to the end of the body, the barrier keeps the machine scheduler from gathering a whole iteration's
+        // loads at the top: either way 128 registers of buffers and spills).
+        auto fetch = [&](Cx2* ga, Cx2* kb, int i, int qtr) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                ga[e] = quad(g_rs, i, 4 * qtr + e);
+                kb[e] = quad(k_rs, m - i, 4 * qtr + e);
             }
-            v[e] = Cx2::mul(v[e], pack2(bin(kfc, ka), bin(kfc, kb)));
+        };
+        auto accumulate = [&](int qtr, const Cx2* ga, const Cx2* kb) {
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                Cx2& acc = v[4 * qtr + e];
+                acc = Cx2::add(acc, Cx2::mul(ga[e], kb[e]));
+                asm volatile("" : "+v"(acc.re), "+v"(acc.im));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        Cx2 a0[4], b0[4];
+        if (m > 0) fetch(a0, b0, 0, 0);
+        if (m + 1 < S) {                          // keep G_m (uniform branch; the last segment's spectrum is never read again)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) quad_w(g_rs, m, e, v[e]);
         }
+#pragma unroll
+        for (int e = 0; e < 16; ++e) v[e] = Cx2::mul(v[e], kv[e]);   // P_m = G_m K'_0
+        // (each thread re-reads only quads it wrote itself: no fence.  The last step is peeled: with the request for step i + 1
+        //  under a condition, the wait counts at the join are those of the path WITHOUT it -- every step then drains to vmcnt(0))
+        auto step = [&](int i, auto next) {
+            Cx2 a1[4], b1[4];
+            fetch(a1, b1, i, 1);
+            accumulate(0, a0, b0);
+            fetch(a0, b0, i, 2);
+            accumulate(1, a1, b1);
+            fetch(a1, b1, i, 3);
+            accumulate(2, a0, b0);
+            if constexpr (decltype(next)::value) fetch(a0, b0, i + 1, 0);
+            accumulate(3, a1, b1);
+        };
 #pragma unroll 1
-        for (int i = 0; i < m; ++i) {             // P_m += G_i K_{m-i}; each thread re-reads only bins it wrote
-            const float2* gi = gs + (size_t)i * N;
-            const float2* kj = kfc + (size_t)(m - i) * N;
+        for (int i = 0; i + 1 < m; ++i) step(i, std::true_type{});
+        if (m > 0) step(m - 1, std::false_type{});
+        {
+            int ns = LAST;
 #pragma unroll
-            for (int e0 = 0; e0 < 16; e0 += 8) {
-                Cx2 a[8], b[8];
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const int ka = 2 * ((e0 + e) / LAST) + KR * ((e0 + e) % LAST), kb = ka + 1;
-                    a[e] = pack2(bin(gi, ka), bin(gi, kb));
-                    b[e] = pack2(bin(kj, ka), bin(kj, kb));
-                }
-#pragma unroll
-                for (int e = 0; e < 8; ++e) v[e0 + e] = Cx2::add(v[e0 + e], Cx2::mul(a[e], b[e]));
+            for (int p = 1; p <= P::NPASS - 1; ++p) {
+                pass_twiddles<LOGN, 16, true>(wall + TL::inv(p), ltid, ns, tw);
+                ns *= 16;
             }
         }
 #pragma unroll
