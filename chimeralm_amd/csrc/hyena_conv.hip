@@ -302,7 +302,8 @@ __device__ __forceinline__ void raw_decode(const Raw<T>& r, int t0, bool valid, 
 // IDS source: x[a3][0..9] = table row a3 of the ten token ids t0-2 .. t0+7 (zero outside the read)
 // SELECT: load every entry and select afterwards (ids are always inside the 16-row table).  The segmented kernel needs that
 // form: there hipcc turns the conditional loads into one divergent branch per element (1,600 spilled registers).
-template <bool SELECT = false>
+// ROWS: bit a3 set = row a3 wanted (the others are left untouched)
+template <bool SELECT = false, int ROWS = 7>
 __device__ __forceinline__ void ids_decode(uint2 d, unsigned short p, int t0, bool valid, const float* zt, float (*x)[10]) {
     const unsigned w[3] = {p, d.x, d.y};
 #pragma unroll
@@ -312,6 +313,7 @@ __device__ __forceinline__ void ids_decode(uint2 d, unsigned short p, int t0, bo
         const bool ok = j < 2 ? (valid && t0 > 0) : valid;
 #pragma unroll
         for (int a3 = 0; a3 < 3; ++a3) {
+            if (!((ROWS >> a3) & 1)) continue;
             if constexpr (SELECT) {
                 const float val = zt[a3 * 16 + id];
                 x[a3][j] = ok ? val : 0.f;
@@ -634,7 +636,7 @@ template <typename T, bool IDS>
 __global__ __launch_bounds__(Plan<14>::NT) void hyena_conv_pers_kernel(
     const T* __restrict__ z, T* __restrict__ y, const float2* __restrict__ kf, const float2* __restrict__ tw,
     const float* __restrict__ ktime, const float* __restrict__ short_w, const float* __restrict__ short_b, int B, int L,
-    int Lp, const unsigned char* __restrict__ ids8, const float* __restrict__ ztab) {
+    int Lp, const unsigned char* __restrict__ ids8, const float* __restrict__ ztab, int use_xcd) {
     constexpr int LOGN = 14;
     using P = Plan<LOGN>;
     using TL = TwLayout<LOGN>;
@@ -653,7 +655,7 @@ __global__ __launch_bounds__(Plan<14>::NT) void hyena_conv_pers_kernel(
     // Unit order.  Workgroups go round-robin to the 8 XCDs (id % 8), each with its own L2; a channel's spectrum (128 KB) is
     // shared by all read pairs of the channel.  XCD x therefore takes the channels c = x (mod 8), and its workgroups walk
     // (channel, pair) channel-major: a spectrum is fetched from HBM by one XCD, once, instead of by all eight.
-    const bool xcd_order = (gridDim.x % XCDS) == 0;
+    const bool xcd_order = use_xcd && (gridDim.x % XCDS) == 0;
     const int xcd = blockIdx.x % XCDS, wg_in_xcd = blockIdx.x / XCDS, wgs_per_xcd = gridDim.x / XCDS;
     const int first = xcd_order ? wg_in_xcd : (int)blockIdx.x, stride = xcd_order ? wgs_per_xcd : (int)gridDim.x;
     const int n_mine = xcd_order ? n_units / XCDS : n_units;            // D is a multiple of XCDS
@@ -748,8 +750,8 @@ __global__ __launch_bounds__(Plan<14>::NT) void hyena_conv_pers_kernel(
             const bool valid = t0 < L;
             float xa[3][10], xb[3][10], gA[8], gB[8], x1[8], v[8], x1b[8], vb[8];
             if constexpr (IDS) {
-                ids_decode<true>(cur.idd[ch][0], cur.idp[ch][0], t0, valid, zt, xa);
-                ids_decode<true>(cur.idd[ch][1], cur.idp[ch][1], t0, valid && hasB, zt, xb);
+                ids_decode<true, 6>(cur.idd[ch][0], cur.idp[ch][0], t0, valid, zt, xa);
+                ids_decode<true, 6>(cur.idd[ch][1], cur.idp[ch][1], t0, valid && hasB, zt, xb);
             } else {
 #pragma unroll
                 for (int a3 = 1; a3 < 3; ++a3) {
@@ -864,8 +866,13 @@ __global__ __launch_bounds__(Plan<14>::NT) void hyena_conv_pers_kernel(
             float xa[10], xb[10], x0a[8], x0b[8];
             if constexpr (IDS) {
                 float xa3[3][10], xb3[3][10];
-                ids_decode<true>(cur.idd[ch][0], cur.idp[ch][0], t0, valid, zt, xa3);
-                ids_decode<true>(cur.idd[ch][1], cur.idp[ch][1], t0, valid && hasB, zt, xb3);
+                // opaque copies: otherwise the 40 extracted ids (common subexpressions with phase A) are kept across the
+                // transform -- in scratch
+#pragma unroll
+                for (int rd = 0; rd < 2; ++rd)
+                    asm volatile("" : "+v"(cur.idd[ch][rd].x), "+v"(cur.idd[ch][rd].y), "+v"(cur.idp[ch][rd]));
+                ids_decode<true, 1>(cur.idd[ch][0], cur.idp[ch][0], t0, valid, zt, xa3);
+                ids_decode<true, 1>(cur.idd[ch][1], cur.idp[ch][1], t0, valid && hasB, zt, xb3);
 #pragma unroll
                 for (int e = 0; e < 10; ++e) xa[e] = xa3[0][e], xb[e] = xb3[0][e];
             } else {
@@ -924,8 +931,9 @@ static void launch_conv_pers_inst(const void* z, void* y, const float2* kf, cons
     }();
     const int n_units = ((B + 1) / 2) * D;
     dim3 grid(n_units < cus ? n_units : cus), block(P::NT);
+    static const int use_xcd = !(std::getenv("CLM_CONV_NO_XCD") && std::getenv("CLM_CONV_NO_XCD")[0] == '1');
     hipLaunchKernelGGL(kern, grid, block, lds, st, reinterpret_cast<const T*>(z), reinterpret_cast<T*>(y), kf, tw, ktime, short_w,
-                       short_b, B, L, Lp, ids8, ztab);
+                       short_b, B, L, Lp, ids8, ztab, use_xcd);
 }
 
 // ================================================================================================ 8k reads: split transform
@@ -1237,7 +1245,7 @@ __global__ __launch_bounds__(Plan<14>::NT) void hyena_conv_seg_kernel(
     int KS, const float2* __restrict__ tw, const float* __restrict__ short_w, const float* __restrict__ short_b,
     float2* __restrict__ gscratch /*[pairs][256][S][N]*/, int B, int L, int Lp, int S,
     const float* __restrict__ krev /*[256][krev_stride], LONE only*/, int krev_stride,
-    const unsigned char* __restrict__ ids8 /*[B][Lp], IDS only*/, const float* __restrict__ ztab /*[16][768]*/) {
+    const unsigned char* __restrict__ ids8 /*[B][Lp], IDS only*/, const float* __restrict__ ztab /*[16][768]*/, int use_xcd) {
     constexpr int LOGN = 14;
     using P = Plan<LOGN>;
     using TL = TwLayout<LOGN>;
@@ -1251,7 +1259,7 @@ __global__ __launch_bounds__(Plan<14>::NT) void hyena_conv_seg_kernel(
     // XCD-aware order (see hyena_conv_pers_kernel): all read pairs of a channel on one XCD, so that its S partition spectra
     // (S x 128 KB, read (S+1)S/2 times per unit) are served by that XCD's L2 instead of being fetched by all eight
     const int pairs = (B + 1) / 2, xcd = blockIdx.x % XCDS, slot = blockIdx.x / XCDS;
-    const int c = XCDS * (slot / pairs) + xcd, pair = slot % pairs;
+    const int c = use_xcd ? XCDS * (slot / pairs) + xcd : (int)blockIdx.x / pairs, pair = use_xcd ? slot % pairs : (int)blockIdx.x % pairs;
     const int bA = 2 * pair, bB = 2 * pair + 1;
     const bool hasB = bB < B;
     const T* zA = z + (size_t)bA * D3 * Lp;
@@ -1330,8 +1338,8 @@ __global__ __launch_bounds__(Plan<14>::NT) void hyena_conv_seg_kernel(
                 const bool valid = t0 < L;
                 float xa[3][10], xb[3][10], gA[8], gB[8], x1[8], v[8];
                 if constexpr (IDS) {
-                    ids_decode<true>(idd[ch][0], idp[ch][0], t0, valid, ztm, xa);
-                    ids_decode<true>(idd[ch][1], idp[ch][1], t0, valid && hasB, ztm, xb);
+                    ids_decode<true, 6>(idd[ch][0], idp[ch][0], t0, valid, ztm, xa);
+                    ids_decode<true, 6>(idd[ch][1], idp[ch][1], t0, valid && hasB, ztm, xb);
                 } else {
 #pragma unroll
                     for (int a3 = 1; a3 < 3; ++a3) {
@@ -1561,8 +1569,12 @@ __global__ __launch_bounds__(Plan<14>::NT) void hyena_conv_seg_kernel(
                 float xa[10], xb[10];
                 if constexpr (IDS) {
                     float xa3[3][10], xb3[3][10];
-                    ids_decode<true>(idd[ch][0], idp[ch][0], t0, valid, ztm, xa3);
-                    ids_decode<true>(idd[ch][1], idp[ch][1], t0, valid && hasB, ztm, xb3);
+                    // opaque copies: otherwise the 40 extracted ids (common subexpressions with phase A) are kept across the
+                    // transform -- in scratch
+#pragma unroll
+                    for (int rd = 0; rd < 2; ++rd) asm volatile("" : "+v"(idd[ch][rd].x), "+v"(idd[ch][rd].y), "+v"(idp[ch][rd]));
+                    ids_decode<true, 1>(idd[ch][0], idp[ch][0], t0, valid, ztm, xa3);
+                    ids_decode<true, 1>(idd[ch][1], idp[ch][1], t0, valid && hasB, ztm, xb3);
 #pragma unroll
                     for (int e = 0; e < 10; ++e) xa[e] = xa3[0][e], xb[e] = xb3[0][e];
                 } else {
@@ -1638,8 +1650,9 @@ static void launch_conv_seg_inst(const void* z, void* y, const float2* kf, int K
     }
     static_assert(D % XCDS == 0, "channels split evenly over the XCDs");
     dim3 grid(((B + 1) / 2) * D), block(P::NT);
+    static const int use_xcd = !(std::getenv("CLM_CONV_NO_XCD") && std::getenv("CLM_CONV_NO_XCD")[0] == '1');
     hipLaunchKernelGGL(kern, grid, block, lds, st, reinterpret_cast<const T*>(z), reinterpret_cast<T*>(y), kf, KS, tw,
-                       short_w, short_b, gscratch, B, L, Lp, S, krev, krev_stride, ids8, ztab);
+                       short_w, short_b, gscratch, B, L, Lp, S, krev, krev_stride, ids8, ztab, use_xcd);
 }
 template <typename T>
 static void launch_conv_seg_t(const void* z, void* y, const float2* kf, int KS, const float2* tw, const float* short_w,
@@ -1816,10 +1829,15 @@ void launch_hyena_conv(int prec, const void* z, void* y, const float2* kf, const
     // per unit, for A/B runs and the developer stamps)
     static const bool oneshot = (std::getenv("CLM_CONV_ONESHOT") && std::getenv("CLM_CONV_ONESHOT")[0] == '1') ||
                                 (std::getenv("CLM_STAMP") && std::getenv("CLM_STAMP")[0] == '1');
-    // (block 0's id-decoding variant keeps the one-shot kernel: with the id words held across the transform it spills)
-    if (logn == 14 && prec != PREC_F32 && !oneshot && !(ids8 != nullptr && ztab != nullptr)) {
-        if (prec == PREC_BF16) launch_conv_pers_inst<bf16_t, false>(z, y, kf, tw, ktime, short_w, short_b, B, L, Lp, nullptr, nullptr, st);
-        else launch_conv_pers_inst<f16_t, false>(z, y, kf, tw, ktime, short_w, short_b, B, L, Lp, nullptr, nullptr, st);
+    if (logn == 14 && prec != PREC_F32 && !oneshot) {
+        const bool ids = ids8 != nullptr && ztab != nullptr;
+        if (prec == PREC_BF16) {
+            if (ids) launch_conv_pers_inst<bf16_t, true>(nullptr, y, kf, tw, ktime, short_w, short_b, B, L, Lp, ids8, ztab, st);
+            else launch_conv_pers_inst<bf16_t, false>(z, y, kf, tw, ktime, short_w, short_b, B, L, Lp, nullptr, nullptr, st);
+        } else {
+            if (ids) launch_conv_pers_inst<f16_t, true>(nullptr, y, kf, tw, ktime, short_w, short_b, B, L, Lp, ids8, ztab, st);
+            else launch_conv_pers_inst<f16_t, false>(z, y, kf, tw, ktime, short_w, short_b, B, L, Lp, nullptr, nullptr, st);
+        }
         return;
     }
 #define CLM_CONV_CASE(n) \
