@@ -959,6 +959,15 @@ static void launch_conv_pers_inst(const void* z, void* y, const float2* kf, cons
 // 256-thread workgroups, two per CU, even result held in registers: 14.1 ms unrolled (57 KB of code, 25-36 spilled dwords),
 // 18.2 ms with the two trips rolled (85 spilled dwords).  Overlapping the LDS and VALU phases needs four waves per SIMD, i.e.
 // 16 points per thread instead of 32 -- a different pass geometry, not built.
+// A third form, built, measured and REMOVED (round 2): one workgroup keeps TWO units in registers (2 x 64 data registers per
+// thread), half a pass apart, and time-shares the one LDS buffer -- every wave issues the LDS instructions of one unit's
+// exchange and the butterflies of the other unit in the same barrier interval (no wave specialisation, so both waves of a
+// SIMD are in VALU code together), barriers waiting for LDS traffic only, ds / VALU instructions interleaved 2 : 10 with
+// sched_group_barrier (a wave stalls at issue with 15 LDS instructions outstanding).  Bit-identical results; 1.04 ms per launch
+// against 0.80 for hyena_conv_pers_kernel.  A timing-only build of just its transform passes (no gating, no global traffic):
+// 0.66 ms interleaved, 0.72 ms with each exchange issued in a row -- against ~0.60 ms for the same passes run one unit at a
+// time.  LDS transfers and packed-fp32 VALU work of the SAME waves do not overlap to any useful degree on this CU (both move
+// through the SIMD's register file), so the 2 x 64 registers and the second barrier pair per pass buy nothing.
 // exp(-2 pi i e / 16384), e = 0..7: the within-chunk factors of w_N^n (literals: folded into the unrolled code)
 #define CLM_DIF_WC                                                                                                          \
     {{1.0f, -0.0f}, {0.99999992646f, -3.8349518757e-4f}, {0.99999970586f, -7.6699031874e-4f}, {0.99999933819f, -1.1504853371e-3f}, \
