@@ -90,7 +90,9 @@ __device__ __forceinline__ void inproj_blocks(const typename CT<PREC>::elem* As,
         phase_tm<PREC, K, K, false>(As, wp, nb, 0, wp, nb + 1 < NBLOCKS ? nb + 1 : 0, 0, wave, lane, bs, acc, hook, 2 * nb);
         // epilogue: rows = tokens (register quads = 4 consecutive tokens), cols = feature (lane) -> zs[feature][token]
         const int nbase = nb * 256 + wave * 32;
-        const float bias = bias_all[nbase + lrow];
+        int lrow_e = lrow;                                     // opaque copy: the table address is formed here, not kept (spilled)
+        asm volatile("" : "+v"(lrow_e));                       // across the MFMA phase -- see the GELU store of tail16_kernel
+        const float bias = bias_all[nbase + lrow_e];
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
@@ -388,7 +390,12 @@ __device__ __forceinline__ void tail_load_y_piece(const TailArgs& m, uint4 (&yx)
     for (int i = 4 * half; i < 4 * half + 4; ++i)
         yx[i] = *reinterpret_cast<const uint4*>(src + (size_t)((tid >> 4) + 32 * i) * m.Lp + tkc);
 }
-template <typename E>
+// PIECES: how many of the four residual pieces the hooks request.  fp16c: three -- with all four (64 registers) plus the y
+// pieces (32) live next to the accumulators and the two (hi, lo) weight sets, hipcc spilled one piece AS IT LOADED it
+// (four times `global_load_dwordx4; s_waitcnt vmcnt(0); scratch_store`: four serialised HBM round trips inside the in_proj
+// stage of every tile, and a scratch reload with its own vmcnt(0) in the next tile's out_proj epilogue).  The fourth piece is
+// requested when the stage's accumulators are dead (tail16_kernel, after inproj_blocks).
+template <typename E, int PIECES>
 struct ResidHook {
     const TailArgs& m;
     float4 (&hv)[4][4];
@@ -397,8 +404,8 @@ struct ResidHook {
     unsigned long long* stamp;                             // developer build only (nullptr otherwise)
     __device__ __forceinline__ void operator()(int step) const {
         if (stamp && tid == 0) stamp[21 + step] = __builtin_amdgcn_s_memtime();
-        if (step < 4) tail_load_resid_piece(m, hv[step], step, b, t0, wave, lrow, lhalf);
-        else tail_load_y_piece<E>(m, yx, step - 4, b, t0, tid);
+        if (step < PIECES) tail_load_resid_piece(m, hv[step], step, b, t0, wave, lrow, lhalf);
+        else if (step >= 4) tail_load_y_piece<E>(m, yx, step - 4, b, t0, tid);
     }
 };
 
@@ -451,7 +458,8 @@ __global__ __launch_bounds__(512) void tail16_kernel(TailArgs m, unsigned long l
     // hoisted out of the tile loop and kept (that costs ~190 spilled registers)
     int tid_l = threadIdx.x;
     asm volatile("" : "+v"(tid_l));
-    const int tid = tid_l, lane = tid & 63, wave = tid >> 6, lrow = lane & 31, lhalf = lane >> 5;
+    // (the wave index as a scalar: every address term derived from it stays out of the vector registers)
+    const int tid = tid_l, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lrow = lane & 31, lhalf = lane >> 5;
     const int b = tile / tiles_x, t0 = (tile % tiles_x) * BM;
     CLM_STAMP_AT(0);
     if (STAMP && threadIdx.x == 0) stamps[(size_t)tile * TAIL_NSTAMP + 27] = __builtin_amdgcn_s_memrealtime();   // 100 MHz
@@ -510,6 +518,12 @@ __global__ __launch_bounds__(512) void tail16_kernel(TailArgs m, unsigned long l
         __syncthreads();
         CLM_STAMP_AT(5 + 3 * j);
         {
+            // the row address is re-derived here from an opaque copy of the lane: kept from the top of the tile it was spilled
+            // (fp16c), and its reload -- a vector memory load -- put an `s_waitcnt vmcnt(0)` in front of the first store of this
+            // VALU-only phase, i.e. a wait for the fc2 half-set just requested
+            int lane_g = lane;
+            asm volatile("" : "+v"(lane_g));
+            elem* hrow = Hs + (lane_g & 31) * RS16 + wave * 32 + 4 * (lane_g >> 5);
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const float4 bb = b1v[q];
@@ -518,7 +532,7 @@ __global__ __launch_bounds__(512) void tail16_kernel(TailArgs m, unsigned long l
                     const f32x2 g0 = gelu_tanh2(f32x2{acc1[mt][4 * q + 0] + bb.x, acc1[mt][4 * q + 1] + bb.y});
                     const f32x2 g1 = gelu_tanh2(f32x2{acc1[mt][4 * q + 2] + bb.z, acc1[mt][4 * q + 3] + bb.w});
                     u16x4 pk = {to_bits<PREC>(g0.x), to_bits<PREC>(g0.y), to_bits<PREC>(g1.x), to_bits<PREC>(g1.y)};
-                    *reinterpret_cast<u16x4*>(Hs + (mt * 32 + lrow) * RS16 + wave * 32 + 8 * q + 4 * lhalf) = pk;
+                    *reinterpret_cast<u16x4*>(hrow + mt * 32 * RS16 + 8 * q) = pk;
                 }
             }
         }
@@ -589,9 +603,12 @@ __global__ __launch_bounds__(512) void tail16_kernel(TailArgs m, unsigned long l
             // bs[1] is re-requested by the block loop (same addresses, L2-resident): keeps the loop identical to in_proj16
             // the 128 KiB of residual rows trickle in as four pieces behind the weight requests of the first four half-blocks
             // (requested in one go before the LayerNorm they stalled every later load of the stage: +9k cycles)
+            constexpr int PIECES = PREC == PREC_F16C ? 2 : 4;
             inproj_blocks<PREC>(As, Hs, wn, Bt + BT_NB, m.n_z, b, t0, Lp, wave, lane, bs, acc1,
-                                ResidHook<elem>{m, hv, yx, nb_, nt0, wave, lrow, lhalf, tid,
-                                                STAMP ? stamps + (size_t)tile * TAIL_NSTAMP : nullptr});
+                                ResidHook<elem, PIECES>{m, hv, yx, nb_, nt0, wave, lrow, lhalf, tid,
+                                                        STAMP ? stamps + (size_t)tile * TAIL_NSTAMP : nullptr});
+#pragma unroll
+            for (int mt = PIECES; mt < 4; ++mt) tail_load_resid_piece(m, hv[mt], mt, nb_, nt0, wave, lrow, lhalf);
         } else {
             score_pool_tile<PREC>(m.sp, As, reinterpret_cast<float*>(Hs), b, tile % tiles_x, tid, bs, acc1);
             // (requested before the score stage these 96 registers spill through its erf epilogue: one launch in four)
