@@ -138,6 +138,8 @@ __device__ __forceinline__ void zero_acc(f32x16 (&acc)[4]) {
 // P1 / P2: [16][128] floats each, outside As.  Ends with a barrier (As complete); the first internal barrier also orders
 // every earlier LDS access of the workgroup before the As writes.
 // KEEP: the normalised fp32 values also replace the accumulator contents (post-norm blocks: they are the next residual).
+// (gamma / beta from an LDS table instead of the global loads behind the barriers below, with beta folded into the consuming
+//  layer's bias where possible: measured in tail16_kernel, 1.572 vs 1.573 ms per launch -- not kept.)
 template <int PREC, bool KEEP = false>
 __device__ __forceinline__ void ln_acc_to_tile(f32x16 (&acc2)[4], float* P1, float* P2, const float* __restrict__ g,
                                                const float* __restrict__ bta, float eps, typename CT<PREC>::elem* As,
