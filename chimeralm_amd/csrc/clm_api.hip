@@ -101,6 +101,7 @@ struct clm_handle {
     bool split_tail = false;      // CLM_SPLIT_TAIL=1: separate out_proj16 + mlp16 kernels instead of the fused tail (A/B runs)
     bool no_fuse_next = false;    // CLM_NO_FUSE_NEXT=1: separate in_proj / score kernels instead of fusing them into the tail
     bool no_idconv = false;       // CLM_NO_IDCONV=1: run block 0's in_proj instead of the id-table convolution (A/B runs)
+    int conv_flags = 0;           // CLM_CONV_ONESHOT=1 / CLM_CONV_NO_XCD=1: CONV_* switches of the convolution launchers (A/B runs, tests)
     bool no_lone_peel = false;    // CLM_NO_LONE_PEEL=1: keep the lone last token of 128 k + 1-token reads in a tile of its own (A/B runs)
     bool split_conv = false;      // CLM_SPLIT_CONV=1: 8k reads through hyena_conv_eo_kernel (two 8192-point problems; measured slower, kept for A/B)
     bool force_generic = false;   // CLM_GENERIC_GEMM=1: route 16-bit modes through the generic kernels (A/B runs)
@@ -496,11 +497,11 @@ int forward_chunk(clm_handle* h, const void* ids, int ids_dtype, int64_t row_str
                                       Lp, idconv ? h->ids8 : nullptr, idconv ? h->ztab : nullptr, st);
             else if (S == 1)
                 launch_hyena_conv(prec, h->z, h->y, fs->kf[i], fs->tw, fs->ktime[i], lw.short_w, lw.short_b, Bc, L, Lp,
-                                  fs->logn, idconv ? h->ids8 : nullptr, idconv ? h->ztab : nullptr, st);
+                                  fs->logn, idconv ? h->ids8 : nullptr, idconv ? h->ztab : nullptr, st, h->conv_flags);
             else
                 launch_hyena_conv_seg(prec, h->z, h->y, fs->kf[i], fs->KS, fs->tw, lw.short_w, lw.short_b, h->gscratch, Bc,
                                       L, Lp, S, kr ? kr->p[i] : nullptr, kr ? kr->stride : 0, idconv ? h->ids8 : nullptr,
-                                      idconv ? h->ztab : nullptr, st);
+                                      idconv ? h->ztab : nullptr, st, h->conv_flags);
         }
         if (stop_here(h, i, CLM_STAGE_CONV)) return CLM_OK;
         const bool stop_mid = stop_here(h, i, CLM_STAGE_OUTPROJ);
@@ -633,6 +634,8 @@ int clm_create(const clm_config* cfg, int device, clm_handle** out) {
     h->no_idconv = std::getenv("CLM_NO_IDCONV") && std::getenv("CLM_NO_IDCONV")[0] == '1';
     h->split_tail = std::getenv("CLM_SPLIT_TAIL") && std::getenv("CLM_SPLIT_TAIL")[0] == '1';
     h->no_lone_peel = std::getenv("CLM_NO_LONE_PEEL") && std::getenv("CLM_NO_LONE_PEEL")[0] == '1';
+    if (std::getenv("CLM_CONV_ONESHOT") && std::getenv("CLM_CONV_ONESHOT")[0] == '1') h->conv_flags |= CONV_ONESHOT;
+    if (std::getenv("CLM_CONV_NO_XCD") && std::getenv("CLM_CONV_NO_XCD")[0] == '1') h->conv_flags |= CONV_NO_XCD;
     h->split_conv = std::getenv("CLM_SPLIT_CONV") && std::getenv("CLM_SPLIT_CONV")[0] == '1';
     h->cfg = *cfg;
     h->device = device;

@@ -228,9 +228,12 @@ void launch_twiddles(float2* tw, int logn, hipStream_t st);   // tw[m] = exp(-2 
 // y = ((causal_conv(v*x1, k) + D*(v*x1)) * x0)   with (x0,x1,v) = short_filter(z)    [B,256,Lp]; D lives in kf
 // ids8/ztab non-null (16-bit modes, block 0): x0|x1|v come from the 16-row table ztab[id][768] via the token ids
 // ids8 [B][Lp] instead of z (in_proj of block 0 is not launched)
+// flags (A/B switches of the engine, CLM_CONV_ONESHOT=1 / CLM_CONV_NO_XCD=1 at clm_create):
+constexpr int CONV_ONESHOT = 1;   // 16384-point class, 16-bit: one workgroup per unit (hyena_conv_kernel) instead of the persistent kernel
+constexpr int CONV_NO_XCD = 2;    // units in plain order instead of all read pairs of a channel on one XCD
 void launch_hyena_conv(int prec, const void* z, void* y, const float2* kf, const float2* tw, const float* ktime,
                        const float* short_w, const float* short_b, int B, int L, int Lp, int logn,
-                       const unsigned char* ids8, const float* ztab, hipStream_t st);
+                       const unsigned char* ids8, const float* ztab, hipStream_t st, int flags = 0);
 // 8k reads (4098 .. 8193 tokens): the 16384-point convolution as two 8192-point problems (even / odd bins), two workgroups per CU.
 // kf2 [256][2][8192] from launch_spectrum_split(kf of the 16384-point class); twM = the 8192-point twiddle table, twN the 16384 one
 void launch_spectrum_split(const float2* kf, float2* kf2, int logn, hipStream_t st);
@@ -250,7 +253,7 @@ void launch_hyena_conv_seg(int prec, const void* z, void* y, const float2* kf, i
                            const float* short_b, float2* gscratch, int B, int L, int Lp, int S,
                            const float* krev /*null unless conv_lone_tail(L)*/, int krev_stride,
                            const unsigned char* ids8 /*16-bit modes, block 0: as launch_hyena_conv*/, const float* ztab,
-                           hipStream_t st);
+                           hipStream_t st, int flags = 0);
 
 // head (head.hip)
 void launch_softmax_stats(const float* scores, float* stats /*[B][2] = max, sum*/, int B, int L, hipStream_t st);

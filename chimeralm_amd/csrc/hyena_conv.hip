@@ -915,7 +915,7 @@ __global__ __launch_bounds__(Plan<14>::NT) void hyena_conv_pers_kernel(
 template <typename T, bool IDS>
 static void launch_conv_pers_inst(const void* z, void* y, const float2* kf, const float2* tw, const float* ktime,
                                   const float* short_w, const float* short_b, int B, int L, int Lp, const unsigned char* ids8,
-                                  const float* ztab, hipStream_t st) {
+                                  const float* ztab, int use_xcd, hipStream_t st) {
     using P = Plan<14>;
     constexpr size_t lds = (size_t)2 * padded_size(P::N) * sizeof(float) + 256;
     auto kern = hyena_conv_pers_kernel<T, IDS>;
@@ -931,7 +931,6 @@ static void launch_conv_pers_inst(const void* z, void* y, const float2* kf, cons
     }();
     const int n_units = ((B + 1) / 2) * D;
     dim3 grid(n_units < cus ? n_units : cus), block(P::NT);
-    static const int use_xcd = !(std::getenv("CLM_CONV_NO_XCD") && std::getenv("CLM_CONV_NO_XCD")[0] == '1');
     hipLaunchKernelGGL(kern, grid, block, lds, st, reinterpret_cast<const T*>(z), reinterpret_cast<T*>(y), kf, tw, ktime, short_w,
                        short_b, B, L, Lp, ids8, ztab, use_xcd);
 }
@@ -1647,7 +1646,7 @@ template <typename T, bool LONE, bool IDS>
 static void launch_conv_seg_inst(const void* z, void* y, const float2* kf, int KS, const float2* tw, const float* short_w,
                               const float* short_b, float2* gscratch, int B, int L, int Lp, int S,
                               const float* krev, int krev_stride, const unsigned char* ids8, const float* ztab,
-                              hipStream_t st) {
+                              int use_xcd, hipStream_t st) {
     using P = Plan<14>;
     constexpr size_t lds = (size_t)2 * padded_size(P::N) * sizeof(float) + 256;   // + the 3x16 id table
     auto kern = hyena_conv_seg_kernel<T, LONE, IDS>;
@@ -1659,16 +1658,15 @@ static void launch_conv_seg_inst(const void* z, void* y, const float2* kf, int K
     }
     static_assert(D % XCDS == 0, "channels split evenly over the XCDs");
     dim3 grid(((B + 1) / 2) * D), block(P::NT);
-    static const int use_xcd = !(std::getenv("CLM_CONV_NO_XCD") && std::getenv("CLM_CONV_NO_XCD")[0] == '1');
     hipLaunchKernelGGL(kern, grid, block, lds, st, reinterpret_cast<const T*>(z), reinterpret_cast<T*>(y), kf, KS, tw,
                        short_w, short_b, gscratch, B, L, Lp, S, krev, krev_stride, ids8, ztab, use_xcd);
 }
 template <typename T>
 static void launch_conv_seg_t(const void* z, void* y, const float2* kf, int KS, const float2* tw, const float* short_w,
                               const float* short_b, float2* gscratch, int B, int L, int Lp, int S, const float* krev,
-                              int krev_stride, const unsigned char* ids8, const float* ztab, hipStream_t st) {
+                              int krev_stride, const unsigned char* ids8, const float* ztab, int use_xcd, hipStream_t st) {
 #define CLM_SEG(LONE, IDS)                                                                                               \
-    launch_conv_seg_inst<T, LONE, IDS>(z, y, kf, KS, tw, short_w, short_b, gscratch, B, L, Lp, S, krev, krev_stride, ids8, ztab, st)
+    launch_conv_seg_inst<T, LONE, IDS>(z, y, kf, KS, tw, short_w, short_b, gscratch, B, L, Lp, S, krev, krev_stride, ids8, ztab, use_xcd, st)
     if constexpr (std::is_same<T, float>::value) {           // fp32 mode never takes the id path
         if (krev) CLM_SEG(true, false);
         else CLM_SEG(false, false);
@@ -1684,13 +1682,14 @@ static void launch_conv_seg_t(const void* z, void* y, const float2* kf, int KS, 
 
 void launch_hyena_conv_seg(int prec, const void* z, void* y, const float2* kf, int KS, const float2* tw, const float* short_w,
                            const float* short_b, float2* gscratch, int B, int L, int Lp, int S, const float* krev,
-                           int krev_stride, const unsigned char* ids8, const float* ztab, hipStream_t st) {
+                           int krev_stride, const unsigned char* ids8, const float* ztab, hipStream_t st, int flags) {
+    const int use_xcd = !(flags & CONV_NO_XCD);
     if (prec == PREC_F32)
-        launch_conv_seg_t<float>(z, y, kf, KS, tw, short_w, short_b, gscratch, B, L, Lp, S, krev, krev_stride, nullptr, nullptr, st);
+        launch_conv_seg_t<float>(z, y, kf, KS, tw, short_w, short_b, gscratch, B, L, Lp, S, krev, krev_stride, nullptr, nullptr, use_xcd, st);
     else if (prec == PREC_BF16)
-        launch_conv_seg_t<bf16_t>(z, y, kf, KS, tw, short_w, short_b, gscratch, B, L, Lp, S, krev, krev_stride, ids8, ztab, st);
+        launch_conv_seg_t<bf16_t>(z, y, kf, KS, tw, short_w, short_b, gscratch, B, L, Lp, S, krev, krev_stride, ids8, ztab, use_xcd, st);
     else
-        launch_conv_seg_t<f16_t>(z, y, kf, KS, tw, short_w, short_b, gscratch, B, L, Lp, S, krev, krev_stride, ids8, ztab, st);
+        launch_conv_seg_t<f16_t>(z, y, kf, KS, tw, short_w, short_b, gscratch, B, L, Lp, S, krev, krev_stride, ids8, ztab, use_xcd, st);
 }
 
 // ztab[id][n] = in_proj(LN1(embedding[id]))[n] of block 0, fp32: one workgroup per token id
@@ -1833,19 +1832,19 @@ static void launch_conv_p(int prec, const void* z, void* y, const float2* kf, co
 
 void launch_hyena_conv(int prec, const void* z, void* y, const float2* kf, const float2* tw, const float* ktime,
                        const float* short_w, const float* short_b, int B, int L, int Lp, int logn,
-                       const unsigned char* ids8, const float* ztab, hipStream_t st) {
-    // 16384-point class, 16-bit activations: persistent workgroups with next-unit requests (CLM_CONV_ONESHOT=1: one workgroup
-    // per unit, for A/B runs and the developer stamps)
-    static const bool oneshot = (std::getenv("CLM_CONV_ONESHOT") && std::getenv("CLM_CONV_ONESHOT")[0] == '1') ||
-                                (std::getenv("CLM_STAMP") && std::getenv("CLM_STAMP")[0] == '1');
-    if (logn == 14 && prec != PREC_F32 && !oneshot) {
+                       const unsigned char* ids8, const float* ztab, hipStream_t st, int flags) {
+    // 16384-point class, 16-bit activations: persistent workgroups with next-unit requests (CONV_ONESHOT: one workgroup per
+    // unit -- A/B runs; the developer stamps live in that kernel only)
+    static const bool stamp = std::getenv("CLM_STAMP") && std::getenv("CLM_STAMP")[0] == '1';
+    if (logn == 14 && prec != PREC_F32 && !(flags & CONV_ONESHOT) && !stamp) {
         const bool ids = ids8 != nullptr && ztab != nullptr;
+        const int xcd = !(flags & CONV_NO_XCD);
         if (prec == PREC_BF16) {
-            if (ids) launch_conv_pers_inst<bf16_t, true>(nullptr, y, kf, tw, ktime, short_w, short_b, B, L, Lp, ids8, ztab, st);
-            else launch_conv_pers_inst<bf16_t, false>(z, y, kf, tw, ktime, short_w, short_b, B, L, Lp, nullptr, nullptr, st);
+            if (ids) launch_conv_pers_inst<bf16_t, true>(nullptr, y, kf, tw, ktime, short_w, short_b, B, L, Lp, ids8, ztab, xcd, st);
+            else launch_conv_pers_inst<bf16_t, false>(z, y, kf, tw, ktime, short_w, short_b, B, L, Lp, nullptr, nullptr, xcd, st);
         } else {
-            if (ids) launch_conv_pers_inst<f16_t, true>(nullptr, y, kf, tw, ktime, short_w, short_b, B, L, Lp, ids8, ztab, st);
-            else launch_conv_pers_inst<f16_t, false>(z, y, kf, tw, ktime, short_w, short_b, B, L, Lp, nullptr, nullptr, st);
+            if (ids) launch_conv_pers_inst<f16_t, true>(nullptr, y, kf, tw, ktime, short_w, short_b, B, L, Lp, ids8, ztab, xcd, st);
+            else launch_conv_pers_inst<f16_t, false>(z, y, kf, tw, ktime, short_w, short_b, B, L, Lp, nullptr, nullptr, xcd, st);
         }
         return;
     }

@@ -238,6 +238,34 @@ def test_split_transform_convolution_kernel(sd, built_lib, monkeypatch, prec, B,
     e0.close(), e1.close()
 
 
+@pytest.mark.parametrize("prec,B,L,env", [("fp16c", 5, 8193, "CLM_CONV_ONESHOT"), ("fp16c", 3, 6000, "CLM_CONV_ONESHOT"),
+                                          ("bf16", 4, 4098, "CLM_CONV_ONESHOT"), ("fp16c", 5, 8193, "CLM_CONV_NO_XCD"),
+                                          ("fp16c", 3, 20000, "CLM_CONV_NO_XCD")])
+def test_persistent_convolution_equals_one_workgroup_per_unit(sd, built_lib, monkeypatch, prec, B, L, env):
+    """Reads of 4,098..8,193 tokens in the 16-bit modes run through hyena_conv_pers_kernel (persistent workgroups, next unit's rows
+    requested behind the last inverse pass, XCD-aware unit order; block 0: its id-table variant).  Against hyena_conv_kernel
+    (CLM_CONV_ONESHOT=1) the same transform but x0's short filter evaluated in phase C: fp32-rounding-level differences in y that
+    flip a few 16-bit roundings -- logits agree to a fraction of the mode's error, and both kernels stand against the oracle.
+    The plain unit order (CLM_CONV_NO_XCD=1) only permutes which workgroup does which unit: bit-identical, for the segmented
+    long-read kernel too (20,000 tokens).  Odd batches: a unit with one read."""
+    from chimeralm_amd.engine import Engine
+
+    ids = _ids(B, L, seed=97, pads=3)
+    t = torch.from_numpy(ids).cuda()
+    e0 = Engine("cuda:0", precision=prec, chunk_reads=4)
+    monkeypatch.setenv(env, "1")                         # read by clm_create
+    e1 = Engine("cuda:0", precision=prec, chunk_reads=4)
+    monkeypatch.delenv(env)
+    e0.load_state_dict(sd), e1.load_state_dict(sd)
+    a, b = e0.forward(t).cpu(), e1.forward(t).cpu()
+    if env == "CLM_CONV_NO_XCD":
+        assert torch.equal(a, b), (a - b).abs().max().item()
+    else:
+        assert (a - b).abs().max() < 3e-4
+        _check(e1, prec, ids, sd)
+    e0.close(), e1.close()
+
+
 @pytest.mark.parametrize("prec,B,L", [("fp32", 3, 8194), ("fp32", 2, 16385), ("fp16", 3, 20000), ("fp16", 3, 24577),
                                       ("fp32", 1, 8200), ("fp16c", 3, 20000), ("fp16c", 2, 16385)])
 def test_long_reads_segmented_convolution(engines, sd, prec, B, L):
