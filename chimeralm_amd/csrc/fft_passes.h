@@ -29,6 +29,13 @@ struct PassGeom {
     static constexpr bool FULL = (NB % NT == 0);   // every thread owns exactly IT butterflies: no bounds checks at all
     static CLM_HD bool has_a(int tid, int p) { return FULL || jba(tid, p) < NB; }
     static CLM_HD bool has_b(int tid, int p) { return 2 * p + 1 < IT && (FULL || jbb(tid, p) < NB); }
+    // padded LDS index of lane b's butterfly, given lane a's: jbb = jba + NT and NT is a multiple of the padding period, so the
+    // distance is a CONSTANT.  Written as `pa + constant` (not pad_index(jbb), a second address register) the two lanes of a
+    // component are one ds_read2st64_b32 straight into the register pair the packed arithmetic wants; with two base registers
+    // hipcc paired the loads across r instead (same lane, inputs r and r + 1) and rebuilt every pair with v_mov -- 470 moves
+    // per unit, 8 % of the convolution kernel's issue cycles.
+    static_assert(NT % 32 == 0, "lane distance is a whole number of padding periods");
+    static CLM_HDC int pb_of(int pa) { return pa + pad_offset(NT); }
 };
 
 template <int LOGN, int R>
@@ -37,12 +44,15 @@ CLM_HD void pass_load(const float* re, const float* im, Cx2* v, int tid) {
 #pragma unroll
     for (int p = 0; p < G::NP; ++p) {
         const bool ha = G::has_a(tid, p), hb = G::has_b(tid, p);
-        const int pa = pad_index(G::jba(tid, p)), pb = pad_index(G::jbb(tid, p));   // bases; r*NB is the immediate
+        // one base per component (lane a's butterfly); input r and lane b are immediates: r*NB and NT elements further on
+        const float* ra = re + pad_index(G::jba(tid, p));
+        const float* ia = im + pad_index(G::jba(tid, p));
+        constexpr int dB = G::pb_of(0);
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             const int off = pad_offset(r * G::NB);
-            v[p * R + r].re = make_v2(ha ? re[pa + off] : 0.f, hb ? re[pb + off] : 0.f);
-            v[p * R + r].im = make_v2(ha ? im[pa + off] : 0.f, hb ? im[pb + off] : 0.f);
+            v[p * R + r].re = make_v2(ha ? ra[off] : 0.f, hb ? ra[off + dB] : 0.f);
+            v[p * R + r].im = make_v2(ha ? ia[off] : 0.f, hb ? ia[off + dB] : 0.f);
         }
     }
 }
@@ -57,12 +67,14 @@ CLM_HD void pass_first_lower(const float* re, const float* im, Cx2* v, int tid) 
 #pragma unroll
     for (int p = 0; p < G::NP; ++p) {
         const bool ha = G::has_a(tid, p), hb = G::has_b(tid, p);
-        const int pa = pad_index(G::jba(tid, p)), pb = pad_index(G::jbb(tid, p));
+        const float* ra = re + pad_index(G::jba(tid, p));
+        const float* ia = im + pad_index(G::jba(tid, p));
+        constexpr int dB = G::pb_of(0);
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
             const int off = pad_offset(r * G::NB);
-            v[p * 16 + r].re = make_v2(ha ? re[pa + off] : 0.f, hb ? re[pb + off] : 0.f);
-            v[p * 16 + r].im = make_v2(ha ? im[pa + off] : 0.f, hb ? im[pb + off] : 0.f);
+            v[p * 16 + r].re = make_v2(ha ? ra[off] : 0.f, hb ? ra[off + dB] : 0.f);
+            v[p * 16 + r].im = make_v2(ha ? ia[off] : 0.f, hb ? ia[off + dB] : 0.f);
         }
         Dft16Lo<false>::run(v + p * 16);
     }
@@ -107,7 +119,7 @@ CLM_HD void pass_store_lower(float* re, float* im, const Cx2* v, int tid, bool k
     constexpr int Ns = G::NB;                                   // last pass: sub-transform size N/16 = number of butterflies
 #pragma unroll
     for (int p = 0; p < G::NP; ++p) {
-        const int pa = pad_index(G::jba(tid, p)), pb = pad_index(G::jbb(tid, p));     // k = jb, output jb + q*Ns
+        const int pa = pad_index(G::jba(tid, p)), pb = G::pb_of(pa);                   // k = jb, output jb + q*Ns
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
             const int off = pad_offset(q * Ns);
