@@ -41,6 +41,7 @@ struct FilterSet {
     float2* kf[NLAYER] = {};
     float2* tw = nullptr;
     float2* kf2[NLAYER] = {};     // 16384-point class only: even | odd bins of kf (split-transform kernel)
+    float2* kfp[NLAYER] = {};     // 16384-point class only: kf lane-packed for the persistent kernel (launch_spectrum_lanepack)
     float2* twM = nullptr;        //                          twiddles of the 8192-point passes
     std::vector<ReversedFilter> krev;
 };
@@ -230,6 +231,8 @@ void free_filter_set(FilterSet& f) {
         if (f.kf[i]) (void)hipFree(f.kf[i]);
         if (f.kf2[i]) (void)hipFree(f.kf2[i]);
         f.kf2[i] = nullptr;
+        if (f.kfp[i]) (void)hipFree(f.kfp[i]);
+        f.kfp[i] = nullptr;
         for (auto& r : f.krev)
             if (r.p[i]) (void)hipFree(r.p[i]);
         f.ktime[i] = nullptr;
@@ -354,6 +357,10 @@ int ensure_filters(clm_handle* h, int L, hipStream_t st, FilterSet** out, const 
                           W(h, p + "implicit_filter.6.weight"), W(h, p + "modulation.deltas"), f.ktime[i], f.Lf, st);
             if (S == 1) {
                 launch_filter_spectrum(f.ktime[i], W(h, p + "bias"), f.kf[i], scratch, f.Lf, logn, 0, f.Lf, -1, st);
+                if (logn == 14 && h->cfg.precision != CLM_PREC_F32) {
+                    HIPCHK(h, hipMalloc((void**)&f.kfp[i], (size_t)D * N * sizeof(float2)));
+                    launch_spectrum_lanepack(f.kf[i], f.kfp[i], 1, 0, st);
+                }
                 if (logn == 14 && h->split_conv) {
                     HIPCHK(h, hipMalloc((void**)&f.kf2[i], (size_t)D * N * sizeof(float2)));
                     launch_spectrum_split(f.kf[i], f.kf2[i], logn, st);
@@ -497,7 +504,7 @@ int forward_chunk(clm_handle* h, const void* ids, int ids_dtype, int64_t row_str
                                       Lp, idconv ? h->ids8 : nullptr, idconv ? h->ztab : nullptr, st);
             else if (S == 1)
                 launch_hyena_conv(prec, h->z, h->y, fs->kf[i], fs->tw, fs->ktime[i], lw.short_w, lw.short_b, Bc, L, Lp,
-                                  fs->logn, idconv ? h->ids8 : nullptr, idconv ? h->ztab : nullptr, st, h->conv_flags);
+                                  fs->logn, idconv ? h->ids8 : nullptr, idconv ? h->ztab : nullptr, st, h->conv_flags, fs->kfp[i]);
             else
                 launch_hyena_conv_seg(prec, h->z, h->y, fs->kf[i], fs->KS, fs->tw, lw.short_w, lw.short_b, h->gscratch, Bc,
                                       L, Lp, S, kr ? kr->p[i] : nullptr, kr ? kr->stride : 0, idconv ? h->ids8 : nullptr,

@@ -233,7 +233,9 @@ constexpr int CONV_ONESHOT = 1;   // 16384-point class, 16-bit: one workgroup pe
 constexpr int CONV_NO_XCD = 2;    // units in plain order instead of all read pairs of a channel on one XCD
 void launch_hyena_conv(int prec, const void* z, void* y, const float2* kf, const float2* tw, const float* ktime,
                        const float* short_w, const float* short_b, int B, int L, int Lp, int logn,
-                       const unsigned char* ids8, const float* ztab, hipStream_t st, int flags = 0);
+                       const unsigned char* ids8, const float* ztab, hipStream_t st, int flags = 0,
+                       const float2* kf_packed = nullptr /*16384-point class: kf through launch_spectrum_lanepack(kf, ., 1, 0);
+                                                           without it the one-workgroup-per-unit kernel runs*/);
 // 8k reads (4098 .. 8193 tokens): the 16384-point convolution as two 8192-point problems (even / odd bins), two workgroups per CU.
 // kf2 [256][2][8192] from launch_spectrum_split(kf of the 16384-point class); twM = the 8192-point twiddle table, twN the 16384 one
 void launch_spectrum_split(const float2* kf, float2* kf2, int logn, hipStream_t st);

@@ -634,7 +634,7 @@ struct ConvGateRaw {                                   // x1 / v rows of one uni
 
 template <typename T, bool IDS>
 __global__ __launch_bounds__(Plan<14>::NT) void hyena_conv_pers_kernel(
-    const T* __restrict__ z, T* __restrict__ y, const float2* __restrict__ kf, const float2* __restrict__ tw,
+    const T* __restrict__ z, T* __restrict__ y, const float2* __restrict__ kf /*lane-packed*/, const float2* __restrict__ tw,
     const float* __restrict__ ktime, const float* __restrict__ short_w, const float* __restrict__ short_b, int B, int L,
     int Lp, const unsigned char* __restrict__ ids8, const float* __restrict__ ztab, int use_xcd) {
     constexpr int LOGN = 14;
@@ -730,7 +730,9 @@ __global__ __launch_bounds__(Plan<14>::NT) void hyena_conv_pers_kernel(
         unit_of(u, c, pair);
         const int bA = 2 * pair, bB = 2 * pair + 1;
         const bool hasB = bB < B;
-        const float2* kfc = kf + (size_t)c * N;
+        // the channel's spectrum, lane-packed (launch_spectrum_lanepack): quad (e, thread) = (re, re, im, im) of the two bins of
+        // butterfly pair e -- one 16-byte load straight into the registers of the product, no shuffles
+        const float4* kfc = reinterpret_cast<const float4*>(kf) + (size_t)c * (N / 2);
         float sw[3][3], sb[3];
 #pragma unroll
         for (int q = 0; q < 3; ++q) {
@@ -808,7 +810,11 @@ __global__ __launch_bounds__(Plan<14>::NT) void hyena_conv_pers_kernel(
         }
         {
             Cx2 kv[16];
-            spectrum_fetch<LOGN, LAST>(kv, ltid, kfc);
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const float4 q4 = kfc[e * NT + ltid];
+                kv[e] = Cx2{make_v2(q4.x, q4.y), make_v2(q4.z, q4.w)};
+            }
             pass_load<LOGN, LAST>(bre, bim, v, ltid);
             pass_compute_w<LOGN, LAST, false>(v, ltid, true, wall + TL::fwd_last());
             spectrum_multiply_and_first_inverse_v<LOGN, LAST>(v, ltid, kv, tail ? gtail[0] : 0.f, tail ? gtail[1] : 0.f);
@@ -1832,11 +1838,12 @@ static void launch_conv_p(int prec, const void* z, void* y, const float2* kf, co
 
 void launch_hyena_conv(int prec, const void* z, void* y, const float2* kf, const float2* tw, const float* ktime,
                        const float* short_w, const float* short_b, int B, int L, int Lp, int logn,
-                       const unsigned char* ids8, const float* ztab, hipStream_t st, int flags) {
+                       const unsigned char* ids8, const float* ztab, hipStream_t st, int flags, const float2* kf_packed) {
     // 16384-point class, 16-bit activations: persistent workgroups with next-unit requests (CONV_ONESHOT: one workgroup per
     // unit -- A/B runs; the developer stamps live in that kernel only)
     static const bool stamp = std::getenv("CLM_STAMP") && std::getenv("CLM_STAMP")[0] == '1';
-    if (logn == 14 && prec != PREC_F32 && !(flags & CONV_ONESHOT) && !stamp) {
+    if (logn == 14 && prec != PREC_F32 && !(flags & CONV_ONESHOT) && !stamp && kf_packed) {
+        kf = kf_packed;
         const bool ids = ids8 != nullptr && ztab != nullptr;
         const int xcd = !(flags & CONV_NO_XCD);
         if (prec == PREC_BF16) {

@@ -261,7 +261,7 @@ def test_persistent_convolution_equals_one_workgroup_per_unit(sd, built_lib, mon
     if env == "CLM_CONV_NO_XCD":
         assert torch.equal(a, b), (a - b).abs().max().item()
     else:
-        assert (a - b).abs().max() < 3e-4
+        assert (a - b).abs().max() < 0.3 * TOL[prec]          # a fraction of the mode's own error bound
         _check(e1, prec, ids, sd)
     e0.close(), e1.close()
 
