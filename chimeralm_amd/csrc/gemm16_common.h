@@ -139,7 +139,9 @@ __device__ __forceinline__ void zero_acc(f32x16 (&acc)[4]) {
 // every earlier LDS access of the workgroup before the As writes.
 // KEEP: the normalised fp32 values also replace the accumulator contents (post-norm blocks: they are the next residual).
 // (gamma / beta from an LDS table instead of the global loads behind the barriers below, with beta folded into the consuming
-//  layer's bias where possible: measured in tail16_kernel, 1.572 vs 1.573 ms per launch -- not kept.)
+//  layer's bias where possible: measured in tail16_kernel, 1.572 vs 1.573 ms per launch -- not kept.  The statistics and the
+//  affine step on register pairs (v_pk_*_f32, half the arithmetic instructions but 190 more v_mov for splats and pairs):
+//  1.568 vs 1.578 ms in the in_proj variant, 1.431 vs 1.422 in the score variant -- not kept either.)
 template <int PREC, bool KEEP = false>
 __device__ __forceinline__ void ln_acc_to_tile(f32x16 (&acc2)[4], float* P1, float* P2, const float* __restrict__ g,
                                                const float* __restrict__ bta, float eps, typename CT<PREC>::elem* As,
