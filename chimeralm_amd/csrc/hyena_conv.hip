@@ -745,49 +745,57 @@ __global__ __launch_bounds__(Plan<14>::NT) void hyena_conv_pers_kernel(
             __syncthreads();
         }
         // ---------------------------------------------------------------- phase A: gate from the rows requested a unit ago
-        float gAt = 0.f, gBt = 0.f;
+        // FULL (uniform): every token a thread touches exists in both reads of the pair (L >= N/2, two reads) -- true for every
+        // unit of an even batch of 8k-bp reads: the ~120 per-element selects of the general form drop out
+        const bool full_unit = L >= HALF && hasB;
+        auto phase_a = [&](auto fullc) {
+            constexpr bool FULL = decltype(fullc)::value;
+            float gAt = 0.f, gBt = 0.f;
 #pragma unroll
-        for (int ch = 0; ch < CH; ++ch) {
-            const int t0 = 8 * (ltid + ch * NT);
-            const bool valid = t0 < L;
-            float xa[3][10], xb[3][10], gA[8], gB[8], x1[8], v[8], x1b[8], vb[8];
-            if constexpr (IDS) {
-                ids_decode<true, 6>(cur.idd[ch][0], cur.idp[ch][0], t0, valid, zt, xa);
-                ids_decode<true, 6>(cur.idd[ch][1], cur.idp[ch][1], t0, valid && hasB, zt, xb);
-            } else {
+            for (int ch = 0; ch < CH; ++ch) {
+                const int t0 = 8 * (ltid + ch * NT);
+                const bool valid = FULL ? true : t0 < L, validB = FULL ? true : (valid && hasB);
+                float xa[3][10], xb[3][10], gA[8], gB[8], x1[8], v[8], x1b[8], vb[8];
+                if constexpr (IDS) {
+                    ids_decode<true, 6>(cur.idd[ch][0], cur.idp[ch][0], t0, valid, zt, xa);
+                    ids_decode<true, 6>(cur.idd[ch][1], cur.idp[ch][1], t0, validB, zt, xb);
+                } else {
 #pragma unroll
-                for (int a3 = 1; a3 < 3; ++a3) {
-                    raw_decode(cur.r[ch][0][a3 - 1], t0, valid, xa[a3]);
-                    raw_decode(cur.r[ch][1][a3 - 1], t0, valid && hasB, xb[a3]);
+                    for (int a3 = 1; a3 < 3; ++a3) {
+                        raw_decode(cur.r[ch][0][a3 - 1], t0, valid, xa[a3]);
+                        raw_decode(cur.r[ch][1][a3 - 1], t0, validB, xb[a3]);
+                    }
+                }
+                fir3_pair(xa[1], xb[1], sw[1][0], sw[1][1], sw[1][2], sb[1], x1, x1b);
+                fir3_pair(xa[2], xb[2], sw[2][0], sw[2][1], sw[2][2], sb[2], v, vb);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    gA[e] = (FULL || t0 + e < L) ? v[e] * x1[e] : 0.f;
+                    gB[e] = (FULL || (hasB && t0 + e < L)) ? vb[e] * x1b[e] : 0.f;
+                }
+                lds_store8(bre + pad_index(t0), gA);
+                lds_store8(bim + pad_index(t0), gB);
+                if (ch == CH - 1 && tail && ltid == TAIL_TID) {   // token HALF: taps are x[8], x[9] of this chunk and z[HALF]
+                    float ta[3] = {0.f, 0.f, 0.f}, tb[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int a3 = 1; a3 < 3; ++a3) {
+                        const float za = IDS ? zt[a3 * 16 + (cur.idt[0] & 15)] : to_float(cur.ztail[0][a3 - 1]);
+                        const float zb = IDS ? zt[a3 * 16 + (cur.idt[1] & 15)] : to_float(cur.ztail[1][a3 - 1]);
+                        ta[a3] = sb[a3] + sw[a3][0] * xa[a3][8] + sw[a3][1] * xa[a3][9] + sw[a3][2] * za;
+                        tb[a3] = sb[a3] + sw[a3][0] * xb[a3][8] + sw[a3][1] * xb[a3][9] + sw[a3][2] * zb;
+                    }
+                    gAt = ta[1] * ta[2];
+                    gBt = hasB ? tb[1] * tb[2] : 0.f;
                 }
             }
-            fir3_pair(xa[1], xb[1], sw[1][0], sw[1][1], sw[1][2], sb[1], x1, x1b);
-            fir3_pair(xa[2], xb[2], sw[2][0], sw[2][1], sw[2][2], sb[2], v, vb);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                gA[e] = (t0 + e < L) ? v[e] * x1[e] : 0.f;
-                gB[e] = (hasB && t0 + e < L) ? vb[e] * x1b[e] : 0.f;
+            // (gtail is its own LDS words: the previous unit's phase C, its last reader, is behind the barrier that ended that unit)
+            if (tail && ltid == TAIL_TID) {
+                gtail[0] = gAt;
+                gtail[1] = gBt;
             }
-            lds_store8(bre + pad_index(t0), gA);
-            lds_store8(bim + pad_index(t0), gB);
-            if (ch == CH - 1 && tail && ltid == TAIL_TID) {   // token HALF: taps are x[8], x[9] of this chunk and z[HALF]
-                float ta[3] = {0.f, 0.f, 0.f}, tb[3] = {0.f, 0.f, 0.f};
-#pragma unroll
-                for (int a3 = 1; a3 < 3; ++a3) {
-                    const float za = IDS ? zt[a3 * 16 + (cur.idt[0] & 15)] : to_float(cur.ztail[0][a3 - 1]);
-                    const float zb = IDS ? zt[a3 * 16 + (cur.idt[1] & 15)] : to_float(cur.ztail[1][a3 - 1]);
-                    ta[a3] = sb[a3] + sw[a3][0] * xa[a3][8] + sw[a3][1] * xa[a3][9] + sw[a3][2] * za;
-                    tb[a3] = sb[a3] + sw[a3][0] * xb[a3][8] + sw[a3][1] * xb[a3][9] + sw[a3][2] * zb;
-                }
-                gAt = ta[1] * ta[2];
-                gBt = hasB ? tb[1] * tb[2] : 0.f;
-            }
-        }
-        __syncthreads();
-        if (tail && ltid == TAIL_TID) {
-            gtail[0] = gAt;
-            gtail[1] = gBt;
-        }
+        };
+        if (full_unit) phase_a(std::true_type{});
+        else phase_a(std::false_type{});
         __syncthreads();
 
         // ---------------------------------------------------------------- phase B: FFT, spectrum product, inverse FFT
@@ -863,56 +871,61 @@ __global__ __launch_bounds__(Plan<14>::NT) void hyena_conv_pers_kernel(
         __syncthreads();
 
         // ---------------------------------------------------------------- phase C: x0 through the short filter, gate, store
-        T* yA = y + ((size_t)bA * D + c) * Lp;
-        T* yB = y + ((size_t)(hasB ? bB : bA) * D + c) * Lp;
+        auto phase_c = [&](auto fullc) {
+            constexpr bool FULL = decltype(fullc)::value;
+            T* yA = y + ((size_t)bA * D + c) * Lp;
+            T* yB = y + ((size_t)(hasB ? bB : bA) * D + c) * Lp;
 #pragma unroll
-        for (int ch = 0; ch < CH; ++ch) {
-            const int t0 = 8 * (ltid + ch * NT);
-            const bool valid = t0 < L;
-            float xa[10], xb[10], x0a[8], x0b[8];
-            if constexpr (IDS) {
-                float xa3[3][10], xb3[3][10];
-                // opaque copies: otherwise the 40 extracted ids (common subexpressions with phase A) are kept across the
-                // transform -- in scratch
+            for (int ch = 0; ch < CH; ++ch) {
+                const int t0 = 8 * (ltid + ch * NT);
+                const bool valid = FULL ? true : t0 < L, validB = FULL ? true : (valid && hasB);
+                float xa[10], xb[10], x0a[8], x0b[8];
+                if constexpr (IDS) {
+                    float xa3[3][10], xb3[3][10];
+                    // opaque copies: otherwise the 40 extracted ids (common subexpressions with phase A) are kept across the
+                    // transform -- in scratch
 #pragma unroll
-                for (int rd = 0; rd < 2; ++rd)
-                    asm volatile("" : "+v"(cur.idd[ch][rd].x), "+v"(cur.idd[ch][rd].y), "+v"(cur.idp[ch][rd]));
-                ids_decode<true, 1>(cur.idd[ch][0], cur.idp[ch][0], t0, valid, zt, xa3);
-                ids_decode<true, 1>(cur.idd[ch][1], cur.idp[ch][1], t0, valid && hasB, zt, xb3);
+                    for (int rd = 0; rd < 2; ++rd)
+                        asm volatile("" : "+v"(cur.idd[ch][rd].x), "+v"(cur.idd[ch][rd].y), "+v"(cur.idp[ch][rd]));
+                    ids_decode<true, 1>(cur.idd[ch][0], cur.idp[ch][0], t0, valid, zt, xa3);
+                    ids_decode<true, 1>(cur.idd[ch][1], cur.idp[ch][1], t0, validB, zt, xb3);
 #pragma unroll
-                for (int e = 0; e < 10; ++e) xa[e] = xa3[0][e], xb[e] = xb3[0][e];
-            } else {
-                raw_decode(x0r[ch][0], t0, valid, xa);
-                raw_decode(x0r[ch][1], t0, valid && hasB, xb);
-            }
-            fir3_pair(xa, xb, sw[0][0], sw[0][1], sw[0][2], sb[0], x0a, x0b);
-            if (t0 < Lp) {
-                float oA[8], oB[8];
-                lds_load8(bre + pad_index(t0), oA);
-                lds_load8(bim + pad_index(t0), oB);
-                if (tail && t0 == 0) {  // remove the one wrapped product k[L-1]*g[L-1] from output 0
-                    const float kl = ktime[(size_t)(L - 1) * D + c];
-                    oA[0] -= kl * gtail[0];
-                    oB[0] -= kl * gtail[1];
+                    for (int e = 0; e < 10; ++e) xa[e] = xa3[0][e], xb[e] = xb3[0][e];
+                } else {
+                    raw_decode(x0r[ch][0], t0, valid, xa);
+                    raw_decode(x0r[ch][1], t0, validB, xb);
                 }
+                fir3_pair(xa, xb, sw[0][0], sw[0][1], sw[0][2], sb[0], x0a, x0b);
+                if (t0 < Lp) {
+                    float oA[8], oB[8];
+                    lds_load8(bre + pad_index(t0), oA);
+                    lds_load8(bim + pad_index(t0), oB);
+                    if (tail && t0 == 0) {  // remove the one wrapped product k[L-1]*g[L-1] from output 0
+                        const float kl = ktime[(size_t)(L - 1) * D + c];
+                        oA[0] -= kl * gtail[0];
+                        oB[0] -= kl * gtail[1];
+                    }
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const bool ok = t0 + e < L;
-                    oA[e] = ok ? oA[e] * x0a[e] : 0.f;
-                    oB[e] = ok ? oB[e] * x0b[e] : 0.f;
+                    for (int e = 0; e < 8; ++e) {
+                        const bool ok = FULL || t0 + e < L;
+                        oA[e] = ok ? oA[e] * x0a[e] : 0.f;
+                        oB[e] = ok ? oB[e] * x0b[e] : 0.f;
+                    }
+                    store8<T>(yA + t0, oA);
+                    if (hasB) store8<T>(yB + t0, oB);
                 }
-                store8<T>(yA + t0, oA);
-                if (hasB) store8<T>(yB + t0, oB);
+                if (ch == CH - 1 && tail && ltid == TAIL_TID) {     // token HALF: x0 from x[8], x[9] of this chunk and z[HALF]
+                    const float za = IDS ? zt[cur.idt[0] & 15] : to_float(x0tail[0]);
+                    const float zb = IDS ? zt[cur.idt[1] & 15] : to_float(x0tail[1]);
+                    const float x0At = sb[0] + sw[0][0] * xa[8] + sw[0][1] * xa[9] + sw[0][2] * za;
+                    const float x0Bt = sb[0] + sw[0][0] * xb[8] + sw[0][1] * xb[9] + sw[0][2] * zb;
+                    yA[HALF] = from_float<T>(bre[pad_index(HALF)] * x0At);
+                    if (hasB) yB[HALF] = from_float<T>(bim[pad_index(HALF)] * x0Bt);
+                }
             }
-            if (ch == CH - 1 && tail && ltid == TAIL_TID) {     // token HALF: x0 from x[8], x[9] of this chunk and z[HALF]
-                const float za = IDS ? zt[cur.idt[0] & 15] : to_float(x0tail[0]);
-                const float zb = IDS ? zt[cur.idt[1] & 15] : to_float(x0tail[1]);
-                const float x0At = sb[0] + sw[0][0] * xa[8] + sw[0][1] * xa[9] + sw[0][2] * za;
-                const float x0Bt = sb[0] + sw[0][0] * xb[8] + sw[0][1] * xb[9] + sw[0][2] * zb;
-                yA[HALF] = from_float<T>(bre[pad_index(HALF)] * x0At);
-                if (hasB) yB[HALF] = from_float<T>(bim[pad_index(HALF)] * x0Bt);
-            }
-        }
+        };
+        if (full_unit) phase_c(std::true_type{});
+        else phase_c(std::false_type{});
         cur = nxt;
         __syncthreads();                                  // the buffer (and zt / gtail) are rewritten by the next unit
     }
@@ -1373,7 +1386,7 @@ __global__ __launch_bounds__(Plan<14>::NT) void hyena_conv_seg_kernel(
                 lds_store8(bim + pad_index(tl), gB);
             }
         } else {
-    #pragma unroll
+#pragma unroll
             for (int ch = 0; ch < CH; ++ch) {
                 const int tl = 8 * (ltid + ch * NT), t0 = seg0 + tl;
                 float gA[8], gB[8];
@@ -1381,19 +1394,19 @@ __global__ __launch_bounds__(Plan<14>::NT) void hyena_conv_seg_kernel(
                     float x1[8], v[8];
                     short_filter8<T>(zA + (size_t)(1 * D + c) * Lp, t0, sw[1][0], sw[1][1], sw[1][2], sb[1], x1);
                     short_filter8<T>(zA + (size_t)(2 * D + c) * Lp, t0, sw[2][0], sw[2][1], sw[2][2], sb[2], v);
-    #pragma unroll
+#pragma unroll
                     for (int e = 0; e < 8; ++e) gA[e] = (t0 + e < L) ? v[e] * x1[e] : 0.f;
                     if (hasB) {
                         short_filter8<T>(zB + (size_t)(1 * D + c) * Lp, t0, sw[1][0], sw[1][1], sw[1][2], sb[1], x1);
                         short_filter8<T>(zB + (size_t)(2 * D + c) * Lp, t0, sw[2][0], sw[2][1], sw[2][2], sb[2], v);
-    #pragma unroll
+#pragma unroll
                         for (int e = 0; e < 8; ++e) gB[e] = (t0 + e < L) ? v[e] * x1[e] : 0.f;
                     } else {
-    #pragma unroll
+#pragma unroll
                         for (int e = 0; e < 8; ++e) gB[e] = 0.f;
                     }
                 } else {
-    #pragma unroll
+#pragma unroll
                     for (int e = 0; e < 8; ++e) gA[e] = 0.f, gB[e] = 0.f;
                 }
                 lds_store8(bre + pad_index(tl), gA);
