@@ -1,0 +1,54 @@
+"""Compiler-side regression guard (CPU: hipcc cross-compiles gfx950 without a GPU).
+
+DESIGN.md section 4.7: what cost the hot kernels most in round 2 was not their structure but registers hipcc spilled --
+scratch loads and stores are vector-memory instructions, `vmcnt` retires in order, so a reload in the middle of a tuned loop
+waits for every weight set / row request issued before it.  `chimeralm_amd.build` keeps hipcc's per-kernel resource remarks of
+the last build in `csrc/kernel_resources.txt`; this test holds the kernels of the headline path to (almost) no scratch."""
+import re
+
+from chimeralm_amd import build as B
+
+
+def _resources():
+    B.build()
+    out, name = {}, None
+    for ln in B.RESOURCES.read_text().splitlines():
+        if ln.startswith("Function Name: "):
+            name = ln.split(": ", 1)[1].strip()
+            out[name] = {}
+        elif name and ":" in ln:
+            k, v = ln.strip().split(":", 1)
+            out[name][k.strip()] = v.strip()
+    return out
+
+
+def _scratch(res, pattern):
+    hits = {n: int(r["ScratchSize [bytes/lane]"]) for n, r in res.items() if re.search(pattern, n)}
+    assert hits, f"no kernel matches {pattern}"
+    return hits
+
+
+def test_hot_kernels_have_no_scratch_in_their_loops():
+    res = _resources()
+    # bytes per lane allowed: 0 for the kernels that are > 90 % of the headline step; a few dwords elsewhere (set-up values
+    # spilled outside the loops)
+    budget = [
+        (r"tail16_kernelILi3ELb0ELi1E", 0),                      # fp16c tail, in_proj variant (3 of 4 launches)
+        (r"tail16_kernelILi3ELb0ELi2E", 16),                     # fp16c tail, score variant
+        (r"tail16_kernelILi2ELb0ELi1E", 0),                      # plain fp16
+        (r"hyena_conv_pers_kernelINS_5f16_tELb0E", 0),           # 8k convolution, blocks 1-3
+        (r"hyena_conv_pers_kernelINS_5f16_tELb1E", 16),          # block 0 (token ids)
+        (r"hyena_conv_kernelILi13ENS_5f16_tELb0ELb0E", 0),       # 4k reads
+        (r"hyena_conv_seg_kernelINS_5f16_tELb1ELb0E", 64),       # long reads (was 324 before the buffer addressing)
+        (r"hyena_conv_seg_kernelINS_5f16_tELb0ELb0E", 0),
+    ]
+    for pattern, allowed in budget:
+        for name, got in _scratch(res, pattern).items():
+            assert got <= allowed, f"{name}: {got} bytes of scratch per lane (budget {allowed})"
+
+
+def test_tile_kernels_keep_two_waves_per_simd():
+    res = _resources()
+    for name, r in res.items():
+        if re.search(r"tail16_kernelILi[123]ELb0", name) or "hyena_conv_pers_kernel" in name:
+            assert int(r["Occupancy [waves/SIMD]"]) >= 2, name
