@@ -1,0 +1,205 @@
+// Probe for DESIGN.md section 8's lever: the `lo` half of the compensated fp16 mode (weights w = hi + lo, lo ~ 2^-11 w) as ONE
+// fp8 product on the block-scaled K = 64 MFMA instead of four fp16 MFMAs.
+//   1. operand layout of v_mfma_scale_f32_32x32x64_f8f6f4 with e4m3 operands, checked with exact small-integer data
+//      (assumed: lane l holds row / column l & 31 and the 32 bytes k = 32 (l >> 5) + j of its 8 registers; scale = 2^(byte - 127)
+//      for the lane's 32-element block);
+//   2. cycles of the instruction against v_mfma_f32_32x32x16_f16 (back to back, one wave per SIMD);
+//   3. error of  a . hi  (fp16 MFMA)  +  fp8(a) . fp8(lo * 2^S) * 2^-S  (scaled MFMA)  against the exact product, next to hi only and
+//      to the current hi + lo pair of fp16 MFMAs -- 64-deep dot products of N(0,1) activations with N(0, 0.05^2) weights.
+//   hipcc --offload-arch=gfx950 -O3 -o /tmp/mfma_fp8_lo tools/micro/mfma_fp8_lo.cpp && /tmp/mfma_fp8_lo
+#include <hip/hip_runtime.h>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <random>
+#include <vector>
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+
+// OCP e4m3fn (bias 7, max 448, no infinities), round to nearest even, saturating
+static uint8_t to_e4m3(float x) {
+    const uint8_t s = std::signbit(x) ? 0x80 : 0;
+    float a = std::fabs(x);
+    if (!(a == a)) return 0x7f;
+    if (a >= 448.f) return s | 0x7e;
+    if (a < std::ldexp(1.f, -10)) return s;                     // below half the smallest subnormal (2^-9)
+    int e;
+    std::frexp(a, &e);                                           // a = m 2^e, m in [0.5, 1)
+    int E = e - 1;                                               // a = (1.f) 2^E
+    if (E < -6) E = -6;                                          // subnormal: fixed exponent 2^-6, 3 fraction bits
+    const float q = std::nearbyint(std::ldexp(a, 3 - E));        // in units of 2^(E-3)
+    int mant = (int)q;                                           // 8..16 for normals, 0..8 for subnormals
+    int be = E + 7;
+    if (E == -6 && mant < 8) return s | (uint8_t)mant;           // subnormal (exponent field 0)
+    if (mant == 16) { mant = 8; ++be; }
+    if (be > 15 || (be == 15 && mant - 8 > 6)) return s | 0x7e;
+    return s | (uint8_t)(be << 3) | (uint8_t)(mant - 8);
+}
+static float from_e4m3(uint8_t b) {
+    const float sg = (b & 0x80) ? -1.f : 1.f;
+    const int be = (b >> 3) & 15, m = b & 7;
+    if (be == 0) return sg * std::ldexp((float)m, -9);
+    return sg * std::ldexp(1.f + m / 8.f, be - 7);
+}
+
+// one 32 x 32 tile, K = 64: D = A(32 x 64) . B(64 x 32) through the scaled MFMA; a8 / b8 row-major [32][64] bytes
+__global__ void fp8_tile(const uint8_t* a8, const uint8_t* b8 /*[col][k]*/, float* d /*[32][32]*/, int scale_a, int scale_b) {
+    const int l = threadIdx.x, r = l & 31, h = l >> 5;
+    i32x8 a, b;
+    std::memcpy(&a, a8 + r * 64 + 32 * h, 32);
+    std::memcpy(&b, b8 + r * 64 + 32 * h, 32);
+    f32x16 acc = {};
+    acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, acc, 0 /*A: e4m3*/, 0 /*B: e4m3*/, 0, scale_a, 0, scale_b);
+    for (int reg = 0; reg < 16; ++reg) d[((reg & 3) + 8 * (reg >> 2) + 4 * h) * 32 + r] = acc[reg];   // row, col = lane
+}
+
+// accuracy: hi by four fp16 MFMAs, lo by (a) four fp16 MFMAs, (b) one fp8 MFMA; a16 [32][64] halfs, whi / wlo [32 cols][64] halfs,
+// a8 / lo8 [32][64] bytes in the MFMA's k order
+__global__ void acc_probe(const _Float16* a16, const _Float16* whi, const _Float16* wlo, const uint8_t* a8, const uint8_t* lo8,
+                          int scale_lo, float* d_hi, float* d_pair, float* d_fp8) {
+    const int l = threadIdx.x, r = l & 31, h = l >> 5;
+    f32x16 hi = {}, pr = {};
+    for (int s = 0; s < 4; ++s) {
+        f16x8 a, bh, bl;
+        for (int j = 0; j < 8; ++j) {
+            a[j] = a16[r * 64 + 16 * s + 8 * h + j];
+            bh[j] = whi[r * 64 + 16 * s + 8 * h + j];
+            bl[j] = wlo[r * 64 + 16 * s + 8 * h + j];
+        }
+        hi = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bh, hi, 0, 0, 0);
+        pr = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bh, pr, 0, 0, 0);
+        pr = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bl, pr, 0, 0, 0);
+    }
+    i32x8 a, b;
+    std::memcpy(&a, a8 + r * 64 + 32 * h, 32);
+    std::memcpy(&b, lo8 + r * 64 + 32 * h, 32);
+    f32x16 f8 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, hi, 0, 0, 0, 127, 0, scale_lo);
+    for (int reg = 0; reg < 16; ++reg) {
+        const int o = ((reg & 3) + 8 * (reg >> 2) + 4 * h) * 32 + r;
+        d_hi[o] = hi[reg], d_pair[o] = pr[reg], d_fp8[o] = f8[reg];
+    }
+}
+
+template <int KIND>   // 0: fp16 32x32x16, 1: scaled fp8 32x32x64
+__global__ void rate_probe(unsigned long long* out, int iters, float* sink) {
+    f32x16 acc[4] = {};
+    f16x8 ah = {}, bh = {};
+    i32x8 a8 = {}, b8 = {};
+    for (int j = 0; j < 8; ++j) { ah[j] = (_Float16)(0.01f * (threadIdx.x + j)); bh[j] = (_Float16)(0.02f * j); a8[j] = 0x38383838 + j; b8[j] = 0x30303030 + threadIdx.x; }
+    __syncthreads();
+    const unsigned long long m0 = __builtin_amdgcn_s_memtime();
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            if (KIND == 0) acc[k & 3] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[k & 3], 0, 0, 0);
+            else acc[k & 3] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, b8, acc[k & 3], 0, 0, 0, 127, 0, 120);
+        }
+    }
+    const unsigned long long m1 = __builtin_amdgcn_s_memtime();
+    float s = 0;
+    for (int k = 0; k < 4; ++k) for (int r = 0; r < 16; ++r) s += acc[k][r];
+    if (s == 123.456f) sink[0] = s;
+    if ((threadIdx.x & 63) == 0) atomicMax(&out[blockIdx.x], m1 - m0);
+}
+
+template <typename T>
+static T* dev(const std::vector<T>& v) {
+    T* p;
+    (void)hipMalloc(&p, v.size() * sizeof(T));
+    (void)hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice);
+    return p;
+}
+
+int main() {
+    // ---- 1. layout with exact data: A[i][k] = (i + k) % 5, B[k][j] = (2 j + k) % 7 - 3 (all exact in e4m3), scale 2^-3 on B
+    {
+        std::vector<uint8_t> a8(32 * 64), b8(32 * 64);
+        std::vector<float> ref(32 * 32, 0.f);
+        for (int i = 0; i < 32; ++i)
+            for (int k = 0; k < 64; ++k) a8[i * 64 + k] = to_e4m3((float)((i + k) % 5)), b8[i * 64 + k] = to_e4m3((float)((2 * i + k) % 7 - 3));
+        for (int i = 0; i < 32; ++i)
+            for (int j = 0; j < 32; ++j)
+                for (int k = 0; k < 64; ++k) ref[i * 32 + j] += (float)((i + k) % 5) * (float)((2 * j + k) % 7 - 3) * 0.125f;
+        float* d;
+        (void)hipMalloc(&d, 32 * 32 * 4);
+        hipLaunchKernelGGL(fp8_tile, dim3(1), dim3(64), 0, 0, dev(a8), dev(b8), d, 127, 124);
+        std::vector<float> got(32 * 32);
+        (void)hipMemcpy(got.data(), d, got.size() * 4, hipMemcpyDeviceToHost);
+        int bad = 0;
+        for (int i = 0; i < 32 * 32; ++i) bad += got[i] != ref[i];
+        std::printf("[layout] e4m3 x e4m3 32x32x64, rows/cols on lane & 31, k = 32 (lane >> 5) + byte, scale_b = 2^-3: %d of 1024 outputs differ from the exact product%s\n",
+                    bad, bad ? "  (first: got %g want %g)" : "");
+        if (bad) std::printf("          got %g want %g\n", got[0], ref[0]);
+    }
+    // ---- 2. rate
+    {
+        unsigned long long* out;
+        float* sink;
+        const int nb = 256, iters = 2000;
+        (void)hipMalloc(&out, nb * 8);
+        (void)hipMalloc(&sink, 4);
+        for (int kind = 0; kind < 2; ++kind) {
+            (void)hipMemset(out, 0, nb * 8);
+            if (kind == 0) hipLaunchKernelGGL(rate_probe<0>, dim3(nb), dim3(256), 0, 0, out, iters, sink);
+            else hipLaunchKernelGGL(rate_probe<1>, dim3(nb), dim3(256), 0, 0, out, iters, sink);
+            std::vector<unsigned long long> h(nb);
+            (void)hipMemcpy(h.data(), out, nb * 8, hipMemcpyDeviceToHost);
+            double mean = 0;
+            for (auto t : h) mean += (double)t;
+            mean /= nb;
+            std::printf("[rate] %s: %.1f s_memtime ticks per MFMA (one wave per SIMD, 256 CUs busy)\n",
+                        kind == 0 ? "v_mfma_f32_32x32x16_f16            " : "v_mfma_scale_f32_32x32x64 (e4m3)", mean / (16.0 * iters));
+        }
+    }
+    // ---- 3. accuracy of the compensated product
+    {
+        std::mt19937 rng(7);
+        std::normal_distribution<float> na(0.f, 1.f), nw(0.f, 0.05f);
+        const int trials = 64;
+        double e_hi = 0, e_pair = 0, e_f8 = 0, ref_rms = 0;
+        float *d_hi, *d_pair, *d_f8;
+        (void)hipMalloc(&d_hi, 4096), (void)hipMalloc(&d_pair, 4096), (void)hipMalloc(&d_f8, 4096);
+        for (int t = 0; t < trials; ++t) {
+            std::vector<_Float16> a16(32 * 64), whi(32 * 64), wlo(32 * 64);
+            std::vector<float> w(32 * 64);
+            std::vector<uint8_t> a8(32 * 64), lo8(32 * 64);
+            float lomax = 0.f;
+            for (int i = 0; i < 32 * 64; ++i) {
+                a16[i] = (_Float16)na(rng);
+                w[i] = nw(rng);
+                whi[i] = (_Float16)w[i];
+                wlo[i] = (_Float16)(w[i] - (float)whi[i]);
+                lomax = std::fmax(lomax, std::fabs((float)wlo[i]));
+            }
+            const int S = (int)std::floor(std::log2(256.f / lomax));         // lo * 2^S below 256 < 448
+            // the fp8 operands in the MFMA's k order: lane half h, byte 8 s + j  <-  k = 16 s + 8 h + j (the fp16 fragments' order)
+            for (int r = 0; r < 32; ++r)
+                for (int h = 0; h < 2; ++h)
+                    for (int s = 0; s < 4; ++s)
+                        for (int j = 0; j < 8; ++j) {
+                            const int k = 16 * s + 8 * h + j, dst = r * 64 + 32 * h + 8 * s + j;
+                            a8[dst] = to_e4m3((float)a16[r * 64 + k]);
+                            lo8[dst] = to_e4m3(std::ldexp((float)wlo[r * 64 + k], S));
+                        }
+            hipLaunchKernelGGL(acc_probe, dim3(1), dim3(64), 0, 0, dev(a16), dev(whi), dev(wlo), dev(a8), dev(lo8), 127 - S, d_hi, d_pair, d_f8);
+            std::vector<float> hi(1024), pr(1024), f8(1024);
+            (void)hipMemcpy(hi.data(), d_hi, 4096, hipMemcpyDeviceToHost);
+            (void)hipMemcpy(pr.data(), d_pair, 4096, hipMemcpyDeviceToHost);
+            (void)hipMemcpy(f8.data(), d_f8, 4096, hipMemcpyDeviceToHost);
+            for (int i = 0; i < 32; ++i)
+                for (int j = 0; j < 32; ++j) {
+                    double ref = 0;
+                    for (int k = 0; k < 64; ++k) ref += (double)(float)a16[i * 64 + k] * (double)w[j * 64 + k];
+                    const int o = i * 32 + j;
+                    e_hi += (hi[o] - ref) * (hi[o] - ref), e_pair += (pr[o] - ref) * (pr[o] - ref), e_f8 += (f8[o] - ref) * (f8[o] - ref);
+                    ref_rms += ref * ref;
+                }
+        }
+        const double n = trials * 1024.0;
+        std::printf("[error] 64-deep products, rms of the exact value %.3g; rms error: hi only %.3g, hi + lo (fp16 pair) %.3g, hi + fp8 lo %.3g\n",
+                    std::sqrt(ref_rms / n), std::sqrt(e_hi / n), std::sqrt(e_pair / n), std::sqrt(e_f8 / n));
+    }
+    return 0;
+}
