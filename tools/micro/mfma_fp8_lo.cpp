@@ -58,7 +58,7 @@ __global__ void fp8_tile(const uint8_t* a8, const uint8_t* b8 /*[col][k]*/, floa
 // accuracy: hi by four fp16 MFMAs, lo by (a) four fp16 MFMAs, (b) one fp8 MFMA; a16 [32][64] halfs, whi / wlo [32 cols][64] halfs,
 // a8 / lo8 [32][64] bytes in the MFMA's k order
 __global__ void acc_probe(const _Float16* a16, const _Float16* whi, const _Float16* wlo, const uint8_t* a8, const uint8_t* lo8,
-                          int scale_lo, float* d_hi, float* d_pair, float* d_fp8) {
+                          int scale_lo, float* d_hi, float* d_pair, float* d_fp8, float* d_bf8) {
     const int l = threadIdx.x, r = l & 31, h = l >> 5;
     f32x16 hi = {}, pr = {};
     for (int s = 0; s < 4; ++s) {
@@ -76,9 +76,23 @@ __global__ void acc_probe(const _Float16* a16, const _Float16* whi, const _Float
     std::memcpy(&a, a8 + r * 64 + 32 * h, 32);
     std::memcpy(&b, lo8 + r * 64 + 32 * h, 32);
     f32x16 f8 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, hi, 0, 0, 0, 127, 0, scale_lo);
+    // the activation operand converted IN REGISTERS from the fp16 fragments (what the kernel would do), as e5m2: no overflow
+    // below 57344 (v_cvt_scalef32_pk_fp8_f16 turns |x| >= 464 into NaN, it does not saturate)
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    typedef short s2 __attribute__((ext_vector_type(2)));
+    i32x8 ab;
+    for (int s = 0; s < 4; ++s)
+        for (int jj = 0; jj < 2; ++jj) {
+            const _Float16* p = a16 + r * 64 + 16 * s + 8 * h + 4 * jj;
+            s2 w = {0, 0};
+            w = __builtin_amdgcn_cvt_scalef32_pk_bf8_f16(w, h2{p[0], p[1]}, 1.0f, false);
+            w = __builtin_amdgcn_cvt_scalef32_pk_bf8_f16(w, h2{p[2], p[3]}, 1.0f, true);
+            ab[2 * s + jj] = __builtin_bit_cast(int, w);
+        }
+    f32x16 fb = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(ab, b, hi, 1 /*A: e5m2*/, 0, 0, 127, 0, scale_lo);
     for (int reg = 0; reg < 16; ++reg) {
         const int o = ((reg & 3) + 8 * (reg >> 2) + 4 * h) * 32 + r;
-        d_hi[o] = hi[reg], d_pair[o] = pr[reg], d_fp8[o] = f8[reg];
+        d_hi[o] = hi[reg], d_pair[o] = pr[reg], d_fp8[o] = f8[reg], d_bf8[o] = fb[reg];
     }
 }
 
@@ -158,9 +172,9 @@ int main() {
         std::mt19937 rng(7);
         std::normal_distribution<float> na(0.f, 1.f), nw(0.f, 0.05f);
         const int trials = 64;
-        double e_hi = 0, e_pair = 0, e_f8 = 0, ref_rms = 0;
-        float *d_hi, *d_pair, *d_f8;
-        (void)hipMalloc(&d_hi, 4096), (void)hipMalloc(&d_pair, 4096), (void)hipMalloc(&d_f8, 4096);
+        double e_hi = 0, e_pair = 0, e_f8 = 0, e_b8 = 0, ref_rms = 0;
+        float *d_hi, *d_pair, *d_f8, *d_b8;
+        (void)hipMalloc(&d_hi, 4096), (void)hipMalloc(&d_pair, 4096), (void)hipMalloc(&d_f8, 4096), (void)hipMalloc(&d_b8, 4096);
         for (int t = 0; t < trials; ++t) {
             std::vector<_Float16> a16(32 * 64), whi(32 * 64), wlo(32 * 64);
             std::vector<float> w(32 * 64);
@@ -183,23 +197,24 @@ int main() {
                             a8[dst] = to_e4m3((float)a16[r * 64 + k]);
                             lo8[dst] = to_e4m3(std::ldexp((float)wlo[r * 64 + k], S));
                         }
-            hipLaunchKernelGGL(acc_probe, dim3(1), dim3(64), 0, 0, dev(a16), dev(whi), dev(wlo), dev(a8), dev(lo8), 127 - S, d_hi, d_pair, d_f8);
-            std::vector<float> hi(1024), pr(1024), f8(1024);
+            hipLaunchKernelGGL(acc_probe, dim3(1), dim3(64), 0, 0, dev(a16), dev(whi), dev(wlo), dev(a8), dev(lo8), 127 - S, d_hi, d_pair, d_f8, d_b8);
+            std::vector<float> hi(1024), pr(1024), f8(1024), b8(1024);
             (void)hipMemcpy(hi.data(), d_hi, 4096, hipMemcpyDeviceToHost);
             (void)hipMemcpy(pr.data(), d_pair, 4096, hipMemcpyDeviceToHost);
             (void)hipMemcpy(f8.data(), d_f8, 4096, hipMemcpyDeviceToHost);
+            (void)hipMemcpy(b8.data(), d_b8, 4096, hipMemcpyDeviceToHost);
             for (int i = 0; i < 32; ++i)
                 for (int j = 0; j < 32; ++j) {
                     double ref = 0;
                     for (int k = 0; k < 64; ++k) ref += (double)(float)a16[i * 64 + k] * (double)w[j * 64 + k];
                     const int o = i * 32 + j;
-                    e_hi += (hi[o] - ref) * (hi[o] - ref), e_pair += (pr[o] - ref) * (pr[o] - ref), e_f8 += (f8[o] - ref) * (f8[o] - ref);
+                    e_hi += (hi[o] - ref) * (hi[o] - ref), e_pair += (pr[o] - ref) * (pr[o] - ref), e_f8 += (f8[o] - ref) * (f8[o] - ref), e_b8 += (b8[o] - ref) * (b8[o] - ref);
                     ref_rms += ref * ref;
                 }
         }
         const double n = trials * 1024.0;
-        std::printf("[error] 64-deep products, rms of the exact value %.3g; rms error: hi only %.3g, hi + lo (fp16 pair) %.3g, hi + fp8 lo %.3g\n",
-                    std::sqrt(ref_rms / n), std::sqrt(e_hi / n), std::sqrt(e_pair / n), std::sqrt(e_f8 / n));
+        std::printf("[error] 64-deep products, rms of the exact value %.3g; rms error: hi only %.3g, hi + lo (fp16 pair) %.3g, hi + fp8 lo %.3g (activations e4m3, host-rounded), %.3g (activations e5m2, converted in registers)\n",
+                    std::sqrt(ref_rms / n), std::sqrt(e_hi / n), std::sqrt(e_pair / n), std::sqrt(e_f8 / n), std::sqrt(e_b8 / n));
     }
     return 0;
 }
