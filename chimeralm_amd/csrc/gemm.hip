@@ -47,6 +47,13 @@ __global__ void pack_weight_kernel(const float* __restrict__ w, typename CT<PREC
 //   out[(((nt*(K/16) + ks)*2 + hl)*64 + lane)*8 + j]
 // (|lo| <= 2^-12 |w| is an fp16 subnormal for |w| < 0.25; v_mfma_f32_32x32x16_f16 keeps subnormal inputs --
 // tools/micro/mfma_denorm.cpp -- and the 2^-24 subnormal spacing still leaves the pair within 2^-19 of |w| = 0.06.)
+// Compensated mode, stream of one (32-column tile, 64-deep group of four k-steps) = 8 fragment slots of 64 lanes x 16 bytes:
+//   slots 0..3   hi = fp16(w) of k-steps 0..3 (the fp16 MFMA fragments as in pack_weight_kernel)
+//   slots 4, 5   lo = e4m3((w - hi) * 2^LO8_SHIFT): the lane's 32 bytes of the K = 64 scaled MFMA, byte 8 s + j = k-step s,
+//                element j -- the order in which the activation fragments of the four k-steps convert in registers
+//   slots 6, 7   unused (never loaded: the stream keeps its 8-slot stride)
+// |w - hi| <= 2^-11 |w|: with 2^17 the e4m3 range (448) holds every |w| < 8, larger ones saturate (their lo term is then short,
+// never wrong in sign or NaN).
 __global__ void pack_weight_split_kernel(const float* __restrict__ w, f16_t* __restrict__ out, int n, int k) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (size_t)n * k) return;
@@ -57,10 +64,12 @@ __global__ void pack_weight_split_kernel(const float* __restrict__ w, f16_t* __r
     const int ksteps = k / 16, ks = int(q % ksteps), nt = int(q / ksteps);
     const float v = w[(size_t)(nt * 32 + (lane & 31)) * k + ks * 16 + 8 * (lane >> 5) + j];
     const f16_t hi = from_float<f16_t>(v);
-    const f16_t lo = from_float<f16_t>(v - to_float(hi));
-    const size_t base = ((((size_t)nt * ksteps + ks) * 2) * 64 + lane) * 8 + j;
-    out[base] = hi;
-    out[base + 64 * 8] = lo;
+    const float lo = fminf(fmaxf((v - to_float(hi)) * LO8_SCALE, -448.f), 448.f);
+    const int group = ks / 4, s = ks % 4;
+    const size_t set = ((size_t)nt * (ksteps / 4) + group) * (8 * 64 * 8);            // in 16-bit units
+    out[set + ((size_t)s * 64 + lane) * 8 + j] = hi;
+    const int two = __builtin_amdgcn_cvt_pk_fp8_f32(lo, 0.f, 0, false);                // e4m3, round to nearest even
+    reinterpret_cast<unsigned char*>(out + set)[(size_t)(4 + (s >> 1)) * 1024 + lane * 16 + (s & 1) * 8 + j] = (unsigned char)(two & 0xff);
 }
 
 size_t packed_weight_bytes(int prec, int n, int k) {

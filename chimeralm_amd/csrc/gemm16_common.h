@@ -31,6 +31,46 @@ __device__ __forceinline__ void compute_tm(const typename CT<PREC>::elem* As, in
     // and two half-sets live), and every MFMA then pays a full LDS latency: fc1 ran at half the rate of fc2.
     constexpr int FR = WFR<PREC>, KP = KPS<PREC>, NI = 4 * KP, R = AHEAD + 1;
     const typename CT<PREC>::elem* a0 = As + lrow * RS16 + part * KP * 16 + lhalf * 8;
+    if constexpr (PREC == PREC_F16C) {
+        // Compensated mode.  Items run ROW-TILE major (mt = i >> 2, k-step = i & 3): a row tile's four activation fragments feed
+        // four fp16 MFMAs with the hi fragments and, converted to e5m2 in registers as they pass (8 registers), ONE K = 64 fp8
+        // MFMA with the lo bytes -- half the cycles of the four fp16 lo MFMAs it replaces, 2.9e-6 instead of 8.3e-5 rms on
+        // a 64-deep product (tools/micro/mfma_fp8_lo.cpp).
+        static_assert(KP == 4 && NI == 16, "a set is one 64-deep group");
+        u16x8 afc[R];
+        i32x8 a8 = {0, 0, 0, 0, 0, 0, 0, 0};          // converted in place, row tile after row tile (frag_to_bf8)
+        i32x8 w8;
+        {
+            const unsigned* lo32 = reinterpret_cast<const unsigned*>(&src[0][4]);
+#pragma unroll
+            for (int r = 0; r < 8; ++r) w8[r] = (int)lo32[r];
+        }
+#pragma unroll
+        for (int i = 0; i < AHEAD; ++i) afc[i % R] = *reinterpret_cast<const u16x8*>(a0 + (i >> 2) * 32 * RS16 + (i & 3) * 16);
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            if (i + AHEAD < NI) {
+                const int n = i + AHEAD;
+                afc[n % R] = *reinterpret_cast<const u16x8*>(a0 + (n >> 2) * 32 * RS16 + (n & 3) * 16);
+            }
+            const int mt = i >> 2, ks = i & 3;
+            if (ROWS_N) acc[mt] = mfma<PREC>(src[0][ks], afc[i % R], acc[mt]);
+            else acc[mt] = mfma<PREC>(afc[i % R], src[0][ks], acc[mt]);
+            int w0 = a8[2 * ks], w1 = a8[2 * ks + 1];
+            frag_to_bf8(afc[i % R], w0, w1);
+            a8[2 * ks] = w0, a8[2 * ks + 1] = w1;
+            if (ks == 3) acc[mt] = mfma_lo8<ROWS_N>(w8, a8, acc[mt]);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x100, AHEAD, 0);
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            if (i + AHEAD < NI) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+            if ((i & 3) == 3) __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        }
+        return;
+    }
     u16x8 af[R];
 #pragma unroll
     for (int i = 0; i < AHEAD; ++i) af[i % R] = *reinterpret_cast<const u16x8*>(a0 + (i & 3) * 32 * RS16 + (i >> 2) * 16);
@@ -62,6 +102,32 @@ __device__ __forceinline__ void compute_km(const typename CT<PREC>::elem* Ys, in
     constexpr int FR = WFR<PREC>, KP = KPS<PREC>;
     const int li = lane & 15, g1 = (lane >> 4) & 1, h = lane >> 5, q = li >> 2, p = li & 3;
     const typename CT<PREC>::elem* base = Ys + (8 * h + q) * RSKM + 16 * g1 + 4 * p;
+    if constexpr (PREC == PREC_F16C) {      // as compute_tm: row-tile major, four fp16 hi MFMAs + one fp8 lo MFMA per row tile
+        i32x8 w8;
+        {
+            const unsigned* lo32 = reinterpret_cast<const unsigned*>(&src[0][4]);
+#pragma unroll
+            for (int r = 0; r < 8; ++r) w8[r] = (int)lo32[r];
+        }
+        i32x8 a8 = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const typename CT<PREC>::elem* p0 = base + ((part * KP + ks) * 16) * RSKM + mt * 32;
+                v4i16 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4i16_ptr)(p0));
+                v4i16 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4i16_ptr)(p0 + 4 * RSKM));
+                u16x8 af = {(unsigned short)lo[0], (unsigned short)lo[1], (unsigned short)lo[2], (unsigned short)lo[3],
+                            (unsigned short)hi[0], (unsigned short)hi[1], (unsigned short)hi[2], (unsigned short)hi[3]};
+                acc[mt] = mfma<PREC>(src[0][ks], af, acc[mt]);
+                int w0 = a8[2 * ks], w1 = a8[2 * ks + 1];
+                frag_to_bf8(af, w0, w1);
+                a8[2 * ks] = w0, a8[2 * ks + 1] = w1;
+            }
+            acc[mt] = mfma_lo8<true>(w8, a8, acc[mt]);
+        }
+        return;
+    }
 #pragma unroll
     for (int ks = 0; ks < KP; ++ks) {
 #pragma unroll

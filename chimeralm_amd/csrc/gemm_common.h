@@ -32,9 +32,39 @@ struct CT<PREC_F16C> {
     using frag = u16x8;
     static constexpr int MFMA_K = 16, BM = 128, RS = 264;
 };
-// weight fragments per k-step in the packed stream: 1, or 2 (hi, lo) in the compensated mode
+// fragment slots per k-step in the packed stream: 1, or 2 in the compensated mode (per group of four k-steps: four hi
+// fragments, the lo bytes of the K = 64 fp8 MFMA in two slots, two slots unused -- pack_weight_split_kernel)
 template <int PREC>
 constexpr int WFR = PREC == PREC_F16C ? 2 : 1;
+// lo half of the compensated mode: e4m3((w - hi) * 2^17), undone by the MFMA's block scale 2^-17 (E8M0 byte 127 - 17)
+constexpr float LO8_SCALE = 131072.f;
+constexpr int LO8_E8M0 = 127 - 17;
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+// acc += w_lo . a: `w8` the lane's 32 e4m3 bytes of the weight tile, `a8` its 32 e5m2 bytes of the activation tile (the same 64
+// k in the same order); W_IS_A: the weights are the MFMA's A operand (accumulator rows = output features)
+template <bool W_IS_A>
+__device__ __forceinline__ f32x16 mfma_lo8(i32x8 w8, i32x8 a8, f32x16 c) {
+    if (W_IS_A) return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(w8, a8, c, 0 /*e4m3*/, 1 /*e5m2*/, 0, LO8_E8M0, 0, 127);
+    return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, w8, c, 1, 0, 0, 127, 0, LO8_E8M0);
+}
+// the 8 halfs of an activation fragment -> 8 e5m2 bytes, written INTO w0 / w1 (two registers of the MFMA's 8-register operand).
+// e5m2, not e4m3: v_cvt_scalef32_pk_fp8_f16 turns |x| >= 464 into NaN instead of saturating, e5m2 reaches 57344
+// (tools/micro/mfma_fp8_lo.cpp).  The instruction keeps the other half of its destination, i.e. the destination is also an
+// input: given the operand register's previous contents (both halves are rewritten) it converts in place -- a zero or a fresh
+// register there costs a v_mov per register and conversion.
+__device__ __forceinline__ void frag_to_bf8(u16x8 af, int& w0, int& w1) {
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+    typedef short s2 __attribute__((ext_vector_type(2)));
+    const h8 v = __builtin_bit_cast(h8, af);
+    s2 a = __builtin_bit_cast(s2, w0), b = __builtin_bit_cast(s2, w1);
+    a = __builtin_amdgcn_cvt_scalef32_pk_bf8_f16(a, h2{v[0], v[1]}, 1.0f, false);
+    a = __builtin_amdgcn_cvt_scalef32_pk_bf8_f16(a, h2{v[2], v[3]}, 1.0f, true);
+    b = __builtin_amdgcn_cvt_scalef32_pk_bf8_f16(b, h2{v[4], v[5]}, 1.0f, false);
+    b = __builtin_amdgcn_cvt_scalef32_pk_bf8_f16(b, h2{v[6], v[7]}, 1.0f, true);
+    w0 = __builtin_bit_cast(int, a);
+    w1 = __builtin_bit_cast(int, b);
+}
 
 template <int PREC>
 __device__ __forceinline__ f32x16 mfma(typename CT<PREC>::frag a, typename CT<PREC>::frag b, f32x16 c);
@@ -289,7 +319,8 @@ __device__ __forceinline__ void load_set(const typename CT<PREC>::frag* wp, int 
         const typename CT<PREC>::frag* p =
             wp + ((size_t)(nb * 8 + wave * NT + nt) * KSTEPS_ALL + kc * KSTEPS + part * KP) * (FR * 64) + lane;
 #pragma unroll
-        for (int ks = 0; ks < SETK; ++ks) dst[nt][ks] = p[(size_t)ks * 64];
+        for (int ks = 0; ks < SETK; ++ks)
+            if (PREC != PREC_F16C || ks < 6) dst[nt][ks] = p[(size_t)ks * 64];     // compensated mode: slots 6, 7 are unused
     }
 }
 template <int PREC, int EPI>
