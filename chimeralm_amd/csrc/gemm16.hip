@@ -390,11 +390,12 @@ __device__ __forceinline__ void tail_load_y_piece(const TailArgs& m, uint4 (&yx)
     for (int i = 4 * half; i < 4 * half + 4; ++i)
         yx[i] = *reinterpret_cast<const uint4*>(src + (size_t)((tid >> 4) + 32 * i) * m.Lp + tkc);
 }
-// PIECES: how many of the four residual pieces the hooks request.  fp16c: three -- with all four (64 registers) plus the y
-// pieces (32) live next to the accumulators and the two (hi, lo) weight sets, hipcc spilled one piece AS IT LOADED it
-// (four times `global_load_dwordx4; s_waitcnt vmcnt(0); scratch_store`: four serialised HBM round trips inside the in_proj
-// stage of every tile, and a scratch reload with its own vmcnt(0) in the next tile's out_proj epilogue).  The fourth piece is
-// requested when the stage's accumulators are dead (tail16_kernel, after inproj_blocks).
+// PIECES: how many of the four residual pieces the hooks request.  fp16c: none -- with all four (64 registers) plus the y
+// pieces (32) live next to the accumulators and the weight sets, hipcc spilled one piece AS IT LOADED it (four times
+// `global_load_dwordx4; s_waitcnt vmcnt(0); scratch_store`: four serialised HBM round trips inside the in_proj stage of every
+// tile, and a scratch reload with its own vmcnt(0) in the next tile's out_proj epilogue).  All four are requested when the
+// stage's accumulators are dead (tail16_kernel, after inproj_blocks); same-box timings of the in_proj variant with 2 / 1 / 0
+// pieces in the hooks: 1.437 / 1.428 / 1.407 ms per launch.
 template <typename E, int PIECES>
 struct ResidHook {
     const TailArgs& m;
@@ -478,9 +479,10 @@ __global__ __launch_bounds__(512) void tail16_kernel(TailArgs m, unsigned long l
     }
     __syncthreads();
     CLM_STAMP_AT(1);
-    // ---- 1. out_proj, then r = acc + h + b_out (kept in acc2)
-    zero_acc(acc2);
-    phase_km<PREC, D, D>(Ys, wo, 0, 0, w1, 0, 0, wave, lane, bs, acc2);   // (first fc1 set requested under the last set)
+    // ---- 1. r = h + b_out + out_proj(y) (kept in acc2): the accumulators START from the residual rows, so their 64 registers
+    // are free again before the first MFMA instead of staying live through the phase (where hipcc spilled a quad of them at
+    // the end of the previous tile, behind an s_waitcnt vmcnt(0)).  The rows were requested a tile ago and the weight sets
+    // requested after them cannot be waited for before they land anyway (vmcnt retires in order).
     {
         const float* bo = Bt + BT_BOUT + wave * 32 + 4 * lhalf;
 #pragma unroll
@@ -488,13 +490,14 @@ __global__ __launch_bounds__(512) void tail16_kernel(TailArgs m, unsigned long l
             const float4 bb = *reinterpret_cast<const float4*>(bo + 8 * q);
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt) {
-                acc2[mt][4 * q + 0] += hv[mt][q].x + bb.x;
-                acc2[mt][4 * q + 1] += hv[mt][q].y + bb.y;
-                acc2[mt][4 * q + 2] += hv[mt][q].z + bb.z;
-                acc2[mt][4 * q + 3] += hv[mt][q].w + bb.w;
+                acc2[mt][4 * q + 0] = hv[mt][q].x + bb.x;
+                acc2[mt][4 * q + 1] = hv[mt][q].y + bb.y;
+                acc2[mt][4 * q + 2] = hv[mt][q].z + bb.z;
+                acc2[mt][4 * q + 3] = hv[mt][q].w + bb.w;
             }
         }
     }
+    phase_km<PREC, D, D>(Ys, wo, 0, 0, w1, 0, 0, wave, lane, bs, acc2);   // (first fc1 set requested under the last set)
     CLM_STAMP_AT(2);
     // ---- 2./3. LayerNorm-2 of r straight from the accumulators -> As (16-bit)
     ln_acc_to_tile<PREC>(acc2, P1, P2, m.ln_g, m.ln_b, m.eps, As, t0, L, wave, lrow, lhalf);
@@ -603,7 +606,7 @@ __global__ __launch_bounds__(512) void tail16_kernel(TailArgs m, unsigned long l
             // bs[1] is re-requested by the block loop (same addresses, L2-resident): keeps the loop identical to in_proj16
             // the 128 KiB of residual rows trickle in as four pieces behind the weight requests of the first four half-blocks
             // (requested in one go before the LayerNorm they stalled every later load of the stage: +9k cycles)
-            constexpr int PIECES = PREC == PREC_F16C ? 2 : 4;
+            constexpr int PIECES = PREC == PREC_F16C ? 0 : 4;
             inproj_blocks<PREC>(As, Hs, wn, Bt + BT_NB, m.n_z, b, t0, Lp, wave, lane, bs, acc1,
                                 ResidHook<elem, PIECES>{m, hv, yx, nb_, nt0, wave, lrow, lhalf, tid,
                                                         STAMP ? stamps + (size_t)tile * TAIL_NSTAMP : nullptr});
