@@ -255,16 +255,29 @@ def main():
     batches = [torch.from_numpy(synthetic_ids(i, a.batch, a.bases)[lo:hi]).to(device) for i in range(n_data)]
     logits2 = [torch.empty((hi - lo, 2), dtype=torch.float32, device=device) for _ in range(2)]
     logits = logits2[0]
-    gather = cdist.LogitsGather(device)      # N > 1: the all-gather runs on its own stream, behind the forward it belongs to
+    gather = cdist.LogitsGather(device, timed=True)   # N > 1: the all-gather runs on its own stream, behind the forward it belongs to
+    dev_ids = cdist.assert_distinct_devices(device)   # every rank's PCI identity; raises under nccl if two ranks share a GPU
+    gather_done = [None, None]               # `done` event of the gather that last read logits2[k]
 
     def step(i):
         buf = logits2[i & 1]
+        if gather_done[i & 1] is not None:   # forward i overwrites the buffer gather i - 2 read on the side stream: order them
+            torch.cuda.current_stream(device).wait_event(gather_done[i & 1])
         eng.forward(batches[i % n_data], out=buf)
-        return gather.submit(buf)[0] if world > 1 else buf   # forward i + 1 is enqueued while gather i is in flight
+        if world == 1:
+            return buf
+        full, gather_done[i & 1] = gather.submit(buf)   # forward i + 1 is enqueued while gather i is in flight
+        return full
+
+    selfcheck = None
+    if a.precision != "fp32":                # the mode against the exact-fp32 kernels of the same engine on this run's weights / reads
+        d, nd = eng.selfcheck(batches[0][: min(4, hi - lo)])
+        selfcheck = {"max_abs_dlogit_vs_exact_fp32": d, "labels_differ": nd, "sample": f"first {min(4, hi - lo)} reads of batch 0"}
 
     for i in range(a.warmup):
         step(i)
     torch.cuda.synchronize(device)
+    gather.spans_ms(reset=True)
     eng.profile_read(reset=True)
     eng.profile_enable(True)
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]
@@ -284,6 +297,9 @@ def main():
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t.item())
     prof = eng.profile_read(reset=True)
+    gather_ms = sorted(gather.spans_ms()) if world > 1 else []
+    if world > 1:                            # the collective's result, checked once: this rank's rows of the gathered batch
+        assert torch.equal(out[lo:hi], logits2[(a.steps - 1) & 1]), "all-gather returned other logits than this rank computed"
     lat = sorted(e0.elapsed_time(e1) for e0, e1 in ev)
     dev_names = [f"rank {rank}: cuda:{device.index} {torch.cuda.get_device_name(device)}"]
     if world > 1:
@@ -395,7 +411,13 @@ def main():
             "config": config,
             "distributed": {"backend": torch.distributed.get_backend() if world > 1 else None,
                             "world_size": torch.distributed.get_world_size() if world > 1 else 1,
-                            "devices": dev_names, "gather": "side stream, one step behind" if world > 1 else None},
+                            "devices": dev_names, "device_ids": dev_ids, "distinct_devices": len(set(dev_ids)) == len(dev_ids),
+                            "rccl_version": ".".join(map(str, torch.cuda.nccl.version())) if world > 1 and backend == "nccl" else None,
+                            "gather": "side stream, one step behind" if world > 1 else None,
+                            # HIP-event time of the [B/N, 2] all-gather on its side stream, per step of the timed region (rank 0)
+                            "gather_ms_p50": gather_ms[len(gather_ms) // 2] if gather_ms else None,
+                            "gather_ms_max": gather_ms[-1] if gather_ms else None},
+            "selfcheck": selfcheck,
             "fp32_exact_reads_per_s": fp32_rate,
             "pcie_inclusive_reads_per_s": host_rate,
             "dense_tflops_per_gpu": 6_423_040 * L * (hi - lo) * a.steps / elapsed / 1e12,

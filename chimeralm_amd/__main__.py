@@ -36,7 +36,8 @@ def predict(
     num_workers: int = typer.Option(0, "--workers", "-w", help="Number of workers"),
     ckpt_path: Path | None = typer.Option(None, "--ckpt", "-c", hidden=True, help="Path to the checkpoint file"),
     weights: str = typer.Option("yangliz5/chimeralm", "--weights", help="Directory/file with model.safetensors"),
-    precision: str = typer.Option("fp16c", "--precision", help="arithmetic of the dense projections: fp16c (fp16 x hi+lo weight pairs, within 1e-3 of the fp32 reference; default) | fp32 (exact) | fp16 | bf16 (reduced precision)"),
+    precision: str = typer.Option("fp16c", "--precision", help="arithmetic of the dense projections: fp16c (default: fp16 activations x fp16 hi + fp8 lo weights at 16-bit MFMA rate, checked against the exact-fp32 kernels on the loaded weights before the first batch, replaced by them if more than --selfcheck-tol off) | fp32 (exact, the reference's) | fp16 | bf16 (reduced precision)"),
+    selfcheck_tol: float = typer.Option(5e-4, "--selfcheck-tol", help="largest |logit difference| from exact fp32 the fp16c mode may show in its self-check (0 disables the check)"),
     feeder: str = typer.Option("native", "--feeder", help="BAM input: native (C++ decoder thread, pinned ring) | python"),
     random: bool = typer.Option(False, "--random", "-r", help="Make the prediction not deterministic"),
     verbose: bool = typer.Option(False, "--verbose", "-v", help="Enable verbose output"),
@@ -75,10 +76,12 @@ def predict(
         raise RuntimeError(f"Batch size ({batch_size}) is not divisible by the number of devices ({world}).")
     if ckpt_path is not None:
         log.info(f"Loading model from {ckpt_path}")
-        model = lm.ChimeraLM.new(precision=precision).load_reference_checkpoint(ckpt_path)
+        model = lm.ChimeraLM.new(precision=precision, selfcheck=None if selfcheck_tol > 0 else False,
+                                 selfcheck_tol=selfcheck_tol).load_reference_checkpoint(ckpt_path)
     else:
         log.info(f"Loading model weights {weights}")
-        model = lm.ChimeraLM.from_pretrained(weights, precision=precision)
+        model = lm.ChimeraLM.from_pretrained(weights, precision=precision, selfcheck=None if selfcheck_tol > 0 else False,
+                                             selfcheck_tol=selfcheck_tol)
     output_path.mkdir(parents=True, exist_ok=True)
     writer = callbacks.PredictionWriter(output_dir=output_path, write_interval="batch")
     if feeder == "native":
@@ -96,6 +99,10 @@ def predict(
         n = loop.run_predict(model, dm, writer, device, rank=rank, gather=world > 1 and gather_logits,
                              on_batch=_gathered_sink(output_path, rank) if gather_logits else None)
     distributed.barrier()
+    rep = getattr(model.net, "selfcheck_report", None)
+    if rep:
+        log.info(f"[rank {rank}] precision {precision}: self-check against exact fp32 max |dlogit| {rep.get('max_abs_dlogit', 0.0):.2e} "
+                 f"(threshold {rep.get('tol')}) -> {'FELL BACK to exact fp32' if rep.get('fallback') else 'kept'}")
     log.info(f"[rank {rank}] {n} reads; predictions saved to {output_path}")
 
 

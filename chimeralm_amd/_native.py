@@ -21,7 +21,7 @@ PRECISIONS = {"fp32": PREC_F32, "f32": PREC_F32, "bf16": PREC_BF16, "fp16": PREC
 STAGES = ["embed", "ln1_in_proj", "short_long_conv", "out_proj", "ln2_fc1_gelu", "fc2", "lnf_pool_score",
           "softmax_pool", "head_mlp", "filter", "out_proj_ln2_mlp", "ln2_mlp"]
 N_STAGES = len(STAGES)
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 
 class ClmConfig(C.Structure):
@@ -58,6 +58,10 @@ SYMBOLS = {
     "clm_forward_staged": (C.c_int, [_H, C.c_int, C.c_void_p, C.c_void_p]),
     "clm_stage_wait": (C.c_int, [_H, C.c_int]),
     "clm_check": (C.c_int, [_H, C.c_void_p]),
+    "clm_selfcheck": (C.c_int, [_H, C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_float),
+                                C.POINTER(C.c_int)]),
+    "clm_set_fallback": (C.c_int, [_H, C.c_int]),
+    "clm_effective_precision": (C.c_int, [_H, C.c_int]),
     "clm_attention_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "clm_tf_create": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(_H)]),
     "clm_tf_load_weight": (C.c_int, [_H, C.c_char_p, C.c_void_p, C.c_int, C.POINTER(C.c_int64), C.c_int]),

@@ -649,11 +649,21 @@ int clm_bam_sort_index(const char* in_bam, const char* out_sorted_bam, const cha
         }
         rr.clear();
         cleanup();
-        if (!ok && sw.wr.err.empty()) return bam_fail(CLM_E_INVALID, std::string(out_sorted_bam) + ": a temporary sort run could not be read back");
+        if (!ok && sw.wr.err.empty()) {
+            std::remove(out_sorted_bam);                         // no partial output left behind, as clm_bam_filter_ex
+            return bam_fail(CLM_E_INVALID, std::string(out_sorted_bam) + ": a temporary sort run could not be read back");
+        }
     }
-    if (!ok || !sw.wr.finish()) return bam_fail(CLM_E_INVALID, sw.wr.err);
+    if (!ok || !sw.wr.finish()) {
+        std::remove(out_sorted_bam);                             // (unlinked while still open on the failure paths: fine on POSIX)
+        return bam_fail(CLM_E_INVALID, sw.wr.err);
+    }
     const std::string bai_path = out_bai ? std::string(out_bai) : std::string(out_sorted_bam) + ".bai";
-    if (!sw.write_bai(bai_path)) return bam_fail(CLM_E_INVALID, bai_path + ": cannot write the index");
+    if (!sw.write_bai(bai_path)) {
+        std::remove(out_sorted_bam);
+        std::remove(bai_path.c_str());
+        return bam_fail(CLM_E_INVALID, bai_path + ": cannot write the index");
+    }
     if (n_records) *n_records = (int64_t)sw.n_records;
     return CLM_OK;
 }

@@ -4,6 +4,7 @@
 // HyenaDNA block order of SURVEY.md section 8(a) rows 5-13.
 #include <cstdio>
 #include <cstdlib>
+#include <cmath>
 #include <cstring>
 #include <map>
 #include <algorithm>
@@ -64,11 +65,16 @@ struct clm_handle {
     // packed / derived weights
     void* packed[NLAYER][4] = {};
     void* packed_score = nullptr;
-    // fp16c only: exact-fp32 packing of the same weights for reads shorter than f16c_min_len (see forward_chunk)
+    // 16-bit handles: exact-fp32 packing of the same weights (fp16c's reads shorter than f16c_min_len, clm_selfcheck, clm_set_fallback)
     void* packed32[NLAYER][4] = {};
     void* packed_score32 = nullptr;
     LayerW lw32[NLAYER]{};
     int f16c_min_len = 2048;
+    // clm_selfcheck / clm_set_fallback: the exact-fp32 kernels of the same handle as referee of, and replacement for, the 16-bit path
+    int force_prec = -1;          // >= 0 inside clm_selfcheck: the arithmetic forward_chunk runs in, whatever the length
+    bool fallback32 = false;      // every read through the exact-fp32 kernels (a 16-bit handle whose self-check failed)
+    float* sc_logits = nullptr;   // [2][sc_cap][2] device: logits of the two passes of a self-check
+    int sc_cap = 0;
     // host batches: two device staging buffers fed by the handle's own copy stream
     struct Stage {
         void* buf = nullptr;
@@ -90,6 +96,7 @@ struct clm_handle {
     uint64_t clock = 0;
     // workspace (one chunk of reads)
     int ws_B = 0, ws_L = 0;
+    size_t ws_es_full = 0;        // activation element size the workspace holds at ws_L tokens (4 once the fp32 kernels may run at any length)
     size_t ws_z_bytes = 0, ws_y_bytes = 0, ws_es = 0;   // ws_es: element size z / y were last written with
     float* h = nullptr;
     void *z = nullptr, *y = nullptr, *u = nullptr;
@@ -260,6 +267,7 @@ void free_workspace(clm_handle* h) {
     h->scores = h->stats = h->partial = h->pooled = h->lone_ws = nullptr;
     h->ids8 = nullptr;
     h->ws_B = h->ws_L = 0;
+    h->ws_es_full = 0;
 }
 
 void free_packed(clm_handle* h) {
@@ -279,13 +287,16 @@ void free_packed(clm_handle* h) {
 const float* W(clm_handle* h, const std::string& key) { return h->w[key].d; }
 
 int ensure_workspace(clm_handle* h, int Bc, int L, hipStream_t st) {
-    if (Bc <= h->ws_B && L <= h->ws_L) return CLM_OK;
+    // element size of z / y / u at full length: 4 when the exact-fp32 kernels may run reads of any length (fp32 handle, self-check
+    // referee pass, fallback); fp16c otherwise keeps 2-byte buffers with room for 4-byte reads below f16c_min_len
+    const size_t es_need = (h->cfg.precision == PREC_F32 || h->fallback32 || h->force_prec == PREC_F32) ? 4 : 2;
+    if (Bc <= h->ws_B && L <= h->ws_L && es_need <= h->ws_es_full) return CLM_OK;
     HIPCHK(h, hipStreamSynchronize(st));
     int nb = Bc > h->ws_B ? Bc : h->ws_B, nl = L > h->ws_L ? L : h->ws_L;
+    const size_t es = std::max(es_need, h->ws_es_full);
     free_workspace(h);
-    // fp16c: 2-byte activations at nl tokens, or 4-byte ones for the reads below f16c_min_len that run in fp32
     const size_t Lp = (size_t)round_up(nl, 64);
-    size_t es = elem_size(h->cfg.precision), nl_es = (size_t)nl * es, Lp_es = Lp * es;
+    size_t nl_es = (size_t)nl * es, Lp_es = Lp * es;
     if (h->cfg.precision == PREC_F16C) {
         const size_t ls = (size_t)std::min(nl, h->f16c_min_len - 1);
         nl_es = std::max(nl_es, ls * 4);
@@ -316,6 +327,7 @@ int ensure_workspace(clm_handle* h, int Bc, int L, hipStream_t st) {
     h->ws_z_bytes = n_z; h->ws_y_bytes = n_y; h->ws_es = 0;
     h->ws_B = nb;
     h->ws_L = nl;
+    h->ws_es_full = es;
     return CLM_OK;
 }
 
@@ -430,6 +442,8 @@ struct StageTimer {
 };
 
 int effective_prec(const clm_handle* h, int L) {
+    if (h->force_prec >= 0) return h->force_prec;
+    if (h->fallback32) return (int)PREC_F32;
     return (h->cfg.precision == PREC_F16C && L < h->f16c_min_len) ? (int)PREC_F32 : h->cfg.precision;
 }
 
@@ -730,7 +744,7 @@ int clm_finalize(clm_handle* h) {
         lw.b_fc1 = W(h, p + "mlp.fc1.bias"); lw.b_fc2 = W(h, p + "mlp.fc2.bias");
         lw.short_w = W(h, p + "mixer.short_filter.weight"); lw.short_b = W(h, p + "mixer.short_filter.bias");
         lw.filt_bias = W(h, p + "mixer.filter_fn.bias");
-        if (prec == PREC_F16C) {
+        if (prec != PREC_F32) {   // the exact-fp32 packing next to the 16-bit one: fp16c's short reads, clm_selfcheck, clm_set_fallback
             if ((rc = pack_as(PREC_F32, p + "mixer.in_proj.weight", D3, D, &h->packed32[i][0]))) return rc;
             if ((rc = pack_as(PREC_F32, p + "mixer.out_proj.weight", D, D, &h->packed32[i][1]))) return rc;
             if ((rc = pack_as(PREC_F32, p + "mlp.fc1.weight", DI, D, &h->packed32[i][2]))) return rc;
@@ -743,7 +757,7 @@ int clm_finalize(clm_handle* h) {
     {
         int rc;
         if ((rc = pack("head.attention.0.weight", D, D, &h->packed_score))) return rc;
-        if (prec == PREC_F16C && (rc = pack_as(PREC_F32, "head.attention.0.weight", D, D, &h->packed_score32))) return rc;
+        if (prec != PREC_F32 && (rc = pack_as(PREC_F32, "head.attention.0.weight", D, D, &h->packed_score32))) return rc;
     }
     HIPCHK(h, hipMalloc((void**)&h->ztab, (size_t)VOCAB * D3 * 4));
     launch_ztab(W(h, "bb.embeddings.word_embeddings.weight"), W(h, "bb.layers.0.norm1.weight"),
@@ -869,6 +883,74 @@ int clm_check(clm_handle* h, void* stream) {
     return check_bad_ids(h);
 }
 
+int clm_selfcheck(clm_handle* h, const void* ids, int ids_dtype, int64_t ids_row_stride, int B, int L, void* stream,
+                  float* max_abs_diff, int* labels_differ) {
+    if (!h) return CLM_E_INVALID;
+    if (!h->finalized) return fail(h, CLM_E_STATE, "clm_selfcheck before clm_finalize");
+    if (!ids || !max_abs_diff || B < 1 || L < 1 || ids_row_stride < L) return fail(h, CLM_E_INVALID, "clm_selfcheck: bad argument");
+    if (ids_dtype != CLM_DT_I64 && ids_dtype != CLM_DT_I32 && ids_dtype != CLM_DT_U8)
+        return fail(h, CLM_E_INVALID, "clm_selfcheck: ids dtype must be i64, i32 or u8");
+    HIPCHK(h, hipSetDevice(h->device));
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    *max_abs_diff = 0.f;
+    if (labels_differ) *labels_differ = 0;
+    if (h->cfg.precision == PREC_F32) return CLM_OK;             // the handle IS the referee
+    if (B > h->sc_cap) {
+        HIPCHK(h, hipStreamSynchronize(st));
+        if (h->sc_logits) HIPCHK(h, hipFree(h->sc_logits));
+        h->sc_logits = nullptr;
+        HIPCHK(h, hipMalloc((void**)&h->sc_logits, (size_t)2 * B * NCLS * 4));
+        h->sc_cap = B;
+    }
+    // pass 0: the arithmetic the handle's mode runs reads of this length in (whatever clm_set_fallback says); pass 1: exact fp32
+    const int mode_prec = (h->cfg.precision == PREC_F16C && L < h->f16c_min_len) ? (int)PREC_F32 : h->cfg.precision;
+    const bool prof = h->prof;
+    h->prof = false;                                            // not part of anybody's timed region
+    const size_t ies = ids_dtype == CLM_DT_I64 ? 8 : (ids_dtype == CLM_DT_I32 ? 4 : 1);
+    const int chunk = h->cfg.chunk_reads;
+    int rc = CLM_OK;
+    for (int pass = 0; pass < 2 && !rc; ++pass) {
+        h->force_prec = pass == 0 ? mode_prec : (int)PREC_F32;
+        for (int b0 = 0; b0 < B && !rc; b0 += chunk) {
+            const int Bc = B - b0 < chunk ? B - b0 : chunk;
+            const char* p = reinterpret_cast<const char*>(ids) + (size_t)b0 * ids_row_stride * ies;
+            rc = forward_chunk(h, p, ids_dtype, ids_row_stride, Bc, L, h->sc_logits + ((size_t)pass * h->sc_cap + b0) * NCLS, st);
+        }
+    }
+    h->force_prec = -1;
+    h->prof = prof;
+    if (rc) return rc;
+    std::vector<float> host((size_t)2 * h->sc_cap * NCLS);
+    HIPCHK(h, hipMemcpyAsync(host.data(), h->sc_logits, host.size() * 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(h, hipStreamSynchronize(st));
+    float worst = 0.f;
+    int differ = 0;
+    for (int b = 0; b < B; ++b) {
+        const float* a = &host[(size_t)b * NCLS];
+        const float* r = &host[((size_t)h->sc_cap + b) * NCLS];
+        for (int c = 0; c < NCLS; ++c) {
+            const float d = std::fabs(a[c] - r[c]);
+            worst = (d > worst || d != d) ? (d != d ? INFINITY : d) : worst;   // NaN anywhere = infinitely wrong
+        }
+        differ += (a[1] > a[0]) != (r[1] > r[0]);
+    }
+    *max_abs_diff = worst;
+    if (labels_differ) *labels_differ = differ;
+    return CLM_OK;
+}
+
+int clm_set_fallback(clm_handle* h, int on) {
+    if (!h) return CLM_E_INVALID;
+    if (!h->finalized) return fail(h, CLM_E_STATE, "clm_set_fallback before clm_finalize");
+    h->fallback32 = on != 0 && h->cfg.precision != PREC_F32;
+    return CLM_OK;
+}
+
+int clm_effective_precision(const clm_handle* h, int L) {
+    if (!h || L < 1) return CLM_E_INVALID;
+    return effective_prec(h, L);
+}
+
 int clm_debug_stop_after(clm_handle* h, int layer, int stage) {
     if (!h) return CLM_E_INVALID;
     h->stop_layer = layer;
@@ -950,6 +1032,7 @@ int clm_destroy(clm_handle* h) {
     free_workspace(h);
     free_filters(h);
     free_packed(h);
+    if (h->sc_logits) (void)hipFree(h->sc_logits);
     for (auto& sg : h->stage) {
         if (sg.buf) (void)hipFree(sg.buf);
         if (sg.copied) (void)hipEventDestroy(sg.copied);

@@ -110,10 +110,12 @@ __device__ __forceinline__ f32x2 gelu_tanh2(f32x2 x) {
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.7071067811865476f)); }
 
 // ---- kernel launchers (definitions in the .hip files); all are asynchronous on `st` --------------------
-// PREC_F16C ("fp16c"): fp16 activations x weights held as an fp16 PAIR hi + lo (w = hi + lo to ~22 bits), two MFMAs per
-// product into one fp32 accumulator.  The rounding of the packed weights is the one error of the fp16 mode that is
-// coherent across tokens (every token sees the same perturbed matrix, so the attention pooling cannot average it
-// out): tests/error_model.py attributes 1.0e-3 of the fp16 mode's 1.3e-3 logit error to it.
+// PREC_F16C ("fp16c"): fp16 activations x weights held as hi + lo, hi = fp16(w), lo = e4m3((w - hi) * 2^17): per 64-deep group
+// four fp16 MFMAs with hi and ONE block-scaled K = 64 fp8 MFMA with lo (activation fragments converted to e5m2 in registers) into
+// one fp32 accumulator.  The rounding of the packed weights is the one error of the fp16 mode that is coherent across tokens
+// (every token sees the same perturbed matrix, so the attention pooling cannot average it out): tests/error_model.py
+// attributes 1.0e-3 of the fp16 mode's 1.3e-3 logit error to it.  What is left is the fp16 rounding of the activation operands
+// (measured 1.2e-4 .. 9.6e-4 in the logits); clm_selfcheck measures it on the loaded weights.
 enum Prec { PREC_F32 = 0, PREC_BF16 = 1, PREC_F16 = 2, PREC_F16C = 3 };
 
 struct LayerW {            // device pointers, fp32 unless noted

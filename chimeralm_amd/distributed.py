@@ -57,9 +57,11 @@ class LogitsGather:
     this object's own stream, so the next batch's kernels are enqueued and run while the 2 KiB exchange is in flight; the
     caller picks the result up one batch later (`done.synchronize()` / `wait`).  RCCL when the backend is "nccl"."""
 
-    def __init__(self, device: torch.device):
+    def __init__(self, device: torch.device, timed: bool = False):
         self.device = device
         self.side = torch.cuda.Stream(device) if device.type == "cuda" else None
+        self.timed = timed                 # keep (start, end) events of every collective on the side stream (bench.py)
+        self._spans: list = []
 
     def submit(self, local_logits: torch.Tensor):
         """-> (gathered [B, C] tensor, event that fires when it is complete)."""
@@ -75,7 +77,13 @@ class LogitsGather:
         ready.record(torch.cuda.current_stream(self.device))
         with torch.cuda.stream(self.side):
             self.side.wait_event(ready)
+            if self.timed:
+                t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                t0.record(self.side)
             dist.all_gather_into_tensor(out, local_logits.contiguous())
+            if self.timed:
+                t1.record(self.side)
+                self._spans.append((t0, t1))
             done = torch.cuda.Event()
             done.record(self.side)
         local_logits.record_stream(self.side)
@@ -85,6 +93,42 @@ class LogitsGather:
     def wait(self):
         if self.side is not None:
             self.side.synchronize()
+
+    def spans_ms(self, reset: bool = True) -> list[float]:
+        """Device time of every timed collective so far (HIP events on the side stream); synchronises that stream."""
+        self.wait()
+        out = [a.elapsed_time(b) for a, b in self._spans]
+        if reset:
+            self._spans = []
+        return out
+
+
+def device_identity(device: torch.device) -> str:
+    """What tells two GPUs of a node apart: PCI bus id (or the UUID) of the device this rank computes on."""
+    p = torch.cuda.get_device_properties(device)
+    for attr in ("pci_bus_id", "uuid"):
+        v = getattr(p, attr, None)
+        if v not in (None, ""):
+            dom = getattr(p, "pci_domain_id", 0)
+            dev = getattr(p, "pci_device_id", 0)
+            return f"{dom:04x}:{int(v):02x}:{dev:02x}" if attr == "pci_bus_id" and isinstance(v, int) else str(v)
+    return f"cuda:{device.index}"
+
+
+def assert_distinct_devices(device: torch.device) -> list[str]:
+    """Every rank's device identity, gathered; under "nccl" (RCCL) two ranks on ONE device cannot form a communicator that
+    works -- fail fast with a message that says which ranks collide instead of hanging in the first collective."""
+    me = device_identity(device)
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return [me]
+    ids: list = [None] * dist.get_world_size()
+    dist.all_gather_object(ids, me)
+    if dist.get_backend() == "nccl" and len(set(ids)) != len(ids):
+        dup = {i: [r for r, v in enumerate(ids) if v == i] for i in set(ids) if ids.count(i) > 1}
+        raise RuntimeError(f"ranks share a GPU under the nccl (RCCL) backend: {dup}; launch one process per GPU "
+                           "(torch.distributed.run --nproc-per-node N sets LOCAL_RANK = device index) or rehearse with "
+                           "CLM_DIST_BACKEND=gloo")
+    return ids
 
 
 def free_port() -> int:

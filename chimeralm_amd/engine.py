@@ -130,6 +130,31 @@ class Engine:
         stream = torch.cuda.current_stream(self.device).cuda_stream
         self._check(self._lib.clm_check(self._h, C.c_void_p(stream)))
 
+    # ------------------------------------------------------------------ 16-bit mode vs the reference's arithmetic
+    def selfcheck(self, input_ids: torch.Tensor) -> tuple[float, int]:
+        """Run `input_ids` through this engine's mode AND through the exact-fp32 kernels of the same handle; returns
+        (max |logit difference|, number of reads whose label differs).  Synchronises the current stream (`clm_selfcheck`)."""
+        if input_ids.dim() != 2 or input_ids.device != self.device or input_ids.dtype not in _IDS_DT:
+            raise ValueError("selfcheck wants input_ids [batch, length] (int64 / int32 / uint8) on the engine's device")
+        if input_ids.stride(1) != 1:
+            input_ids = input_ids.contiguous()
+        B, L = input_ids.shape
+        diff, differ = C.c_float(0.0), C.c_int(0)
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        self._check(self._lib.clm_selfcheck(self._h, C.c_void_p(input_ids.data_ptr()), _IDS_DT[input_ids.dtype],
+                                            input_ids.stride(0), B, L, C.c_void_p(stream), C.byref(diff), C.byref(differ)))
+        return float(diff.value), int(differ.value)
+
+    def set_fallback(self, on: bool = True):
+        """Every later forward of this engine runs in the exact-fp32 kernels (`clm_set_fallback`)."""
+        self._check(self._lib.clm_set_fallback(self._h, int(on)))
+
+    def effective_precision(self, length: int) -> str:
+        code = self._lib.clm_effective_precision(self._h, int(length))
+        if code < 0:
+            raise EngineError(code, "clm_effective_precision")
+        return {N.PREC_F32: "fp32", N.PREC_BF16: "bf16", N.PREC_F16: "fp16", N.PREC_F16C: "fp16c"}[code]
+
     def stage_wait(self, staged: int):
         self._check(self._lib.clm_stage_wait(self._h, int(staged)))
 

@@ -79,6 +79,12 @@ def filter_bam_by_predcition(bam_path: Path, prediction_path: Path, *, index: bo
                                C.byref(dropped), C.byref(unplaced)))
     if unplaced.value:
         log.info(f"{unplaced.value} records without a reference placement left out (an index walk does not reach them)")
+    if kept.value == 0:
+        # the reference's `bam_file.fetch()` (:131) RAISES on a BAM without an index; an unaligned BAM gives no record here
+        # either -- say so loudly instead of handing back an empty, sorted, indexed file without a word
+        why = (f"all {unplaced.value} remaining records lack a reference placement (an unaligned / unindexed BAM: the reference's "
+               "index walk would have raised here)" if unplaced.value else "every record belongs to a read labelled 1")
+        log.warning(f"{output_path} holds NO records: {why}")
     result = {"kept": kept.value, "dropped": dropped.value, "unplaced": unplaced.value, "filtered": output_path, "sorted": None}
     if index:
         log.info(f"Sorting {output_path}")

@@ -174,14 +174,23 @@ _HEAD_KEYS = ("attention.0.weight", "attention.0.bias", "attention.2.weight", "a
 class HyenaDna(nn.Module):
     """Drop-in for the reference's `HyenaDna` net: same signature, same state_dict keys, MI355X forward.
 
-    Extra keyword-only arguments (engine knobs, absent in the reference): `precision` selects the arithmetic of the dense
-    projections -- "fp32" (exact, the reference's), "fp16c" (fp16 activations x hi + lo fp16 weight pairs: 16-bit MFMA rate
-    within the reference's 1e-3 logit tolerance; reads below 2,048 tokens run in fp32 kernels), "fp16" / "bf16" (reduced
-    precision, outside that tolerance) -- and `chunk_reads` the number of reads pushed through all layers together.
+    Extra keyword-only arguments (engine knobs, absent in the reference):
+    `precision` selects the arithmetic of the dense projections -- "fp32" (exact, the reference's), "fp16c" (fp16 activations x
+    weights held as fp16 hi + fp8 lo: 16-bit MFMA rate; measured 1.2e-4 .. 9.6e-4 from the fp32 reference on seeded weights,
+    DESIGN.md section 2; reads below 2,048 tokens run in fp32 kernels), "fp16" / "bf16" (reduced precision, outside the
+    reference's 1e-3 tolerance); `chunk_reads` the number of reads pushed through all layers together.
+    `selfcheck` (default: on for "fp16c") -- the reference runs ONE precision, fp32, always (hyena.py:244-256); a 16-bit mode's
+    distance from it depends on the weights, so it is MEASURED on the weights actually loaded: before the first batch after every
+    weight (re)load a seeded synthetic sample (4 reads of 2,048 and of 4,097 tokens, the lengths where the mode's error is
+    largest) and the first reads of that batch -- and of any later batch less than half as long as every batch checked so far --
+    run through both the mode and the exact-fp32 kernels of the same engine (`clm_selfcheck`).  If the largest logit
+    difference exceeds `selfcheck_tol` (5e-4, half the tolerance) the engine falls back to exact fp32 for good (logged);
+    `selfcheck_report` holds what was measured.
     """
 
     def __init__(self, number_of_classes: int, head: nn.Module, backbone_name: str = "hyenadna-small-32k-seqlen", *,
-                 freeze_backbone: bool = False, precision: str = "fp16c", chunk_reads: int = 64):
+                 freeze_backbone: bool = False, precision: str = "fp16c", chunk_reads: int = 64,
+                 selfcheck: bool | None = None, selfcheck_tol: float = 5e-4):
         super().__init__()
         if number_of_classes != 2:
             raise NotImplementedError("the engine implements the binary (2-class) head only")
@@ -194,11 +203,15 @@ class HyenaDna(nn.Module):
         self.head = head
         self.precision = precision
         self.chunk_reads = chunk_reads
+        self.selfcheck = (precision == "fp16c") if selfcheck is None else bool(selfcheck)
+        self.selfcheck_tol = float(selfcheck_tol)
+        self.selfcheck_report: dict = {}
         if freeze_backbone:
             for p in self.backbone.parameters():
                 p.requires_grad = False
         self._engine: Engine | None = None
         self._engine_sig = None
+        self._checked_min_len: int | None = None          # shortest batch a self-check has covered since the last weight load
 
     # -------------------------------------------------------------------------------- engine plumbing
     def _signature(self):
@@ -215,7 +228,55 @@ class HyenaDna(nn.Module):
         if sig != self._engine_sig:
             self._engine.load_state_dict(self.state_dict())
             self._engine_sig = sig
+            self._engine.set_fallback(False)               # new weights: the mode gets a new hearing
+            self._checked_min_len = None
+            self.selfcheck_report = {}
         return self._engine
+
+    # -------------------------------------------------------------------------------- the 16-bit mode on trial
+    _SAMPLE_LENGTHS = (2048, 4097)
+
+    def _selfcheck(self, eng: Engine, input_ids: torch.Tensor) -> None:
+        """See the class docstring.  Runs on torch's current stream and synchronises it (a few ms per sample)."""
+        B, L = input_ids.shape
+        rep = self.selfcheck_report
+        samples = []
+        if self._checked_min_len is None:                  # first batch since the weights were loaded
+            g = torch.Generator().manual_seed(20240)
+            for Ls in self._SAMPLE_LENGTHS:
+                ids = torch.randint(7, 11, (4, Ls), generator=g, dtype=torch.uint8)
+                ids[:, -1] = 1                              # [SEP]
+                ids[0, : Ls // 3] = 4                       # one read left-padded, as the collator pads
+                samples.append((f"synthetic 4 x {Ls}", ids.to(eng.device)))
+        samples.append((f"batch rows 0..{min(B, 4) - 1} x {L}", input_ids[: min(B, 4)]))
+        for name, ids in samples:
+            if eng.cfg.precision == 0 or (self.precision == "fp16c" and ids.shape[1] < 2048):
+                continue                                    # the mode itself runs these in exact fp32
+            diff, differ = eng.selfcheck(ids)
+            rep.setdefault("samples", []).append({"sample": name, "max_abs_dlogit": diff, "labels_differ": differ})
+            rep["max_abs_dlogit"] = max(rep.get("max_abs_dlogit", 0.0), diff)
+        rep["tol"], rep["precision"] = self.selfcheck_tol, self.precision
+        self._checked_min_len = L if self._checked_min_len is None else min(L, self._checked_min_len)
+        if rep.get("max_abs_dlogit", 0.0) > self.selfcheck_tol and not rep.get("fallback"):
+            eng.set_fallback(True)
+            rep["fallback"] = True
+            import logging
+            import warnings
+
+            msg = (f"chimeralm_amd: precision={self.precision!r} differs from the exact-fp32 kernels by "
+                   f"{rep['max_abs_dlogit']:.2e} in the logits on the loaded weights (threshold {self.selfcheck_tol:.1e}); "
+                   "falling back to exact fp32 for this model (about 5x slower, the reference's arithmetic)")
+            logging.getLogger("chimeralm_amd").warning(msg)
+            warnings.warn(msg, RuntimeWarning, stacklevel=3)
+        rep.setdefault("fallback", False)
+
+    def guard(self, eng: Engine, input_ids: torch.Tensor) -> None:
+        """Self-check of the 16-bit mode where one is due (first batch since a weight load; a batch less than half as long as
+        every batch checked so far).  `forward` calls it; loops that drive the engine directly (predict.run_predict_native) call
+        it with the batch's first reads."""
+        if self.selfcheck and self.precision != "fp32" and not self.selfcheck_report.get("fallback") and (
+                self._checked_min_len is None or 2 * input_ids.shape[1] < self._checked_min_len):
+            self._selfcheck(eng, input_ids)
 
     def forward(self, input_ids: torch.Tensor, input_quals: torch.Tensor | None = None) -> torch.Tensor:
         """`input_quals` is accepted and ignored, exactly as the reference does (hyena.py:244-256)."""
@@ -223,6 +284,7 @@ class HyenaDna(nn.Module):
             raise RuntimeError("chimeralm_amd.HyenaDna runs on an MI355X only (move the batch to 'cuda'); "
                                "there is no CPU forward")
         eng = self.engine(input_ids.device)
+        self.guard(eng, input_ids)
         logits = eng.forward(input_ids)
         if getattr(self.head, "save_attention", False):
             B, L = input_ids.shape

@@ -128,11 +128,28 @@ def run_predict(model, datamodule, writer, device: torch.device, *, rank: int = 
             pending = now
             n_reads += logits.shape[0]
             batch_idx += 1
+        _check_engine(model, device, batch_idx)
         if gatherer is not None:
             _drain_gather(pending, gatherer, rows, device, batch_idx, writer, trainer, model, on_batch)
         elif pending is not None:
             pending.flush(writer, trainer, model, on_batch)
     return n_reads
+
+
+def _check_engine(model, device: torch.device, batch_idx: int) -> None:
+    """Errors only the device sees (token ids outside the embedding table: the reference raises IndexError inside the forward,
+    hyena.py:249) are reported by the NEXT engine call -- after the last batch there is none, so ask once more before its file
+    is written.  The message names the batch range it can belong to."""
+    net = getattr(model, "net", None)
+    eng = getattr(net, "_engine", None)
+    if eng is None:
+        return
+    from .engine import EngineError
+
+    try:
+        eng.check()
+    except EngineError as e:
+        raise EngineError(e.code, f"{e} [detected after batch {batch_idx - 1}, the last of this rank]") from None
 
 
 def run_predict_native(model, feeder, writer, device: torch.device, *, rank: int = 0, gather: bool = False,
@@ -154,6 +171,8 @@ def run_predict_native(model, feeder, writer, device: torch.device, *, rank: int
             nxt = feeder.next()                               # already decoded by the feeder thread, normally
             nxt_staged = (eng.stage_host_ids(nxt.ids_ptr, DT_U8, nxt.row_stride, nxt.n_reads, nxt.n_tokens)
                           if nxt is not None else -1)         # H2D of batch i+1 overlaps the forward of batch i
+            # the 16-bit mode against the exact-fp32 kernels on this batch's first reads, where a self-check is due (HyenaDna.guard)
+            model.net.guard(eng, torch.from_numpy(cur.ids[:4, : cur.n_tokens].copy()).to(device))
             logits = eng.forward_staged(staged, cur.n_reads)
             eng.stage_wait(staged)                            # the copy has left the slot ...
             feeder.release(cur)                               # ... which goes back to the decoder
@@ -166,6 +185,7 @@ def run_predict_native(model, feeder, writer, device: torch.device, *, rank: int
             n_reads += cur.n_reads
             batch_idx += 1
             cur, staged = nxt, nxt_staged
+        _check_engine(model, device, batch_idx)
         if gatherer is not None:
             _drain_gather(pending, gatherer, rows, device, batch_idx, writer, trainer, model, on_batch)
         elif pending is not None:

@@ -4,7 +4,7 @@ The Hydra entry route of the reference's predict path (/root/reference/eval.py:3
 configs/eval.yaml, instantiate datamodule / model / callbacks / trainer from their `_target_`s and run
 `trainer.predict(model=model, dataloaders=datamodule, ckpt_path=cfg.ckpt_path, return_predictions=False)`.
 Prediction files land in `${paths.output_dir}/predicts/{rank}_{batch}.txt` (configs/callbacks/write.yaml).
-Uses `hydra` when it is installed; otherwise the built-in composer (chimeralm_amd/config.py) reads the same files.
+The built-in composer (chimeralm_amd/config.py) reads the files -- whether or not hydra-core is installed: one behaviour everywhere.
 Multi-GPU: `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 eval.py trainer=ddp ...`.
 """
 from __future__ import annotations
@@ -41,22 +41,13 @@ def evaluate(cfg):
 def main(argv: list[str] | None = None):
     logging.basicConfig(level=logging.INFO, format="%(message)s")
     argv = list(sys.argv[1:] if argv is None else argv)
-    try:
-        import hydra  # noqa: F401
-        from omegaconf import OmegaConf
+    # One composer everywhere: chimeralm_amd/config.py reads the same files and override grammar.  (`hydra.compose` outside
+    # `@hydra.main` sets no HydraConfig, so configs/paths/default.yaml's ${hydra:runtime.output_dir} could not resolve, and
+    # `hydra.run.dir=` would be taken as a plain override: an installed hydra-core would have crashed this route, not helped it.)
+    from chimeralm_amd.config import compose
 
-        from hydra import compose as hcompose, initialize_config_dir
-
-        with initialize_config_dir(version_base="1.3", config_dir=str(ROOT / "configs")):
-            cfg = hcompose(config_name="eval.yaml", overrides=argv, return_hydra_config=False)
-        from chimeralm_amd.config import _wrap
-
-        cfg = _wrap(OmegaConf.to_container(cfg, resolve=True))
-    except ImportError:
-        from chimeralm_amd.config import compose
-
-        out = next((a.split("=", 1)[1] for a in argv if a.startswith("hydra.run.dir=")), None)
-        cfg = compose(ROOT / "configs", "eval.yaml", [a for a in argv if not a.startswith("hydra.")], output_dir=out)
+    out = next((a.split("=", 1)[1] for a in argv if a.startswith("hydra.run.dir=")), None)
+    cfg = compose(ROOT / "configs", "eval.yaml", [a for a in argv if not a.startswith("hydra.")], output_dir=out)
     if cfg.get("extras", {}).get("print_config"):
         import yaml
 

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define CLM_ABI_VERSION 1
+#define CLM_ABI_VERSION 2
 
 /* error codes */
 #define CLM_OK 0
@@ -124,6 +124,23 @@ int clm_stage_wait(clm_handle* h, int staged);
  * id (no wild read) and flag the handle; the flag is reported ONCE, as CLM_E_INVALID with the message in clm_last_error,
  * by the next clm_forward / clm_forward_staged / clm_stage_wait, or by clm_check, which first waits for `stream`. */
 int clm_check(clm_handle* h, void* stream);
+
+/* ---- the 16-bit modes checked against, and replaced by, the reference's arithmetic -------------------------------------
+ * The reference computes the whole forward in ONE precision, fp32 (hyena.py:244-256).  A 16-bit handle (CLM_PREC_F16C / F16 /
+ * BF16) also holds the exact-fp32 packing of its weights and the exact-fp32 kernels, so the deviation of its mode from the
+ * reference's arithmetic can be MEASURED on the weights that were loaded and on reads the caller chooses, instead of assumed
+ * from other weights:
+ *   clm_selfcheck   runs `ids` (device memory, as clm_forward) through the handle's mode AND through the exact-fp32 kernels
+ *                   and returns the largest |logit difference| (`max_abs_diff`, host; +inf if anything is not finite) and the
+ *                   number of reads whose argmax differs (`labels_differ`, may be NULL).  Synchronises `stream`.  Not affected
+ *                   by clm_set_fallback; 0 for a CLM_PREC_F32 handle and for lengths the mode itself runs in fp32.
+ *   clm_set_fallback(h, 1)   every later clm_forward* of this handle runs in the exact-fp32 kernels (the caller's reaction to a
+ *                   self-check above its threshold: chimeralm_amd/hyena.py uses 5e-4, half the reference tolerance); 0 undoes it.
+ *   clm_effective_precision  the CLM_PREC_* code reads of L tokens run in right now. */
+int clm_selfcheck(clm_handle* h, const void* ids, int ids_dtype, int64_t ids_row_stride, int B, int L, void* stream,
+                  float* max_abs_diff, int* labels_differ);
+int clm_set_fallback(clm_handle* h, int on);
+int clm_effective_precision(const clm_handle* h, int L);
 
 /* ---- SequenceCNNTransformer -----------------------------------------------------------
  * Multi-head self-attention of nn.TransformerEncoderLayer as the reference builds it

@@ -1,6 +1,6 @@
 /* abi_client.c -- a plain-C client of the engine's C ABI (no Python, no torch in the process).
  *
- *   abi_client <weights.bin> <ids.bin> <B> <L> <precision: 0 fp32 | 1 bf16 | 2 fp16>
+ *   abi_client <weights.bin> <ids.bin> <B> <L> <precision: 0 fp32 | 1 bf16 | 2 fp16 | 3 fp16c>
  *
  * weights.bin: repeated records  { u32 key_len, key bytes, u32 ndim, i64 shape[ndim], f32 data[prod(shape)] }  (written by
  * tests/test_gpu_c_abi.py from a state_dict with the reference's checkpoint keys); ids.bin: B*L token ids as uint8.
@@ -88,6 +88,15 @@ int main(int argc, char** argv) {
     CHECK_HIP(hipMemcpyAsync(logits, d_logits, (size_t)B * 2 * sizeof(float), hipMemcpyDeviceToHost, stream));
     CHECK_HIP(hipStreamSynchronize(stream));
     for (int b = 0; b < B; ++b) printf("%.9g %.9g\n", logits[2 * b], logits[2 * b + 1]);
+
+    /* the mode against the exact-fp32 kernels of the same handle, on these reads (stderr: "selfcheck <max |dlogit|> <labels differing>") */
+    {
+        float diff = -1.f;
+        int differ = -1;
+        CHECK_CLM(h, clm_selfcheck(h, d_ids, CLM_DT_U8, L, B, L, stream, &diff, &differ));
+        fprintf(stderr, "selfcheck %.9g %d\n", diff, differ);
+        if (clm_effective_precision(h, L) < 0) return 5;
+    }
 
     /* error convention: a bad call returns a negative code and leaves a message, nothing is thrown */
     if (clm_forward(h, d_ids, CLM_DT_U8, L, -1, L, d_logits, stream) != CLM_E_INVALID || !clm_last_error(h)[0]) {

@@ -33,10 +33,12 @@ def write_weights(path: Path, sd: dict) -> None:
             f.write(a.tobytes())
 
 
-@pytest.mark.parametrize("prec,code,tol", [("fp32", 0, 1e-3), ("fp16", 2, 5e-3)])
-def test_c_client_matches_oracle(tmp_path, built_lib, prec, code, tol):
+@pytest.mark.parametrize("prec,code,tol,bases", [("fp32", 0, 1e-3, 700), ("fp16", 2, 5e-3, 700), ("fp16c", 3, 1e-3, 2600)])
+def test_c_client_matches_oracle(tmp_path, built_lib, prec, code, tol, bases):
+    """fp16c (code 3, the CLI / bench default) at a length its fp16 kernels run (>= 2,048 tokens); the client also calls
+    clm_selfcheck and prints what it measured."""
     sd = ho.make_state_dict(0, head_scale=3.0)
-    ids, _ = ho.synthetic_batch(7, 5, 700)
+    ids, _ = ho.synthetic_batch(7, 5, bases)
     ids[1, :9] = 4                                           # a left-padded read
     B, L = ids.shape
     write_weights(tmp_path / "weights.bin", sd)
@@ -50,3 +52,9 @@ def test_c_client_matches_oracle(tmp_path, built_lib, prec, code, tol):
     assert got.shape == ref.shape
     assert np.abs(got - ref).max() <= tol
     assert (got.argmax(1) == ref.argmax(1)).all()
+    sc = [ln.split() for ln in r.stderr.splitlines() if ln.startswith("selfcheck ")]
+    assert len(sc) == 1 and int(sc[0][2]) == 0
+    if prec == "fp32":
+        assert float(sc[0][1]) == 0.0
+    else:
+        assert 0.0 < float(sc[0][1]) <= tol

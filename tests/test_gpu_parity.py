@@ -86,19 +86,104 @@ def test_fp16c_parity_shapes(engines, sd, B, L):
     _check(engines["fp16c"], "fp16c", _ids(B, L, pads=min(3, L - 1)), sd)
 
 
-@pytest.mark.parametrize("wseed", [1, 2, 3])
-def test_fp16c_other_weight_draws(built_lib, wseed):
-    """The gate must not hinge on one weight draw: three more seeded state dicts, at the shortest length that still runs the
-    fp16 kernels (2048 tokens: the least averaging, i.e. the largest error of the mode) and at 100 tokens (fp32 kernels)."""
+@pytest.mark.parametrize("wseed", range(8))
+def test_fp16c_gate_over_weight_draws_and_lengths(built_lib, wseed):
+    """The gate must not hinge on one weight draw or one length: the margin study of round 2 (tests/fp16c_margin.py,
+    profiles/r02_fp16c_margin.txt) as a test -- eight seeded state dicts x {2,048, 3,000, 4,097, 8,193} tokens, batches of 4 random
+    ACGT reads, one of them left-padded by a third, every batch at GATE.  (No "margin" factor is asserted: the worst batch of
+    round 2's study sat at 9.6e-4; what protects unseen weights is the self-check + fp32 fallback, tested below.)  The worst
+    case of the run is printed (pytest -s) and asserted per batch."""
     from chimeralm_amd.engine import Engine
 
     sdw = ho.make_state_dict(wseed, head_scale=3.0)
     e = Engine("cuda:0", precision="fp16c", chunk_reads=4)
     e.load_state_dict(sdw)
-    err = _check(e, "fp16c", _ids(6, 2048, seed=50 + wseed, pads=1), sdw)
-    assert err <= 0.7 * GATE, f"fp16c at its shortest fp16 length: {err:.2e} leaves no margin under the gate"
-    _check(e, "fp16c", _ids(6, 100, seed=60 + wseed), sdw)
+    for L in (2048, 3000, 4097, 8193):
+        rng = np.random.default_rng(1000 * wseed + L)
+        ids = rng.integers(7, 11, size=(4, L)).astype(np.uint8)
+        ids[:, -1] = 1
+        ids[0, : L // 3] = 4
+        err = _check(e, "fp16c", ids, sdw, dtype=torch.uint8)
+        sc, _ = e.selfcheck(torch.from_numpy(ids).cuda())
+        print(f"weights {wseed}  L {L:5d}: |fp16c - oracle| {err:.2e}   |fp16c - fp32 kernels| (clm_selfcheck) {sc:.2e}")
+        # the self-check referee (exact-fp32 kernels) is itself within ~2e-5 of the oracle: what it measures IS the mode's error
+        assert abs(sc - err) <= 6e-5
+    if wseed in (1, 2, 3):
+        _check(e, "fp16c", _ids(6, 100, seed=60 + wseed), sdw)        # 100 tokens: the fp32 kernels inside the mode
     e.close()
+
+
+def test_selfcheck_and_fallback_through_the_c_abi(engines, sd):
+    """clm_selfcheck runs a batch through the handle's 16-bit mode AND the exact-fp32 kernels of the same handle:
+    the difference it reports is exactly max |mode logits - fp32-engine logits|; clm_set_fallback(1) makes every later forward
+    of the 16-bit handle bit-identical to the fp32 engine's (same kernels, same packing), clm_set_fallback(0) undoes it."""
+    e, e32 = engines["fp16c"], engines["fp32"]
+    for B, L in ((4, 2500), (3, 8193), (2, 16385)):
+        t = torch.from_numpy(_ids(B, L, seed=301, pads=3)).cuda()
+        a, r = e.forward(t).cpu(), e32.forward(t).cpu()
+        diff, differ = e.selfcheck(t)
+        assert diff == float((a - r).abs().max()) and 0 < diff <= GATE
+        assert differ == int((a.argmax(1) != r.argmax(1)).sum())
+        assert torch.equal(e.forward(t).cpu(), a)                          # the self-check leaves the mode as it was
+        e.set_fallback(True)
+        assert e.effective_precision(L) == "fp32"
+        assert torch.equal(e.forward(t).cpu(), r)
+        assert e.selfcheck(t)[0] == diff                                   # not affected by the fallback switch
+        e.set_fallback(False)
+        assert e.effective_precision(L) == "fp16c"
+        assert torch.equal(e.forward(t).cpu(), a)
+    short = torch.from_numpy(_ids(3, 700, seed=302)).cuda()                # the mode itself runs these in fp32: nothing to measure
+    assert e.selfcheck(short) == (0.0, 0) and e.effective_precision(700) == "fp32"
+    assert e32.selfcheck(short) == (0.0, 0)
+    bf = engines["bf16"]                                                   # any 16-bit handle holds the referee
+    d16, _ = bf.selfcheck(torch.from_numpy(_ids(3, 1000, seed=303)).cuda())
+    assert GATE < d16 < TOL["bf16"]
+
+
+def test_module_selfcheck_falls_back_to_fp32_when_the_mode_breaks(built_lib):
+    """`HyenaDna(precision="fp16c")` measures the mode on the LOADED weights before its first batch (seeded synthetic reads at
+    2,048 / 4,097 tokens + the batch's first reads) and falls back to exact fp32 above 5e-4.  Two weight sets: the seeded
+    draw 0 with the head weights scaled x1 (the mode passes and stays) and x6 (seven head layers: logits and their errors
+    grow ~20x over the parity tests' x3: the mode breaks; the module must notice, warn, and from then on give the fp32 engine's
+    logits bit for bit)."""
+    import warnings
+
+    from chimeralm_amd import lm
+    from chimeralm_amd.engine import Engine
+
+    ids = torch.from_numpy(_ids(5, 3000, seed=311, pads=2).astype(np.int64)).cuda()
+    good = ho.make_state_dict(0, head_scale=1.0)
+    m = lm.ChimeraLM.new(precision="fp16c")
+    m.load_state_dict(good, strict=True)
+    with warnings.catch_warnings():
+        warnings.simplefilter("error", RuntimeWarning)
+        out = m.net(ids)
+    rep = m.net.selfcheck_report
+    assert rep["fallback"] is False and 0 < rep["max_abs_dlogit"] <= 5e-4 and len(rep["samples"]) == 3
+    ref = ho.forward(ids.cpu(), good)
+    assert (out.cpu() - ref).abs().max() <= GATE
+    assert m.net.engine(ids.device).effective_precision(3000) == "fp16c"
+    m.net(ids)
+    assert len(m.net.selfcheck_report["samples"]) == 3                      # checked once per weight load ...
+    m.net(ids[:, :1200].contiguous())
+    assert len(m.net.selfcheck_report["samples"]) == 3                      # ... (1,200 tokens run in fp32 inside the mode anyway)
+
+    bad = ho.make_state_dict(0, head_scale=6.0)
+    m.load_state_dict(bad, strict=True)                                     # same module: new weights, new hearing
+    with pytest.warns(RuntimeWarning, match="falling back to exact fp32"):
+        out = m.net(ids)
+    rep = m.net.selfcheck_report
+    assert rep["fallback"] is True and rep["max_abs_dlogit"] > 5e-4
+    e32 = Engine("cuda:0", precision="fp32", chunk_reads=64)
+    e32.load_state_dict(bad)
+    assert torch.equal(out.cpu(), e32.forward(ids).cpu())
+    raw = Engine("cuda:0", precision="fp16c", chunk_reads=64)                # what the unguarded mode would have answered
+    raw.load_state_dict(bad)
+    assert (raw.forward(ids).cpu() - out.cpu()).abs().max() > GATE
+    e32.close(), raw.close()
+    m2 = lm.ChimeraLM.new(precision="fp16c", selfcheck=False)               # opt-out: the raw mode
+    m2.load_state_dict(bad, strict=True)
+    assert m2.net(ids).shape == (5, 2) and m2.net.selfcheck_report == {}
 
 
 def test_intermediates_fp32(engines, sd):
@@ -283,29 +368,35 @@ def test_maximum_length_reads(engines, sd):
     _check(engines["fp16"], "fp16", ids, sd, ref=ref)
 
 
-def test_baseline_batch_size_independent_properties(sd, built_lib):
-    """BASELINE.json's bench configuration (256 reads of 8192 bases + [SEP], fp16, 64-read chunks), where the oracle is too
-    slow for the whole batch: reads are independent units, so (a) two runs are bit-identical, (b) reversing the batch reverses
-    the logits (each read gets another pair partner in the packed FFT: equal up to rounding, not bitwise), (c) reads computed
-    alone equal their rows of the full batch, (d) a sample of rows matches the oracle."""
+@pytest.mark.parametrize("prec,B", [("fp16c", 256), ("fp16c", 32), ("fp16", 256)])
+def test_baseline_batch_size_independent_properties(sd, built_lib, prec, B):
+    """BASELINE.json's bench configurations AT SIZE and in the benched mode: 256 reads of 8192 bases + [SEP] in 64-read chunks
+    (C3: 8,192 convolution units per launch through the persistent XCD-ordered loop, 4,096 tail tiles) and the 32-read shard a
+    GPU gets in the 8-GPU run (C4).  The oracle is too slow for the whole batch; reads are independent units, so (a) two runs
+    are bit-identical, (b) reversing the batch reverses the logits (each read gets another pair partner in the packed FFT:
+    equal up to rounding, not bitwise), (c) reads computed alone equal their rows of the full batch, (d) a sample of rows
+    matches the oracle at the mode's bound (fp16c: GATE), (e) fp16c: the exact-fp32 kernels agree on a sample (clm_selfcheck)."""
     from chimeralm_amd.engine import Engine
 
-    ids = _ids(256, 8193, seed=41)
+    ids = _ids(B, 8193, seed=41)
     t = torch.from_numpy(ids).cuda()
-    e = Engine("cuda:0", precision="fp16", chunk_reads=64)
+    e = Engine("cuda:0", precision=prec, chunk_reads=64)
     e.load_state_dict(sd)
     a = e.forward(t).cpu()
     assert torch.isfinite(a).all()
     assert torch.equal(a, e.forward(t).cpu())                                   # (a)
     r = e.forward(torch.flip(t, dims=[0]).contiguous()).cpu()
-    assert (torch.flip(r, dims=[0]) - a).abs().max() < 2e-3                      # (b)
-    pick = [0, 63, 64, 200, 255]
+    assert (torch.flip(r, dims=[0]) - a).abs().max() < 0.5 * TOL[prec]           # (b)
+    pick = [0, B // 4 - 1, B // 4, B - B // 5, B - 1]
     solo = e.forward(t[pick].contiguous()).cpu()
-    assert (solo - a[pick]).abs().max() < 2e-3                                   # (c)
+    assert (solo - a[pick]).abs().max() < 0.5 * TOL[prec]                        # (c)
     ref = ho.forward(torch.from_numpy(ids[pick[:3]].astype(np.int64)), sd)       # (d)
-    assert (a[pick[:3]] - ref).abs().max() <= TOL["fp16"]
-    decided = (ref[:, 0] - ref[:, 1]).abs() > MARGIN["fp16"]
+    assert (a[pick[:3]] - ref).abs().max() <= TOL[prec]
+    decided = (ref[:, 0] - ref[:, 1]).abs() > MARGIN[prec]
     assert torch.equal(a[pick[:3]].argmax(1)[decided], ref.argmax(1)[decided])
+    if prec == "fp16c":                                                          # (e)
+        diff, _ = e.selfcheck(t[B - 8:].contiguous())
+        assert 0 < diff <= GATE
     e.close()
 
 

@@ -30,10 +30,28 @@ def _read(path):
         return None
 
 
+def leased_pci_slot() -> str | None:
+    """PCI slot ("0000:c5:00.0") of the GPU this process computes on (cuda:0 of the lease), for picking ITS hwmon directory:
+    the box's sysfs shows every GPU of a shared 8-GPU host, and "the busiest card" can be another tenant's."""
+    try:
+        import torch
+
+        p = torch.cuda.get_device_properties(0)
+        return f"{getattr(p, 'pci_domain_id', 0):04x}:{p.pci_bus_id:02x}:{p.pci_device_id:02x}.0"
+    except Exception:  # noqa: BLE001
+        return None
+
+
 class Sampler:
-    def __init__(self, period=0.05):
+    def __init__(self, period=0.05, pci_slot: str | None = None):
         self.period, self.rows, self._stop = period, [], threading.Event()
         self.hw = sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*"))
+        self.mine = None                         # hwmon directory of the leased card, by PCI slot
+        if pci_slot:
+            for h in self.hw:
+                ue = _read(os.path.join(os.path.dirname(os.path.dirname(h)), "uevent")) or ""
+                if f"PCI_SLOT_NAME={pci_slot.lower()}" in ue.lower() or pci_slot.lower() in os.path.realpath(h).lower():
+                    self.mine = h
         self.src = "sysfs" if any(_read(f"{h}/power1_average") or _read(f"{h}/power1_input") for h in self.hw) else None
         if self.src is None:
             for tool in ("amd-smi", "rocm-smi"):
@@ -45,7 +63,8 @@ class Sampler:
     def sample(self) -> dict:
         row = {"t": time.perf_counter()}
         if self.src == "sysfs":
-            # the box's sysfs shows every GPU of the host, the process sees one of them: sample all, report the busiest
+            # the box's sysfs shows every GPU of the host, the process sees one of them: sample all; clock / temperature / the
+            # headline power are those of the LEASED card (matched by PCI slot), the busiest one only if that match failed
             best = None
             for h in self.hw:
                 p = _read(f"{h}/power1_average") or _read(f"{h}/power1_input")
@@ -53,7 +72,7 @@ class Sampler:
                     continue
                 card = h.split("/")[4]
                 row[f"power_w_{card}"] = float(p) / 1e6
-                if best is None or float(p) > best[0]:
+                if (self.mine == h) or (self.mine is None and (best is None or float(p) > best[0])):
                     best = (float(p), h)
             if best:
                 h = best[1]
@@ -122,7 +141,7 @@ def summarize(name, rows):
     cards = sorted({k for r in rows for k in r if k.startswith("power_w_")})
     if cards:
         out.append("   mean W per card: " + "  ".join(f"{c[8:]} {sum(r.get(c, 0) for r in rows) / len(rows):.0f}" for c in cards)
-                   + f"   (busiest card sampled for clock/temperature: {rows[len(rows) // 2].get('card')})")
+                   + f"   (card sampled for power / clock / temperature: {rows[len(rows) // 2].get('card')})")
     errs = [r["err"] for r in rows if "err" in r]
     if errs:
         out.append(f"   {len(errs)} failed samples, first: {errs[0]}")
@@ -139,14 +158,16 @@ def main():
     import numpy as np
     import torch
 
-    s0 = Sampler()
-    print(f"telemetry source: {s0.src}; hwmon dirs: {s0.hw}", flush=True)
+    slot = leased_pci_slot()
+    s0 = Sampler(pci_slot=slot)
+    print(f"telemetry source: {s0.src}; leased GPU at PCI {slot} -> hwmon {s0.mine or 'NOT MATCHED (busiest card reported)'}; "
+          f"hwmon dirs: {s0.hw}", flush=True)
     if s0.src is None:
         print("no readable power telemetry on this box (no hwmon power file, no amd-smi / rocm-smi)")
     allrows = []
 
     def run(name, fn):
-        with Sampler() as s:
+        with Sampler(pci_slot=slot) as s:
             t0 = time.perf_counter()
             n = 0
             while time.perf_counter() - t0 < a.seconds:
