@@ -88,6 +88,13 @@ struct clm_handle {
     int next_stage = 0;
     int* bad_ids = nullptr;       // host-mapped flag the id kernels set for a token id outside [0, vocab_rows)
     float* ztab = nullptr;        // [16][768] block-0 in_proj rows per token id (16-bit modes)
+    // gated hand-over of z (TailArgs::zg): filter constants per layer, raw rows either side of the tail kernel's workgroup-range
+    // boundaries, raw rows of every read's last two tiled tokens
+    float4* fir[NLAYER] = {};
+    float2* edge_bnd = nullptr;
+    float2* edge_read = nullptr;
+    int edge_read_cap = 0;
+    bool raw_z = false;           // CLM_RAW_Z=1: the fused in_proj stage writes x0 | x1 | v as before round 3 (A/B runs, tests)
     unsigned char* ids8 = nullptr;   // workspace: clamped ids [B][Lp]
     float* head_t[5] = {};
     LayerW lw[NLAYER]{};
@@ -259,8 +266,9 @@ void free_filters(clm_handle* h) {
 
 void free_workspace(clm_handle* h) {
     for (void* p : {(void*)h->h, h->z, h->y, h->u, (void*)h->scores, (void*)h->stats, (void*)h->partial,
-                    (void*)h->pooled, (void*)h->gscratch, (void*)h->ids8, (void*)h->lone_ws})
+                    (void*)h->pooled, (void*)h->gscratch, (void*)h->ids8, (void*)h->lone_ws, (void*)h->edge_read})
         if (p) (void)hipFree(p);
+    h->edge_read = nullptr;
     h->gscratch = nullptr;
     h->gscratch_elems = 0;
     h->h = nullptr; h->z = h->y = h->u = nullptr;
@@ -280,6 +288,8 @@ void free_packed(clm_handle* h) {
     if (h->packed_score) { (void)hipFree(h->packed_score); h->packed_score = nullptr; }
     if (h->packed_score32) { (void)hipFree(h->packed_score32); h->packed_score32 = nullptr; }
     if (h->ztab) { (void)hipFree(h->ztab); h->ztab = nullptr; }
+    for (int i = 0; i < NLAYER; ++i)
+        if (h->fir[i]) { (void)hipFree(h->fir[i]); h->fir[i] = nullptr; }
     for (int j = 0; j < 5; ++j)
         if (h->head_t[j]) { (void)hipFree(h->head_t[j]); h->head_t[j] = nullptr; }
 }
@@ -317,6 +327,8 @@ int ensure_workspace(clm_handle* h, int Bc, int L, hipStream_t st) {
     HIPCHK(h, hipMalloc((void**)&h->pooled, (size_t)nb * D * 4));
     HIPCHK(h, hipMalloc((void**)&h->lone_ws, lone_token_ws_floats(nb) * 4));
     HIPCHK(h, hipMalloc((void**)&h->ids8, (size_t)nb * Lp));
+    HIPCHK(h, hipMalloc((void**)&h->edge_read, (size_t)nb * D3 * sizeof(float2)));
+    if (!h->edge_bnd) HIPCHK(h, hipMalloc((void**)&h->edge_bnd, (size_t)1024 * 2 * D3 * sizeof(float2)));   // >= any grid (one workgroup per CU)
     if (conv_segments_for(nl) > 1) {
         const size_t pairs = (size_t)(nb + 1) / 2, S = (size_t)conv_segments_for(nl);
         h->gscratch_elems = pairs * D * S * 16384;
@@ -490,6 +502,11 @@ int forward_chunk(clm_handle* h, const void* ids, int ids_dtype, int64_t row_str
     // reads of 128 k + 1 tokens (every 8k-bp read: 8192 bases + [SEP]): the last token would be a tile of its own, a whole extra
     // round of the tail kernel for one token per read; it is causally isolated, so a per-read matrix-vector kernel takes it
     const bool peel = fuse_next && !h->no_lone_peel && L > 128 && L % 128 == 1;
+    // ... and hands z over in the form the convolution reads: x0f and g = x1f * vf, filtered and gated by the in_proj stage itself
+    // (two rows per channel instead of three; gemm16.hip inproj_blocks_gated)
+    const bool zgated = fuse_next && !h->raw_z && !h->split_conv;   // (the split-transform A/B kernel reads the raw rows)
+    if (zgated && tail16_grid(((peel ? L - 1 : L) + 127) / 128 * Bc) > 1024)
+        return fail(h, CLM_E_UNSUPPORTED, "more than 1024 compute units: edge_bnd is sized for 1024 workgroups");
     const void* packed_score = alt32 ? h->packed_score32 : h->packed_score;
     const ScorePoolArgs spa{h->h, W(h, "bb.ln_f.weight"), W(h, "bb.ln_f.bias"), packed_score,
                             W(h, "head.attention.0.bias"), W(h, "head.attention.2.weight"),
@@ -518,11 +535,12 @@ int forward_chunk(clm_handle* h, const void* ids, int ids_dtype, int64_t row_str
                                       Lp, idconv ? h->ids8 : nullptr, idconv ? h->ztab : nullptr, st);
             else if (S == 1)
                 launch_hyena_conv(prec, h->z, h->y, fs->kf[i], fs->tw, fs->ktime[i], lw.short_w, lw.short_b, Bc, L, Lp,
-                                  fs->logn, idconv ? h->ids8 : nullptr, idconv ? h->ztab : nullptr, st, h->conv_flags, fs->kfp[i]);
+                                  fs->logn, idconv ? h->ids8 : nullptr, idconv ? h->ztab : nullptr, st,
+                                  h->conv_flags | ((zgated && i > 0) ? CONV_GATED : 0), fs->kfp[i]);
             else
                 launch_hyena_conv_seg(prec, h->z, h->y, fs->kf[i], fs->KS, fs->tw, lw.short_w, lw.short_b, h->gscratch, Bc,
                                       L, Lp, S, kr ? kr->p[i] : nullptr, kr ? kr->stride : 0, idconv ? h->ids8 : nullptr,
-                                      idconv ? h->ztab : nullptr, st, h->conv_flags);
+                                      idconv ? h->ztab : nullptr, st, h->conv_flags | ((zgated && i > 0) ? CONV_GATED : 0));
         }
         if (stop_here(h, i, CLM_STAGE_CONV)) return CLM_OK;
         const bool stop_mid = stop_here(h, i, CLM_STAGE_OUTPROJ);
@@ -536,10 +554,15 @@ int forward_chunk(clm_handle* h, const void* ids, int ids_dtype, int64_t row_str
                 const LayerW& nx = h->lw[i + 1];
                 ta.n_w = nx.w_in; ta.n_bias = nx.b_in; ta.n_g = nx.ln1_g; ta.n_b = nx.ln1_b; ta.n_z = h->z;
                 next = NEXT_INPROJ;
+                if (zgated) {
+                    ta.zg = 1; ta.n_fir = h->fir[i + 1]; ta.edge_bnd = h->edge_bnd;
+                    ta.edge_read = peel ? h->edge_read : nullptr;
+                }
             } else if (fuse_next) {
                 next = NEXT_SCORE;
             }
             launch_tail16(prec, ta, next, st);
+            if (ta.zg) launch_gated_patch(prec, ta, st);        // tokens 0, 1 of the workgroup ranges that start inside a read
             if (peel) {
                 const std::string p = "bb.layers." + std::to_string(i) + ".", pn = "bb.layers." + std::to_string(i + 1) + ".";
                 const bool last = i + 1 == NLAYER;
@@ -556,6 +579,7 @@ int forward_chunk(clm_handle* h, const void* ids, int ids_dtype, int64_t row_str
                 } else {
                     const LayerW& nx = h->lw[i + 1];
                     la.n_g = nx.ln1_g; la.n_b = nx.ln1_b; la.n_w = W(h, pn + "mixer.in_proj.weight"); la.n_bias = nx.b_in; la.n_z = h->z;
+                    if (ta.zg) { la.n_fir = ta.n_fir; la.edge_read = h->edge_read; }
                 }
                 la.ws = h->lone_ws;
                 la.B = Bc; la.L = L; la.Lp = Lp; la.ntiles = (L + 127) / 128; la.eps = eps;
@@ -658,6 +682,7 @@ int clm_create(const clm_config* cfg, int device, clm_handle** out) {
     if (std::getenv("CLM_CONV_ONESHOT") && std::getenv("CLM_CONV_ONESHOT")[0] == '1') h->conv_flags |= CONV_ONESHOT;
     if (std::getenv("CLM_CONV_NO_XCD") && std::getenv("CLM_CONV_NO_XCD")[0] == '1') h->conv_flags |= CONV_NO_XCD;
     h->split_conv = std::getenv("CLM_SPLIT_CONV") && std::getenv("CLM_SPLIT_CONV")[0] == '1';
+    h->raw_z = std::getenv("CLM_RAW_Z") && std::getenv("CLM_RAW_Z")[0] == '1';
     h->cfg = *cfg;
     h->device = device;
     if (hipHostMalloc((void**)&h->bad_ids, sizeof(int), hipHostMallocMapped) == hipSuccess) *h->bad_ids = 0;
@@ -759,6 +784,11 @@ int clm_finalize(clm_handle* h) {
         if ((rc = pack("head.attention.0.weight", D, D, &h->packed_score))) return rc;
         if (prec != PREC_F32 && (rc = pack_as(PREC_F32, "head.attention.0.weight", D, D, &h->packed_score32))) return rc;
     }
+    if (prec != PREC_F32)
+        for (int i = 0; i < NLAYER; ++i) {
+            HIPCHK(h, hipMalloc((void**)&h->fir[i], (size_t)D * 3 * sizeof(float4)));
+            launch_fir_table(h->lw[i].short_w, h->lw[i].short_b, h->lw[i].b_in, h->fir[i], st);
+        }
     HIPCHK(h, hipMalloc((void**)&h->ztab, (size_t)VOCAB * D3 * 4));
     launch_ztab(W(h, "bb.embeddings.word_embeddings.weight"), W(h, "bb.layers.0.norm1.weight"),
                 W(h, "bb.layers.0.norm1.bias"), W(h, "bb.layers.0.mixer.in_proj.weight"),
@@ -1033,6 +1063,7 @@ int clm_destroy(clm_handle* h) {
     free_filters(h);
     free_packed(h);
     if (h->sc_logits) (void)hipFree(h->sc_logits);
+    if (h->edge_bnd) (void)hipFree(h->edge_bnd);
     for (auto& sg : h->stage) {
         if (sg.buf) (void)hipFree(sg.buf);
         if (sg.copied) (void)hipEventDestroy(sg.copied);

@@ -182,7 +182,23 @@ struct TailArgs {
     void* n_z;
     // NEXT_SCORE (last block): ln_f + attention scores + pooling partials, see score_pool_tile
     ScorePoolArgs sp;
+    // GATED hand-over (NEXT_INPROJ with zg != 0, gemm16.hip inproj_blocks_gated): the in_proj stage applies the next block's 3-tap
+    // short filter and the x1 * v gate itself and writes TWO rows per channel into n_z -- row c = x0f, row 256 + c = g = x1f * vf
+    // (rows 512.. unused) -- instead of x0 | x1 | v: a third less z traffic, and the convolution's phase A becomes a load.
+    int zg;
+    const float4* n_fir;      // [256][3] per channel c and row group q (x0, x1, v): {w0, w1, w2, cb}, cb = short_b + in_proj_b * (w0 + w1 + w2)
+    float2* edge_bnd;         // [gridDim.x][2][768] raw in_proj rows (no bias): [w][0] = tokens 126, 127 of the tile before workgroup w's
+                              // first tile, [w][1] = tokens 0, 1 of that first tile (launch_gated_patch recomputes those two tokens)
+    float2* edge_read;        // [B][768] or null: raw rows of the last two tiled tokens of every read (the peeled lone token's history)
 };
+// tiles of the tail kernel are taken in CONTIGUOUS ranges per workgroup (the short filter's two-token history then comes from the
+// workgroup's own previous tile): range length for `total` tiles on `grid` workgroups
+__host__ __device__ inline int tail_range_len(int total, int grid) { return (total + grid - 1) / grid; }
+int tail16_grid(int total_tiles);   // workgroups launch_tail16 starts for that many tiles
+// the first two tokens of every workgroup range that starts inside a read: recomputed from edge_bnd (gemm16.hip)
+void launch_gated_patch(int prec, const TailArgs& m, hipStream_t st);
+// n_fir of one layer from its short filter and in_proj bias
+void launch_fir_table(const float* short_w /*[768][3]*/, const float* short_b, const float* in_bias, float4* fir /*[256][3]*/, hipStream_t st);
 constexpr int NEXT_NONE = 0, NEXT_INPROJ = 1, NEXT_SCORE = 2;
 // The last token of a read of 128 k + 1 tokens, through the second half of a block (and what follows) as fp32 matrix-vector
 // products: see lone_token.hip.  All weights are the fp32 originals [out][in].
@@ -194,6 +210,8 @@ struct LoneTokenArgs {
     const float *w_out, *b_out, *ln2_g, *ln2_b, *w_fc1, *b_fc1, *w_fc2, *b_fc2;
     int last;                    // 0: n_* = LayerNorm-1 + in_proj of the next block, z column written; 1: n_g / n_b = ln_f, score + partial
     const float *n_g, *n_b, *n_w, *n_bias;
+    const float4* n_fir;         // gated hand-over (see TailArgs): n_z gets x0f / g at this token, history from edge_read
+    const float2* edge_read;
     void* n_z;                   // [B, 768, Lp] 16-bit
     const float *att_w1, *att_b1, *att_w2, *att_b2;
     float *scores, *partial;     // [B, L]; [B, ntiles, POOL_PSTRIDE]
@@ -233,6 +251,8 @@ void launch_twiddles(float2* tw, int logn, hipStream_t st);   // tw[m] = exp(-2 
 // flags (A/B switches of the engine, CLM_CONV_ONESHOT=1 / CLM_CONV_NO_XCD=1 at clm_create):
 constexpr int CONV_ONESHOT = 1;   // 16384-point class, 16-bit: one workgroup per unit (hyena_conv_kernel) instead of the persistent kernel
 constexpr int CONV_NO_XCD = 2;    // units in plain order instead of all read pairs of a channel on one XCD
+constexpr int CONV_GATED = 4;     // z holds x0f (row c) and g = x1f * vf (row 256 + c), filtered and gated by the fused tail kernel
+                                  // (TailArgs::zg); ignored for block 0's id-table path
 void launch_hyena_conv(int prec, const void* z, void* y, const float2* kf, const float2* tw, const float* ktime,
                        const float* short_w, const float* short_b, int B, int L, int Lp, int logn,
                        const unsigned char* ids8, const float* ztab, hipStream_t st, int flags = 0,

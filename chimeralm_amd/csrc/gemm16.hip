@@ -136,6 +136,202 @@ __global__ __launch_bounds__(512) void in_proj16_kernel(GemmArgs a) {
     inproj_blocks<PREC>(As, Zs, wp, a.bias, a.out, b, t0, a.Lp, wave, lane, bs, acc);
 }
 
+// ================================================================================================ in_proj, gated hand-over
+// The in_proj stage of the fused tail kernel in the form the long convolution wants to READ (SURVEY section 7
+// "make the GEMM epilogues write what the conv kernels read"): instead of x0 | x1 | v (three rows per channel, filtered and gated
+// by every convolution workgroup that reads them) it writes
+//     row c        x0f[t] = short_filter(x0)[t]
+//     row 256 + c  g[t]   = short_filter(x1)[t] * short_filter(v)[t]
+// -- a third less z traffic in both kernels, and the 3-tap filter runs ONCE, on the fp32 accumulators (the old path filtered
+// values already rounded to 16 bits).  Reference arithmetic: HyenaOperator's short_filter (Conv1d(768, 768, 3, padding=2,
+// groups=768)[..., :L]) and `v * x1`.
+//   short_filter(z)[t] = sb + w0 (z[t-2] + b) + w1 (z[t-1] + b) + w2 (z[t] + b),  zero padding before the read's first token
+//                      = cb + w0 r[t-2] + w1 r[t-1] + w2 r[t]   with r = the raw accumulator (no bias), cb = sb + b (w0 + w1 + w2),
+//                        and r[-1] = r[-2] = -b at the start of a read (so that r + b = 0 there).
+// Accumulator layout (rows = tokens): lane (feature lrow, half lhalf) holds, per register pair index i = 4 mt + q', the four
+// CONSECUTIVE tokens 32 mt + 8 q' + 4 lhalf + {0..3}; the two tokens before them belong to the partner lane (lane ^ 32): its pair
+// i (lhalf = 1 needs lhalf = 0's) or i - 1 (lhalf = 0 needs lhalf = 1's) -- one ds_bpermute per value.  Pair 0 of the lhalf = 0
+// lanes needs the PREVIOUS TILE's tokens 126, 127: tiles are taken in contiguous ranges per workgroup (tail_range_len), the
+// raw values are kept in an LDS stash from tile to tile; the first tile of a range that starts inside a read is computed with
+// r = -b there and its tokens 0, 1 are recomputed by gated_patch_kernel from the raw values both sides leave in edge_bnd.
+// Block order x1, v, x0: x1f waits in the (dead) fc2 accumulators for v; the y prefetch of the hooks stays in the last block.
+constexpr int ZG_ORDER[3] = {1, 2, 0};
+constexpr int ZG_HALO_FLOATS = 8 * 3 * 32 * 2;          // [wave][q][lrow][2]: raw tokens 126, 127 of the workgroup's previous tile
+
+struct GatedTile {                                       // uniform per tile
+    bool fresh;          // no history in the stash: first token of a read, or first tile of this workgroup's range
+    bool head_bnd;       // first tile of the range, inside a read: leave tokens 0, 1 raw in edge_bnd[w][1]
+    bool tail_bnd;       // last tile of the range and the next tile continues the read: leave tokens 126, 127 in edge_bnd[w + 1][0]
+    bool read_tail;      // last tile of a read: leave tokens 126, 127 in edge_read[b]
+    int w;               // this workgroup
+};
+
+template <int PREC>
+__device__ __forceinline__ void zg_fir_inplace(f32x16 (&a)[4], const float4 f, float p2, float p3, int lane) {
+    const int lhalf = lane >> 5, paddr = (lane ^ 32) << 2;
+    // Every lane hands its tokens 2, 3 of pair i to its partner (e2[i], e3[i] = the PARTNER's): an lhalf = 1 lane needs the
+    // partner's pair i, an lhalf = 0 lane its pair i - 1 (pair 0: the stash).  The select is made on the RECEIVED values: written
+    // as a select between two elements of one accumulator vector, hipcc turns it into a dynamic vector index -- a 15-deep
+    // v_cndmask chain per value (364 of them per block, and 50 spilled registers).
+    float e2[16], e3[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        // (elements copied to scalars first: __builtin_bit_cast straight from a vector element reads element 0 with hipcc 7.2 --
+        //  DESIGN.md section 4.7; here it made all 32 exchanges of a block fetch four values)
+        const float s2 = a[i >> 2][4 * (i & 3) + 2], s3 = a[i >> 2][4 * (i & 3) + 3];
+        e2[i] = __int_as_float(__builtin_amdgcn_ds_bpermute(paddr, __float_as_int(s2)));
+        e3[i] = __int_as_float(__builtin_amdgcn_ds_bpermute(paddr, __float_as_int(s3)));
+    }
+    float r2[16], r3[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        r2[i] = lhalf ? e2[i] : (i ? e2[i ? i - 1 : 0] : p2);
+        r3[i] = lhalf ? e3[i] : (i ? e3[i ? i - 1 : 0] : p3);
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int mt = i >> 2, q = 4 * (i & 3);
+        const float z0 = a[mt][q], z1 = a[mt][q + 1], z2 = a[mt][q + 2], z3 = a[mt][q + 3];
+        a[mt][q + 0] = fmaf(f.z, z0, fmaf(f.y, r3[i], fmaf(f.x, r2[i], f.w)));
+        a[mt][q + 1] = fmaf(f.z, z1, fmaf(f.y, z0, fmaf(f.x, r3[i], f.w)));
+        a[mt][q + 2] = fmaf(f.z, z2, fmaf(f.y, z1, fmaf(f.x, z0, f.w)));
+        a[mt][q + 3] = fmaf(f.z, z3, fmaf(f.y, z2, fmaf(f.x, z1, f.w)));
+    }
+}
+
+// the wave's 128 tokens x 32 channels in `a` -> 16-bit -> row `row0 + lrow` of z (through the wave-private staging tile)
+template <int PREC>
+__device__ __forceinline__ void zg_store_rows(const f32x16 (&a)[4], typename CT<PREC>::elem* zs, void* zout, int b, int row0,
+                                              int t0, int Lp, int lane) {
+    using elem = typename CT<PREC>::elem;
+    const int lrow = lane & 31, lhalf = lane >> 5;
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            u16x4 pk = {to_bits<PREC>(a[mt][4 * q + 0]), to_bits<PREC>(a[mt][4 * q + 1]), to_bits<PREC>(a[mt][4 * q + 2]),
+                        to_bits<PREC>(a[mt][4 * q + 3])};
+            *reinterpret_cast<u16x4*>(zs + lrow * RSOUT + mt * 32 + 8 * q + 4 * lhalf) = pk;
+        }
+    __builtin_amdgcn_sched_barrier(0);
+    elem* zg = reinterpret_cast<elem*>(zout) + ((size_t)b * D3 + row0) * Lp + t0;
+    const int col8 = (lane & 15) * 8;
+    const bool in_row = t0 + col8 < Lp;                    // Lp is a multiple of 64: whole vectors in or out
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int row = i * 4 + (lane >> 4);
+        const uint4 v = *reinterpret_cast<const uint4*>(zs + row * RSOUT + col8);
+        if (in_row) *reinterpret_cast<uint4*>(zg + (size_t)row * Lp + col8) = v;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+template <int PREC, typename Hook>
+__device__ __forceinline__ void inproj_blocks_gated(const typename CT<PREC>::elem* As, typename CT<PREC>::elem* Zs, float* halo,
+                                                    const u16x8* wp, const TailArgs& m, const GatedTile gt, int b, int t0, int wave,
+                                                    int lane, u16x8 (&bs)[2][1][SETK], f32x16 (&accv)[4], f32x16 (&accx)[4],
+                                                    Hook hook) {
+    using elem = typename CT<PREC>::elem;
+    constexpr int K = D;
+    const int lrow = lane & 31, lhalf = lane >> 5;
+    elem* zs = Zs + wave * 32 * RSOUT;
+    float4 firq = make_float4(0.f, 0.f, 0.f, 0.f);
+    static_for<0, 3>([&](auto jc) {
+        constexpr int j = decltype(jc)::value, q = ZG_ORDER[j], qn = ZG_ORDER[(j + 1) % 3];
+        f32x16 (&acc)[4] = (j == 1) ? accv : accx;          // x1 and x0 in accx, v in accv
+        zero_acc(acc);
+        int lrow_e = lrow;                                   // opaque copy: addresses formed here, not kept across the MFMA phase
+        asm volatile("" : "+v"(lrow_e));
+        const int c = wave * 32 + lrow_e;
+        // this block's filter constants: requested now, behind the weight set the first MFMAs wait for (the hook slot)
+        auto hook2 = [&](int step) {
+            if (step == 2 * j) firq = m.n_fir[c * 3 + q];
+            hook(step);
+        };
+        phase_tm<PREC, K, K, false>(As, wp, q, 0, wp, qn, 0, wave, lane, bs, acc, hook2, 2 * j);
+        // ---- history of the tile's first tokens
+        float* hs = halo + ((wave * 3 + q) * 32 + lrow_e) * 2;
+        float p2, p3;
+        if (gt.fresh) {                                      // uniform; one tile in 16 .. 64
+            p2 = p3 = -m.n_bias[q * 256 + c];
+        } else {
+            const float2 hv2 = *reinterpret_cast<const float2*>(hs);
+            p2 = hv2.x, p3 = hv2.y;
+        }
+        const float2 tl = make_float2(acc[3][14], acc[3][15]), hd = make_float2(acc[0][0], acc[0][1]);   // raw tokens 126, 127 / 0, 1
+        if (lhalf) *reinterpret_cast<float2*>(hs) = tl;      // (same wave, after the read above: LDS operations of a wave are in order)
+        if (gt.tail_bnd && lhalf) m.edge_bnd[((size_t)(gt.w + 1) * 2 + 0) * D3 + q * 256 + c] = tl;
+        if (gt.head_bnd && !lhalf) m.edge_bnd[((size_t)gt.w * 2 + 1) * D3 + q * 256 + c] = hd;
+        if (gt.read_tail && lhalf) m.edge_read[(size_t)b * D3 + q * 256 + c] = tl;
+        zg_fir_inplace<PREC>(acc, firq, p2, p3, lane);
+        // x1f waits for vf through a whole MFMA phase in which both accumulators, two weight sets and the fragment ring are live
+        // (hipcc spilled 8 .. 26 of its registers to scratch, behind vmcnt waits): its upper half (tokens 64 .. 127) waits in the
+        // wave's staging tile instead -- unused until g is staged -- as eight conflict-free 16-byte rows per lane
+        float4* xs = reinterpret_cast<float4*>(zs) + lane;
+        static_assert((size_t)32 * RSOUT * sizeof(elem) >= (size_t)8 * 64 * sizeof(float4), "half of x1f fits the staging tile");
+        if constexpr (j == 0) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                xs[k * 64] = make_float4(accx[2 + (k >> 2)][4 * (k & 3) + 0], accx[2 + (k >> 2)][4 * (k & 3) + 1],
+                                         accx[2 + (k >> 2)][4 * (k & 3) + 2], accx[2 + (k >> 2)][4 * (k & 3) + 3]);
+            asm volatile("" ::: "memory");                   // (the tile is re-read / rewritten below through other pointer types)
+        } else if constexpr (j == 1) {                       // g = x1f * vf
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) accv[mt][r] *= accx[mt][r];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const float4 x = xs[k * 64];
+                accv[2 + (k >> 2)][4 * (k & 3) + 0] *= x.x;
+                accv[2 + (k >> 2)][4 * (k & 3) + 1] *= x.y;
+                accv[2 + (k >> 2)][4 * (k & 3) + 2] *= x.z;
+                accv[2 + (k >> 2)][4 * (k & 3) + 3] *= x.w;
+            }
+            asm volatile("" ::: "memory");
+            zg_store_rows<PREC>(accv, zs, m.n_z, b, 256 + wave * 32, t0, m.Lp, lane);
+        } else {
+            zg_store_rows<PREC>(accx, zs, m.n_z, b, wave * 32, t0, m.Lp, lane);
+        }
+    });
+}
+
+// Tokens 0, 1 of the first tile of every workgroup range that starts inside a read (inproj_blocks_gated computed them without
+// their history): recomputed from the raw values either side of the boundary.  One workgroup per boundary, one thread per channel.
+template <typename T>
+__global__ __launch_bounds__(256) void gated_patch_kernel(TailArgs m, int tiles_x, int total, int range) {
+    const int w = blockIdx.x + 1, c = threadIdx.x, tile = w * range;
+    if (tile >= total || tile % tiles_x == 0) return;
+    const int b = tile / tiles_x, t0 = (tile % tiles_x) * 128;
+    float zf[3][2];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        const float4 f = m.n_fir[c * 3 + q];
+        const float2 tl = m.edge_bnd[((size_t)w * 2 + 0) * D3 + q * 256 + c], hd = m.edge_bnd[((size_t)w * 2 + 1) * D3 + q * 256 + c];
+        zf[q][0] = fmaf(f.z, hd.x, fmaf(f.y, tl.y, fmaf(f.x, tl.x, f.w)));
+        zf[q][1] = fmaf(f.z, hd.y, fmaf(f.y, hd.x, fmaf(f.x, tl.y, f.w)));
+    }
+    T* z = reinterpret_cast<T*>(m.n_z) + (size_t)b * D3 * m.Lp + t0;
+    const unsigned x0 = (unsigned)from_float<T>(zf[0][0]).bits | ((unsigned)from_float<T>(zf[0][1]).bits << 16);
+    const unsigned g = (unsigned)from_float<T>(zf[1][0] * zf[2][0]).bits | ((unsigned)from_float<T>(zf[1][1] * zf[2][1]).bits << 16);
+    *reinterpret_cast<unsigned*>(z + (size_t)c * m.Lp) = x0;
+    *reinterpret_cast<unsigned*>(z + (size_t)(256 + c) * m.Lp) = g;
+}
+
+__global__ __launch_bounds__(256) void fir_table_kernel(const float* __restrict__ sw, const float* __restrict__ sb,
+                                                        const float* __restrict__ bias, float4* __restrict__ fir) {
+    const int c = threadIdx.x;
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        const int n = q * 256 + c;
+        const float w0 = sw[n * 3 + 0], w1 = sw[n * 3 + 1], w2 = sw[n * 3 + 2];
+        fir[c * 3 + q] = make_float4(w0, w1, w2, (float)((double)sb[n] + (double)bias[n] * ((double)w0 + (double)w1 + (double)w2)));
+    }
+}
+void launch_fir_table(const float* short_w, const float* short_b, const float* in_bias, float4* fir, hipStream_t st) {
+    hipLaunchKernelGGL(fir_table_kernel, dim3(1), dim3(256), 0, st, short_w, short_b, in_bias, fir);
+}
+
 // ================================================================================================ out_proj
 template <int PREC>
 __global__ __launch_bounds__(512) void out_proj16_kernel(GemmArgs a) {
@@ -410,8 +606,9 @@ struct ResidHook {
     }
 };
 
-template <int PREC, bool STAMP = false, int NEXT = NEXT_NONE>
+template <int PREC, bool STAMP = false, int NEXT = NEXT_NONE, bool ZG = false>
 __global__ __launch_bounds__(512) void tail16_kernel(TailArgs m, unsigned long long* stamps) {
+    static_assert(!ZG || NEXT == NEXT_INPROJ, "the gated hand-over is a form of the fused in_proj stage");
 #define CLM_STAMP_AT(k)                                                                                   \
     do {                                                                                                  \
         if (STAMP && threadIdx.x == 0)                                                                    \
@@ -429,12 +626,19 @@ __global__ __launch_bounds__(512) void tail16_kernel(TailArgs m, unsigned long l
     // bias table, filled once per workgroup: b1[1024] | b2[256] | b_out[256] | in_proj bias of the next block[768].
     // (Read from global memory each of these loads sat in front of an `s_waitcnt vmcnt(0)`: vmcnt retires in order, so the
     // epilogues waited for every weight set and residual prefetch requested before them.)
+    // ZG: the in_proj bias is folded into the filter constants (n_fir); its 768 floats and the 768 behind them are the stash of the
+    // previous tile's last two raw tokens (ZG_HALO_FLOATS, inproj_blocks_gated)
     float* Bt = P2 + 16 * BM;
-    constexpr int BT_B2 = DI, BT_BOUT = DI + D, BT_NB = DI + 2 * D, BT_SIZE = DI + 2 * D + D3;
+    constexpr int BT_B2 = DI, BT_BOUT = DI + D, BT_NB = DI + 2 * D, BT_SIZE = DI + 2 * D + (ZG ? 0 : D3);
     for (int i = threadIdx.x; i < BT_SIZE; i += 512)
         Bt[i] = i < BT_B2 ? m.b1[i] : i < BT_BOUT ? m.b2[i - BT_B2] : i < BT_NB ? m.b_out[i - BT_BOUT]
                 : (NEXT == NEXT_INPROJ ? m.n_bias[i - BT_NB] : 0.f);
+    // Persistent workgroup over a CONTIGUOUS range of tiles (tail_range_len): consecutive tiles of a read follow each other in
+    // one workgroup, which is what lets the gated in_proj stage carry the short filter's two-token history from tile to tile.
     const int L = m.L, Lp = m.Lp, tiles_x = (m.Lmain + BM - 1) / BM, total = tiles_x * m.B;
+    const int range = tail_range_len(total, (int)gridDim.x), tile_begin = (int)blockIdx.x * range,
+              tile_end = tile_begin + range < total ? tile_begin + range : total;
+    if (tile_begin >= total) return;                        // (whole workgroup, before any barrier)
     const frag* wo = reinterpret_cast<const frag*>(m.w_out);
     const frag* w1 = reinterpret_cast<const frag*>(m.w1);
     const frag* w2 = reinterpret_cast<const frag*>(m.w2);
@@ -442,19 +646,19 @@ __global__ __launch_bounds__(512) void tail16_kernel(TailArgs m, unsigned long l
     f32x16 acc1[4], acc2[4];
     frag bs[2][1][SETK];
 
-    // Persistent workgroup: tiles blockIdx.x, blockIdx.x + gridDim.x, ...  The residual rows of the NEXT tile are requested
+    // The residual rows of the NEXT tile are requested
     // before the in_proj / score stage of the current one, so that 128 KiB of the 192 KiB a tile has to pull from HBM
     // arrive under compute (one workgroup per CU: nothing else would hide them; stamps showed 20 % of a tile's time there).
     // (Starting the workgroups staggered by fractions of a tile, to spread the HBM-heavy phases of the chip over time,
     // was measured too: 2 % slower -- the phases are latency-bound per CU, not a chip-wide bandwidth burst.)
     float4 hv[4][4];                                       // residual in accumulator layout: token mt*32+lrow, 4 features
     uint4 yx[8];                                           // y tile pieces of this thread
-    tail_load_resid(m, hv, blockIdx.x / tiles_x, (blockIdx.x % tiles_x) * BM, (int)threadIdx.x >> 6, (int)threadIdx.x & 31,
+    tail_load_resid(m, hv, tile_begin / tiles_x, (tile_begin % tiles_x) * BM, (int)threadIdx.x >> 6, (int)threadIdx.x & 31,
                     ((int)threadIdx.x >> 5) & 1);
-    tail_load_y_piece<elem>(m, yx, 0, blockIdx.x / tiles_x, (blockIdx.x % tiles_x) * BM, threadIdx.x);
-    tail_load_y_piece<elem>(m, yx, 1, blockIdx.x / tiles_x, (blockIdx.x % tiles_x) * BM, threadIdx.x);
+    tail_load_y_piece<elem>(m, yx, 0, tile_begin / tiles_x, (tile_begin % tiles_x) * BM, threadIdx.x);
+    tail_load_y_piece<elem>(m, yx, 1, tile_begin / tiles_x, (tile_begin % tiles_x) * BM, threadIdx.x);
 #pragma unroll 1
-    for (int tile = blockIdx.x; tile < total; tile += gridDim.x) {
+    for (int tile = tile_begin; tile < tile_end; ++tile) {
     // the thread index is made opaque once per trip: every address below is re-derived inside the trip instead of being
     // hoisted out of the tile loop and kept (that costs ~190 spilled registers)
     int tid_l = threadIdx.x;
@@ -542,8 +746,9 @@ __global__ __launch_bounds__(512) void tail16_kernel(TailArgs m, unsigned long l
         __syncthreads();
         CLM_STAMP_AT(6 + 3 * j);
         // last slot: next fc1 set; on the last trip the first set of what follows (wrap-around keeps the prefetch unconditional)
-        phase_tm<PREC, DI, D, true, true>(Hs, w2, 0, j, (NEXT != NEXT_NONE && j + 1 == NCH) ? wn : w1, j + 1 < NCH ? j + 1 : 0,
-                                          0, wave, lane, bs, acc2);
+        // (ZG: the in_proj stage starts with block ZG_ORDER[0])
+        phase_tm<PREC, DI, D, true, true>(Hs, w2, 0, j, (NEXT != NEXT_NONE && j + 1 == NCH) ? wn : w1,
+                                          j + 1 < NCH ? j + 1 : (ZG ? ZG_ORDER[0] : 0), 0, wave, lane, bs, acc2);
         CLM_STAMP_AT(7 + 3 * j);
     }
     __syncthreads();                                       // As / Hs are dead: reuse them as the staging tiles
@@ -587,7 +792,7 @@ __global__ __launch_bounds__(512) void tail16_kernel(TailArgs m, unsigned long l
     }
     CLM_STAMP_AT(18);
     // residual rows of this workgroup's next tile (clamped to the current one on the last trip: unconditional loads)
-    const int nt = tile + (int)gridDim.x < total ? tile + (int)gridDim.x : tile;
+    const int nt = tile + 1 < tile_end ? tile + 1 : tile;
     const int nb_ = nt / tiles_x, nt0 = (nt % tiles_x) * BM;
     if constexpr (NEXT == NEXT_NONE) {
         tail_load_resid(m, hv, nb_, nt0, wave, lrow, lhalf);
@@ -596,7 +801,7 @@ __global__ __launch_bounds__(512) void tail16_kernel(TailArgs m, unsigned long l
     }
     // ---- 6. what follows, on the tile still in registers
     if constexpr (NEXT != NEXT_NONE) {
-        load_set<PREC, D, 1>(wn, 0, 0, 1, wave, lane, bs[1]);
+        load_set<PREC, D, 1>(wn, ZG ? ZG_ORDER[0] : 0, 0, 1, wave, lane, bs[1]);
         __builtin_amdgcn_sched_barrier(0);
         // (the first barrier inside orders the staging reads above before the As writes)
         ln_acc_to_tile<PREC>(acc2, P1, P2, NEXT == NEXT_SCORE ? m.sp.ln_g : m.n_g, NEXT == NEXT_SCORE ? m.sp.ln_b : m.n_b,
@@ -606,7 +811,17 @@ __global__ __launch_bounds__(512) void tail16_kernel(TailArgs m, unsigned long l
             // bs[1] is re-requested by the block loop (same addresses, L2-resident): keeps the loop identical to in_proj16
             // the 128 KiB of residual rows trickle in as four pieces behind the weight requests of the first four half-blocks
             // (requested in one go before the LayerNorm they stalled every later load of the stage: +9k cycles)
-            constexpr int PIECES = PREC == PREC_F16C ? 0 : 4;
+            // (ZG: none in the hooks in any mode -- x1f occupies the fc2 accumulators while v is computed)
+            constexpr int PIECES = (PREC == PREC_F16C || ZG) ? 0 : 4;
+            if constexpr (ZG) {
+                const int tx = tile % tiles_x;
+                const GatedTile gt{tile == tile_begin || tx == 0, tile == tile_begin && tx != 0,
+                                   tile + 1 == tile_end && tile + 1 < total && (tile + 1) % tiles_x != 0,
+                                   tx == tiles_x - 1 && m.edge_read != nullptr, (int)blockIdx.x};
+                inproj_blocks_gated<PREC>(As, Hs, Bt + BT_NB, wn, m, gt, b, t0, wave, lane, bs, acc1, acc2,
+                                          ResidHook<elem, PIECES>{m, hv, yx, nb_, nt0, wave, lrow, lhalf, tid,
+                                                                  STAMP ? stamps + (size_t)tile * TAIL_NSTAMP : nullptr});
+            } else
             inproj_blocks<PREC>(As, Hs, wn, Bt + BT_NB, m.n_z, b, t0, Lp, wave, lane, bs, acc1,
                                 ResidHook<elem, PIECES>{m, hv, yx, nb_, nt0, wave, lrow, lhalf, tid,
                                                         STAMP ? stamps + (size_t)tile * TAIL_NSTAMP : nullptr});
@@ -704,11 +919,11 @@ void tail16_dump_stamps() {
     // shader clock during the kernel: s_memtime ticks per s_memrealtime tick (constant 100 MHz) between consecutive tiles of
     // one workgroup (tile w and w + grid)
     {
-        int dev = 0, cus = 256;
-        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        const int range = tail_range_len((int)s_stamp_wgs, tail16_grid((int)s_stamp_wgs));
         double dm = 0, dr = 0;
-        for (size_t w = 0; w + cus < s_stamp_wgs; ++w) {
-            const unsigned long long *p = &hst[w * TAIL_NSTAMP], *q = &hst[(w + cus) * TAIL_NSTAMP];
+        for (size_t w = 0; w + 1 < s_stamp_wgs; ++w) {
+            if ((w + 1) % range == 0) continue;             // w + 1 starts another workgroup's range
+            const unsigned long long *p = &hst[w * TAIL_NSTAMP], *q = &hst[(w + 1) * TAIL_NSTAMP];
             if (!p[0] || !q[0] || !p[27] || !q[27]) continue;
             dm += double(q[0] - p[0]);
             dr += double(q[27] - p[27]);
@@ -720,28 +935,43 @@ void tail16_dump_stamps() {
     std::fprintf(stderr, "\n");
 }
 
-template <int PREC, int NEXT>
+template <int PREC, int NEXT, bool ZG = false>
 static void launch_tail_inst(const TailArgs& m, dim3 grid, size_t lds, hipStream_t st) {
-    static bool once = (set_lds(tail16_kernel<PREC, false, NEXT>, lds), true);
+    if (ZG) lds += (size_t)(ZG_HALO_FLOATS - D3) * 4;        // the stash takes the in_proj bias table's place and 3 KiB more
+    static bool once = (set_lds(tail16_kernel<PREC, false, NEXT, ZG>, lds), true);
     (void)once;
-    hipLaunchKernelGGL((tail16_kernel<PREC, false, NEXT>), grid, dim3(512), lds, st, m, (unsigned long long*)nullptr);
+    hipLaunchKernelGGL((tail16_kernel<PREC, false, NEXT, ZG>), grid, dim3(512), lds, st, m, (unsigned long long*)nullptr);
 }
 
-void launch_tail16(int prec, const TailArgs& m, int next, hipStream_t st) {
-    constexpr size_t lds = (size_t)2 * 128 * RS16 * 2 + (size_t)2 * 16 * 128 * 4 + (size_t)(DI + 2 * D + D3) * 4;
-    static_assert(lds <= 160 * 1024, "tail kernel LDS");
-    static_assert((size_t)D * RSKM * 2 <= (size_t)2 * 128 * RS16 * 2, "y tile must fit under the partial tables");
-    static_assert((size_t)8 * 32 * RSOUT * 2 <= (size_t)128 * RS16 * 2 + (size_t)2 * 16 * 128 * 4,
-                  "in_proj staging tiles must fit in the Hs region + the (by then dead) LayerNorm tables");
-    const int total = ((m.Lmain + 127) / 128) * m.B;
+static int tail_cus() {
     static const int cus = [] {
         int dev = 0, n = 256;
         if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
         return n > 0 ? n : 256;
     }();
-    dim3 grid(total < cus ? total : cus), block(512);          // persistent: one workgroup per CU (LDS-limited anyway)
+    return cus;
+}
+int tail16_grid(int total_tiles) { return total_tiles < tail_cus() ? total_tiles : tail_cus(); }
+
+void launch_gated_patch(int prec, const TailArgs& m, hipStream_t st) {
+    const int tiles_x = (m.Lmain + 127) / 128, total = tiles_x * m.B, grid = tail16_grid(total);
+    if (grid < 2) return;
+    const int range = tail_range_len(total, grid);
+    if (prec == PREC_BF16) hipLaunchKernelGGL(gated_patch_kernel<bf16_t>, dim3(grid - 1), dim3(256), 0, st, m, tiles_x, total, range);
+    else hipLaunchKernelGGL(gated_patch_kernel<f16_t>, dim3(grid - 1), dim3(256), 0, st, m, tiles_x, total, range);
+}
+
+void launch_tail16(int prec, const TailArgs& m, int next, hipStream_t st) {
+    constexpr size_t lds = (size_t)2 * 128 * RS16 * 2 + (size_t)2 * 16 * 128 * 4 + (size_t)(DI + 2 * D + D3) * 4;
+    static_assert(lds + (size_t)(ZG_HALO_FLOATS - D3) * 4 <= 160 * 1024, "tail kernel LDS (gated form: + the history stash)");
+    static_assert((size_t)D * RSKM * 2 <= (size_t)2 * 128 * RS16 * 2, "y tile must fit under the partial tables");
+    static_assert((size_t)8 * 32 * RSOUT * 2 <= (size_t)128 * RS16 * 2 + (size_t)2 * 16 * 128 * 4,
+                  "in_proj staging tiles must fit in the Hs region + the (by then dead) LayerNorm tables");
+    const int total = ((m.Lmain + 127) / 128) * m.B;
+    dim3 grid(tail16_grid(total)), block(512);                 // persistent: one workgroup per CU (LDS-limited anyway)
+    const bool zg = m.zg != 0 && next == NEXT_INPROJ;
     static const bool stamp = std::getenv("CLM_STAMP") && std::getenv("CLM_STAMP")[0] == '1';
-    if (stamp && (prec == PREC_F16 || prec == PREC_F16C) && next == NEXT_INPROJ) {
+    if (stamp && prec == PREC_F16C && next == NEXT_INPROJ) {   // developer build: the in_proj variant of the benched mode, stamped
         const size_t wgs = (size_t)total;
         if (wgs > s_stamp_wgs) {
             if (s_stamp_buf) (void)hipFree(s_stamp_buf);
@@ -749,15 +979,22 @@ void launch_tail16(int prec, const TailArgs& m, int next, hipStream_t st) {
             s_stamp_wgs = wgs;
         }
         (void)hipMemsetAsync(s_stamp_buf, 0, wgs * TAIL_NSTAMP * 8, st);
-        if (prec == PREC_F16) {
-            static bool once = (set_lds(tail16_kernel<PREC_F16, true, NEXT_INPROJ>, lds), true);
+        if (zg) {
+            constexpr size_t ldz = lds + (size_t)(ZG_HALO_FLOATS - D3) * 4;
+            static bool once = (set_lds(tail16_kernel<PREC_F16C, true, NEXT_INPROJ, true>, ldz), true);
             (void)once;
-            hipLaunchKernelGGL((tail16_kernel<PREC_F16, true, NEXT_INPROJ>), grid, block, lds, st, m, s_stamp_buf);
+            hipLaunchKernelGGL((tail16_kernel<PREC_F16C, true, NEXT_INPROJ, true>), grid, block, ldz, st, m, s_stamp_buf);
         } else {
             static bool once = (set_lds(tail16_kernel<PREC_F16C, true, NEXT_INPROJ>, lds), true);
             (void)once;
             hipLaunchKernelGGL((tail16_kernel<PREC_F16C, true, NEXT_INPROJ>), grid, block, lds, st, m, s_stamp_buf);
         }
+        return;
+    }
+    if (zg) {
+        if (prec == PREC_BF16) launch_tail_inst<PREC_BF16, NEXT_INPROJ, true>(m, grid, lds, st);
+        else if (prec == PREC_F16C) launch_tail_inst<PREC_F16C, NEXT_INPROJ, true>(m, grid, lds, st);
+        else launch_tail_inst<PREC_F16, NEXT_INPROJ, true>(m, grid, lds, st);
         return;
     }
     if (prec == PREC_BF16) {

@@ -184,6 +184,19 @@ __device__ __forceinline__ void load8<f16_t>(const f16_t* p, float* o) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) o[i] = (float)h[i];
 }
+// 8 x 16-bit -> fp32
+template <typename T>
+__device__ __forceinline__ void cvt8(const uint4 d, float* o) {
+    const unsigned w[4] = {d.x, d.y, d.z, d.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        T lo, hi;
+        lo.bits = (unsigned short)(w[i] & 0xffffu);
+        hi.bits = (unsigned short)(w[i] >> 16);
+        o[2 * i] = to_float(lo);
+        o[2 * i + 1] = to_float(hi);
+    }
+}
 template <typename T>
 __device__ __forceinline__ void store8(T* p, const float* v);
 template <>
@@ -366,7 +379,8 @@ constexpr int CONV_NSTAMP = 16;
 // IDS: first block only.  The residual stream entering block 0 is the embedding row of the token id, so the block's
 // in_proj output is one of 16 precomputed rows (ztab, fp32): the kernel reads the ids (1 byte per token, shared by all 256
 // channel workgroups of a read) and looks x0 / x1 / v up instead of reading z -- in_proj of block 0 is never launched.
-template <int LOGN, typename T, bool STAMP = false, bool IDS = false>
+// GATED: z holds x0f (row c) and g = x1f * vf (row 256 + c), filtered and gated by the producer (see hyena_conv_pers_kernel).
+template <int LOGN, typename T, bool STAMP = false, bool IDS = false, bool GATED = false>
 __global__ __launch_bounds__(Plan<LOGN>::NT) void hyena_conv_kernel(
     const T* __restrict__ z, T* __restrict__ y, const float2* __restrict__ kf, const float2* __restrict__ tw,
     const float* __restrict__ ktime, const float* __restrict__ short_w, const float* __restrict__ short_b, int B, int L,
@@ -427,6 +441,49 @@ __global__ __launch_bounds__(Plan<LOGN>::NT) void hyena_conv_kernel(
     // every global load of the phase is issued before the first use (see Raw<T>)
     constexpr int TAIL_TID = HALF / 8 - 1 - (CH - 1) * NT;   // owner of tokens [HALF-8, HALF): also computes token HALF
     const bool tail = (L == HALF + 1);
+    static_assert(!(GATED && (IDS || std::is_same<T, float>::value)), "the gated hand-over exists in the fused 16-bit path only");
+    float x0A[CH][8], x0B[CH][8];
+    float x0At = 0.f, gAt = 0.f, x0Bt = 0.f, gBt = 0.f;
+    if constexpr (GATED) {
+        uint4 gr[CH][2][2];                                  // [chunk][read][x0f, g]
+        T gtl[2][2];
+#pragma unroll
+        for (int rd = 0; rd < 2; ++rd)
+#pragma unroll
+            for (int a2 = 0; a2 < 2; ++a2) {
+                const T* row = (rd == 0 ? zA : zB) + (size_t)(a2 * D + c) * Lp;
+#pragma unroll
+                for (int ch = 0; ch < CH; ++ch) {
+                    const int t0 = 8 * (tid + ch * NT);
+                    gr[ch][rd][a2] = *reinterpret_cast<const uint4*>(row + ((t0 < HALF && t0 < L) ? t0 : 0));
+                }
+                gtl[rd][a2] = row[(tail && tid == TAIL_TID) ? HALF : 0];
+            }
+#pragma unroll
+        for (int ch = 0; ch < CH; ++ch) {
+            const int t0 = 8 * (tid + ch * NT);
+            if (t0 < HALF) {
+                float gA[8], gB[8];
+                cvt8<T>(gr[ch][0][0], x0A[ch]);
+                cvt8<T>(gr[ch][1][0], x0B[ch]);
+                cvt8<T>(gr[ch][0][1], gA);
+                cvt8<T>(gr[ch][1][1], gB);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    gA[e] = (t0 + e < L) ? gA[e] : 0.f;
+                    gB[e] = (hasB && t0 + e < L) ? gB[e] : 0.f;
+                }
+                lds_store8(bre + pad_index(t0), gA);
+                lds_store8(bim + pad_index(t0), gB);
+            }
+        }
+        if (tail && tid == TAIL_TID) {
+            x0At = to_float(gtl[0][0]);
+            gAt = to_float(gtl[0][1]);
+            x0Bt = to_float(gtl[1][0]);
+            gBt = hasB ? to_float(gtl[1][1]) : 0.f;
+        }
+    } else {
     Raw<T> raw[IDS ? 1 : CH][2][IDS ? 1 : 3];
     T ztail[2][3];
     uint2 idd[CH][2];                                        // IDS: 8 token ids of the chunk
@@ -464,8 +521,6 @@ __global__ __launch_bounds__(Plan<LOGN>::NT) void hyena_conv_kernel(
             }
         }
     }
-    float x0A[CH][8], x0B[CH][8];
-    float x0At = 0.f, gAt = 0.f, x0Bt = 0.f, gBt = 0.f;
 #pragma unroll
     for (int ch = 0; ch < CH; ++ch) {
         const int t0 = 8 * (tid + ch * NT);
@@ -508,6 +563,7 @@ __global__ __launch_bounds__(Plan<LOGN>::NT) void hyena_conv_kernel(
                 gBt = hasB ? tb[1] * tb[2] : 0.f;
             }
         }
+    }
     }
     CLM_STAMP_AT(13);
     // (the upper half of the transform input is zero padding: it is neither written nor read -- pass_first_lower)
@@ -623,16 +679,20 @@ __global__ __launch_bounds__(Plan<LOGN>::NT) void hyena_conv_kernel(
 //     last pass, phase C and the next phase A -- where the transform's 64 data registers are dead);
 //   * the pass twiddles are loaded once per workgroup instead of once per unit.
 // Units are taken round-robin by gridDim.x = #CUs workgroups; LOGN = 14 (reads of 4098 .. 8193 tokens) only.
-template <typename T, bool IDS>
+// GATED (the fused tail kernel's hand-over, gemm16.hip inproj_blocks_gated): z row c holds x0f, row 256 + c holds g = x1f * vf --
+// already filtered and gated by the producer -- so phase A is a load + convert of ONE row and phase C a multiply with one row.
+template <typename T, bool IDS, bool GATED = false>
 struct ConvGateRaw {                                   // x1 / v rows of one unit, both reads (IDS: the token ids instead)
-    Raw<T> r[2][2][2];                                 // [chunk][read][x1, v]
+    Raw<T> r[GATED ? 1 : 2][2][GATED ? 1 : 2];         // [chunk][read][x1, v]
     T ztail[2][2];
     uint2 idd[2][2];
     unsigned short idp[2][2];
     unsigned char idt[2];
+    uint4 g[2][2];                                     // GATED: 8 samples of g per [chunk][read]
+    T gtail[2];
 };
 
-template <typename T, bool IDS>
+template <typename T, bool IDS, bool GATED = false>
 __global__ __launch_bounds__(Plan<14>::NT) void hyena_conv_pers_kernel(
     const T* __restrict__ z, T* __restrict__ y, const float2* __restrict__ kf /*lane-packed*/, const float2* __restrict__ tw,
     const float* __restrict__ ktime, const float* __restrict__ short_w, const float* __restrict__ short_b, int B, int L,
@@ -680,12 +740,24 @@ __global__ __launch_bounds__(Plan<14>::NT) void hyena_conv_pers_kernel(
             ns *= 16;
         }
     }
+    static_assert(!(GATED && IDS), "block 0 looks its rows up by token id: nothing to hand over");
     // requests of the gate rows (x1, v) of unit u: no control flow between the loads (all in flight together)
-    auto request_gate = [&](int q, ConvGateRaw<T, IDS>& g, int ltid) {
+    auto request_gate = [&](int q, ConvGateRaw<T, IDS, GATED>& g, int ltid) {
         int c, pair;
         unit_of(q, c, pair);
         const int bA = 2 * pair, bB = (2 * pair + 1 < B) ? 2 * pair + 1 : bA;
-        if constexpr (IDS) {
+        if constexpr (GATED) {
+#pragma unroll
+            for (int rd = 0; rd < 2; ++rd) {
+                const T* row = z + ((size_t)(rd == 0 ? bA : bB) * D3 + D + c) * Lp;
+#pragma unroll
+                for (int ch = 0; ch < CH; ++ch) {
+                    const int t0 = 8 * (ltid + ch * NT);
+                    g.g[ch][rd] = *reinterpret_cast<const uint4*>(row + (t0 < L ? t0 : 0));      // clamped, never out of the row
+                }
+                g.gtail[rd] = row[(tail && ltid == TAIL_TID) ? HALF : 0];
+            }
+        } else if constexpr (IDS) {
 #pragma unroll
             for (int rd = 0; rd < 2; ++rd) {
                 const unsigned char* ir = ids8 + (size_t)(rd == 0 ? bA : bB) * Lp;
@@ -716,7 +788,7 @@ __global__ __launch_bounds__(Plan<14>::NT) void hyena_conv_pers_kernel(
         }
     };
 
-    ConvGateRaw<T, IDS> cur;
+    ConvGateRaw<T, IDS, GATED> cur;
     request_gate(first < n_mine ? first : 0, cur, tid);
 
 #pragma unroll 1
@@ -751,6 +823,28 @@ __global__ __launch_bounds__(Plan<14>::NT) void hyena_conv_pers_kernel(
         auto phase_a = [&](auto fullc) {
             constexpr bool FULL = decltype(fullc)::value;
             float gAt = 0.f, gBt = 0.f;
+            if constexpr (GATED) {
+#pragma unroll
+                for (int ch = 0; ch < CH; ++ch) {
+                    const int t0 = 8 * (ltid + ch * NT);
+                    float gA[8], gB[8];
+                    cvt8<T>(cur.g[ch][0], gA);
+                    cvt8<T>(cur.g[ch][1], gB);
+                    if constexpr (!FULL) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            gA[e] = t0 + e < L ? gA[e] : 0.f;
+                            gB[e] = (hasB && t0 + e < L) ? gB[e] : 0.f;
+                        }
+                    }
+                    lds_store8(bre + pad_index(t0), gA);
+                    lds_store8(bim + pad_index(t0), gB);
+                }
+                if (tail && ltid == TAIL_TID) {
+                    gtail[0] = to_float(cur.gtail[0]);
+                    gtail[1] = hasB ? to_float(cur.gtail[1]) : 0.f;
+                }
+            } else {
 #pragma unroll
             for (int ch = 0; ch < CH; ++ch) {
                 const int t0 = 8 * (ltid + ch * NT);
@@ -792,6 +886,7 @@ __global__ __launch_bounds__(Plan<14>::NT) void hyena_conv_pers_kernel(
             if (tail && ltid == TAIL_TID) {
                 gtail[0] = gAt;
                 gtail[1] = gBt;
+            }
             }
         };
         if (full_unit) phase_a(std::true_type{});
@@ -847,7 +942,18 @@ __global__ __launch_bounds__(Plan<14>::NT) void hyena_conv_pers_kernel(
         T x0tail[2];
         const T* zA = z + (size_t)bA * D3 * Lp;
         const T* zB = z + (size_t)(hasB ? bB : bA) * D3 * Lp;
-        if constexpr (!IDS) {
+        if constexpr (GATED) {                           // (x0f: no history needed -- only the 16-byte vector of Raw<T> is used)
+#pragma unroll
+            for (int rd = 0; rd < 2; ++rd) {
+                const T* row = (rd == 0 ? zA : zB) + (size_t)c * Lp;
+#pragma unroll
+                for (int ch = 0; ch < CH; ++ch) {
+                    const int t0 = 8 * (ltid + ch * NT);
+                    x0r[ch][rd].d = *reinterpret_cast<const uint4*>(row + (t0 < L ? t0 : 0));
+                }
+                x0tail[rd] = row[(tail && ltid == TAIL_TID) ? HALF : 0];
+            }
+        } else if constexpr (!IDS) {
 #pragma unroll
             for (int rd = 0; rd < 2; ++rd) {
                 const T* row = (rd == 0 ? zA : zB) + (size_t)c * Lp;
@@ -859,7 +965,7 @@ __global__ __launch_bounds__(Plan<14>::NT) void hyena_conv_pers_kernel(
                 x0tail[rd] = row[(tail && ltid == TAIL_TID) ? HALF : 0];
             }
         }
-        ConvGateRaw<T, IDS> nxt;
+        ConvGateRaw<T, IDS, GATED> nxt;
         {
             const int un = u + stride;
             request_gate(un < n_mine ? un : u, nxt, ltid);       // clamped: unconditional loads
@@ -879,8 +985,11 @@ __global__ __launch_bounds__(Plan<14>::NT) void hyena_conv_pers_kernel(
             for (int ch = 0; ch < CH; ++ch) {
                 const int t0 = 8 * (ltid + ch * NT);
                 const bool valid = FULL ? true : t0 < L, validB = FULL ? true : (valid && hasB);
-                float xa[10], xb[10], x0a[8], x0b[8];
-                if constexpr (IDS) {
+                float xa[10] = {}, xb[10] = {}, x0a[8], x0b[8];
+                if constexpr (GATED) {
+                    cvt8<T>(x0r[ch][0].d, x0a);
+                    cvt8<T>(x0r[ch][1].d, x0b);
+                } else if constexpr (IDS) {
                     float xa3[3][10], xb3[3][10];
                     // opaque copies: otherwise the 40 extracted ids (common subexpressions with phase A) are kept across the
                     // transform -- in scratch
@@ -895,7 +1004,7 @@ __global__ __launch_bounds__(Plan<14>::NT) void hyena_conv_pers_kernel(
                     raw_decode(x0r[ch][0], t0, valid, xa);
                     raw_decode(x0r[ch][1], t0, validB, xb);
                 }
-                fir3_pair(xa, xb, sw[0][0], sw[0][1], sw[0][2], sb[0], x0a, x0b);
+                if constexpr (!GATED) fir3_pair(xa, xb, sw[0][0], sw[0][1], sw[0][2], sb[0], x0a, x0b);
                 if (t0 < Lp) {
                     float oA[8], oB[8];
                     lds_load8(bre + pad_index(t0), oA);
@@ -917,8 +1026,8 @@ __global__ __launch_bounds__(Plan<14>::NT) void hyena_conv_pers_kernel(
                 if (ch == CH - 1 && tail && ltid == TAIL_TID) {     // token HALF: x0 from x[8], x[9] of this chunk and z[HALF]
                     const float za = IDS ? zt[cur.idt[0] & 15] : to_float(x0tail[0]);
                     const float zb = IDS ? zt[cur.idt[1] & 15] : to_float(x0tail[1]);
-                    const float x0At = sb[0] + sw[0][0] * xa[8] + sw[0][1] * xa[9] + sw[0][2] * za;
-                    const float x0Bt = sb[0] + sw[0][0] * xb[8] + sw[0][1] * xb[9] + sw[0][2] * zb;
+                    const float x0At = GATED ? za : sb[0] + sw[0][0] * xa[8] + sw[0][1] * xa[9] + sw[0][2] * za;
+                    const float x0Bt = GATED ? zb : sb[0] + sw[0][0] * xb[8] + sw[0][1] * xb[9] + sw[0][2] * zb;
                     yA[HALF] = from_float<T>(bre[pad_index(HALF)] * x0At);
                     if (hasB) yB[HALF] = from_float<T>(bim[pad_index(HALF)] * x0Bt);
                 }
@@ -931,13 +1040,13 @@ __global__ __launch_bounds__(Plan<14>::NT) void hyena_conv_pers_kernel(
     }
 }
 
-template <typename T, bool IDS>
+template <typename T, bool IDS, bool GATED = false>
 static void launch_conv_pers_inst(const void* z, void* y, const float2* kf, const float2* tw, const float* ktime,
                                   const float* short_w, const float* short_b, int B, int L, int Lp, const unsigned char* ids8,
                                   const float* ztab, int use_xcd, hipStream_t st) {
     using P = Plan<14>;
     constexpr size_t lds = (size_t)2 * padded_size(P::N) * sizeof(float) + 256;
-    auto kern = hyena_conv_pers_kernel<T, IDS>;
+    auto kern = hyena_conv_pers_kernel<T, IDS, GATED>;
     static bool attr_done = false;
     if (!attr_done) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -1266,7 +1375,8 @@ void launch_spectrum_lanepack(const float2* src, float2* dst, int KS, int j, hip
 // sums ride along with phase A of every segment -- instead of a whole transform pipeline for a single token (S+1 segments:
 // +25 % of the kernel at 32769 tokens, +50 % at 16385).
 // IDS (16-bit modes, block 0): x0 | x1 | v looked up in ztab by token id, as in hyena_conv_kernel.
-template <typename T, bool LONE, bool IDS>
+// GATED: z holds x0f / g, filtered and gated by the producer (see hyena_conv_pers_kernel).
+template <typename T, bool LONE, bool IDS, bool GATED = false>
 __global__ __launch_bounds__(Plan<14>::NT) void hyena_conv_seg_kernel(
     const T* __restrict__ z, T* __restrict__ y, const float2* __restrict__ kf /*[256][KS][N] lane-packed (launch_spectrum_lanepack), KS >= S partitions stored*/,
     int KS, const float2* __restrict__ tw, const float* __restrict__ short_w, const float* __restrict__ short_b,
@@ -1333,7 +1443,33 @@ __global__ __launch_bounds__(Plan<14>::NT) void hyena_conv_seg_kernel(
         //  here, its 32 registers were the bulk of 80-135 spilled registers per thread, i.e. scratch traffic per segment)
         uint2 idd[CH][2];                                    // IDS: 8 token ids of the chunk
         unsigned short idp[CH][2];                           //      and the two before it
-        if constexpr (!std::is_same<T, float>::value) {
+        static_assert(!(GATED && (IDS || std::is_same<T, float>::value)), "the gated hand-over exists in the fused 16-bit path only");
+        if constexpr (GATED) {
+            uint4 gr[CH][2];
+#pragma unroll
+            for (int rd = 0; rd < 2; ++rd) {
+                const T* row = (rd == 0 ? zA : zB) + (size_t)(D + c) * Lp;
+#pragma unroll
+                for (int ch = 0; ch < CH; ++ch) {
+                    const int t0 = seg0 + 8 * (ltid + ch * NT);
+                    gr[ch][rd] = *reinterpret_cast<const uint4*>(row + (t0 < L ? t0 : 0));
+                }
+            }
+#pragma unroll
+            for (int ch = 0; ch < CH; ++ch) {
+                const int tl = 8 * (ltid + ch * NT), t0 = seg0 + tl;
+                float gA[8], gB[8];
+                cvt8<T>(gr[ch][0], gA);
+                cvt8<T>(gr[ch][1], gB);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    gA[e] = (t0 + e < L) ? gA[e] : 0.f;
+                    gB[e] = (hasB && t0 + e < L) ? gB[e] : 0.f;
+                }
+                lds_store8(bre + pad_index(tl), gA);
+                lds_store8(bim + pad_index(tl), gB);
+            }
+        } else if constexpr (!std::is_same<T, float>::value) {
             // all loads of the segment up front, no control flow in between (see Raw<T>): four serialized HBM round trips otherwise
             Raw<T> raw[IDS ? 1 : CH][2][IDS ? 1 : 3];
             if constexpr (IDS) {
@@ -1553,7 +1689,17 @@ __global__ __launch_bounds__(Plan<14>::NT) void hyena_conv_seg_kernel(
 #pragma unroll
             for (int p = 1; p <= P::NPASS - 1; ++p) {
                 if (p == P::NPASS - 1) {   // x0 rows of this segment: the last pass to land
-                    if constexpr (!IDS && !std::is_same<T, float>::value) {
+                    if constexpr (GATED) {
+#pragma unroll
+                        for (int rd = 0; rd < 2; ++rd) {
+                            const T* row = (rd == 0 ? zA : zB) + (size_t)c * Lp;
+#pragma unroll
+                            for (int ch = 0; ch < CH; ++ch) {
+                                const int t0 = seg0 + 8 * (ltid + ch * NT);
+                                x0r[ch][rd].d = *reinterpret_cast<const uint4*>(row + (t0 < L ? t0 : 0));
+                            }
+                        }
+                    } else if constexpr (!IDS && !std::is_same<T, float>::value) {
 #pragma unroll
                         for (int rd = 0; rd < 2; ++rd) {
                             const T* row = (rd == 0 ? zA : zB) + (size_t)c * Lp;
@@ -1585,7 +1731,10 @@ __global__ __launch_bounds__(Plan<14>::NT) void hyena_conv_seg_kernel(
             const int tl = 8 * (ltid + ch * NT), t0 = seg0 + tl;
             const bool valid = t0 < L;
             float x0A[8], x0B[8];
-            if constexpr (std::is_same<T, float>::value) {
+            if constexpr (GATED) {
+                cvt8<T>(x0r[ch][0].d, x0A);
+                cvt8<T>(x0r[ch][1].d, x0B);
+            } else if constexpr (std::is_same<T, float>::value) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) x0A[e] = 0.f, x0B[e] = 0.f;
                 if (valid) {
@@ -1642,7 +1791,9 @@ __global__ __launch_bounds__(Plan<14>::NT) void hyena_conv_seg_kernel(
             const float k0 = kr[t];                          // tap 0 (+ skip term)
             // short filter of the one token t (t >= 2 here) on row a3 of read rd: from z, or from the id table
             auto filt = [&](int rd, int a3) {
-                if constexpr (IDS) {
+                if constexpr (GATED) {        // a3 = 0: x0f; a3 = 1: g (called as filt(., 2) * filt(., 1): the v slot counts as 1)
+                    return a3 == 2 ? 1.0f : to_float(((rd == 0 ? zA : zB) + (size_t)(a3 * D + c) * Lp)[t]);
+                } else if constexpr (IDS) {
                     const unsigned char* ir = rd == 0 ? irA : irB;
                     const float* r = zt + a3 * 16;
                     return sb[a3] + sw[a3][0] * r[ir[t - 2] & 15] + sw[a3][1] * r[ir[t - 1] & 15] + sw[a3][2] * r[ir[t] & 15];
@@ -1661,14 +1812,14 @@ __global__ __launch_bounds__(Plan<14>::NT) void hyena_conv_seg_kernel(
     }
 }
 
-template <typename T, bool LONE, bool IDS>
+template <typename T, bool LONE, bool IDS, bool GATED = false>
 static void launch_conv_seg_inst(const void* z, void* y, const float2* kf, int KS, const float2* tw, const float* short_w,
                               const float* short_b, float2* gscratch, int B, int L, int Lp, int S,
                               const float* krev, int krev_stride, const unsigned char* ids8, const float* ztab,
                               int use_xcd, hipStream_t st) {
     using P = Plan<14>;
     constexpr size_t lds = (size_t)2 * padded_size(P::N) * sizeof(float) + 256;   // + the 3x16 id table
-    auto kern = hyena_conv_seg_kernel<T, LONE, IDS>;
+    auto kern = hyena_conv_seg_kernel<T, LONE, IDS, GATED>;
     static bool attr_done = false;
     if (!attr_done) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1683,7 +1834,8 @@ static void launch_conv_seg_inst(const void* z, void* y, const float2* kf, int K
 template <typename T>
 static void launch_conv_seg_t(const void* z, void* y, const float2* kf, int KS, const float2* tw, const float* short_w,
                               const float* short_b, float2* gscratch, int B, int L, int Lp, int S, const float* krev,
-                              int krev_stride, const unsigned char* ids8, const float* ztab, int use_xcd, hipStream_t st) {
+                              int krev_stride, const unsigned char* ids8, const float* ztab, int use_xcd, hipStream_t st,
+                              bool gated) {
 #define CLM_SEG(LONE, IDS)                                                                                               \
     launch_conv_seg_inst<T, LONE, IDS>(z, y, kf, KS, tw, short_w, short_b, gscratch, B, L, Lp, S, krev, krev_stride, ids8, ztab, use_xcd, st)
     if constexpr (std::is_same<T, float>::value) {           // fp32 mode never takes the id path
@@ -1691,6 +1843,11 @@ static void launch_conv_seg_t(const void* z, void* y, const float2* kf, int KS, 
         else CLM_SEG(false, false);
     } else {
         const bool ids = ids8 != nullptr && ztab != nullptr;
+        if (gated && !ids) {
+            if (krev) launch_conv_seg_inst<T, true, false, true>(z, y, kf, KS, tw, short_w, short_b, gscratch, B, L, Lp, S, krev, krev_stride, nullptr, nullptr, use_xcd, st);
+            else launch_conv_seg_inst<T, false, false, true>(z, y, kf, KS, tw, short_w, short_b, gscratch, B, L, Lp, S, krev, krev_stride, nullptr, nullptr, use_xcd, st);
+            return;
+        }
         if (krev && ids) CLM_SEG(true, true);
         else if (krev) CLM_SEG(true, false);
         else if (ids) CLM_SEG(false, true);
@@ -1703,12 +1860,13 @@ void launch_hyena_conv_seg(int prec, const void* z, void* y, const float2* kf, i
                            const float* short_b, float2* gscratch, int B, int L, int Lp, int S, const float* krev,
                            int krev_stride, const unsigned char* ids8, const float* ztab, hipStream_t st, int flags) {
     const int use_xcd = !(flags & CONV_NO_XCD);
+    const bool gated = (flags & CONV_GATED) != 0;
     if (prec == PREC_F32)
-        launch_conv_seg_t<float>(z, y, kf, KS, tw, short_w, short_b, gscratch, B, L, Lp, S, krev, krev_stride, nullptr, nullptr, use_xcd, st);
+        launch_conv_seg_t<float>(z, y, kf, KS, tw, short_w, short_b, gscratch, B, L, Lp, S, krev, krev_stride, nullptr, nullptr, use_xcd, st, false);
     else if (prec == PREC_BF16)
-        launch_conv_seg_t<bf16_t>(z, y, kf, KS, tw, short_w, short_b, gscratch, B, L, Lp, S, krev, krev_stride, ids8, ztab, use_xcd, st);
+        launch_conv_seg_t<bf16_t>(z, y, kf, KS, tw, short_w, short_b, gscratch, B, L, Lp, S, krev, krev_stride, ids8, ztab, use_xcd, st, gated);
     else
-        launch_conv_seg_t<f16_t>(z, y, kf, KS, tw, short_w, short_b, gscratch, B, L, Lp, S, krev, krev_stride, ids8, ztab, use_xcd, st);
+        launch_conv_seg_t<f16_t>(z, y, kf, KS, tw, short_w, short_b, gscratch, B, L, Lp, S, krev, krev_stride, ids8, ztab, use_xcd, st, gated);
 }
 
 // ztab[id][n] = in_proj(LN1(embedding[id]))[n] of block 0, fp32: one workgroup per token id
@@ -1790,11 +1948,23 @@ void conv_dump_stamps() {
 template <int LOGN, typename T>
 static void launch_conv_t(const void* z, void* y, const float2* kf, const float2* tw, const float* ktime,
                           const float* short_w, const float* short_b, int B, int L, int Lp, const unsigned char* ids8,
-                          const float* ztab, hipStream_t st) {
+                          const float* ztab, hipStream_t st, bool gated) {
     using P = Plan<LOGN>;
     constexpr size_t lds = (size_t)2 * padded_size(P::N) * sizeof(float) + 256;   // + g[N/2] pair + the 3x16 id table
     dim3 grid((B + 1) / 2, D), block(P::NT);
     if constexpr (!std::is_same<T, float>::value) {
+        if (gated && !ids8) {
+            auto kern = hyena_conv_kernel<LOGN, T, false, false, true>;
+            static bool g_attr_done = false;
+            if (!g_attr_done) {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                g_attr_done = true;
+            }
+            hipLaunchKernelGGL(kern, grid, block, lds, st, reinterpret_cast<const T*>(z), reinterpret_cast<T*>(y), kf, tw, ktime,
+                               short_w, short_b, B, L, Lp, (unsigned long long*)nullptr, (const unsigned char*)nullptr,
+                               (const float*)nullptr);
+            return;
+        }
         if (ids8) {
             auto kern = hyena_conv_kernel<LOGN, T, false, true>;
             static bool ids_attr_done = false;
@@ -1840,13 +2010,13 @@ static void launch_conv_t(const void* z, void* y, const float2* kf, const float2
 template <int LOGN>
 static void launch_conv_p(int prec, const void* z, void* y, const float2* kf, const float2* tw, const float* ktime,
                           const float* short_w, const float* short_b, int B, int L, int Lp, const unsigned char* ids8,
-                          const float* ztab, hipStream_t st) {
+                          const float* ztab, hipStream_t st, bool gated) {
     if (prec == PREC_F32)
-        launch_conv_t<LOGN, float>(z, y, kf, tw, ktime, short_w, short_b, B, L, Lp, nullptr, nullptr, st);
+        launch_conv_t<LOGN, float>(z, y, kf, tw, ktime, short_w, short_b, B, L, Lp, nullptr, nullptr, st, false);
     else if (prec == PREC_BF16)
-        launch_conv_t<LOGN, bf16_t>(z, y, kf, tw, ktime, short_w, short_b, B, L, Lp, ids8, ztab, st);
+        launch_conv_t<LOGN, bf16_t>(z, y, kf, tw, ktime, short_w, short_b, B, L, Lp, ids8, ztab, st, gated);
     else
-        launch_conv_t<LOGN, f16_t>(z, y, kf, tw, ktime, short_w, short_b, B, L, Lp, ids8, ztab, st);
+        launch_conv_t<LOGN, f16_t>(z, y, kf, tw, ktime, short_w, short_b, B, L, Lp, ids8, ztab, st, gated);
 }
 
 void launch_hyena_conv(int prec, const void* z, void* y, const float2* kf, const float2* tw, const float* ktime,
@@ -1855,21 +2025,24 @@ void launch_hyena_conv(int prec, const void* z, void* y, const float2* kf, const
     // 16384-point class, 16-bit activations: persistent workgroups with next-unit requests (CONV_ONESHOT: one workgroup per
     // unit -- A/B runs; the developer stamps live in that kernel only)
     static const bool stamp = std::getenv("CLM_STAMP") && std::getenv("CLM_STAMP")[0] == '1';
-    if (logn == 14 && prec != PREC_F32 && !(flags & CONV_ONESHOT) && !stamp && kf_packed) {
+    const bool ids = ids8 != nullptr && ztab != nullptr;
+    const bool gated = (flags & CONV_GATED) != 0 && !ids;
+    if (logn == 14 && prec != PREC_F32 && !(flags & CONV_ONESHOT) && !(stamp && !gated) && kf_packed) {
         kf = kf_packed;
-        const bool ids = ids8 != nullptr && ztab != nullptr;
         const int xcd = !(flags & CONV_NO_XCD);
         if (prec == PREC_BF16) {
             if (ids) launch_conv_pers_inst<bf16_t, true>(nullptr, y, kf, tw, ktime, short_w, short_b, B, L, Lp, ids8, ztab, xcd, st);
+            else if (gated) launch_conv_pers_inst<bf16_t, false, true>(z, y, kf, tw, ktime, short_w, short_b, B, L, Lp, nullptr, nullptr, xcd, st);
             else launch_conv_pers_inst<bf16_t, false>(z, y, kf, tw, ktime, short_w, short_b, B, L, Lp, nullptr, nullptr, xcd, st);
         } else {
             if (ids) launch_conv_pers_inst<f16_t, true>(nullptr, y, kf, tw, ktime, short_w, short_b, B, L, Lp, ids8, ztab, xcd, st);
+            else if (gated) launch_conv_pers_inst<f16_t, false, true>(z, y, kf, tw, ktime, short_w, short_b, B, L, Lp, nullptr, nullptr, xcd, st);
             else launch_conv_pers_inst<f16_t, false>(z, y, kf, tw, ktime, short_w, short_b, B, L, Lp, nullptr, nullptr, xcd, st);
         }
         return;
     }
 #define CLM_CONV_CASE(n) \
-    case n: launch_conv_p<n>(prec, z, y, kf, tw, ktime, short_w, short_b, B, L, Lp, ids8, ztab, st); break;
+    case n: launch_conv_p<n>(prec, z, y, kf, tw, ktime, short_w, short_b, B, L, Lp, ids8, ztab, st, gated); break;
     switch (logn) {
         CLM_CONV_CASE(8)
         CLM_CONV_CASE(9)

@@ -71,7 +71,7 @@ __device__ __forceinline__ float4 layer_norm_quad(const float* src, const float*
 // (64 rows each): a workgroup's L2 -> CU bandwidth is what bounds a matrix-vector product (one workgroup per read doing the whole
 // chain measured 65 us per launch -- more than the 75 us the peeled tile saves at 32 reads; split over 4-16 workgroups per
 // stage the chain takes ~25 us incl. launch gaps).  Vectors between stages live in a small fp32 scratch (ws: r | u | h' per read).
-enum { LS_OUT = 0, LS_FC1 = 1, LS_FC2 = 2, LS_NEXT = 3, LS_ATT = 4, LS_SCORE = 5 };
+enum { LS_OUT = 0, LS_FC1 = 1, LS_FC2 = 2, LS_NEXT = 3, LS_ATT = 4, LS_SCORE = 5, LS_NEXT_GATED = 6 };
 constexpr int LT_ROWS = 64;                                       // rows per workgroup: 8 waves x 8 rows (fc2: two trips of 4)
 constexpr int WS_R = 0, WS_U = D, WS_H = D + DI, WS_STRIDE = D + DI + D;
 
@@ -105,6 +105,27 @@ __global__ __launch_bounds__(LT_THREADS) void lone_stage_kernel(LoneTokenArgs a)
         matvec<1, 0>(a.n_w + (size_t)n0 * D, a.n_bias + n0, x, LT_ROWS, nullptr, vin, wave, lane);
         __syncthreads();
         if (tid < LT_ROWS) reinterpret_cast<T*>(a.n_z)[((size_t)b * D3 + n0 + tid) * a.Lp + t] = from_float<T>(vin[tid]);
+    } else if constexpr (STAGE == LS_NEXT_GATED) {   // the gated hand-over (gemm16.hip inproj_blocks_gated) at this token: channels
+        // n0 .. n0 + 63, rows x0 | x1 | v raw (no bias), the short filter's history = the raw rows of tokens t - 2, t - 1 the last
+        // tile of the read left in edge_read; x0f -> row c, g = x1f * vf -> row 256 + c
+        const float4 x[1] = {layer_norm_quad(ws + WS_H, a.n_g, a.n_b, a.eps, lane)};
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+            matvec<1, 0>(a.n_w + (size_t)(q * D + n0) * D, nullptr, x, LT_ROWS, nullptr, vin + q * LT_ROWS, wave, lane);
+        __syncthreads();
+        if (tid < LT_ROWS) {
+            const int c = n0 + tid;
+            float zf[3];
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                const float4 f = a.n_fir[c * 3 + q];
+                const float2 hist = a.edge_read[(size_t)b * D3 + q * D + c];
+                zf[q] = fmaf(f.z, vin[q * LT_ROWS + tid], fmaf(f.y, hist.y, fmaf(f.x, hist.x, f.w)));
+            }
+            T* z = reinterpret_cast<T*>(a.n_z) + (size_t)b * D3 * a.Lp + t;
+            z[(size_t)c * a.Lp] = from_float<T>(zf[0]);
+            z[(size_t)(D + c) * a.Lp] = from_float<T>(zf[1] * zf[2]);
+        }
     } else if constexpr (STAGE == LS_ATT) {     // ln_f; attention.0 + GELU(erf) -> ws.u[0..255]; ln_f row = this token's pooling vector
         const float4 x[1] = {layer_norm_quad(ws + WS_H, a.n_g, a.n_b, a.eps, lane)};
         if (blockIdx.x == 0 && wave == 0)
@@ -130,7 +151,9 @@ static void launch_lone_t(const LoneTokenArgs& a, hipStream_t st) {
     hipLaunchKernelGGL((lone_stage_kernel<T, LS_OUT>), dim3(D / LT_ROWS, a.B), blk, 0, st, a);
     hipLaunchKernelGGL((lone_stage_kernel<T, LS_FC1>), dim3(DI / LT_ROWS, a.B), blk, 0, st, a);
     hipLaunchKernelGGL((lone_stage_kernel<T, LS_FC2>), dim3(D / LT_ROWS, a.B), blk, 0, st, a);
-    if (!a.last) {
+    if (!a.last && a.n_fir) {
+        hipLaunchKernelGGL((lone_stage_kernel<T, LS_NEXT_GATED>), dim3(D / LT_ROWS, a.B), blk, 0, st, a);
+    } else if (!a.last) {
         hipLaunchKernelGGL((lone_stage_kernel<T, LS_NEXT>), dim3(D3 / LT_ROWS, a.B), blk, 0, st, a);
     } else {
         hipLaunchKernelGGL((lone_stage_kernel<T, LS_ATT>), dim3(D / LT_ROWS, a.B), blk, 0, st, a);

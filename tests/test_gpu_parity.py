@@ -312,10 +312,12 @@ def test_split_transform_convolution_kernel(sd, built_lib, monkeypatch, prec, B,
 
     ids = _ids(B, L, seed=71, pads=3)
     t = torch.from_numpy(ids).cuda()
+    monkeypatch.setenv("CLM_RAW_Z", "1")                 # the split kernel reads the raw x0 | x1 | v rows: compare like with like
     e0 = Engine("cuda:0", precision=prec, chunk_reads=4)
     monkeypatch.setenv("CLM_SPLIT_CONV", "1")
     e1 = Engine("cuda:0", precision=prec, chunk_reads=4)
     monkeypatch.delenv("CLM_SPLIT_CONV")
+    monkeypatch.delenv("CLM_RAW_Z")
     e0.load_state_dict(sd), e1.load_state_dict(sd)
     a, b = e0.forward(t).cpu(), e1.forward(t).cpu()
     assert (a - b).abs().max() < (2e-5 if prec == "fp32" else 3e-4)
@@ -348,6 +350,36 @@ def test_persistent_convolution_equals_one_workgroup_per_unit(sd, built_lib, mon
     else:
         assert (a - b).abs().max() < 0.3 * TOL[prec]          # a fraction of the mode's own error bound
         _check(e1, prec, ids, sd)
+    e0.close(), e1.close()
+
+
+@pytest.mark.parametrize("prec,B,L", [("fp16c", 5, 8193), ("fp16c", 3, 6000), ("fp16c", 4, 4097), ("fp16", 3, 1000), ("bf16", 2, 300),
+                                      ("fp16c", 3, 20000), ("fp16c", 2, 16385), ("fp16", 7, 2049), ("fp16c", 1, 8193)])
+def test_gated_hand_over_equals_raw_rows(sd, built_lib, monkeypatch, prec, B, L):
+    """Round 3: the fused tail kernel's in_proj stage applies the next block's short filter and the x1 * v gate itself and hands
+    the convolution x0f and g (two rows per channel instead of x0 | x1 | v); tiles go to the workgroups in contiguous ranges, the
+    filter's two-token history travels from tile to tile in LDS, the first two tokens of a range that starts inside a read are
+    recomputed by a patch kernel, the peeled last token takes its history from the read's last tile.  Against the previous
+    hand-over (CLM_RAW_Z=1: three rows, filtered and gated by the convolution): the same arithmetic up to WHERE the 16-bit
+    rounding of z sits (before the filter then, after it now) -- logits agree to a fraction of the mode's bound, and both stand
+    against the oracle.  Shapes: persistent 8k kernel (full and ragged units, odd batch, a lone read), one-shot kernels of three
+    transform sizes, the segmented kernel with and without its dot-product tail; 5 x 64 tiles on 256 workgroups = ranges of 2
+    tiles (a patched boundary every second tile), 1 x 64 tiles = one tile per workgroup (every tile patched)."""
+    from chimeralm_amd.engine import Engine
+
+    ids = _ids(B, L, seed=131, pads=3)
+    t = torch.from_numpy(ids).cuda()
+    e0 = Engine("cuda:0", precision=prec, chunk_reads=8)
+    monkeypatch.setenv("CLM_RAW_Z", "1")
+    e1 = Engine("cuda:0", precision=prec, chunk_reads=8)
+    monkeypatch.delenv("CLM_RAW_Z")
+    e0.load_state_dict(sd), e1.load_state_dict(sd)
+    a, b = e0.forward(t).cpu(), e1.forward(t).cpu()
+    assert torch.equal(a, e0.forward(t).cpu())                  # deterministic
+    assert (a - b).abs().max() < 0.4 * TOL[prec]
+    ea = _check(e0, prec, ids, sd)
+    eb = _check(e1, prec, ids, sd)
+    print(f"{prec} {B} x {L}: |gated - oracle| {ea:.2e}  |raw rows - oracle| {eb:.2e}  |gated - raw| {(a - b).abs().max():.2e}")
     e0.close(), e1.close()
 
 
