@@ -750,7 +750,9 @@ int clm_finalize(clm_handle* h) {
     hipStream_t st = 0;
     auto pack_as = [&](int pr, const std::string& key, int n, int k, void** out) -> int {
         HIPCHK(h, hipMalloc(out, packed_weight_bytes(pr, n, k)));
-        launch_pack_weight(pr, W(h, key), *out, n, k, st);
+        HIPCHK(h, hipMemsetAsync(*out, 0, packed_weight_bytes(pr, n, k), st));
+        // fp16c: every GEMM but the k-major out_proj takes its lo half in the 6-bit form (gemm_common.h mfma_lo6)
+        launch_pack_weight(pr, W(h, key), *out, n, k, st, key.find("out_proj") == std::string::npos);
         return CLM_OK;
     };
     auto pack = [&](const std::string& key, int n, int k, void** out) -> int { return pack_as(prec, key, n, k, out); };

@@ -101,6 +101,9 @@ __device__ __forceinline__ float gelu_tanh(float x) {
 // two at a time: the element-wise part maps onto v_pk_mul_f32 / v_pk_fma_f32 / v_pk_add_f32
 using f32x2 = float __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ f32x2 gelu_tanh2(f32x2 x) {
+#ifdef CLM_EXP_NOGELU   // timing-only build: no transcendental
+    return x * 0.5f;
+#endif
     f32x2 p = x * (GELU_A + GELU_B * (x * x));
     f32x2 d = {1.0f + __builtin_amdgcn_exp2f(p.x), 1.0f + __builtin_amdgcn_exp2f(p.y)};
     f32x2 r = {__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
@@ -227,7 +230,9 @@ void tail16_dump_stamps();   // developer build only (CLM_STAMP=1)
 void conv_dump_stamps();
 size_t packed_weight_bytes(int prec, int n, int k);
 // pack W [n][k] fp32 (device) into MFMA fragment order of the compute dtype
-void launch_pack_weight(int prec, const float* w, void* out, int n, int k, hipStream_t st);
+// lo6 (PREC_F16C only): the lo half as e2m3 + block scale for the token-major GEMMs (compute_tm: in_proj, fc1, fc2, pooling score);
+// false = e4m3 at the fixed scale 2^-17 (the k-major out_proj, compute_km)
+void launch_pack_weight(int prec, const float* w, void* out, int n, int k, hipStream_t st, bool lo6 = false);
 
 // long convolution (hyena_conv.hip)
 constexpr int SEG_LEN = 8192;                     // tokens per segment of the long-read path (half a 16384 transform)

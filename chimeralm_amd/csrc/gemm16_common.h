@@ -31,35 +31,45 @@ __device__ __forceinline__ void compute_tm(const typename CT<PREC>::elem* As, in
     // and two half-sets live), and every MFMA then pays a full LDS latency: fc1 ran at half the rate of fc2.
     constexpr int FR = WFR<PREC>, KP = KPS<PREC>, NI = 4 * KP, R = AHEAD + 1;
     const typename CT<PREC>::elem* a0 = As + lrow * RS16 + part * KP * 16 + lhalf * 8;
+#ifdef CLM_EXP_A0       // timing-only build: every A fragment of a set is its first one (one LDS read per set instead of 16)
+#define CLM_A_OFF(x) 0
+#else
+#define CLM_A_OFF(x) (x)
+#endif
     if constexpr (PREC == PREC_F16C) {
         // Compensated mode.  Items run ROW-TILE major (mt = i >> 2, k-step = i & 3): a row tile's four activation fragments feed
-        // four fp16 MFMAs with the hi fragments and, converted to e5m2 in registers as they pass (8 registers), ONE K = 64 fp8
-        // MFMA with the lo bytes -- half the cycles of the four fp16 lo MFMAs it replaces, 2.9e-6 instead of 8.3e-5 rms on
-        // a 64-deep product (tools/micro/mfma_fp8_lo.cpp).
+        // four fp16 MFMAs with the hi fragments and, converted to e2m1 in registers as they pass (4 registers), ONE K = 64 scaled
+        // MFMA with the e2m3 lo values at the 4/6-bit rate: 32 cycles -- a quarter of the four fp16 lo MFMAs of the first form of
+        // the mode, half of the e4m3 x e5m2 form of round 2 (gemm_common.h mfma_lo6; tools/micro/mfma_fp6_lo.cpp).
         static_assert(KP == 4 && NI == 16, "a set is one 64-deep group");
         u16x8 afc[R];
-        i32x8 a8 = {0, 0, 0, 0, 0, 0, 0, 0};          // converted in place, row tile after row tile (frag_to_bf8)
-        i32x8 w8;
+        i32x8 a4 = {0, 0, 0, 0, 0, 0, 0, 0};          // e2m1, converted in place, row tile after row tile (frag_to_fp4): dwords 0..3
+        i32x8 w6;                                      // the lane's 32 e2m3 lo values (dwords 0..5); dword 6 of the slot pair = scale
+        int wscale;
         {
             const unsigned* lo32 = reinterpret_cast<const unsigned*>(&src[0][4]);
 #pragma unroll
-            for (int r = 0; r < 8; ++r) w8[r] = (int)lo32[r];
+            for (int r = 0; r < 6; ++r) w6[r] = (int)lo32[r];
+            w6[6] = 0, w6[7] = 0;
+            wscale = (int)lo32[6];
         }
 #pragma unroll
-        for (int i = 0; i < AHEAD; ++i) afc[i % R] = *reinterpret_cast<const u16x8*>(a0 + (i >> 2) * 32 * RS16 + (i & 3) * 16);
+        for (int i = 0; i < AHEAD; ++i) afc[i % R] = *reinterpret_cast<const u16x8*>(a0 + CLM_A_OFF((i >> 2) * 32 * RS16 + (i & 3) * 16));
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
             if (i + AHEAD < NI) {
                 const int n = i + AHEAD;
-                afc[n % R] = *reinterpret_cast<const u16x8*>(a0 + (n >> 2) * 32 * RS16 + (n & 3) * 16);
+                afc[n % R] = *reinterpret_cast<const u16x8*>(a0 + CLM_A_OFF((n >> 2) * 32 * RS16 + (n & 3) * 16));
             }
             const int mt = i >> 2, ks = i & 3;
             if (ROWS_N) acc[mt] = mfma<PREC>(src[0][ks], afc[i % R], acc[mt]);
             else acc[mt] = mfma<PREC>(afc[i % R], src[0][ks], acc[mt]);
-            int w0 = a8[2 * ks], w1 = a8[2 * ks + 1];
-            frag_to_bf8(afc[i % R], w0, w1);
-            a8[2 * ks] = w0, a8[2 * ks + 1] = w1;
-            if (ks == 3) acc[mt] = mfma_lo8<ROWS_N>(w8, a8, acc[mt]);
+#ifndef CLM_EXP_NOLO    // timing-only build without the lo half: what the lo MFMA + the conversions cost
+            int w0 = a4[ks];
+            frag_to_fp4(afc[i % R], w0);
+            a4[ks] = w0;
+            if (ks == 3) acc[mt] = mfma_lo6<ROWS_N>(w6, wscale, a4, acc[mt]);
+#endif
         }
         __builtin_amdgcn_sched_group_barrier(0x100, AHEAD, 0);
 #pragma unroll
@@ -67,7 +77,9 @@ __device__ __forceinline__ void compute_tm(const typename CT<PREC>::elem* As, in
             if (i + AHEAD < NI) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
             __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+#ifndef CLM_EXP_NOLO
             if ((i & 3) == 3) __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+#endif
         }
         return;
     }
@@ -214,6 +226,11 @@ __device__ __forceinline__ void ln_acc_to_tile(f32x16 (&acc2)[4], float* P1, flo
                                                int t0, int L, int wave, int lrow, int lhalf) {
     constexpr int BM = 128;
     float mean[4], rstd[4];
+#ifdef CLM_EXP_NOLN     // timing-only build (tools/build_variant.sh): no statistics; one barrier kept (orders earlier LDS reads before As)
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) mean[mt] = 0.f, rstd[mt] = 1.f;
+    __syncthreads();
+#else
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) {
         float s = 0.f;
@@ -244,6 +261,7 @@ __device__ __forceinline__ void ln_acc_to_tile(f32x16 (&acc2)[4], float* P1, flo
         for (int w = 0; w < 16; ++w) v += P2[w * BM + mt * 32 + lrow];
         rstd[mt] = 1.0f / sqrtf(v * (1.0f / D) + eps);
     }
+#endif
     const float* gp = g + wave * 32 + 4 * lhalf;
     const float* bp = bta + wave * 32 + 4 * lhalf;
 #pragma unroll

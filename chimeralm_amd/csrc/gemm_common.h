@@ -66,6 +66,35 @@ __device__ __forceinline__ void frag_to_bf8(u16x8 af, int& w0, int& w1) {
     w1 = __builtin_bit_cast(int, b);
 }
 
+// ---- round 3: the lo half of the token-major GEMMs (in_proj, fc1, fc2, pooling score) on the DOUBLE-RATE form of the scaled MFMA:
+// both operands in the 4/6-bit class run v_mfma_scale_f32_32x32x64_f8f6f4 in 32 cycles instead of 64 (tools/micro/mfma_fp6_lo.cpp,
+// profiles/r03_mfma_fp6_lo.txt).  Weights: lo = e2m3((w - hi) * 2^S) with ONE E8M0 scale 2^-S per (output row, 32-deep k block) =
+// per lane, chosen at packing time from the block's largest |lo| (the coherent part of the error: 3e-6 rms on a 64-deep product,
+// as the e4m3 form).  Activations: e2m1 (fp4), converted in registers with v_cvt_scalef32_pk_fp4_f16 (4 per fragment, in place,
+// as the e5m2 conversions before) at scale 1: range +-6, steps 0.5 .. 2 -- coarse, but the error it adds is that of the lo PRODUCT
+// (2^-11 of the result) and independent from token to token: 1.3e-5 rms against the 5e-5 the fp16 rounding of the activation
+// operand itself leaves.  The k-major out_proj (compute_km) keeps the e4m3 x e5m2 form: its operand y has no bounded range.
+constexpr int LO6_A_E8M0 = 127;                     // activations are converted at scale 1
+// the 8 halfs of an activation fragment -> 8 e2m1 values written INTO w (one dword of the MFMA's 4-dword operand)
+__device__ __forceinline__ void frag_to_fp4(u16x8 af, int& w) {
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+    const h8 v = __builtin_bit_cast(h8, af);
+    unsigned x = (unsigned)w;
+    x = __builtin_amdgcn_cvt_scalef32_pk_fp4_f16(x, h2{v[0], v[1]}, 1.0f, 0);
+    x = __builtin_amdgcn_cvt_scalef32_pk_fp4_f16(x, h2{v[2], v[3]}, 1.0f, 1);
+    x = __builtin_amdgcn_cvt_scalef32_pk_fp4_f16(x, h2{v[4], v[5]}, 1.0f, 2);
+    x = __builtin_amdgcn_cvt_scalef32_pk_fp4_f16(x, h2{v[6], v[7]}, 1.0f, 3);
+    w = (int)x;
+}
+// acc += w_lo . a: `w6` the lane's 32 e2m3 values of the weight tile (dwords 0..5) with their scale byte in `wscale`, `a4` its 32
+// e2m1 values of the activation tile (dwords 0..3; the same 64 k in the same order)
+template <bool W_IS_A>
+__device__ __forceinline__ f32x16 mfma_lo6(i32x8 w6, int wscale, i32x8 a4, f32x16 c) {
+    if (W_IS_A) return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(w6, a4, c, 2 /*e2m3*/, 4 /*e2m1*/, 0, wscale, 0, LO6_A_E8M0);
+    return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a4, w6, c, 4, 2, 0, LO6_A_E8M0, 0, wscale);
+}
+
 template <int PREC>
 __device__ __forceinline__ f32x16 mfma(typename CT<PREC>::frag a, typename CT<PREC>::frag b, f32x16 c);
 template <>
@@ -318,6 +347,9 @@ __device__ __forceinline__ void load_set(const typename CT<PREC>::frag* wp, int 
     for (int nt = 0; nt < NT; ++nt) {
         const typename CT<PREC>::frag* p =
             wp + ((size_t)(nb * 8 + wave * NT + nt) * KSTEPS_ALL + kc * KSTEPS + part * KP) * (FR * 64) + lane;
+#ifdef CLM_EXP_W0   // timing-only build (tools/build_variant.sh): every set is the wave's first one -- weights from the L1, wrong results
+        p = wp + (size_t)(wave * NT + nt) * KSTEPS_ALL * (FR * 64) + lane;
+#endif
 #pragma unroll
         for (int ks = 0; ks < SETK; ++ks)
             if (PREC != PREC_F16C || ks < 6) dst[nt][ks] = p[(size_t)ks * 64];     // compensated mode: slots 6, 7 are unused
