@@ -751,8 +751,7 @@ int clm_finalize(clm_handle* h) {
     auto pack_as = [&](int pr, const std::string& key, int n, int k, void** out) -> int {
         HIPCHK(h, hipMalloc(out, packed_weight_bytes(pr, n, k)));
         HIPCHK(h, hipMemsetAsync(*out, 0, packed_weight_bytes(pr, n, k), st));
-        // fp16c: every GEMM but the k-major out_proj takes its lo half in the 6-bit form (gemm_common.h mfma_lo6)
-        launch_pack_weight(pr, W(h, key), *out, n, k, st, key.find("out_proj") == std::string::npos);
+        launch_pack_weight(pr, W(h, key), *out, n, k, st);
         return CLM_OK;
     };
     auto pack = [&](const std::string& key, int n, int k, void** out) -> int { return pack_as(prec, key, n, k, out); };
@@ -975,6 +974,14 @@ int clm_set_fallback(clm_handle* h, int on) {
     if (!h) return CLM_E_INVALID;
     if (!h->finalized) return fail(h, CLM_E_STATE, "clm_set_fallback before clm_finalize");
     h->fallback32 = on != 0 && h->cfg.precision != PREC_F32;
+    return CLM_OK;
+}
+
+int clm_set_short_read_len(clm_handle* h, int min_len) {
+    if (!h || min_len < 1) return fail(h, CLM_E_INVALID, "clm_set_short_read_len: bad argument");
+    if (h->cfg.precision != PREC_F16C) return fail(h, CLM_E_UNSUPPORTED, "clm_set_short_read_len: not a CLM_PREC_F16C handle");
+    h->f16c_min_len = min_len;
+    h->ws_B = h->ws_L = 0;        // the workspace is sized for 4-byte activations below the switch: let the next forward re-derive it
     return CLM_OK;
 }
 

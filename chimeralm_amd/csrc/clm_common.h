@@ -114,8 +114,8 @@ __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + e
 
 // ---- kernel launchers (definitions in the .hip files); all are asynchronous on `st` --------------------
 // PREC_F16C ("fp16c"): fp16 activations x weights held as hi + lo, hi = fp16(w), lo = e4m3((w - hi) * 2^17): per 64-deep group
-// four fp16 MFMAs with hi and ONE block-scaled K = 64 fp8 MFMA with lo (activation fragments converted to e5m2 in registers) into
-// one fp32 accumulator.  The rounding of the packed weights is the one error of the fp16 mode that is coherent across tokens
+// four fp16 MFMAs with hi and ONE block-scaled K = 64 fp8 MFMA with lo (the activation fragments' upper bytes, i.e. the halfs
+// truncated to e5m2, gathered in registers) into one fp32 accumulator.  The rounding of the packed weights is the one error of the fp16 mode that is coherent across tokens
 // (every token sees the same perturbed matrix, so the attention pooling cannot average it out): tests/error_model.py
 // attributes 1.0e-3 of the fp16 mode's 1.3e-3 logit error to it.  What is left is the fp16 rounding of the activation operands
 // (measured 1.2e-4 .. 9.6e-4 in the logits); clm_selfcheck measures it on the loaded weights.
@@ -230,9 +230,7 @@ void tail16_dump_stamps();   // developer build only (CLM_STAMP=1)
 void conv_dump_stamps();
 size_t packed_weight_bytes(int prec, int n, int k);
 // pack W [n][k] fp32 (device) into MFMA fragment order of the compute dtype
-// lo6 (PREC_F16C only): the lo half as e2m3 + block scale for the token-major GEMMs (compute_tm: in_proj, fc1, fc2, pooling score);
-// false = e4m3 at the fixed scale 2^-17 (the k-major out_proj, compute_km)
-void launch_pack_weight(int prec, const float* w, void* out, int n, int k, hipStream_t st, bool lo6 = false);
+void launch_pack_weight(int prec, const float* w, void* out, int n, int k, hipStream_t st);
 
 // long convolution (hyena_conv.hip)
 constexpr int SEG_LEN = 8192;                     // tokens per segment of the long-read path (half a 16384 transform)

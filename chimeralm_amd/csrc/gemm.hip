@@ -49,7 +49,7 @@ __global__ void pack_weight_kernel(const float* __restrict__ w, typename CT<PREC
 // tools/micro/mfma_denorm.cpp -- and the 2^-24 subnormal spacing still leaves the pair within 2^-19 of |w| = 0.06.)
 // Compensated mode, stream of one (32-column tile, 64-deep group of four k-steps) = 8 fragment slots of 64 lanes x 16 bytes:
 //   slots 0..3   hi = fp16(w) of k-steps 0..3 (the fp16 MFMA fragments as in pack_weight_kernel)
-//   slots 4, 5   lo = e4m3((w - hi) * 2^LO8_SHIFT): the lane's 32 bytes of the K = 64 scaled MFMA, byte 8 s + j = k-step s,
+//   slots 4, 5   lo = e4m3((w - hi) * 2^17 * LO8_TRUNC_GAIN): the lane's 32 bytes of the K = 64 scaled MFMA, byte 8 s + j = k-step s,
 //                element j -- the order in which the activation fragments of the four k-steps convert in registers
 //   slots 6, 7   unused (never loaded: the stream keeps its 8-slot stride)
 // |w - hi| <= 2^-11 |w|: with 2^17 the e4m3 range (448) holds every |w| < 8, larger ones saturate (their lo term is then short,
@@ -64,7 +64,8 @@ __global__ void pack_weight_split_kernel(const float* __restrict__ w, f16_t* __r
     const int ksteps = k / 16, ks = int(q % ksteps), nt = int(q / ksteps);
     const float v = w[(size_t)(nt * 32 + (lane & 31)) * k + ks * 16 + 8 * (lane >> 5) + j];
     const f16_t hi = from_float<f16_t>(v);
-    const float lo = fminf(fmaxf((v - to_float(hi)) * LO8_SCALE, -448.f), 448.f);
+    // (x LO8_TRUNC_GAIN: the activations reach the lo product TRUNCATED to e5m2, 0.9155 of their value on average -- gemm_common.h)
+    const float lo = fminf(fmaxf((v - to_float(hi)) * (LO8_SCALE * LO8_TRUNC_GAIN), -448.f), 448.f);
     const int group = ks / 4, s = ks % 4;
     const size_t set = ((size_t)nt * (ksteps / 4) + group) * (8 * 64 * 8);            // in 16-bit units
     out[set + ((size_t)s * 64 + lane) * 8 + j] = hi;
@@ -72,70 +73,13 @@ __global__ void pack_weight_split_kernel(const float* __restrict__ w, f16_t* __r
     reinterpret_cast<unsigned char*>(out + set)[(size_t)(4 + (s >> 1)) * 1024 + lane * 16 + (s & 1) * 8 + j] = (unsigned char)(two & 0xff);
 }
 
-// e2m3 (OCP FP6: 1 sign, 2 exponent bits, bias 1, 3 mantissa bits; subnormal step 0.125, largest 7.5): round to nearest even, saturating
-__device__ __forceinline__ unsigned to_e2m3(float x) {
-    const unsigned s = x < 0.f ? 0x20u : 0u;
-    const float a = fabsf(x);
-    if (!(a < 7.5f)) return s | 0x1fu;                           // (also NaN)
-    int E = a >= 4.f ? 2 : a >= 2.f ? 1 : 0;                      // value = (1 + m / 8) 2^E for a >= 1; E = 0 also carries the subnormals
-    int q = (int)rintf(ldexpf(a, 3 - E));                         // units of 2^(E - 3): 8 .. 16 for normals, 0 .. 8 below 1
-    if (q == 16) { q = 8; ++E; }
-    if (q < 8) return s | (unsigned)q;                            // subnormal (exponent field 0)
-    if (E > 2) return s | 0x1fu;
-    return s | ((unsigned)(E + 1) << 3) | (unsigned)(q - 8);
-}
-// The lo half of the token-major GEMMs as e2m3 with a block scale (gemm_common.h mfma_lo6): runs AFTER pack_weight_split_kernel and
-// rewrites slots 4, 5 of every set.  One thread = one lane of one (32-column tile, 64-deep group): its 32 values, value 8 s + j =
-// k-step s, element j (k = 16 s + 8 (lane >> 5) + j), value v at bits [6 v, 6 v + 6) of dwords 0..5; dword 6 = the E8M0 scale byte
-// (2^(byte - 127) multiplies the stored values back); dword 7 unused.  Scale: the block's largest |lo| lands in [4, 8).
-__global__ void pack_weight_lo6_kernel(const float* __restrict__ w, f16_t* __restrict__ out, int n, int k) {
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int groups = k / 64;
-    if (i >= (size_t)(n / 32) * groups * 64) return;
-    const int lane = int(i % 64), group = int((i / 64) % groups), nt = int(i / 64 / groups);
-    const float* row = w + (size_t)(nt * 32 + (lane & 31)) * k + group * 64 + 8 * (lane >> 5);
-    float lo[32], mx = 0.f;
-#pragma unroll
-    for (int s = 0; s < 4; ++s)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const float v = row[16 * s + j];
-            lo[8 * s + j] = v - to_float(from_float<f16_t>(v));
-            mx = fmaxf(mx, fabsf(lo[8 * s + j]));
-        }
-    int e = 0;
-    if (mx > 0.f) (void)frexpf(mx, &e);                            // mx = m 2^e, m in [0.5, 1)
-    int S = 3 - e;                                                 // lo * 2^S: largest in [4, 8)
-    S = S > 120 ? 120 : S;                                         // (an all-zero or denormal-small block: any scale does)
-    unsigned d[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll
-    for (int v = 0; v < 32; ++v) {
-        const unsigned code = to_e2m3(ldexpf(lo[v], S));
-        const int bit = 6 * v;
-        d[bit >> 5] |= code << (bit & 31);
-        if ((bit & 31) > 26) d[(bit >> 5) + 1] |= code >> (32 - (bit & 31));
-    }
-    d[6] = (unsigned)(127 - S);
-    const size_t set = ((size_t)nt * groups + group) * (8 * 64 * 8);                  // in 16-bit units
-    unsigned* slot4 = reinterpret_cast<unsigned*>(reinterpret_cast<unsigned char*>(out + set) + 4 * 1024 + lane * 16);
-    unsigned* slot5 = reinterpret_cast<unsigned*>(reinterpret_cast<unsigned char*>(out + set) + 5 * 1024 + lane * 16);
-#pragma unroll
-    for (int r = 0; r < 4; ++r) slot4[r] = d[r], slot5[r] = d[4 + r];
-}
-
 size_t packed_weight_bytes(int prec, int n, int k) {
     return (size_t)n * k * (prec == PREC_F32 ? 4 : prec == PREC_F16C ? 4 : 2);
 }
 
-void launch_pack_weight(int prec, const float* w, void* out, int n, int k, hipStream_t st, bool lo6) {
+void launch_pack_weight(int prec, const float* w, void* out, int n, int k, hipStream_t st) {
     size_t total = (size_t)n * k;
     dim3 grid((unsigned)((total + 255) / 256)), block(256);
-    if (prec == PREC_F16C && lo6) {      // token-major GEMMs: hi as always, then the lo half as e2m3 + block scale over slots 4, 5
-        hipLaunchKernelGGL(pack_weight_split_kernel, grid, block, 0, st, w, (f16_t*)out, n, k);
-        const size_t lanes = (size_t)(n / 32) * (k / 64) * 64;
-        hipLaunchKernelGGL(pack_weight_lo6_kernel, dim3((unsigned)((lanes + 255) / 256)), block, 0, st, w, (f16_t*)out, n, k);
-        return;
-    }
     if (prec == PREC_F32)
         hipLaunchKernelGGL(pack_weight_kernel<PREC_F32>, grid, block, 0, st, w, (float*)out, n, k);
     else if (prec == PREC_BF16)

@@ -38,20 +38,17 @@ __device__ __forceinline__ void compute_tm(const typename CT<PREC>::elem* As, in
 #endif
     if constexpr (PREC == PREC_F16C) {
         // Compensated mode.  Items run ROW-TILE major (mt = i >> 2, k-step = i & 3): a row tile's four activation fragments feed
-        // four fp16 MFMAs with the hi fragments and, converted to e2m1 in registers as they pass (4 registers), ONE K = 64 scaled
-        // MFMA with the e2m3 lo values at the 4/6-bit rate: 32 cycles -- a quarter of the four fp16 lo MFMAs of the first form of
-        // the mode, half of the e4m3 x e5m2 form of round 2 (gemm_common.h mfma_lo6; tools/micro/mfma_fp6_lo.cpp).
+        // four fp16 MFMAs with the hi fragments and, their upper bytes gathered as e5m2 as they pass (8 registers, two v_perm_b32
+        // per fragment: gemm_common.h frag_to_e5m2t), ONE K = 64 fp8 MFMA with the lo bytes -- half the cycles of the four fp16
+        // lo MFMAs it replaces, 2.9e-6 instead of 8.3e-5 rms on a 64-deep product (tools/micro/mfma_fp8_lo.cpp).
         static_assert(KP == 4 && NI == 16, "a set is one 64-deep group");
         u16x8 afc[R];
-        i32x8 a4 = {0, 0, 0, 0, 0, 0, 0, 0};          // e2m1, converted in place, row tile after row tile (frag_to_fp4): dwords 0..3
-        i32x8 w6;                                      // the lane's 32 e2m3 lo values (dwords 0..5); dword 6 of the slot pair = scale
-        int wscale;
+        i32x8 a8 = {0, 0, 0, 0, 0, 0, 0, 0};          // the row tile's 32 e5m2 bytes, gathered fragment by fragment (frag_to_e5m2t)
+        i32x8 w8;
         {
             const unsigned* lo32 = reinterpret_cast<const unsigned*>(&src[0][4]);
 #pragma unroll
-            for (int r = 0; r < 6; ++r) w6[r] = (int)lo32[r];
-            w6[6] = 0, w6[7] = 0;
-            wscale = (int)lo32[6];
+            for (int r = 0; r < 8; ++r) w8[r] = (int)lo32[r];
         }
 #pragma unroll
         for (int i = 0; i < AHEAD; ++i) afc[i % R] = *reinterpret_cast<const u16x8*>(a0 + CLM_A_OFF((i >> 2) * 32 * RS16 + (i & 3) * 16));
@@ -64,11 +61,11 @@ __device__ __forceinline__ void compute_tm(const typename CT<PREC>::elem* As, in
             const int mt = i >> 2, ks = i & 3;
             if (ROWS_N) acc[mt] = mfma<PREC>(src[0][ks], afc[i % R], acc[mt]);
             else acc[mt] = mfma<PREC>(afc[i % R], src[0][ks], acc[mt]);
-#ifndef CLM_EXP_NOLO    // timing-only build without the lo half: what the lo MFMA + the conversions cost
-            int w0 = a4[ks];
-            frag_to_fp4(afc[i % R], w0);
-            a4[ks] = w0;
-            if (ks == 3) acc[mt] = mfma_lo6<ROWS_N>(w6, wscale, a4, acc[mt]);
+#ifndef CLM_EXP_NOLO    // timing-only build without the lo half: what the lo MFMA + the byte gathers cost
+            int w0, w1;
+            frag_to_e5m2t(afc[i % R], w0, w1);
+            a8[2 * ks] = w0, a8[2 * ks + 1] = w1;
+            if (ks == 3) acc[mt] = mfma_lo8<ROWS_N>(w8, a8, acc[mt]);
 #endif
         }
         __builtin_amdgcn_sched_group_barrier(0x100, AHEAD, 0);
@@ -76,8 +73,8 @@ __device__ __forceinline__ void compute_tm(const typename CT<PREC>::elem* As, in
         for (int i = 0; i < NI; ++i) {
             if (i + AHEAD < NI) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
 #ifndef CLM_EXP_NOLO
+            __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
             if ((i & 3) == 3) __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
 #endif
         }
@@ -132,8 +129,8 @@ __device__ __forceinline__ void compute_km(const typename CT<PREC>::elem* Ys, in
                 u16x8 af = {(unsigned short)lo[0], (unsigned short)lo[1], (unsigned short)lo[2], (unsigned short)lo[3],
                             (unsigned short)hi[0], (unsigned short)hi[1], (unsigned short)hi[2], (unsigned short)hi[3]};
                 acc[mt] = mfma<PREC>(src[0][ks], af, acc[mt]);
-                int w0 = a8[2 * ks], w1 = a8[2 * ks + 1];
-                frag_to_bf8(af, w0, w1);
+                int w0, w1;
+                frag_to_e5m2t(af, w0, w1);
                 a8[2 * ks] = w0, a8[2 * ks + 1] = w1;
             }
             acc[mt] = mfma_lo8<true>(w8, a8, acc[mt]);
@@ -211,9 +208,9 @@ __device__ __forceinline__ void zero_acc(f32x16 (&acc)[4]) {
 }
 
 // LayerNorm over the 256 features of every token of a tile whose values sit in accumulator registers (rows = this wave's
-// 32 features as register quads, lane = token): per-lane partial over 16 features -> LDS tables -> totals over the 16
-// partials of the 8 waves, two-pass variance; the normalised tile goes to As in the compute dtype (rows beyond L as zeros).
-// P1 / P2: [16][128] floats each, outside As.  Ends with a barrier (As complete); the first internal barrier also orders
+// 32 features as register quads, lane = token): per-lane (sum, squared deviations) over 16 features -> LDS tables -> combined
+// over the 16 partials of the 8 waves; the normalised tile goes to As in the compute dtype (rows beyond L as zeros).
+// P1 / P2: [16][128] floats each, outside As.  Ends with a barrier (As complete); the internal barrier also orders
 // every earlier LDS access of the workgroup before the As writes.
 // KEEP: the normalised fp32 values also replace the accumulator contents (post-norm blocks: they are the next residual).
 // (gamma / beta from an LDS table instead of the global loads behind the barriers below, with beta folded into the consuming
@@ -230,7 +227,7 @@ __device__ __forceinline__ void ln_acc_to_tile(f32x16 (&acc2)[4], float* P1, flo
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) mean[mt] = 0.f, rstd[mt] = 1.f;
     __syncthreads();
-#else
+#elif !defined(CLM_EXP_LN1X)     // the two-exchange form: mean first, then the deviations about it
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) {
         float s = 0.f;
@@ -260,6 +257,49 @@ __device__ __forceinline__ void ln_acc_to_tile(f32x16 (&acc2)[4], float* P1, flo
 #pragma unroll
         for (int w = 0; w < 16; ++w) v += P2[w * BM + mt * 32 + lrow];
         rstd[mt] = 1.0f / sqrtf(v * (1.0f / D) + eps);
+    }
+#else
+    // A/B build (-DCLM_EXP_LN1X), MEASURED SLOWER in round 3 and therefore not the default: ONE exchange instead of two -- every
+    // lane leaves the sum of its 16 values AND their squared deviations about ITS OWN mean; the 16 partials of a token combine
+    // exactly (Chan et al.):  mean = sum_w s_w / 256,  M2 = sum_w [ m2_w + 16 (s_w / 16 - mean)^2 ]  (no E[x^2] - mean^2
+    // cancellation; no spills with the row tiles kept apart by sched_barrier -- the first attempt, DESIGN.md section 4.3, spilled
+    // 110+ registers).  Same box, tail kernel per step: 22.45 ms two exchanges, 22.76 ms one: the statistics cost 10 % of the kernel
+    // (timing-only build without them) as VALU + LDS instructions, not as barriers -- the saved barrier buys less than the
+    // combination's extra arithmetic and the doubled table reads per exchange cost.
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+        float s = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s += acc2[mt][r];
+        const float mu = s * (1.0f / 16.0f);
+        float v = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float d = acc2[mt][r] - mu;
+            v = fmaf(d, d, v);
+        }
+        P1[(wave * 2 + lhalf) * BM + mt * 32 + lrow] = s;
+        P2[(wave * 2 + lhalf) * BM + mt * 32 + lrow] = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+        float sw[16];
+        float s = 0.f;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) {
+            sw[w] = P1[w * BM + mt * 32 + lrow];
+            s += sw[w];
+        }
+        mean[mt] = s * (1.0f / D);
+        float v = 0.f;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) {
+            const float d = sw[w] * (1.0f / 16.0f) - mean[mt];
+            v += fmaf(16.0f * d, d, P2[w * BM + mt * 32 + lrow]);
+        }
+        rstd[mt] = 1.0f / sqrtf(v * (1.0f / D) + eps);
+        __builtin_amdgcn_sched_barrier(0);
     }
 #endif
     const float* gp = g + wave * 32 + 4 * lhalf;

@@ -47,52 +47,25 @@ __device__ __forceinline__ f32x16 mfma_lo8(i32x8 w8, i32x8 a8, f32x16 c) {
     if (W_IS_A) return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(w8, a8, c, 0 /*e4m3*/, 1 /*e5m2*/, 0, LO8_E8M0, 0, 127);
     return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, w8, c, 1, 0, 0, 127, 0, LO8_E8M0);
 }
-// the 8 halfs of an activation fragment -> 8 e5m2 bytes, written INTO w0 / w1 (two registers of the MFMA's 8-register operand).
-// e5m2, not e4m3: v_cvt_scalef32_pk_fp8_f16 turns |x| >= 464 into NaN instead of saturating, e5m2 reaches 57344
-// (tools/micro/mfma_fp8_lo.cpp).  The instruction keeps the other half of its destination, i.e. the destination is also an
-// input: given the operand register's previous contents (both halves are rewritten) it converts in place -- a zero or a fresh
-// register there costs a v_mov per register and conversion.
-__device__ __forceinline__ void frag_to_bf8(u16x8 af, int& w0, int& w1) {
-    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
-    typedef _Float16 h8 __attribute__((ext_vector_type(8)));
-    typedef short s2 __attribute__((ext_vector_type(2)));
-    const h8 v = __builtin_bit_cast(h8, af);
-    s2 a = __builtin_bit_cast(s2, w0), b = __builtin_bit_cast(s2, w1);
-    a = __builtin_amdgcn_cvt_scalef32_pk_bf8_f16(a, h2{v[0], v[1]}, 1.0f, false);
-    a = __builtin_amdgcn_cvt_scalef32_pk_bf8_f16(a, h2{v[2], v[3]}, 1.0f, true);
-    b = __builtin_amdgcn_cvt_scalef32_pk_bf8_f16(b, h2{v[4], v[5]}, 1.0f, false);
-    b = __builtin_amdgcn_cvt_scalef32_pk_bf8_f16(b, h2{v[6], v[7]}, 1.0f, true);
-    w0 = __builtin_bit_cast(int, a);
-    w1 = __builtin_bit_cast(int, b);
-}
-
-// ---- round 3: the lo half of the token-major GEMMs (in_proj, fc1, fc2, pooling score) on the DOUBLE-RATE form of the scaled MFMA:
-// both operands in the 4/6-bit class run v_mfma_scale_f32_32x32x64_f8f6f4 in 32 cycles instead of 64 (tools/micro/mfma_fp6_lo.cpp,
-// profiles/r03_mfma_fp6_lo.txt).  Weights: lo = e2m3((w - hi) * 2^S) with ONE E8M0 scale 2^-S per (output row, 32-deep k block) =
-// per lane, chosen at packing time from the block's largest |lo| (the coherent part of the error: 3e-6 rms on a 64-deep product,
-// as the e4m3 form).  Activations: e2m1 (fp4), converted in registers with v_cvt_scalef32_pk_fp4_f16 (4 per fragment, in place,
-// as the e5m2 conversions before) at scale 1: range +-6, steps 0.5 .. 2 -- coarse, but the error it adds is that of the lo PRODUCT
-// (2^-11 of the result) and independent from token to token: 1.3e-5 rms against the 5e-5 the fp16 rounding of the activation
-// operand itself leaves.  The k-major out_proj (compute_km) keeps the e4m3 x e5m2 form: its operand y has no bounded range.
-constexpr int LO6_A_E8M0 = 127;                     // activations are converted at scale 1
-// the 8 halfs of an activation fragment -> 8 e2m1 values written INTO w (one dword of the MFMA's 4-dword operand)
-__device__ __forceinline__ void frag_to_fp4(u16x8 af, int& w) {
-    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
-    typedef _Float16 h8 __attribute__((ext_vector_type(8)));
-    const h8 v = __builtin_bit_cast(h8, af);
-    unsigned x = (unsigned)w;
-    x = __builtin_amdgcn_cvt_scalef32_pk_fp4_f16(x, h2{v[0], v[1]}, 1.0f, 0);
-    x = __builtin_amdgcn_cvt_scalef32_pk_fp4_f16(x, h2{v[2], v[3]}, 1.0f, 1);
-    x = __builtin_amdgcn_cvt_scalef32_pk_fp4_f16(x, h2{v[4], v[5]}, 1.0f, 2);
-    x = __builtin_amdgcn_cvt_scalef32_pk_fp4_f16(x, h2{v[6], v[7]}, 1.0f, 3);
-    w = (int)x;
-}
-// acc += w_lo . a: `w6` the lane's 32 e2m3 values of the weight tile (dwords 0..5) with their scale byte in `wscale`, `a4` its 32
-// e2m1 values of the activation tile (dwords 0..3; the same 64 k in the same order)
-template <bool W_IS_A>
-__device__ __forceinline__ f32x16 mfma_lo6(i32x8 w6, int wscale, i32x8 a4, f32x16 c) {
-    if (W_IS_A) return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(w6, a4, c, 2 /*e2m3*/, 4 /*e2m1*/, 0, wscale, 0, LO6_A_E8M0);
-    return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a4, w6, c, 4, 2, 0, LO6_A_E8M0, 0, wscale);
+// the 8 halfs of an activation fragment -> 8 e5m2 bytes (two registers of the MFMA's 8-register operand) BY TRUNCATION: the upper
+// byte of an IEEE half (sign, 5 exponent bits, 2 mantissa bits) IS an e5m2 number, so the "conversion" is a byte gather -- two
+// v_perm_b32 per fragment instead of the four v_cvt_scalef32_pk_bf8_f16 of round 2, with no dependence on the operand register's
+// previous contents.  The conversions were a third of the tail kernel's VALU instructions (every wave converts the whole
+// activation tile for itself): same box, tail kernel per step 21.3 -> 20.45 ms (round 3, tools/build_variant.sh A/B).
+// Truncation is biased towards zero: the mean of trunc(a) / a over log-uniform mantissas is (1/5 + 1/6 + 1/7 + 1/8) / ln 2 =
+// 0.9154 (0.9158 measured on N(0,1) halfs) -- folded into the packed lo weights (LO8_TRUNC_GAIN, pack_weight_split_kernel), after
+// which the relative error of the operand is 5.5 % rms, that of round-to-nearest e5m2 5.3 %: token-random noise on a term that
+// enters at 2^-11.  Infinities / NaN keep their meaning; fp16 subnormals become e5m2 subnormals.
+// (Also measured and not kept, round 3: the lo product in the 4/6-bit class of the scaled MFMA -- e2m1 activations x e2m3
+//  weights with a block scale run it in 32 cycles instead of 64, tools/micro/mfma_fp6_lo.cpp -- tail 22.8 -> 22.2 ms per step
+//  against 20.45 here: the four conversions per fragment, not the MFMA cycles, were what the lo half cost.)
+constexpr float LO8_TRUNC_GAIN = 1.0f / 0.9155f;
+__device__ __forceinline__ void frag_to_e5m2t(u16x8 af, int& w0, int& w1) {
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    const u32x4 d = __builtin_bit_cast(u32x4, af);
+    const unsigned d0 = d[0], d1 = d[1], d2 = d[2], d3 = d[3];   // (scalars first: bit_cast of a vector ELEMENT reads element 0, hipcc 7.2)
+    w0 = (int)__builtin_amdgcn_perm(d1, d0, 0x07050301u);         // bytes 1, 3 of d0 then of d1: the upper bytes of halfs 0..3
+    w1 = (int)__builtin_amdgcn_perm(d3, d2, 0x07050301u);
 }
 
 template <int PREC>

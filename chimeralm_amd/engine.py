@@ -149,6 +149,10 @@ class Engine:
         """Every later forward of this engine runs in the exact-fp32 kernels (`clm_set_fallback`)."""
         self._check(self._lib.clm_set_fallback(self._h, int(on)))
 
+    def set_f16c_min_len(self, min_len: int):
+        """fp16c: reads shorter than `min_len` tokens run in the exact-fp32 kernels (`clm_set_short_read_len`)."""
+        self._check(self._lib.clm_set_short_read_len(self._h, int(min_len)))
+
     def effective_precision(self, length: int) -> str:
         code = self._lib.clm_effective_precision(self._h, int(length))
         if code < 0:

@@ -181,11 +181,13 @@ class HyenaDna(nn.Module):
     reference's 1e-3 tolerance); `chunk_reads` the number of reads pushed through all layers together.
     `selfcheck` (default: on for "fp16c") -- the reference runs ONE precision, fp32, always (hyena.py:244-256); a 16-bit mode's
     distance from it depends on the weights, so it is MEASURED on the weights actually loaded: before the first batch after every
-    weight (re)load a seeded synthetic sample (4 reads of 2,048 and of 4,097 tokens, the lengths where the mode's error is
-    largest) and the first reads of that batch -- and of any later batch less than half as long as every batch checked so far --
-    run through both the mode and the exact-fp32 kernels of the same engine (`clm_selfcheck`).  If the largest logit
-    difference exceeds `selfcheck_tol` (5e-4, half the tolerance) the engine falls back to exact fp32 for good (logged);
-    `selfcheck_report` holds what was measured.
+    weight (re)load seeded synthetic samples of 4,097, 2,048, 1,024, 512 and 256 tokens and the first reads of that batch -- and
+    of any later batch less than half as long as every batch checked so far -- run through both the mode and the exact-fp32
+    kernels of the same engine (`clm_selfcheck`).  If the largest logit difference at the longest sample or on a batch exceeds
+    `selfcheck_tol` (5e-4, half the tolerance) the engine falls back to exact fp32 for good (logged); otherwise the shortest
+    sample length that still passes (with every longer one) becomes the length below which reads take the fp32 kernels inside
+    the mode (`clm_set_short_read_len`; 2,048 unmeasured) -- the mode's error is a sum of per-token roundings that the pooling averages
+    like 1 / sqrt(L), so where that switch belongs is a property of the weights.  `selfcheck_report` holds what was measured.
     """
 
     def __init__(self, number_of_classes: int, head: nn.Module, backbone_name: str = "hyenadna-small-32k-seqlen", *,
@@ -234,27 +236,45 @@ class HyenaDna(nn.Module):
         return self._engine
 
     # -------------------------------------------------------------------------------- the 16-bit mode on trial
-    _SAMPLE_LENGTHS = (2048, 4097)
+    _SAMPLE_LENGTHS = (4097, 2048, 1024, 512, 256)       # descending: the mode's error grows like 1 / sqrt(L)
 
     def _selfcheck(self, eng: Engine, input_ids: torch.Tensor) -> None:
         """See the class docstring.  Runs on torch's current stream and synchronises it (a few ms per sample)."""
         B, L = input_ids.shape
         rep = self.selfcheck_report
-        samples = []
-        if self._checked_min_len is None:                  # first batch since the weights were loaded
-            g = torch.Generator().manual_seed(20240)
-            for Ls in self._SAMPLE_LENGTHS:
-                ids = torch.randint(7, 11, (4, Ls), generator=g, dtype=torch.uint8)
-                ids[:, -1] = 1                              # [SEP]
-                ids[0, : Ls // 3] = 4                       # one read left-padded, as the collator pads
-                samples.append((f"synthetic 4 x {Ls}", ids.to(eng.device)))
-        samples.append((f"batch rows 0..{min(B, 4) - 1} x {L}", input_ids[: min(B, 4)]))
-        for name, ids in samples:
-            if eng.cfg.precision == 0 or (self.precision == "fp16c" and ids.shape[1] < 2048):
-                continue                                    # the mode itself runs these in exact fp32
+        f16c = self.precision == "fp16c"
+
+        def measure(name, ids):
             diff, differ = eng.selfcheck(ids)
             rep.setdefault("samples", []).append({"sample": name, "max_abs_dlogit": diff, "labels_differ": differ})
-            rep["max_abs_dlogit"] = max(rep.get("max_abs_dlogit", 0.0), diff)
+            return diff
+
+        if self._checked_min_len is None:                  # first batch since the weights were loaded
+            g = torch.Generator().manual_seed(20240)
+            if f16c:
+                eng.set_f16c_min_len(1)                    # measure the 16-bit kernels themselves at every sample length
+            min_ok = None
+            for Ls in self._SAMPLE_LENGTHS:
+                n = 4 if Ls >= 2048 else 8
+                ids = torch.randint(7, 11, (n, Ls), generator=g, dtype=torch.uint8)
+                ids[:, -1] = 1                              # [SEP]
+                ids[0, : Ls // 3] = 4                       # one read left-padded, as the collator pads
+                d = measure(f"synthetic {n} x {Ls}", ids.to(eng.device))
+                if d > self.selfcheck_tol:
+                    if min_ok is None:                      # not even the longest sample passes: the mode is off for good
+                        rep["max_abs_dlogit"] = d
+                    break
+                rep["max_abs_dlogit"] = max(rep.get("max_abs_dlogit", 0.0), d)
+                min_ok = Ls
+                if not f16c:
+                    break                                   # fp16 / bf16: one verdict, no length switch
+            if f16c:
+                # reads shorter than the shortest sample length that passed (with every longer one) take the fp32 kernels
+                rep["f16c_min_len"] = min_ok if min_ok is not None else 2048
+                eng.set_f16c_min_len(rep["f16c_min_len"])
+        if eng.effective_precision(L) != "fp32":
+            d = measure(f"batch rows 0..{min(B, 4) - 1} x {L}", input_ids[: min(B, 4)])
+            rep["max_abs_dlogit"] = max(rep.get("max_abs_dlogit", 0.0), d)
         rep["tol"], rep["precision"] = self.selfcheck_tol, self.precision
         self._checked_min_len = L if self._checked_min_len is None else min(L, self._checked_min_len)
         if rep.get("max_abs_dlogit", 0.0) > self.selfcheck_tol and not rep.get("fallback"):

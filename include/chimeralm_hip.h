@@ -52,7 +52,7 @@ extern "C" {
 #define CLM_PREC_BF16 1
 #define CLM_PREC_F16 2
 /* F16C: fp16 activations x weights held as hi + lo, hi = fp16(w) and lo = e4m3((w - hi) * 2^17): per 64-deep group four fp16
- * MFMAs with hi and one block-scaled fp8 MFMA with lo (activations converted to e5m2 in registers), one fp32 accumulator.  The mode
+ * MFMAs with hi and one block-scaled fp8 MFMA with lo (activations truncated to e5m2 in registers), one fp32 accumulator.  The mode
  * that runs at 16-bit MFMA rate AND stays within the reference's 1e-3 logit tolerance (weight rounding is the error
  * that attention pooling cannot average out, tests/error_model.py); z / y are stored as fp16 like CLM_PREC_F16. */
 #define CLM_PREC_F16C 3
@@ -141,6 +141,11 @@ int clm_selfcheck(clm_handle* h, const void* ids, int ids_dtype, int64_t ids_row
                   float* max_abs_diff, int* labels_differ);
 int clm_set_fallback(clm_handle* h, int on);
 int clm_effective_precision(const clm_handle* h, int L);
+/* CLM_PREC_F16C only: reads shorter than `min_len` tokens run in the exact-fp32 kernels inside the mode (default 2,048: the
+ * mode's error is a sum of per-token fp16 roundings that the attention pooling averages like 1 / sqrt(L); below some length it
+ * no longer fits half the tolerance).  That length depends on the weights: the caller may MEASURE it with clm_selfcheck on reads
+ * of decreasing length (chimeralm_amd/hyena.py does, at 1,024 / 512 / 256 tokens) and lower or raise the switch. */
+int clm_set_short_read_len(clm_handle* h, int min_len);
 
 /* ---- SequenceCNNTransformer -----------------------------------------------------------
  * Multi-head self-attention of nn.TransformerEncoderLayer as the reference builds it
