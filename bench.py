@@ -49,11 +49,13 @@ STAGE_FLOPS_PER_TOKEN = {"ln1_in_proj": 2 * D * 3 * D, "out_proj": 2 * D * D, "l
 TAIL_BYTES_PER_TOKEN = {"out_proj_ln2_mlp": {2: D * 2 + 2 * D * 4, 4: D * 4 + 2 * D * 4},
                         "ln2_mlp": {2: 2 * D * 4, 4: 2 * D * 4},
                         "ln1_in_proj": {2: D * 4 + 3 * D * 2, 4: D * 4 + 3 * D * 4}}
+Z_ROWS = 3 if os.environ.get("CLM_RAW_Z") == "1" else 2   # rows per channel the fused in_proj stage hands the convolution (gated: x0f, g)
 
 
 def stage_bytes_per_token(stage: str, es: int) -> float:
     """Algorithmic HBM bytes per token and launch of the bandwidth-bound stages (es = activation element size)."""
-    return {"short_long_conv": 3 * D * es + D * es,      # read z (x0|x1|v), write y
+    # read z (blocks 1-3: x0f, g in the gated hand-over, x0 | x1 | v before round 3; block 0: one id byte), write y
+    return {"short_long_conv": ((NLAYER - 1) * Z_ROWS * D * es + 1) / NLAYER + D * es,
             "embed": 1 + D * 4, "softmax_pool": D * 4 + 8}.get(stage, 0.0)
 
 
@@ -379,7 +381,7 @@ def main():
             roof["traffic"], roof["traffic_unit"], roof["traffic_source"] = tr["hbm_bytes_per_launch"], "bytes/launch", tr["source"]
             alg = stage_bytes_per_token(dom, es) or TAIL_BYTES_PER_TOKEN.get(dom, {}).get(es, 0.0)
             if fused_next:   # + z of the next block (3 of 4 launches); block 0 reads ids instead of its residual rows
-                alg += 3 * D * es * (NLAYER - 1) / NLAYER - D * 4 / NLAYER
+                alg += Z_ROWS * D * es * (NLAYER - 1) / NLAYER - D * 4 / NLAYER
             roof["algorithmic_hbm_bytes_per_launch"] = alg * tokens_per_launch
         if roof["bound"] == "mfma":
             # MFMA work actually issued (fp16c: two instructions per product) against the same peaks: pipe occupancy
