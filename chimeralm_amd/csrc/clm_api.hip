@@ -44,6 +44,8 @@ struct FilterSet {
     float2* kf2[NLAYER] = {};     // 16384-point class only: even | odd bins of kf (split-transform kernel)
     float2* kfp[NLAYER] = {};     // 16384-point class only: kf lane-packed for the persistent kernel (launch_spectrum_lanepack)
     float2* twM = nullptr;        //                          twiddles of the 8192-point passes
+    float2* kf16[NLAYER] = {};    // KEY_LONG, 16-bit modes: partition spectra of the 16,384-token segments (hyena_conv_seg16_kernel)
+    float2* twN = nullptr;        //                          exp(-2 pi i n / 32768), n < 16384: the split transform's twist
     std::vector<ReversedFilter> krev;
 };
 
@@ -94,6 +96,8 @@ struct clm_handle {
     float2* edge_bnd = nullptr;
     float2* edge_read = nullptr;
     int edge_read_cap = 0;
+    bool seg16 = false;           // CLM_SEG16=1: blocks 1..3 of long reads through the 16,384-token-segment kernel (hyena_conv_seg16_kernel:
+                                  // measured 15 % slower than the 8,192-token segments at 32k x 32, off by default; tests keep it correct)
     bool raw_z = false;           // CLM_RAW_Z=1: the fused in_proj stage writes x0 | x1 | v as before round 3 (A/B runs, tests)
     unsigned char* ids8 = nullptr;   // workspace: clamped ids [B][Lp]
     float* head_t[5] = {};
@@ -247,6 +251,8 @@ void free_filter_set(FilterSet& f) {
         f.kf2[i] = nullptr;
         if (f.kfp[i]) (void)hipFree(f.kfp[i]);
         f.kfp[i] = nullptr;
+        if (f.kf16[i]) (void)hipFree(f.kf16[i]);
+        f.kf16[i] = nullptr;
         for (auto& r : f.krev)
             if (r.p[i]) (void)hipFree(r.p[i]);
         f.ktime[i] = nullptr;
@@ -255,8 +261,10 @@ void free_filter_set(FilterSet& f) {
     f.krev.clear();
     if (f.tw) (void)hipFree(f.tw);
     if (f.twM) (void)hipFree(f.twM);
+    if (f.twN) (void)hipFree(f.twN);
     f.tw = nullptr;
     f.twM = nullptr;
+    f.twN = nullptr;
 }
 
 void free_filters(clm_handle* h) {
@@ -401,6 +409,32 @@ int ensure_filters(clm_handle* h, int L, hipStream_t st, FilterSet** out, const 
                 HIPCHK(h, hipFree(tmp));
             }
         }
+        if (S > 1 && h->cfg.precision != CLM_PREC_F32 && h->seg16) {
+            // 16,384-token segments (hyena_conv_seg16_kernel): partition j = taps [16384 j, 16384 (j + 1)) below and partition j - 1
+            // above, as a 32768-point spectrum, split into even | odd bins, each lane-packed like a 16384-point spectrum
+            constexpr int N2 = 32768, M2 = 16384;
+            double2* scratch15 = nullptr;
+            float2 *tmp15 = nullptr, *tmp2 = nullptr;
+            HIPCHK(h, hipMalloc((void**)&scratch15, (size_t)D * N2 * sizeof(double2)));
+            HIPCHK(h, hipMalloc((void**)&tmp15, (size_t)D * N2 * sizeof(float2)));
+            HIPCHK(h, hipMalloc((void**)&tmp2, (size_t)D * N2 * sizeof(float2)));
+            HIPCHK(h, hipMalloc((void**)&f.twN, (size_t)M2 * sizeof(float2)));
+            launch_twiddles(f.twN, 15, st);
+            for (int i = 0; i < NLAYER; ++i) {
+                std::string p = "bb.layers." + std::to_string(i) + ".mixer.filter_fn.";
+                HIPCHK(h, hipMalloc((void**)&f.kf16[i], (size_t)D * 4 * M2 * sizeof(float2)));
+                for (int j = 0; j < 2; ++j) {
+                    launch_filter_spectrum(f.ktime[i], W(h, p + "bias"), tmp15, scratch15, f.Lf, 15, j * M2, M2, (j - 1) * M2, st);
+                    launch_spectrum_split(tmp15, tmp2, 15, st);
+                    for (int par = 0; par < 2; ++par)
+                        launch_spectrum_lanepack(tmp2 + (size_t)par * M2, f.kf16[i], 4, 2 * j + par, st, N2);
+                }
+            }
+            HIPCHK(h, hipStreamSynchronize(st));
+            HIPCHK(h, hipFree(scratch15));
+            HIPCHK(h, hipFree(tmp15));
+            HIPCHK(h, hipFree(tmp2));
+        }
         HIPCHK(h, hipGetLastError());
         HIPCHK(h, hipStreamSynchronize(st));
         HIPCHK(h, hipFree(scratch));
@@ -537,7 +571,11 @@ int forward_chunk(clm_handle* h, const void* ids, int ids_dtype, int64_t row_str
                 launch_hyena_conv(prec, h->z, h->y, fs->kf[i], fs->tw, fs->ktime[i], lw.short_w, lw.short_b, Bc, L, Lp,
                                   fs->logn, idconv ? h->ids8 : nullptr, idconv ? h->ztab : nullptr, st,
                                   h->conv_flags | ((zgated && i > 0) ? CONV_GATED : 0), fs->kfp[i]);
-            else
+            else if (zgated && i > 0 && fs->kf16[i]) {   // long reads, blocks 1..3 of the fused 16-bit path: 16,384-token segments
+                const bool lone16 = kr && (L - 1) % 16384 == 0;
+                launch_hyena_conv_seg16(prec, h->z, h->y, fs->kf16[i], fs->tw, fs->twN, h->gscratch, Bc, L, Lp,
+                                        lone16 ? kr->p[i] : nullptr, lone16 ? kr->stride : 0, st, h->conv_flags);
+            } else
                 launch_hyena_conv_seg(prec, h->z, h->y, fs->kf[i], fs->KS, fs->tw, lw.short_w, lw.short_b, h->gscratch, Bc,
                                       L, Lp, S, kr ? kr->p[i] : nullptr, kr ? kr->stride : 0, idconv ? h->ids8 : nullptr,
                                       idconv ? h->ztab : nullptr, st, h->conv_flags | ((zgated && i > 0) ? CONV_GATED : 0));
@@ -683,6 +721,7 @@ int clm_create(const clm_config* cfg, int device, clm_handle** out) {
     if (std::getenv("CLM_CONV_NO_XCD") && std::getenv("CLM_CONV_NO_XCD")[0] == '1') h->conv_flags |= CONV_NO_XCD;
     h->split_conv = std::getenv("CLM_SPLIT_CONV") && std::getenv("CLM_SPLIT_CONV")[0] == '1';
     h->raw_z = std::getenv("CLM_RAW_Z") && std::getenv("CLM_RAW_Z")[0] == '1';
+    h->seg16 = std::getenv("CLM_SEG16") && std::getenv("CLM_SEG16")[0] == '1';
     h->cfg = *cfg;
     h->device = device;
     if (hipHostMalloc((void**)&h->bad_ids, sizeof(int), hipHostMallocMapped) == hipSuccess) *h->bad_ids = 0;

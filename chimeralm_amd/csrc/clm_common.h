@@ -266,7 +266,15 @@ void launch_hyena_conv(int prec, const void* z, void* y, const float2* kf, const
 void launch_spectrum_split(const float2* kf, float2* kf2, int logn, hipStream_t st);
 // partition spectrum j (natural order, src [256][16384]) -> slice j of the lane-packed [256][KS][16][512] quads of the
 // segmented kernel (hyena_conv_seg_kernel)
-void launch_spectrum_lanepack(const float2* src, float2* dst, int KS, int j, hipStream_t st);
+// (src_stride: elements between the channels of `src`, default 16384)
+void launch_spectrum_lanepack(const float2* src, float2* dst, int KS, int j, hipStream_t st, size_t src_stride = 0);
+// long reads, 16,384-token segments through the split transform (hyena_conv_seg16_kernel): gated input, 16-bit modes only.
+// kf16 [256][2 partitions][2 parities][16384] lane-packed (launch_spectrum_lanepack with KS = 4, j = 2 * partition + parity, of the
+// even | odd halves launch_spectrum_split makes of a 32768-point partition spectrum); tw the 16384-point twiddles, twN
+// exp(-2 pi i n / 32768), n < 16384; gscratch [pairs][256][2][16384]
+int conv_segments16_for(int L);                   // 0 for L <= 8193, else ceil((L - 1) / 16384)
+void launch_hyena_conv_seg16(int prec, const void* z, void* y, const float2* kf16, const float2* tw, const float2* twN,
+                             float2* gscratch, int B, int L, int Lp, const float* krev, int krev_stride, hipStream_t st, int flags = 0);
 void launch_hyena_conv_dif(int prec, const void* z, void* y, const float2* kf2, const float2* twM, const float2* twN,
                            const float* ktime, const float* short_w, const float* short_b, int B, int L, int Lp,
                            const unsigned char* ids8, const float* ztab, hipStream_t st);

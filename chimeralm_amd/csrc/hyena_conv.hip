@@ -1343,11 +1343,12 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, size_
 // Partition spectrum j of every channel from natural bin order (src [256][N]) into the lane-packed layout the segmented kernel
 // reads (dst [256][KS][16][512] quads): quad (e, t) = (re, re, im, im) of bins t + 512 ka and t + 512 (ka + 1),
 // ka = 2 (e / 4) + 8 (e % 4) -- the two butterflies thread t holds in pair e of the last forward pass (radix 4, 512 threads).
-__global__ __launch_bounds__(512) void spectrum_lanepack_kernel(const float2* __restrict__ src, float4* __restrict__ dst, int KS, int j) {
+__global__ __launch_bounds__(512) void spectrum_lanepack_kernel(const float2* __restrict__ src, float4* __restrict__ dst, int KS, int j,
+                                                                size_t src_stride) {
     constexpr int N = 16384, NT = 512, LAST = Plan<14>::LAST;
     static_assert(LAST == 4 && Plan<14>::NT == NT, "pair geometry of the 16384-point plan");
     const int c = blockIdx.x, t = threadIdx.x;
-    const float2* s = src + (size_t)c * N;
+    const float2* s = src + (size_t)c * src_stride;
     float4* d = dst + ((size_t)c * KS + j) * (N / 2);
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
@@ -1356,8 +1357,9 @@ __global__ __launch_bounds__(512) void spectrum_lanepack_kernel(const float2* __
         d[e * NT + t] = make_float4(a.x, b.x, a.y, b.y);
     }
 }
-void launch_spectrum_lanepack(const float2* src, float2* dst, int KS, int j, hipStream_t st) {
-    hipLaunchKernelGGL(spectrum_lanepack_kernel, dim3(D), dim3(512), 0, st, src, reinterpret_cast<float4*>(dst), KS, j);
+void launch_spectrum_lanepack(const float2* src, float2* dst, int KS, int j, hipStream_t st, size_t src_stride) {
+    hipLaunchKernelGGL(spectrum_lanepack_kernel, dim3(D), dim3(512), 0, st, src, reinterpret_cast<float4*>(dst), KS, j,
+                       src_stride ? src_stride : (size_t)16384);
 }
 
 // ================================================================================================ long reads
@@ -1867,6 +1869,339 @@ void launch_hyena_conv_seg(int prec, const void* z, void* y, const float2* kf, i
         launch_conv_seg_t<bf16_t>(z, y, kf, KS, tw, short_w, short_b, gscratch, B, L, Lp, S, krev, krev_stride, ids8, ztab, use_xcd, st, gated);
     else
         launch_conv_seg_t<f16_t>(z, y, kf, KS, tw, short_w, short_b, gscratch, B, L, Lp, S, krev, krev_stride, ids8, ztab, use_xcd, st, gated);
+}
+
+// ================================================================================================ long reads, 16,384-token segments
+// Round 3.  hyena_conv_seg_kernel moves 5.8 GB per 32 x 32,769 launch where 1.6 GB are algorithmic: S = 4
+// segments of 8,192 tokens mean S (S - 1) / 2 = 6 spectral products per unit, each re-reading a 128 KB segment spectrum from the
+// global scratch, and three spectra written -- and the kernel runs at the 3 TB/s that traffic gets through the fabric.  With
+// segments of M = 16,384 tokens a 32k-bp read has TWO (a 16k-bp read one: no product at all), i.e. ONE product per unit.  The
+// transform of such a segment has 2 M = 32,768 points and does not fit the LDS -- but its input is half zero and only half of its
+// output is wanted, so it is two independent M-point problems over the even and the odd bins (the decomposition of
+// hyena_conv_eo_kernel, emulated on the host by fft_core_test.cpp test_conv_split13):
+//     X[2j]   = DFT_M(x)[j]                        y[n] = IDFT_M(X_e K_e)[n] + w_N^-n IDFT_M(X_o K_o)[n],   n < M,  N = 2 M
+//     X[2j+1] = DFT_M(x w_N^n)[j]
+// run ONE AFTER THE OTHER in the one 147 KiB buffer: the even problem's result waits in 64 registers per thread through the odd
+// problem's passes (no spill: the pass twiddles are requested pass group by pass group and the spectra of the product in quarters,
+// as in hyena_conv_seg_kernel).  Neither problem is pruned (all M inputs, all M outputs), so a segment costs four full M-point
+// transforms where two 8,192-token segments cost four pruned ones (+ ~15 % butterfly work) -- against 1.5 MB -> 0.9 MB of traffic
+// per unit.  Partition spectra: K'_j = spectrum_N([taps of partition j | taps of partition j - 1]) as in the 8k-segment kernel,
+// split into even / odd bins and lane-packed (kf16 [256][2 partitions][2][M quads]).  GATED input only (the fused tail kernel's
+// hand-over: blocks 1..3 of the 16-bit path); block 0 (token ids), fp32 and the raw-row A/B path keep hyena_conv_seg_kernel.
+// MEASURED SLOWER and therefore OFF by default (CLM_SEG16=1 selects it; tests keep it correct): same box, 32 x 32,769 tokens in
+// fp16c, convolution launches of blocks 1..3: 2.18 ms against 1.90 ms for hyena_conv_seg_kernel (1,717 vs 1,797 reads/s).  The
+// 5.8 GB the 8,192-token segments move do not bound them: a unit is four transform pipelines either way (here un-pruned, there
+// pruned), each with its exposed row / twiddle / spectrum requests -- what hyena_conv_pers_kernel hides with its next-unit
+// prefetches -- and halving the scratch traffic buys less than the pruned first / last passes and the 64 registers of the
+// waiting even result cost.
+// LONE: L = S2 * M + 1 (16,385, 32,769): the last output as a dot product with the reversed filter, as in the 8k-segment kernel.
+constexpr int SEG16_LEN = 16384;
+#define CLM_DIF_WC15                                                                                                        \
+    {{1.0f, -0.0f}, {0.99999998162f, -1.9174759731e-4f}, {0.99999992647f, -3.8349518757e-4f}, {0.99999983455f, -5.7524276373e-4f}, \
+     {0.99999970586f, -7.6699031874e-4f}, {0.99999954041f, -9.5873784555e-4f}, {0.99999933819f, -1.1504853371e-3f},          \
+     {0.99999909921f, -1.3422327864e-3f}}
+
+template <typename T, bool LONE>
+__global__ __launch_bounds__(Plan<14>::NT) void hyena_conv_seg16_kernel(
+    const T* __restrict__ z /*gated: row c = x0f, row 256 + c = g*/, T* __restrict__ y,
+    const float2* __restrict__ kf16 /*[256][2][2][M] lane-packed quads: partition j, parity*/, const float2* __restrict__ tw /*M-point*/,
+    const float2* __restrict__ twN /*exp(-2 pi i n / 2M), n < M*/, float2* __restrict__ gscratch /*[pairs][256][2][M]: segment 0's spectra*/,
+    int B, int L, int Lp, int S2, const float* __restrict__ krev, int krev_stride, int use_xcd) {
+    constexpr int LOGN = 14;
+    using P = Plan<LOGN>;
+    using TL = TwLayout<LOGN>;
+    constexpr int M = P::N, NT = P::NT, LAST = P::LAST, CH = M / 8 / NT;
+    static_assert(M == SEG16_LEN && CH == 4 && NT == 512, "four 8-token chunks per thread");
+    constexpr float WC[8][2] = CLM_DIF_WC15;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float* bre = reinterpret_cast<float*>(smem);
+    float* bim = bre + padded_size(M);
+
+    const int tid = threadIdx.x;
+    const int pairs = (B + 1) / 2, xcd = blockIdx.x % XCDS, slot = blockIdx.x / XCDS;
+    const int c = use_xcd ? XCDS * (slot / pairs) + xcd : (int)blockIdx.x / pairs, pair = use_xcd ? slot % pairs : (int)blockIdx.x % pairs;
+    const int bA = 2 * pair, bB = 2 * pair + 1;
+    const bool hasB = bB < B;
+    const T* zA = z + (size_t)bA * D3 * Lp;
+    const T* zB = z + (size_t)(hasB ? bB : bA) * D3 * Lp;
+    T* yA = y + ((size_t)bA * D + c) * Lp;
+    T* yB = y + ((size_t)(hasB ? bB : bA) * D + c) * Lp;
+    const float* kr = LONE ? krev + (size_t)c * krev_stride : nullptr;
+    float dotA = 0.f, dotB = 0.f;
+    // buffer descriptors (uniform): this unit's two scratch spectra (even | odd of segment 0), this channel's four packed spectra
+    const __amdgpu_buffer_rsrc_t g_rs = make_rsrc(gscratch + ((size_t)pair * D + c) * 2 * M, (size_t)2 * M * sizeof(float2));
+    const __amdgpu_buffer_rsrc_t k_rs = make_rsrc(kf16 + (size_t)c * 4 * M, (size_t)4 * M * sizeof(float2));
+    using G = PassGeom<LOGN, LAST>;
+    static_assert(G::NP * LAST == 16 && sizeof(Cx2) == 16, "16 full pairs per thread");
+
+#pragma unroll 1
+    for (int m = 0; m < S2; ++m) {
+        const int seg0 = m * M;
+        int ltid = tid;                    // laundered once per segment (see hyena_conv_seg_kernel)
+        asm volatile("" : "+v"(ltid));
+        const int loff = ltid * (int)sizeof(Cx2);
+        auto quad = [&](const __amdgpu_buffer_rsrc_t& rs, int idx /*spectrum index inside the resource*/, int e) -> Cx2 {
+            const v4u32 r = __builtin_amdgcn_raw_buffer_load_b128(rs, loff, (idx * (M / 2) + NT * e) * (int)sizeof(Cx2), 0);
+            const unsigned r0 = r[0], r1 = r[1], r2 = r[2], r3 = r[3];
+            return Cx2{make_v2(__uint_as_float(r0), __uint_as_float(r1)), make_v2(__uint_as_float(r2), __uint_as_float(r3))};
+        };
+        auto quad_w = [&](const __amdgpu_buffer_rsrc_t& rs, int idx, int e, Cx2 val) {
+            v4u32 r;
+            r[0] = __float_as_uint(val.re.x), r[1] = __float_as_uint(val.re.y);
+            r[2] = __float_as_uint(val.im.x), r[3] = __float_as_uint(val.im.y);
+            __builtin_amdgcn_raw_buffer_store_b128(r, rs, loff, (idx * (M / 2) + NT * e) * (int)sizeof(Cx2), 0);
+        };
+        float ye[CH][2][8];                // the even problem's result (read A | read B), held through the odd problem
+        float2 wb[CH];                     // w_N^tl of this thread's chunks
+#pragma unroll
+        for (int ch = 0; ch < CH; ++ch) wb[ch] = twN[8 * (ltid + ch * NT)];
+
+#pragma unroll 1
+        for (int par = 0; par < 2; ++par) {                  // 0: even bins, 1: odd bins -- a rolled loop: ONE copy of the seven passes
+            const int PAR = __builtin_amdgcn_readfirstlane(par);
+            asm volatile("" : "+v"(ltid));                   // (per problem: no pass address is carried from the even to the odd one)
+            // ---- phase A: the segment's g rows -> LDS (odd problem: times w_N^n)
+            {
+                uint4 gr[CH][2];
+#pragma unroll
+                for (int rd = 0; rd < 2; ++rd) {
+                    const T* row = (rd == 0 ? zA : zB) + (size_t)(D + c) * Lp;
+#pragma unroll
+                    for (int ch = 0; ch < CH; ++ch) {
+                        const int t0 = seg0 + 8 * (ltid + ch * NT);
+                        gr[ch][rd] = *reinterpret_cast<const uint4*>(row + (t0 < L ? t0 : 0));
+                    }
+                }
+#pragma unroll
+                for (int ch = 0; ch < CH; ++ch) {
+                    const int tl = 8 * (ltid + ch * NT), t0 = seg0 + tl;
+                    float gA[8], gB[8];
+                    cvt8<T>(gr[ch][0], gA);
+                    cvt8<T>(gr[ch][1], gB);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        gA[e] = (t0 + e < L) ? gA[e] : 0.f;
+                        gB[e] = (hasB && t0 + e < L) ? gB[e] : 0.f;
+                    }
+                    if (LONE && PAR == 0) {        // this segment's share of the last output's dot product
+                        float kk[8];
+                        load8<float>(kr + t0, kk);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) dotA = fmaf(gA[e], kk[e], dotA), dotB = fmaf(gB[e], kk[e], dotB);
+                    }
+                    if (PAR == 1) {
+                        // (opaque copy of the chunk's base twist: shared with phase C, hipcc computes all 64 twist values of the
+                        //  thread once, above the loop, and keeps them -- in scratch)
+                        float wbx = wb[ch].x, wby = wb[ch].y;
+                        asm volatile("" : "+v"(wbx), "+v"(wby));
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            const float wr = wbx * WC[e][0] - wby * WC[e][1], wi = wbx * WC[e][1] + wby * WC[e][0];
+                            const float xr = gA[e] * wr - gB[e] * wi, xi = gA[e] * wi + gB[e] * wr;
+                            gA[e] = xr, gB[e] = xi;
+                        }
+                    }
+                    lds_store8(bre + pad_index(tl), gA);
+                    lds_store8(bim + pad_index(tl), gB);
+                }
+            }
+            Cx2 wall[TL::TOTAL];
+            {
+                int ns = 16;
+#pragma unroll
+                for (int p = 1; p <= P::NPASS - 2; ++p) {
+                    pass_twiddles<LOGN, 16, false>(wall + TL::fwd(p), ltid, ns, tw);
+                    ns *= 16;
+                }
+                pass_twiddles<LOGN, LAST, false>(wall + TL::fwd_last(), ltid, ns, tw);
+            }
+            __syncthreads();
+            // ---- forward transform: all M inputs (no pruned pass)
+            Cx2 v[16];
+            {
+                int Ns = 1;
+#pragma unroll
+                for (int p = 0; p < P::NPASS - 1; ++p) {
+                    pass_load<LOGN, 16>(bre, bim, v, ltid);
+                    pass_compute_w<LOGN, 16, false>(v, ltid, p > 0, wall + (p > 0 ? TL::fwd(p) : 0));
+                    __syncthreads();
+                    pass_store<LOGN, 16>(bre, bim, v, ltid, Ns);
+                    __syncthreads();
+                    Ns *= 16;
+                }
+            }
+            // ---- last forward pass, spectrum product, first inverse butterfly
+            {
+                pass_load<LOGN, LAST>(bre, bim, v, ltid);
+                pass_compute_w<LOGN, LAST, false>(v, ltid, true, wall + TL::fwd_last());
+                if (m + 1 < S2) {              // segment 0 of two: keep its spectrum for segment 1 (uniform branch)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) quad_w(g_rs, PAR, e, v[e]);
+                }
+                // x K'_0 of this parity, a quarter of the pairs at a time (all 16 quads at once are 64 registers next to the 64 of
+                // the spectrum and the 64 of the waiting even result: spills)
+#pragma unroll
+                for (int qtr = 0; qtr < 4; ++qtr) {
+                    Cx2 kb[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) kb[e] = quad(k_rs, PAR, 4 * qtr + e);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        Cx2& acc = v[4 * qtr + e];
+                        acc = Cx2::mul(acc, kb[e]);
+                        asm volatile("" : "+v"(acc.re), "+v"(acc.im));
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            if (m > 0) {                       // + G_0 K'_1, a quarter of the pairs per step (registers: 2 x 16 at a time)
+#pragma unroll
+                for (int qtr = 0; qtr < 4; ++qtr) {
+                    Cx2 ga[4], kb[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        ga[e] = quad(g_rs, PAR, 4 * qtr + e);
+                        kb[e] = quad(k_rs, 2 + PAR, 4 * qtr + e);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        Cx2& acc = v[4 * qtr + e];
+                        acc = Cx2::add(acc, Cx2::mul(ga[e], kb[e]));
+                        asm volatile("" : "+v"(acc.re), "+v"(acc.im));
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            {
+                int ns = LAST;
+#pragma unroll
+                for (int p = 1; p <= P::NPASS - 1; ++p) {
+                    pass_twiddles<LOGN, 16, true>(wall + TL::inv(p), ltid, ns, tw);
+                    ns *= 16;
+                }
+            }
+#pragma unroll
+            for (int p = 0; p < G::NP; ++p) Dft<LAST, true>::run(v + p * LAST);
+            __syncthreads();
+            pass_store<LOGN, LAST>(bre, bim, v, ltid, 1);
+            __syncthreads();
+            // ---- inverse passes: all M outputs
+            uint4 x0r[CH][2];
+            {
+                int Ns = LAST;
+#pragma unroll
+                for (int p = 1; p <= P::NPASS - 1; ++p) {
+                    {
+                        if (PAR == 1 && p == P::NPASS - 1) {   // x0f rows of this segment: the last pass to land
+#pragma unroll
+                            for (int rd = 0; rd < 2; ++rd) {
+                                const T* row = (rd == 0 ? zA : zB) + (size_t)c * Lp;
+#pragma unroll
+                                for (int ch = 0; ch < CH; ++ch) {
+                                    const int t0 = seg0 + 8 * (ltid + ch * NT);
+                                    x0r[ch][rd] = *reinterpret_cast<const uint4*>(row + (t0 < L ? t0 : 0));
+                                }
+                            }
+                        }
+                    }
+                    pass_load<LOGN, 16>(bre, bim, v, ltid);
+                    pass_compute_w<LOGN, 16, true>(v, ltid, true, wall + TL::inv(p));
+                    __syncthreads();
+                    pass_store<LOGN, 16>(bre, bim, v, ltid, Ns);
+                    __syncthreads();
+                    Ns *= 16;
+                }
+            }
+            if (PAR == 0) {                    // the even result waits in registers; the buffer goes to the odd problem
+#pragma unroll
+                for (int ch = 0; ch < CH; ++ch) {
+                    const int tl = 8 * (ltid + ch * NT);
+                    lds_load8(bre + pad_index(tl), ye[ch][0]);
+                    lds_load8(bim + pad_index(tl), ye[ch][1]);
+                }
+                __syncthreads();
+            } else {
+                // ---- phase C: y = (r_e + conj(w_N^n) r_o) * x0f
+#pragma unroll
+                for (int ch = 0; ch < CH; ++ch) {
+                    const int tl = 8 * (ltid + ch * NT), t0 = seg0 + tl;
+                    float oA[8], oB[8], x0a[8], x0b[8];
+                    lds_load8(bre + pad_index(tl), oA);
+                    lds_load8(bim + pad_index(tl), oB);
+                    cvt8<T>(x0r[ch][0], x0a);
+                    cvt8<T>(x0r[ch][1], x0b);
+                    float wbx = wb[ch].x, wby = wb[ch].y;
+                    asm volatile("" : "+v"(wbx), "+v"(wby));
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const float wr = wbx * WC[e][0] - wby * WC[e][1], wi = wbx * WC[e][1] + wby * WC[e][0];
+                        const bool ok = t0 + e < L;
+                        const float a = ye[ch][0][e] + (oA[e] * wr + oB[e] * wi), b = ye[ch][1][e] + (oB[e] * wr - oA[e] * wi);
+                        oA[e] = ok ? a * x0a[e] : 0.f;
+                        oB[e] = ok ? b * x0b[e] : 0.f;
+                    }
+                    if (t0 < Lp) {
+                        store8<T>(yA + t0, oA);
+                        if (hasB) store8<T>(yB + t0, oB);
+                    }
+                }
+                __syncthreads();   // the LDS buffer is refilled by the next segment
+            }
+        }
+    }
+    if constexpr (LONE) {
+        const float a = wave_sum(dotA), b = wave_sum(dotB);
+        if ((tid & 63) == 0) {
+            bre[tid >> 6] = a;
+            bim[tid >> 6] = b;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            const int t = L - 1;
+            float sa = 0.f, sbb = 0.f;
+#pragma unroll
+            for (int w = 0; w < NT / 64; ++w) sa += bre[w], sbb += bim[w];
+            const float k0 = kr[t];                          // tap 0 (+ skip term)
+            auto at = [&](int rd, int row) { return to_float(((rd == 0 ? zA : zB) + (size_t)(row * D + c) * Lp)[t]); };
+            yA[t] = from_float<T>(fmaf(at(0, 1), k0, sa) * at(0, 0));
+            if (hasB) yB[t] = from_float<T>(fmaf(at(1, 1), k0, sbb) * at(1, 0));
+        }
+        for (int t = L + tid; t < Lp; t += NT) {             // padding columns stay zero
+            yA[t] = from_float<T>(0.f);
+            if (hasB) yB[t] = from_float<T>(0.f);
+        }
+    }
+}
+
+int conv_segments16_for(int L) { return L <= SEG_LEN + 1 ? 0 : (L - 1 + SEG16_LEN - 1) / SEG16_LEN; }
+
+template <typename T, bool LONE>
+static void launch_conv_seg16_inst(const void* z, void* y, const float2* kf16, const float2* tw, const float2* twN, float2* gscratch,
+                                   int B, int L, int Lp, int S2, const float* krev, int krev_stride, int use_xcd, hipStream_t st) {
+    using P = Plan<14>;
+    constexpr size_t lds = (size_t)2 * padded_size(P::N) * sizeof(float) + 256;
+    auto kern = hyena_conv_seg16_kernel<T, LONE>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_done = true;
+    }
+    dim3 grid(((B + 1) / 2) * D), block(P::NT);
+    hipLaunchKernelGGL(kern, grid, block, lds, st, reinterpret_cast<const T*>(z), reinterpret_cast<T*>(y), kf16, tw, twN, gscratch, B, L,
+                       Lp, S2, krev, krev_stride, use_xcd);
+}
+void launch_hyena_conv_seg16(int prec, const void* z, void* y, const float2* kf16, const float2* tw, const float2* twN,
+                             float2* gscratch, int B, int L, int Lp, const float* krev, int krev_stride, hipStream_t st, int flags) {
+    const int use_xcd = !(flags & CONV_NO_XCD), S2 = conv_segments16_for(L);
+    if (prec == PREC_BF16) {
+        if (krev) launch_conv_seg16_inst<bf16_t, true>(z, y, kf16, tw, twN, gscratch, B, L, Lp, S2, krev, krev_stride, use_xcd, st);
+        else launch_conv_seg16_inst<bf16_t, false>(z, y, kf16, tw, twN, gscratch, B, L, Lp, S2, nullptr, 0, use_xcd, st);
+    } else {
+        if (krev) launch_conv_seg16_inst<f16_t, true>(z, y, kf16, tw, twN, gscratch, B, L, Lp, S2, krev, krev_stride, use_xcd, st);
+        else launch_conv_seg16_inst<f16_t, false>(z, y, kf16, tw, twN, gscratch, B, L, Lp, S2, nullptr, 0, use_xcd, st);
+    }
 }
 
 // ztab[id][n] = in_proj(LN1(embedding[id]))[n] of block 0, fp32: one workgroup per token id
