@@ -1,0 +1,108 @@
+"""CPU: the decisions of `HyenaDna`'s self-check (chimeralm_amd/hyena.py) with the engine replaced by a stub
+whose `selfcheck` answers are scripted -- fallback, the measured short-read switch, when a later batch is checked again.  (The
+measurements themselves -- `clm_selfcheck` against the oracle -- are GPU tests: tests/test_gpu_parity.py.)"""
+from __future__ import annotations
+
+import warnings
+
+import pytest
+import torch
+
+from chimeralm_amd import hyena, lm
+
+
+class StubEngine:
+    """What `HyenaDna._selfcheck` touches of `chimeralm_amd.engine.Engine`."""
+
+    def __init__(self, err_by_len, batch_err=1e-4, precision_code=3):
+        self.err_by_len, self.batch_err = err_by_len, batch_err
+        self.device = torch.device("cpu")
+        self.cfg = type("Cfg", (), {"precision": precision_code})()
+        self.min_len, self.fallback, self.calls = 2048, False, []
+
+    def selfcheck(self, ids):
+        n, L = ids.shape
+        self.calls.append((n, L))
+        return (self.err_by_len.get(L, self.batch_err), 0)
+
+    def set_f16c_min_len(self, n):
+        self.min_len = n
+
+    def set_fallback(self, on):
+        self.fallback = bool(on)
+
+    def effective_precision(self, L):
+        return "fp32" if (self.fallback or L < self.min_len) else "fp16c"
+
+
+def _net():
+    return lm.ChimeraLM.new(precision="fp16c").net
+
+
+def _ids(B, L):
+    return torch.full((B, L), 7, dtype=torch.uint8)
+
+
+def test_all_samples_pass_lowers_the_switch_to_the_shortest_sample():
+    net = _net()
+    eng = StubEngine({4097: 2e-4, 2048: 3e-4, 1024: 4e-4, 512: 4.5e-4, 256: 4.9e-4})
+    net.guard(eng, _ids(6, 3000))
+    rep = net.selfcheck_report
+    assert rep["fallback"] is False and eng.fallback is False and rep["f16c_min_len"] == 256 == eng.min_len
+    assert [c[1] for c in eng.calls] == [4097, 2048, 1024, 512, 256, 3000]       # descending samples, then the batch's first rows
+    assert eng.calls[-1][0] == 4 and abs(rep["max_abs_dlogit"] - 4.9e-4) < 1e-12
+    n = len(eng.calls)
+    net.guard(eng, _ids(6, 3000))                                                # checked once per weight load ...
+    net.guard(eng, _ids(6, 1600))
+    assert len(eng.calls) == n
+    net.guard(eng, _ids(2, 1400))                                                # ... and again for a batch less than half as long
+    assert eng.calls[-1] == (2, 1400) and len(eng.calls) == n + 1
+
+
+def test_first_failing_sample_sets_the_switch_and_keeps_the_mode_for_longer_reads():
+    net = _net()
+    eng = StubEngine({4097: 2e-4, 2048: 3e-4, 1024: 7e-4})
+    net.guard(eng, _ids(4, 5000))
+    rep = net.selfcheck_report
+    assert rep["fallback"] is False and rep["f16c_min_len"] == 2048 == eng.min_len
+    assert [c[1] for c in eng.calls] == [4097, 2048, 1024, 5000]                  # stops at the first failure
+    assert rep["max_abs_dlogit"] == 3e-4                                          # the failing SHORT sample does not count against the mode
+    eng2, net2 = StubEngine({4097: 2e-4, 2048: 6e-4}), _net()                     # 2,048 fails: reads below 4,097 take fp32, the mode stays
+    net2.guard(eng2, _ids(4, 3000))
+    assert net2.selfcheck_report["f16c_min_len"] == 4097 and net2.selfcheck_report["fallback"] is False
+    assert [c[1] for c in eng2.calls] == [4097, 2048]                             # the 3,000-token batch itself runs in fp32: nothing to measure
+
+
+def test_longest_sample_or_batch_above_the_threshold_falls_back_for_good():
+    net = _net()
+    eng = StubEngine({4097: 8e-4})
+    with pytest.warns(RuntimeWarning, match="falling back to exact fp32"):
+        net.guard(eng, _ids(4, 8193))
+    assert net.selfcheck_report["fallback"] is True and eng.fallback is True and eng.min_len == 2048
+    n = len(eng.calls)
+    net.guard(eng, _ids(4, 100))
+    assert len(eng.calls) == n                                                    # nothing more to check once it has fallen back
+    net2, eng2 = _net(), StubEngine({4097: 1e-4, 2048: 1e-4, 1024: 1e-4, 512: 1e-4, 256: 1e-4}, batch_err=9e-4)
+    with pytest.warns(RuntimeWarning):
+        net2.guard(eng2, _ids(4, 8193))                                           # the samples pass, the real batch does not
+    assert net2.selfcheck_report["fallback"] is True and eng2.fallback is True
+
+
+def test_guard_is_off_for_fp32_and_optional_for_the_reduced_modes():
+    m32 = lm.ChimeraLM.new(precision="fp32").net
+    assert m32.selfcheck is False
+    eng = StubEngine({}, precision_code=0)
+    m32.guard(eng, _ids(2, 5000))
+    assert eng.calls == []
+    m16 = lm.ChimeraLM.new(precision="fp16").net                                  # reduced precision on request: not guarded unless asked
+    assert m16.selfcheck is False
+    m16b = lm.ChimeraLM.new(precision="fp16", selfcheck=True).net
+    eng16 = StubEngine({4097: 2e-4}, precision_code=2)
+    with warnings.catch_warnings():
+        warnings.simplefilter("error", RuntimeWarning)
+        m16b.guard(eng16, _ids(3, 3000))
+    assert [c[1] for c in eng16.calls] == [4097, 3000] and eng16.min_len == 2048  # one verdict, no length switch outside fp16c
+    off = lm.ChimeraLM.new(precision="fp16c", selfcheck=False).net
+    eng_off = StubEngine({})
+    off.guard(eng_off, _ids(2, 5000))
+    assert eng_off.calls == [] and off.selfcheck_report == {}
