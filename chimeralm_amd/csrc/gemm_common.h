@@ -316,6 +316,9 @@ __device__ __forceinline__ void load_set(const typename CT<PREC>::frag* wp, int 
                                          typename CT<PREC>::frag (&dst)[NT][SETK]) {
     constexpr int KSTEPS = 256 / CT<PREC>::MFMA_K, KSTEPS_ALL = K / CT<PREC>::MFMA_K;
     constexpr int FR = CT<PREC>::MFMA_K == 16 ? WFR<PREC> : 1, KP = SETK / FR;
+#ifdef CLM_EXP_NOW   // timing-only build: only the first set of a column block is ever loaded -- no weight stream at all, wrong results
+    if (kc != 0 || part != 0) return;
+#endif
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
         const typename CT<PREC>::frag* p =
