@@ -128,8 +128,6 @@ def bench_transformer(a):
     lo, hi = cdist.shard_bounds(a.batch, rank, world)
     L = a.bases + 1
     torch.manual_seed(0)
-    if a.precision == "fp16c":
-        a.precision = "fp16"     # this net's throughput mode; its gate mode is --precision fp32 (csrc/tf_fp32.hip, untuned)
     net = SequenceCNNTransformer(vocab_size=12, max_len=32768, num_encoder_layers=12, precision=a.precision)
     n_data = max(1, min(4, a.steps))
     batches = [torch.from_numpy(synthetic_ids(i, a.batch, a.bases)[lo:hi]).to(device) for i in range(n_data)]
@@ -171,6 +169,7 @@ def bench_transformer(a):
                "config": {"workload": f"synthetic {a.bases}-bp reads, global batch {a.batch}, 1 forward per step, "
                                       "SequenceCNNTransformer (12 layers)", "global_batch": a.batch, "tokens_per_read": L,
                           "reads_per_gpu": hi - lo},
+               "selfcheck": {k: v for k, v in net.selfcheck_report.items() if k != "samples"} or None,
                "roofline": {"bound": "mfma", "kernel": "whole forward (conv stack + encoder + attention)", "achieved": flops,
                             "peak": PEAK_TFLOPS[a.precision], "unit": "TFLOP/s", "frac": flops / PEAK_TFLOPS[a.precision],
                             "traffic": None}}

@@ -68,6 +68,9 @@ SYMBOLS = {
     "clm_tf_load_weight": (C.c_int, [_H, C.c_char_p, C.c_void_p, C.c_int, C.POINTER(C.c_int64), C.c_int]),
     "clm_tf_finalize": (C.c_int, [_H]),
     "clm_tf_forward": (C.c_int, [_H, C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "clm_tf_selfcheck": (C.c_int, [_H, C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_float),
+                                   C.POINTER(C.c_int)]),
+    "clm_tf_set_fallback": (C.c_int, [_H, C.c_int]),
     "clm_tf_debug_fetch": (C.c_int, [_H, C.c_char_p, C.c_void_p, C.c_size_t]),
     "clm_tf_profile_enable": (C.c_int, [_H, C.c_int]),
     "clm_tf_profile_read": (C.c_int, [_H, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.c_int]),

@@ -18,6 +18,7 @@
 // row offset 0 / 1 / 2 and the weight slice W[:, :, dk]; ReLU and the max-pool happen on the accumulator quads (4 consecutive
 // positions of one channel) before anything is written.
 #include <algorithm>
+#include <cmath>
 #include <cstdlib>
 #include <map>
 #include <string>
@@ -69,7 +70,7 @@ __global__ __launch_bounds__(512) void conv3_relu_pool_kernel(const unsigned cha
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lrow = lane & 31, lhalf = lane >> 5;
     const int b = blockIdx.y, t0 = blockIdx.x * 128;
     const frag* wp = reinterpret_cast<const frag*>(wpk);
-    constexpr size_t WSLICE = (size_t)D * D / 8;              // fragments per [256 x 256] slice
+    constexpr size_t WSLICE = (size_t)D * D / 8 * WFR<PREC>;  // fragments per [256 x 256] slice
     f32x16 acc[4];
     frag bs[2][1][SETK];
     load_set<PREC, D, 1>(wp, 0, 0, 0, wave, lane, bs[0]);
@@ -98,16 +99,9 @@ __global__ __launch_bounds__(512) void conv3_relu_pool_kernel(const unsigned cha
     __syncthreads();
     zero_acc(acc);
 #pragma unroll
-    for (int dk = 0; dk < 3; ++dk) {                          // y[t] += W[:, :, dk] x[t + dk - 1]
-        load_set<PREC, D, 1>(wp + dk * WSLICE, 0, 0, 1, wave, lane, bs[1]);
-        __builtin_amdgcn_sched_barrier(0);
-        compute_tm<PREC, false>(As + dk * RS16, 0, lrow, lhalf, bs[0], acc);
-        __builtin_amdgcn_sched_barrier(0);
-        load_set<PREC, D, 1>(wp + (dk < 2 ? dk + 1 : 0) * WSLICE, 0, 0, 0, wave, lane, bs[0]);
-        __builtin_amdgcn_sched_barrier(0);
-        compute_tm<PREC, false>(As + dk * RS16, 1, lrow, lhalf, bs[1], acc);
-        __builtin_amdgcn_sched_barrier(0);
-    }
+    for (int dk = 0; dk < 3; ++dk)                            // y[t] += W[:, :, dk] x[t + dk - 1]
+        phase_tm<PREC, D, D, false>(As + dk * RS16, wp + dk * WSLICE, 0, 0, wp + (dk < 2 ? dk + 1 : 0) * WSLICE, 0, 0, wave, lane, bs,
+                                    acc);
     // rows = positions (register quads = 4 consecutive positions), lane = output channel wave*32 + lrow
     elem* zs = Zs + wave * 64 * ZRS;
     const float bv = bias[wave * 32 + lrow];
@@ -259,14 +253,7 @@ __device__ __forceinline__ void act_blocks(const typename CT<PREC>::elem* As, ty
 #pragma unroll 1
     for (int nb = 0; nb < N / 256; ++nb) {
         zero_acc(acc);
-        load_set<PREC, D, 1>(wp, nb, 0, 1, wave, lane, bs[1]);
-        __builtin_amdgcn_sched_barrier(0);
-        compute_tm<PREC, true>(As, 0, lrow, lhalf, bs[0], acc);
-        __builtin_amdgcn_sched_barrier(0);
-        load_set<PREC, D, 1>(wp, nb + 1 < N / 256 ? nb + 1 : 0, 0, 0, wave, lane, bs[0]);
-        __builtin_amdgcn_sched_barrier(0);
-        compute_tm<PREC, true>(As, 1, lrow, lhalf, bs[1], acc);
-        __builtin_amdgcn_sched_barrier(0);
+        phase_tm<PREC, D, D, true>(As, wp, nb, 0, wp, nb + 1 < N / 256 ? nb + 1 : 0, 0, wave, lane, bs, acc);
         // rows = features (register quads), lane = token
         const float* bp = bias + nb * 256 + wave * 32 + 4 * lhalf;
 #pragma unroll
@@ -311,16 +298,15 @@ __global__ __launch_bounds__(512) void linear16_kernel(LinArgs m) {
         float* P1 = reinterpret_cast<float*>(smem + (size_t)2 * 128 * RS16 * 2);   // tables behind the 128 KiB staging area
         float* P2 = P1 + 16 * 128;
         zero_acc(acc);
+        load_set<PREC, K, 1>(wp, 0, 0, 0, wave, lane, bs[0]);
 #pragma unroll 1
-        for (int kc = 0; kc < K / 256; ++kc) {
-            load_set<PREC, K, 1>(wp, 0, kc, 0, wave, lane, bs[0]);
+        for (int kc = 0; kc < K / 256; ++kc) {                 // (bs[0] holds the chunk's first set: requested a chunk ahead)
             load_set<PREC, K, 1>(wp, 0, kc, 1, wave, lane, bs[1]);
             __builtin_amdgcn_sched_barrier(0);
             if (kc > 0) __syncthreads();                       // every wave is done with the previous chunk of the tile
             stage_rows16<PREC>(a, row0, m.M, K, kc, As, tid);
             __syncthreads();
-            compute_tm<PREC, true>(As, 0, lrow, lhalf, bs[0], acc);
-            compute_tm<PREC, true>(As, 1, lrow, lhalf, bs[1], acc);
+            phase_tm<PREC, K, K, true, true>(As, wp, 0, kc, wp, 0, kc + 1 < K / 256 ? kc + 1 : 0, wave, lane, bs, acc);
         }
         const int l_valid = res_ln<PREC>(acc, m.bias, m.h, m.ln_g, m.ln_b, m.eps, row0, m.M, As, P1, P2);
         store_h_hx<PREC>(acc, m.h, reinterpret_cast<elem*>(m.hx), row0, l_valid, smem, As);
@@ -374,12 +360,7 @@ __global__ __launch_bounds__(512) void enc_ffn16_kernel(FfnArgs m) {
         stage_rows16<PREC>(reinterpret_cast<const elem*>(m.att), row0, m.M, D, 0, As, tid);
         __syncthreads();
         zero_acc(acc2);
-        compute_tm<PREC, true>(As, 0, lrow, lhalf, bs[0], acc2);
-        __builtin_amdgcn_sched_barrier(0);
-        load_set<PREC, D, 1>(w1, 0, 0, 0, wave, lane, bs[0]);   // first fc1 half-set under the second half
-        __builtin_amdgcn_sched_barrier(0);
-        compute_tm<PREC, true>(As, 1, lrow, lhalf, bs[1], acc2);
-        __builtin_amdgcn_sched_barrier(0);
+        phase_tm<PREC, D, D, true, true>(As, wo, 0, 0, w1, 0, 0, wave, lane, bs, acc2);   // (the first fc1 set under its last set)
         res_ln<PREC>(acc2, m.b_o, m.h, m.ln1_g, m.ln1_b, m.eps, row0, m.M, As, P1, P2);   // acc2 = x1, As = x1 (16-bit)
     } else {
         load_set<PREC, D, 1>(w1, 0, 0, 0, wave, lane, bs[0]);
@@ -391,14 +372,7 @@ __global__ __launch_bounds__(512) void enc_ffn16_kernel(FfnArgs m) {
 #pragma unroll 1
     for (int j = 0; j < NCH; ++j) {
         zero_acc(acc1);
-        load_set<PREC, D, 1>(w1, j, 0, 1, wave, lane, bs[1]);
-        __builtin_amdgcn_sched_barrier(0);
-        compute_tm<PREC, true>(As, 0, lrow, lhalf, bs[0], acc1);
-        __builtin_amdgcn_sched_barrier(0);
-        load_set<PREC, TFF, 1>(w2, 0, j, 0, wave, lane, bs[0]);
-        __builtin_amdgcn_sched_barrier(0);
-        compute_tm<PREC, true>(As, 1, lrow, lhalf, bs[1], acc1);
-        __builtin_amdgcn_sched_barrier(0);
+        phase_tm<PREC, D, TFF, true>(As, w1, j, 0, w2, 0, j, wave, lane, bs, acc1);
         __syncthreads();                                       // every wave is done reading the previous chunk of Hs
         {
             const float* b1 = m.b1 + j * 256 + wave * 32 + 4 * lhalf;
@@ -414,14 +388,7 @@ __global__ __launch_bounds__(512) void enc_ffn16_kernel(FfnArgs m) {
             }
         }
         __syncthreads();
-        load_set<PREC, TFF, 1>(w2, 0, j, 1, wave, lane, bs[1]);
-        __builtin_amdgcn_sched_barrier(0);
-        compute_tm<PREC, true>(Hs, 0, lrow, lhalf, bs[0], acc2);
-        __builtin_amdgcn_sched_barrier(0);
-        load_set<PREC, D, 1>(w1, j + 1 < NCH ? j + 1 : 0, 0, 0, wave, lane, bs[0]);
-        __builtin_amdgcn_sched_barrier(0);
-        compute_tm<PREC, true>(Hs, 1, lrow, lhalf, bs[1], acc2);
-        __builtin_amdgcn_sched_barrier(0);
+        phase_tm<PREC, TFF, D, true>(Hs, w2, 0, j, w1, j + 1 < NCH ? j + 1 : 0, 0, wave, lane, bs, acc2);
     }
     if (m.w_qkv) load_set<PREC, D, 1>(reinterpret_cast<const frag*>(m.w_qkv), 0, 0, 0, wave, lane, bs[0]);
     const int l_valid = res_ln<PREC>(acc2, m.b2, whole ? nullptr : m.h, m.ln_g, m.ln_b, m.eps, row0, m.M, As, P1, P2);
@@ -510,12 +477,16 @@ struct clm_tf_handle {
     bool finalized = false;
     // workspace
     size_t cap_rows = 0, cap_tok = 0;
+    size_t cap16[7] = {};                         // bytes of x1, x2, x3, hx, qkv, att, u
     unsigned char* ids8 = nullptr;
     void *x1 = nullptr, *x2 = nullptr, *x3 = nullptr, *hx = nullptr, *qkv = nullptr, *att = nullptr, *u = nullptr;
     float *h = nullptr, *scores = nullptr, *pooled = nullptr;
     float* ws32 = nullptr;                        // fp32 mode: activations of tf_fp32.hip
     size_t cap_ws32 = 0;
     int last_B = 0, last_L3 = 0;
+    bool fallback32 = false;                      // clm_tf_set_fallback: a 16-bit handle runs tf_fp32.hip (the raw fp32 tensors stay loaded)
+    float* sc_logits = nullptr;                   // clm_tf_selfcheck: [2][cap] device logits of the two forwards
+    int sc_cap = 0;
     // profiling taps (clm_tf_profile_*): HIP events on the launch stream around each stage, stages: 0 conv stack + pe/LN,
     // 1 attention, 2 encoder layer kernel (out_proj + LN1 + FFN + LN2 + next QKV; the unfused pieces count here too), 3 pooling head
     bool prof = false;
@@ -591,6 +562,7 @@ void tf_free_ws(clm_tf_handle* h) {
     h->ids8 = nullptr; h->x1 = h->x2 = h->x3 = h->hx = h->qkv = h->att = h->u = nullptr;
     h->h = h->scores = h->pooled = h->ws32 = nullptr;
     h->cap_rows = h->cap_tok = h->cap_ws32 = 0;
+    for (size_t& c : h->cap16) c = 0;
 }
 
 template <int PREC, int EPI, int K, int N>
@@ -687,15 +659,17 @@ extern "C" {
 
 int clm_tf_create(int device, int precision, int n_layers, clm_tf_handle** out) {
     if (!out || n_layers < 1 || n_layers > 64) return tf_fail(nullptr, CLM_E_INVALID, "clm_tf_create: bad argument");
-    if (precision != CLM_PREC_F16 && precision != CLM_PREC_BF16 && precision != CLM_PREC_F32)
-        return tf_fail(nullptr, CLM_E_UNSUPPORTED, "clm_tf_create: precision must be fp32 (exact, the reference's arithmetic), fp16 or bf16");
+    if (precision != CLM_PREC_F16 && precision != CLM_PREC_BF16 && precision != CLM_PREC_F32 && precision != CLM_PREC_F16C)
+        return tf_fail(nullptr, CLM_E_UNSUPPORTED,
+                       "clm_tf_create: precision must be fp32 (exact, the reference's arithmetic), fp16c, fp16 or bf16");
     if (hipSetDevice(device) != hipSuccess) return tf_fail(nullptr, CLM_E_HIP, "clm_tf_create: hipSetDevice failed");
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) != hipSuccess || std::string(prop.gcnArchName).rfind("gfx950", 0) != 0)
         return tf_fail(nullptr, CLM_E_UNSUPPORTED, "clm_tf_create: this engine is built for gfx950 (MI355X) only");
     clm_tf_handle* h = new clm_tf_handle();
     h->device = device;
-    h->prec = precision == CLM_PREC_BF16 ? PREC_BF16 : precision == CLM_PREC_F32 ? PREC_F32 : PREC_F16;
+    h->prec = precision == CLM_PREC_BF16 ? PREC_BF16 : precision == CLM_PREC_F32 ? PREC_F32 : precision == CLM_PREC_F16C ? PREC_F16C
+                                                                                                                       : PREC_F16;
     h->n_layers = n_layers;
     *out = h;
     return CLM_OK;
@@ -772,30 +746,29 @@ int clm_tf_finalize(clm_tf_handle* h) {
     return CLM_OK;
 }
 
-int clm_tf_forward(clm_tf_handle* h, const void* ids, int ids_dtype, int64_t ids_row_stride, int B, int L, float* logits_out,
-                   void* stream) {
-    if (!h) return CLM_E_INVALID;
-    if (!h->finalized) return tf_fail(h, CLM_E_STATE, "clm_tf_forward before clm_tf_finalize");
-    if (!ids || !logits_out || B < 1 || L < 8 || ids_row_stride < L) return tf_fail(h, CLM_E_INVALID, "clm_tf_forward: bad argument (L >= 8)");
-    if (ids_dtype != CLM_DT_I64 && ids_dtype != CLM_DT_I32 && ids_dtype != CLM_DT_U8)
-        return tf_fail(h, CLM_E_INVALID, "clm_tf_forward: ids dtype must be i64, i32 or u8");
+// One forward in the arithmetic `prec32 ? exact fp32 : the handle's 16-bit mode` (workspaces of BOTH kinds may be live: the
+// self-check runs one after the other on the same ids).
+static int tf_run(clm_tf_handle* h, bool prec32, const void* ids, int ids_dtype, int64_t ids_row_stride, int B, int L,
+                  float* logits_out, hipStream_t st) {
     const int L3 = L / 8;
-    if ((int64_t)L3 > h->shape.at("pos_encoder.pe")[1])
-        return tf_fail(h, CLM_E_INVALID, "clm_tf_forward: Sequence too long (" + std::to_string(L3) + " > max_len of pos_encoder.pe)");
-    TFCHK(h, hipSetDevice(h->device));
     const size_t M = (size_t)B * L3, tok = (size_t)B * ((L + 63) / 64 * 64);
-    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    if (h->prec == PREC_F32) {
+    if (M > h->cap_rows || tok > h->cap_tok) {                // shared pieces: ids, residual stream, pooling
+        TFCHK(h, hipDeviceSynchronize());
+        tf_free_ws(h);
+        TFCHK(h, hipMalloc((void**)&h->ids8, tok));
+        TFCHK(h, hipMalloc((void**)&h->h, M * D * 4));
+        TFCHK(h, hipMalloc((void**)&h->scores, M * 4));
+        TFCHK(h, hipMalloc((void**)&h->pooled, (size_t)B * D * 4));
+        h->cap_rows = M; h->cap_tok = tok;
+    }
+    if (prec32) {
         const size_t need = tf32_workspace_floats(B, L);
-        if (M > h->cap_rows || tok > h->cap_tok || need > h->cap_ws32) {
+        if (need > h->cap_ws32) {
             TFCHK(h, hipDeviceSynchronize());
-            tf_free_ws(h);
-            TFCHK(h, hipMalloc((void**)&h->ids8, tok));
+            if (h->ws32) (void)hipFree(h->ws32);
+            h->ws32 = nullptr; h->cap_ws32 = 0;
             TFCHK(h, hipMalloc((void**)&h->ws32, need * 4));
-            TFCHK(h, hipMalloc((void**)&h->h, M * D * 4));
-            TFCHK(h, hipMalloc((void**)&h->scores, M * 4));
-            TFCHK(h, hipMalloc((void**)&h->pooled, (size_t)B * D * 4));
-            h->cap_rows = M; h->cap_tok = tok; h->cap_ws32 = need;
+            h->cap_ws32 = need;
         }
         const int Lp = (L + 63) / 64 * 64;
         launch_embed(ids, ids_dtype, ids_row_stride, nullptr, nullptr, h->ids8, B, L, Lp, st);
@@ -809,25 +782,96 @@ int clm_tf_forward(clm_tf_handle* h, const void* ids, int ids_dtype, int64_t ids
         h->last_B = B; h->last_L3 = L3;
         return hipGetLastError() == hipSuccess ? CLM_OK : tf_fail(h, CLM_E_HIP, "clm_tf_forward (fp32): launch failed");
     }
-    if (M > h->cap_rows || tok > h->cap_tok) {
-        TFCHK(h, hipDeviceSynchronize());
-        tf_free_ws(h);
-        TFCHK(h, hipMalloc((void**)&h->ids8, tok));
-        TFCHK(h, hipMalloc(&h->x1, (size_t)B * (L / 2) * D * 2));
-        TFCHK(h, hipMalloc(&h->x2, (size_t)B * (L / 4) * D * 2));
-        TFCHK(h, hipMalloc(&h->x3, M * D * 2));
-        TFCHK(h, hipMalloc(&h->hx, M * D * 2));
-        TFCHK(h, hipMalloc(&h->qkv, M * tf::TQKV * 2));
-        TFCHK(h, hipMalloc(&h->att, M * D * 2));
-        TFCHK(h, hipMalloc(&h->u, M * tf::TFF * 2));
-        TFCHK(h, hipMalloc((void**)&h->h, M * D * 4));
-        TFCHK(h, hipMalloc((void**)&h->scores, M * 4));
-        TFCHK(h, hipMalloc((void**)&h->pooled, (size_t)B * D * 4));
-        h->cap_rows = M; h->cap_tok = tok;
+    {   // the 16-bit activations, each buffer grown on its own (x1 / x2 scale with B * (L / 2), B * (L / 4), not with M)
+        const size_t need[7] = {(size_t)B * (L / 2) * D * 2, (size_t)B * (L / 4) * D * 2, M * D * 2, M * D * 2, M * tf::TQKV * 2,
+                                M * D * 2, M * tf::TFF * 2};
+        void** buf[7] = {&h->x1, &h->x2, &h->x3, &h->hx, &h->qkv, &h->att, &h->u};
+        bool grow = false;
+        for (int i = 0; i < 7; ++i) grow |= need[i] > h->cap16[i];
+        if (grow) {
+            TFCHK(h, hipDeviceSynchronize());
+            for (int i = 0; i < 7; ++i)
+                if (need[i] > h->cap16[i]) {
+                    if (*buf[i]) (void)hipFree(*buf[i]);
+                    *buf[i] = nullptr; h->cap16[i] = 0;
+                    TFCHK(h, hipMalloc(buf[i], need[i]));
+                    h->cap16[i] = need[i];
+                }
+        }
     }
-    const int rc = h->prec == PREC_BF16 ? tf_forward_t<PREC_BF16>(h, ids, ids_dtype, ids_row_stride, B, L, logits_out, st)
-                                        : tf_forward_t<PREC_F16>(h, ids, ids_dtype, ids_row_stride, B, L, logits_out, st);
+    const int rc = h->prec == PREC_BF16   ? tf_forward_t<PREC_BF16>(h, ids, ids_dtype, ids_row_stride, B, L, logits_out, st)
+                   : h->prec == PREC_F16C ? tf_forward_t<PREC_F16C>(h, ids, ids_dtype, ids_row_stride, B, L, logits_out, st)
+                                          : tf_forward_t<PREC_F16>(h, ids, ids_dtype, ids_row_stride, B, L, logits_out, st);
     if (rc) return tf_fail(h, rc, std::string("clm_tf_forward: ") + hipGetErrorString(hipGetLastError()));
+    return CLM_OK;
+}
+
+static int tf_check_args(clm_tf_handle* h, const char* who, const void* ids, int ids_dtype, int64_t ids_row_stride, int B, int L) {
+    if (!h->finalized) return tf_fail(h, CLM_E_STATE, std::string(who) + " before clm_tf_finalize");
+    if (!ids || B < 1 || L < 8 || ids_row_stride < L) return tf_fail(h, CLM_E_INVALID, std::string(who) + ": bad argument (L >= 8)");
+    if (ids_dtype != CLM_DT_I64 && ids_dtype != CLM_DT_I32 && ids_dtype != CLM_DT_U8)
+        return tf_fail(h, CLM_E_INVALID, std::string(who) + ": ids dtype must be i64, i32 or u8");
+    if ((int64_t)(L / 8) > h->shape.at("pos_encoder.pe")[1])
+        return tf_fail(h, CLM_E_INVALID, std::string(who) + ": Sequence too long (" + std::to_string(L / 8) + " > max_len of pos_encoder.pe)");
+    return CLM_OK;
+}
+
+int clm_tf_forward(clm_tf_handle* h, const void* ids, int ids_dtype, int64_t ids_row_stride, int B, int L, float* logits_out,
+                   void* stream) {
+    if (!h) return CLM_E_INVALID;
+    if (!logits_out) return tf_fail(h, CLM_E_INVALID, "clm_tf_forward: bad argument (L >= 8)");
+    if (int rc = tf_check_args(h, "clm_tf_forward", ids, ids_dtype, ids_row_stride, B, L)) return rc;
+    TFCHK(h, hipSetDevice(h->device));
+    return tf_run(h, h->prec == PREC_F32 || h->fallback32, ids, ids_dtype, ids_row_stride, B, L, logits_out,
+                  reinterpret_cast<hipStream_t>(stream));
+}
+
+// The handle's 16-bit mode on trial against the exact-fp32 kernels of the same handle, on the caller's ids (chimeralm_hip.h;
+// the counterpart of clm_selfcheck).  Synchronises `stream`.
+int clm_tf_selfcheck(clm_tf_handle* h, const void* ids, int ids_dtype, int64_t ids_row_stride, int B, int L, void* stream,
+                     float* max_abs_diff_out, int* labels_differ_out) {
+    if (!h) return CLM_E_INVALID;
+    if (int rc = tf_check_args(h, "clm_tf_selfcheck", ids, ids_dtype, ids_row_stride, B, L)) return rc;
+    if (B > 4096) return tf_fail(h, CLM_E_INVALID, "clm_tf_selfcheck: at most 4096 reads per call");
+    TFCHK(h, hipSetDevice(h->device));
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    float diff = 0.f;
+    int differ = 0;
+    if (h->prec != PREC_F32) {
+        if (B > h->sc_cap) {
+            TFCHK(h, hipDeviceSynchronize());
+            if (h->sc_logits) (void)hipFree(h->sc_logits);
+            h->sc_logits = nullptr; h->sc_cap = 0;
+            TFCHK(h, hipMalloc((void**)&h->sc_logits, (size_t)2 * B * NCLS * 4));
+            h->sc_cap = B;
+        }
+        float* lm = h->sc_logits;
+        float* lx = h->sc_logits + (size_t)h->sc_cap * NCLS;
+        if (int rc = tf_run(h, false, ids, ids_dtype, ids_row_stride, B, L, lm, st)) return rc;
+        if (int rc = tf_run(h, true, ids, ids_dtype, ids_row_stride, B, L, lx, st)) return rc;
+        std::vector<float> a((size_t)B * NCLS), b((size_t)B * NCLS);
+        TFCHK(h, hipMemcpyAsync(a.data(), lm, a.size() * 4, hipMemcpyDeviceToHost, st));
+        TFCHK(h, hipMemcpyAsync(b.data(), lx, b.size() * 4, hipMemcpyDeviceToHost, st));
+        TFCHK(h, hipStreamSynchronize(st));
+        for (int r = 0; r < B; ++r) {
+            int am = 0, bm = 0;
+            for (int c = 0; c < NCLS; ++c) {
+                const float d = std::fabs(a[(size_t)r * NCLS + c] - b[(size_t)r * NCLS + c]);
+                if (!(d <= diff)) diff = d;                    // NaN-propagating maximum
+                if (a[(size_t)r * NCLS + c] > a[(size_t)r * NCLS + am]) am = c;
+                if (b[(size_t)r * NCLS + c] > b[(size_t)r * NCLS + bm]) bm = c;
+            }
+            differ += am != bm;
+        }
+    }
+    if (max_abs_diff_out) *max_abs_diff_out = diff;
+    if (labels_differ_out) *labels_differ_out = differ;
+    return CLM_OK;
+}
+
+int clm_tf_set_fallback(clm_tf_handle* h, int on) {
+    if (!h) return CLM_E_INVALID;
+    h->fallback32 = on != 0;
     return CLM_OK;
 }
 
@@ -883,6 +927,7 @@ int clm_tf_destroy(clm_tf_handle* h) {
     (void)hipSetDevice(h->device);
     (void)hipDeviceSynchronize();
     tf_free_ws(h);
+    if (h->sc_logits) (void)hipFree(h->sc_logits);
     for (auto& r : h->recs) { (void)hipEventDestroy(r.second.first); (void)hipEventDestroy(r.second.second); }
     for (auto& kv : h->w) (void)hipFree(kv.second);
     for (auto& kv : h->packed) (void)hipFree(kv.second);

@@ -5,7 +5,11 @@ Same constructor arguments, same `state_dict()` keys (torch's own modules are us
 `transformer_encoder.layers.{i}.self_attn.in_proj_weight` etc. come out exactly as in the reference, and `pos_encoder.pe` is a
 buffer of the same shape), same `forward(input_ids, input_quals=None) -> logits [B, 2]`, same `number_of_classes` attribute that
 `ClassificationLit` reads.  The arithmetic runs in csrc/tf_model.hip + csrc/attention.hip behind the `clm_tf_*` C ABI; there is no
-CPU path.  Engine knob absent in the reference: `precision` in {"fp32", "fp16", "bf16"} (fp32 = the reference's arithmetic).
+CPU path.  Engine knobs absent in the reference: `precision` in {"fp32", "fp16c", "fp16", "bf16"} (fp32 = the reference's arithmetic;
+fp16c = fp16 activations x weights as fp16 hi + fp8 lo, the Hyena path's compensated mode) and `selfcheck` /
+`selfcheck_tol`: before the first batch after a weight load (and again for a batch less than half as long as any checked so far) the
+16-bit mode is measured against the exact-fp32 kernels of the same engine on seeded reads and on the batch's first reads
+(`clm_tf_selfcheck`); above the threshold the module falls back to fp32 for good and says so.  On by default for fp16c.
 """
 from __future__ import annotations
 
@@ -37,15 +41,20 @@ class TransformerEngineError(RuntimeError):
 class SequenceCNNTransformer(nn.Module):
     def __init__(self, vocab_size: int, max_len: int, d_model: int = 256, cnn_kernel_size: int = 3, dropout: float = 0.1,
                  num_encoder_layers: int = 2, nhead: int = 8, dim_feedforward: int = 1024, number_of_classes: int = 2,
-                 padding_idx: int = 4, *, precision: str = "fp16"):
+                 padding_idx: int = 4, *, precision: str = "fp16", selfcheck: bool | None = None, selfcheck_tol: float = 5e-4):
         super().__init__()
         if (vocab_size, d_model, cnn_kernel_size, nhead, dim_feedforward, number_of_classes) != (12, 256, 3, 8, 1024, 2):
             raise NotImplementedError("the MI355X encoder implements the production shape: vocab 12, d_model 256, kernel 3, "
                                       "8 heads, feed-forward 1024, 2 classes (configs/model/transformer.yaml)")
-        if precision not in ("fp32", "fp16", "bf16"):
-            raise ValueError("precision must be fp32 (exact fp32 products: the reference's arithmetic, the parity mode) or "
-                             "fp16 / bf16 (16-bit MFMA inputs, fp32 accumulation and statistics: the throughput modes)")
+        if precision not in ("fp32", "fp16c", "fp16", "bf16"):
+            raise ValueError("precision must be fp32 (exact fp32 products: the reference's arithmetic, the parity mode), fp16c "
+                             "(fp16 activations x hi + lo weights, self-checked) or fp16 / bf16 (plain 16-bit MFMA inputs, fp32 "
+                             "accumulation and statistics: reduced precision)")
         self.number_of_classes, self.precision, self.num_encoder_layers = number_of_classes, precision, num_encoder_layers
+        self.selfcheck = (precision == "fp16c") if selfcheck is None else bool(selfcheck)
+        self.selfcheck_tol = float(selfcheck_tol)
+        self.selfcheck_report: dict = {}
+        self._checked_min_len: int | None = None
         self.embedding = nn.Embedding(vocab_size, d_model, padding_idx=padding_idx)
         self.pos_encoder = _PosEnc(d_model, max_len)
         conv = lambda: nn.Conv1d(d_model, d_model, kernel_size=cnn_kernel_size, padding=1)  # noqa: E731
@@ -81,8 +90,49 @@ class SequenceCNNTransformer(nn.Module):
                 shape = (C.c_int64 * t.dim())(*t.shape)
                 self._check(lib.clm_tf_load_weight(self._h, k.encode(), C.c_void_p(t.data_ptr()), N.DT_F32, shape, t.dim()))
             self._check(lib.clm_tf_finalize(self._h))
-            self._sig = sig
+            self._check(lib.clm_tf_set_fallback(self._h, 0))
+            self._sig, self._checked_min_len, self.selfcheck_report = sig, None, {}
         return lib
+
+    # ------------------------------------------------------------------ the 16-bit mode on trial
+    def _measure(self, lib, name: str, ids: torch.Tensor) -> float:
+        diff, differ = C.c_float(), C.c_int()
+        dt = {torch.int64: N.DT_I64, torch.int32: N.DT_I32, torch.uint8: N.DT_U8}[ids.dtype]
+        self._check(lib.clm_tf_selfcheck(self._h, C.c_void_p(ids.data_ptr()), dt, ids.stride(0), ids.shape[0], ids.shape[1],
+                                         C.c_void_p(torch.cuda.current_stream(ids.device).cuda_stream), C.byref(diff),
+                                         C.byref(differ)))
+        self.selfcheck_report.setdefault("samples", []).append(
+            {"sample": name, "max_abs_dlogit": diff.value, "labels_differ": differ.value})
+        return diff.value
+
+    def guard(self, lib, input_ids: torch.Tensor) -> None:
+        """Self-check of the 16-bit mode where one is due (see the module docstring)."""
+        rep = self.selfcheck_report
+        L = input_ids.shape[1]
+        if not self.selfcheck or self.precision == "fp32" or rep.get("fallback") or not (
+                self._checked_min_len is None or 2 * L < self._checked_min_len):
+            return
+        worst = rep.get("max_abs_dlogit", 0.0)
+        if self._checked_min_len is None:                      # first batch since the weights were loaded: seeded reads
+            g = torch.Generator().manual_seed(20241)
+            ids = torch.randint(7, 11, (4, 4096), generator=g, dtype=torch.uint8)
+            ids[0, :1300] = 4                                  # one read left-padded, as the collator pads
+            worst = max(worst, self._measure(lib, "synthetic 4 x 4096", ids.to(input_ids.device)))
+        worst = max(worst, self._measure(lib, f"batch rows 0..{min(input_ids.shape[0], 4) - 1} x {L}", input_ids[:4]))
+        rep.update(max_abs_dlogit=worst, tol=self.selfcheck_tol, precision=self.precision)
+        self._checked_min_len = L if self._checked_min_len is None else min(L, self._checked_min_len)
+        if not worst <= self.selfcheck_tol:                    # (NaN fails too)
+            self._check(lib.clm_tf_set_fallback(self._h, 1))
+            rep["fallback"] = True
+            import logging
+            import warnings
+
+            msg = (f"chimeralm_amd: SequenceCNNTransformer precision={self.precision!r} differs from the exact-fp32 kernels by "
+                   f"{worst:.2e} in the logits on the loaded weights (threshold {self.selfcheck_tol:.1e}); falling back to exact "
+                   "fp32 for this model (the reference's arithmetic, about 12x slower)")
+            logging.getLogger("chimeralm_amd").warning(msg)
+            warnings.warn(msg, RuntimeWarning, stacklevel=3)
+        rep.setdefault("fallback", False)
 
     def forward(self, input_ids: torch.Tensor, input_quals: torch.Tensor | None = None) -> torch.Tensor:
         """`input_quals` is accepted and ignored, as in the reference (transformer.py:88)."""
@@ -93,6 +143,7 @@ class SequenceCNNTransformer(nn.Module):
         if input_ids.stride(1) != 1:
             input_ids = input_ids.contiguous()
         lib = self._engine(input_ids.device)
+        self.guard(lib, input_ids)
         B, L = input_ids.shape
         out = torch.empty((B, 2), dtype=torch.float32, device=input_ids.device)
         dt = {torch.int64: N.DT_I64, torch.int32: N.DT_I32, torch.uint8: N.DT_U8}[input_ids.dtype]

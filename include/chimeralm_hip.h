@@ -162,12 +162,19 @@ int clm_attention_fwd(const void* qkv, void* out, int B, int L, int precision, v
  * asserts the same, transformer.py:21).  clm_tf_debug_fetch names: "hidden" fp32 [B, L/8, 256] (encoder output),
  * "scores" fp32 [B, L/8] (pooling scores before the softmax), "pooled" fp32 [B, 256]. */
 typedef struct clm_tf_handle clm_tf_handle;
-int clm_tf_create(int device, int precision /* CLM_PREC_F32 (exact, parity mode) | CLM_PREC_F16 | CLM_PREC_BF16 */, int n_layers,
-                  clm_tf_handle** out);
+int clm_tf_create(int device, int precision /* CLM_PREC_F32 (exact, parity mode) | CLM_PREC_F16C | CLM_PREC_F16 | CLM_PREC_BF16 */,
+                  int n_layers, clm_tf_handle** out);
 int clm_tf_load_weight(clm_tf_handle* h, const char* key, const void* data, int dtype, const int64_t* shape, int ndim);
 int clm_tf_finalize(clm_tf_handle* h);
 int clm_tf_forward(clm_tf_handle* h, const void* ids, int ids_dtype, int64_t ids_row_stride, int B, int L, float* logits_out,
                    void* stream);
+/* Round 3: the 16-bit mode on trial, as clm_selfcheck / clm_set_fallback for the Hyena engine.  A 16-bit handle keeps the raw fp32
+ * tensors, so the exact-fp32 kernels (tf_fp32.hip) can run on the same handle: clm_tf_selfcheck runs `ids` through the handle's
+ * mode and through them, synchronises `stream` and reports max |logit difference| and the number of reads whose label differs
+ * (0 / 0 on an fp32 handle); clm_tf_set_fallback(h, 1) makes every later clm_tf_forward of the handle use the fp32 kernels. */
+int clm_tf_selfcheck(clm_tf_handle* h, const void* ids, int ids_dtype, int64_t ids_row_stride, int B, int L, void* stream,
+                     float* max_abs_diff_out, int* labels_differ_out);
+int clm_tf_set_fallback(clm_tf_handle* h, int on);
 int clm_tf_debug_fetch(clm_tf_handle* h, const char* name, void* host_out, size_t bytes);
 /* Profiling taps of the 16-bit path (bench.py --net transformer): accumulated HIP-event time on the launch stream and number of
  * spans per stage -- 0 conv stack + positional encoding / LayerNorm, 1 attention, 2 encoder layer kernel (out_proj + LayerNorm-1
