@@ -50,9 +50,17 @@ __device__ __forceinline__ int v_row(int k) { return (k & ~12) | ((k & 4) << 1) 
 
 }  // namespace
 
-template <int PREC>
+// HILO (round 3, the transformer's fp16c mode): the output leaves as TWO 16-bit planes, out[0] = fp16(64 a) and out[1] =
+// fp16(64 a - out[0]), `plane` elements apart.  The attention output is close to the same vector at every position of a read
+// (an average of v over all keys), so its rounding to 16 bits is the one activation rounding of this net that does NOT average
+// out in the pooling: measured on the CPU (tests/tf_error_probe.py) it alone moves the logits by 2-4e-3 where every other
+// operand's rounding stays below 1e-3.  The factor 64 (exact) keeps the lo plane out of fp16's subnormal range; out_proj
+// multiplies both planes by the same weights and scales its accumulators by 1/64 (tf_model.hip, enc_ffn16_kernel).
+constexpr float ATT_HILO_SCALE = 64.0f;
+
+template <int PREC, bool HILO = false>
 __global__ __launch_bounds__(256, 4) void attention_fwd_kernel(const typename CT<PREC>::elem* __restrict__ qkv,
-                                                            typename CT<PREC>::elem* __restrict__ out, int L) {
+                                                            typename CT<PREC>::elem* __restrict__ out, int L, size_t plane) {
     using elem = typename CT<PREC>::elem;
     __shared__ __attribute__((aligned(16))) elem Ks[2][KT * KRS];
     __shared__ __attribute__((aligned(16))) elem Vs[2][KT * VRS];
@@ -175,22 +183,32 @@ __global__ __launch_bounds__(256, 4) void attention_fwd_kernel(const typename CT
     const int q = q0 + wave * 32 + n;
     if (q < L) {
         elem* op = out + ((size_t)b * L + q) * D + h * HD + 4 * hf;
+        const float sc = HILO ? inv * ATT_HILO_SCALE : inv;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            u16x4 pk = {from_float<elem>(o[4 * g + 0] * inv).bits, from_float<elem>(o[4 * g + 1] * inv).bits,
-                        from_float<elem>(o[4 * g + 2] * inv).bits, from_float<elem>(o[4 * g + 3] * inv).bits};
+            const elem e0 = from_float<elem>(o[4 * g + 0] * sc), e1 = from_float<elem>(o[4 * g + 1] * sc),
+                       e2 = from_float<elem>(o[4 * g + 2] * sc), e3 = from_float<elem>(o[4 * g + 3] * sc);
+            u16x4 pk = {e0.bits, e1.bits, e2.bits, e3.bits};
             *reinterpret_cast<u16x4*>(op + 8 * g) = pk;
+            if constexpr (HILO) {
+                u16x4 pl = {from_float<elem>(o[4 * g + 0] * sc - to_float(e0)).bits, from_float<elem>(o[4 * g + 1] * sc - to_float(e1)).bits,
+                            from_float<elem>(o[4 * g + 2] * sc - to_float(e2)).bits, from_float<elem>(o[4 * g + 3] * sc - to_float(e3)).bits};
+                *reinterpret_cast<u16x4*>(op + plane + 8 * g) = pl;
+            }
         }
     }
 }
 
-void launch_attention_fwd(int prec, const void* qkv, void* out, int B, int L, hipStream_t st) {
+void launch_attention_fwd(int prec, const void* qkv, void* out, int B, int L, hipStream_t st, bool hilo) {
     static_assert(NH == 8, "the workgroup -> XCD mapping assumes 8 heads");
     dim3 grid((unsigned)(((L + QT - 1) / QT) * NH * B)), block(256);
+    const size_t plane = (size_t)B * L * D;
     if (prec == PREC_BF16)
-        hipLaunchKernelGGL(attention_fwd_kernel<PREC_BF16>, grid, block, 0, st, (const bf16_t*)qkv, (bf16_t*)out, L);
+        hipLaunchKernelGGL(attention_fwd_kernel<PREC_BF16>, grid, block, 0, st, (const bf16_t*)qkv, (bf16_t*)out, L, plane);
+    else if (hilo)
+        hipLaunchKernelGGL((attention_fwd_kernel<PREC_F16, true>), grid, block, 0, st, (const f16_t*)qkv, (f16_t*)out, L, plane);
     else
-        hipLaunchKernelGGL(attention_fwd_kernel<PREC_F16>, grid, block, 0, st, (const f16_t*)qkv, (f16_t*)out, L);
+        hipLaunchKernelGGL(attention_fwd_kernel<PREC_F16>, grid, block, 0, st, (const f16_t*)qkv, (f16_t*)out, L, plane);
 }
 
 }  // namespace clm
@@ -199,6 +217,6 @@ void launch_attention_fwd(int prec, const void* qkv, void* out, int B, int L, hi
 extern "C" int clm_attention_fwd(const void* qkv, void* out, int B, int L, int precision, void* stream) {
     if (!qkv || !out || B < 1 || L < 1 || (precision != CLM_PREC_F16 && precision != CLM_PREC_BF16)) return CLM_E_INVALID;
     clm::launch_attention_fwd(precision == CLM_PREC_BF16 ? clm::PREC_BF16 : clm::PREC_F16, qkv, out, B, L,
-                              reinterpret_cast<hipStream_t>(stream));
+                              reinterpret_cast<hipStream_t>(stream), false);
     return hipGetLastError() == hipSuccess ? CLM_OK : CLM_E_HIP;
 }

@@ -330,7 +330,7 @@ struct FfnArgs {
     void* qkv;                // [M, 768] 16-bit
     // whole-layer form (att != null): the kernel starts from the attention output -- x1 = LN1(h + att W_o^T + b_o) stays in the
     // fc2 accumulators as the feed-forward residual and in LDS as its operand; h is read once and written once per layer
-    const void* att;          // [M, 256] 16-bit
+    const void* att;          // [M, 256] 16-bit; fp16c: two planes [2][M, 256] = fp16(64 a), fp16(64 a - hi) (attention.hip, HILO)
     const void* w_o;
     const float *b_o, *ln1_g, *ln1_b;
 };
@@ -358,9 +358,20 @@ __global__ __launch_bounds__(512) void enc_ffn16_kernel(FfnArgs m) {
         load_set<PREC, D, 1>(wo, 0, 0, 1, wave, lane, bs[1]);
         __builtin_amdgcn_sched_barrier(0);
         stage_rows16<PREC>(reinterpret_cast<const elem*>(m.att), row0, m.M, D, 0, As, tid);
+        if constexpr (PREC == PREC_F16C) stage_rows16<PREC>(reinterpret_cast<const elem*>(m.att) + m.M * D, row0, m.M, D, 0, Hs, tid);
         __syncthreads();
         zero_acc(acc2);
-        phase_tm<PREC, D, D, true, true>(As, wo, 0, 0, w1, 0, 0, wave, lane, bs, acc2);   // (the first fc1 set under its last set)
+        if constexpr (PREC == PREC_F16C) {
+            // out_proj of both planes of the attention output by the same weights, then the exact 1/64 of their common scale
+            phase_tm<PREC, D, D, true, true>(As, wo, 0, 0, wo, 0, 0, wave, lane, bs, acc2);
+            phase_tm<PREC, D, D, true>(Hs, wo, 0, 0, w1, 0, 0, wave, lane, bs, acc2);
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc2[mt][r] *= 1.0f / 64.0f;
+        } else {
+            phase_tm<PREC, D, D, true, true>(As, wo, 0, 0, w1, 0, 0, wave, lane, bs, acc2);   // (the first fc1 set under its last set)
+        }
         res_ln<PREC>(acc2, m.b_o, m.h, m.ln1_g, m.ln1_b, m.eps, row0, m.M, As, P1, P2);   // acc2 = x1, As = x1 (16-bit)
     } else {
         load_set<PREC, D, 1>(w1, 0, 0, 0, wave, lane, bs[0]);
@@ -457,7 +468,7 @@ __global__ __launch_bounds__(256) void pool_head_kernel(const float* __restrict_
 
 }  // namespace tf
 
-void launch_attention_fwd(int prec, const void* qkv, void* out, int B, int L, hipStream_t st);   // attention.hip
+void launch_attention_fwd(int prec, const void* qkv, void* out, int B, int L, hipStream_t st, bool hilo);   // attention.hip
 // tf_fp32.hip: the same forward with exact-fp32 products (the reference's precision), up to the encoder output h
 size_t tf32_workspace_floats(int B, int L);
 int tf32_forward(const unsigned char* ids8, int ids_stride, int B, int L, int n_layers, float* ws, float* h,
@@ -604,7 +615,9 @@ int tf_forward_t(clm_tf_handle* h, const void* ids, int ids_dtype, int64_t strid
         const std::string p = "transformer_encoder.layers." + std::to_string(i) + ".";
         tf::LinArgs a{};
         a.M = M; a.eps = 1e-5f;
-        static const bool unfused_ffn = std::getenv("CLM_TF_UNFUSED_FFN") && std::getenv("CLM_TF_UNFUSED_FFN")[0] == '1';
+        // (the unfused A/B forms read the attention output as ONE 16-bit plane: not for fp16c, whose out_proj takes two)
+        static const bool unfused_ffn_env = std::getenv("CLM_TF_UNFUSED_FFN") && std::getenv("CLM_TF_UNFUSED_FFN")[0] == '1';
+        const bool unfused_ffn = unfused_ffn_env && PREC != PREC_F16C;
         if (i == 0 || unfused_ffn) {   // later layers: computed at the end of the previous layer's feed-forward kernel
             TfTimer t(h, st, 2);
             a.a = h->hx; a.w = h->packed.at(p + "in"); a.bias = W(p + "self_attn.in_proj_bias"); a.out16 = h->qkv; a.relu = 0;
@@ -612,10 +625,11 @@ int tf_forward_t(clm_tf_handle* h, const void* ids, int ids_dtype, int64_t strid
         }
         {
             TfTimer t(h, st, 1);
-            launch_attention_fwd(PREC, h->qkv, h->att, B, L3, st);
+            launch_attention_fwd(PREC, h->qkv, h->att, B, L3, st, PREC == PREC_F16C);   // fp16c: hi and lo planes (attention.hip)
         }
         TfTimer tl(h, st, 2);
-        static const bool unfused_layer = std::getenv("CLM_TF_UNFUSED_LAYER") && std::getenv("CLM_TF_UNFUSED_LAYER")[0] == '1';
+        static const bool unfused_layer_env = std::getenv("CLM_TF_UNFUSED_LAYER") && std::getenv("CLM_TF_UNFUSED_LAYER")[0] == '1';
+        const bool unfused_layer = unfused_layer_env && PREC != PREC_F16C;
         const bool whole_layer = !unfused_layer && !unfused_ffn;   // out_proj + LN1 at the head of the feed-forward kernel
         if (!whole_layer) {
             a.a = h->att; a.w = h->packed.at(p + "out"); a.bias = W(p + "self_attn.out_proj.bias"); a.h = h->h; a.hx = h->hx;
@@ -784,7 +798,7 @@ static int tf_run(clm_tf_handle* h, bool prec32, const void* ids, int ids_dtype,
     }
     {   // the 16-bit activations, each buffer grown on its own (x1 / x2 scale with B * (L / 2), B * (L / 4), not with M)
         const size_t need[7] = {(size_t)B * (L / 2) * D * 2, (size_t)B * (L / 4) * D * 2, M * D * 2, M * D * 2, M * tf::TQKV * 2,
-                                M * D * 2, M * tf::TFF * 2};
+                                M * D * 2 * (h->prec == PREC_F16C ? 2 : 1) /* hi + lo planes */, M * tf::TFF * 2};
         void** buf[7] = {&h->x1, &h->x2, &h->x3, &h->hx, &h->qkv, &h->att, &h->u};
         bool grow = false;
         for (int i = 0; i < 7; ++i) grow |= need[i] > h->cap16[i];

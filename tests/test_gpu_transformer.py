@@ -11,11 +11,12 @@ pytestmark = pytest.mark.gpu
 # fp32 = the reference's arithmetic (exact-fp32 MFMA, csrc/tf_fp32.hip): held to north_star's gate, 1e-3 on the logits.
 # fp16 / bf16 are the throughput modes of this net, REDUCED precision outside the gate: logits of the seeded classifier
 # (scale 3) are 3..9 in magnitude, their bounds are ~0.5 % / 4 % of that; the encoder output (O(1) LayerNorm values) is
-# checked separately.  fp16c (round 3: fp16 activations x hi + lo weights, as on the Hyena path) removes the weight rounding: what
-# is left is the activation rounding, ~4e-4 of the logit magnitude -- inside the gate at logits of magnitude ~1 (scale 1), outside at
-# 5..10 (scale 3); the module measures it on the loaded weights and falls back to fp32 (tests below).
+# checked separately.  fp16c (round 3: fp16 activations x hi + lo weights as on the Hyena path, and the attention output -- the one
+# activation whose rounding does not average out over the positions -- as hi + lo planes) is 3e-5 .. 2.3e-4 from the oracle at logits
+# of magnitude ~1 (scale 1) and 4.5e-4 .. 2e-3 at 5 .. 11 (scale 3: inside the gate from ~2,000 tokens up, outside for short reads);
+# the module measures it on the loaded weights and falls back to fp32 (tests below).
 GATE = 1e-3
-TOL = {"fp32": GATE, "fp16c": 1.2e-2, "fp16": 4e-2, "bf16": 4e-1}
+TOL = {"fp32": GATE, "fp16c": 1.2e-2, "fp16": 4e-2, "bf16": 4e-1}   # (fp16c: 9.6e-3 on the one-position read, <= 2.7e-3 otherwise)
 TOL_HIDDEN = {"fp32": 2e-4, "fp16c": 1e-2, "fp16": 1e-2, "bf16": 1e-1}
 
 
@@ -82,8 +83,8 @@ def test_arguments_and_errors(built_lib):
 
 @pytest.mark.parametrize("seed,B,L", [(0, 2, 1000), (1, 2, 2055), (2, 2, 4101), (3, 2, 8193)])
 def test_fp16c_is_inside_the_gate_at_unit_logits(built_lib, seed, B, L):
-    """Weights at scale 1 (logits of magnitude 0.5 .. 1.3): the compensated mode's raw error stays under the reference's 1e-3
-    (3.0e-4 .. 7.5e-4 measured) where plain fp16 is at 5e-4 .. 3e-3 -- and the guard keeps the mode."""
+    """Weights at scale 1 (logits of magnitude 0.5 .. 1.3): the compensated mode's raw error stays well under the reference's 1e-3
+    (3e-5 .. 2.3e-4 measured) where plain fp16 is at 5e-4 .. 3e-3 -- and the guard keeps the mode."""
     sd = to.make_state_dict(seed, to.PRODUCTION, scale=1.0)
     ids = to.synthetic_ids(100 + seed, B, L)
     ref = to.forward(torch.from_numpy(ids), {k: v.double() for k, v in sd.items()}, dtype=torch.float64).numpy()
@@ -92,44 +93,43 @@ def test_fp16c_is_inside_the_gate_at_unit_logits(built_lib, seed, B, L):
     got = raw(dev).cpu().numpy().astype(np.float64)
     err = np.abs(got - ref).max()
     print(f"fp16c scale 1 seed {seed} L={L}: |logits - oracle| = {err:.2e} (|logit| max {np.abs(ref).max():.2f})")
-    assert err < GATE
+    assert err < 0.4 * GATE
     assert (got.argmax(1) == ref.argmax(1))[np.abs(ref[:, 0] - ref[:, 1]) > 2 * GATE].all()
     raw.close()
     guarded = _model(sd, "fp16c", selfcheck=True)
-    guarded.selfcheck_tol = 9e-4                                # the measured errors sit between the default 5e-4 and the gate
     got_g = guarded(dev).cpu().numpy().astype(np.float64)
     rep = guarded.selfcheck_report
-    assert rep["fallback"] is False and rep["max_abs_dlogit"] <= 9e-4 and np.array_equal(got_g, got)
+    assert rep["fallback"] is False and rep["max_abs_dlogit"] <= rep["tol"] == 5e-4 and np.array_equal(got_g, got)
     guarded.close()
 
 
 def test_selfcheck_falls_back_to_fp32_and_the_abi_agrees(built_lib):
-    """Weights at scale 3 (logits 5 .. 10): the mode is 2e-3 .. 7e-3 off, the module measures that through `clm_tf_selfcheck`,
+    """Weights at scale 3, 1,000-token reads (logits ~5): the mode is 2e-3 off, the module measures that through `clm_tf_selfcheck`,
     falls back, and from then on returns the fp32 engine's bits; the C entry's figure is the difference of the two modes."""
     import ctypes as C
 
     from chimeralm_amd import _native as N
 
-    sd = to.make_state_dict(1, to.PRODUCTION, scale=3.0)
-    ids = torch.from_numpy(to.synthetic_ids(101, 3, 2055)).cuda()
+    sd = to.make_state_dict(0, to.PRODUCTION, scale=3.0)
+    ids = torch.from_numpy(to.synthetic_ids(100, 3, 1000)).cuda()
     exact = _model(sd, "fp32")
     want = exact(ids).cpu()
     raw = _model(sd, "fp16c")
     got_raw = raw(ids).cpu()
     lib = N.load()
     diff, differ = C.c_float(), C.c_int()
-    assert lib.clm_tf_selfcheck(raw._h, C.c_void_p(ids.data_ptr()), N.DT_I64, ids.stride(0), 3, 2055, None, C.byref(diff),
+    assert lib.clm_tf_selfcheck(raw._h, C.c_void_p(ids.data_ptr()), N.DT_I64, ids.stride(0), 3, 1000, None, C.byref(diff),
                                 C.byref(differ)) == 0
     mine = (got_raw - want).abs().max().item()
     print(f"clm_tf_selfcheck: {diff.value:.3e}; |fp16c - fp32| of two handles: {mine:.3e}")
-    assert abs(diff.value - mine) < 1e-6 and diff.value > 1e-3 and differ.value == 0
+    assert abs(diff.value - mine) < 1e-6 and diff.value > 5e-4 and differ.value == 0
     assert torch.equal(raw(ids).cpu(), got_raw)                  # the check leaves the mode as it was
     assert lib.clm_tf_set_fallback(raw._h, 1) == 0
     assert torch.equal(raw(ids).cpu(), want)
     assert lib.clm_tf_set_fallback(raw._h, 0) == 0
     assert torch.equal(raw(ids).cpu(), got_raw)
     # an fp32 handle reports 0 / 0
-    assert lib.clm_tf_selfcheck(exact._h, C.c_void_p(ids.data_ptr()), N.DT_I64, ids.stride(0), 3, 2055, None, C.byref(diff),
+    assert lib.clm_tf_selfcheck(exact._h, C.c_void_p(ids.data_ptr()), N.DT_I64, ids.stride(0), 3, 1000, None, C.byref(diff),
                                 C.byref(differ)) == 0 and diff.value == 0.0 and differ.value == 0
     raw.close()
     guarded = _model(sd, "fp16c", selfcheck=True)
@@ -137,7 +137,7 @@ def test_selfcheck_falls_back_to_fp32_and_the_abi_agrees(built_lib):
         got = guarded(ids).cpu()
     rep = guarded.selfcheck_report
     assert rep["fallback"] is True and rep["max_abs_dlogit"] > rep["tol"] == 5e-4
-    assert torch.equal(got, want) and torch.equal(guarded(ids[:2, :999]).cpu(), exact(ids[:2, :999]).cpu())
+    assert torch.equal(got, want) and torch.equal(guarded(ids[:2, :499]).cpu(), exact(ids[:2, :499]).cpu())
     guarded.load_state_dict(to.make_state_dict(0, to.PRODUCTION, scale=0.25), strict=True)   # new weights: on trial again
     guarded(ids)
     assert guarded.selfcheck_report["fallback"] is False
