@@ -115,9 +115,10 @@ class SequenceCNNTransformer(nn.Module):
         worst = rep.get("max_abs_dlogit", 0.0)
         if self._checked_min_len is None:                      # first batch since the weights were loaded: seeded reads
             g = torch.Generator().manual_seed(20241)
-            ids = torch.randint(7, 11, (4, 4096), generator=g, dtype=torch.uint8)
-            ids[0, :1300] = 4                                  # one read left-padded, as the collator pads
-            worst = max(worst, self._measure(lib, "synthetic 4 x 4096", ids.to(input_ids.device)))
+            Ls = min(4096, 8 * self.pos_encoder.pe.shape[1])   # (a model built with a short max_len cannot take 4,096 tokens)
+            ids = torch.randint(7, 11, (4, Ls), generator=g, dtype=torch.uint8)
+            ids[0, : Ls // 3] = 4                              # one read left-padded, as the collator pads
+            worst = max(worst, self._measure(lib, f"synthetic 4 x {Ls}", ids.to(input_ids.device)))
         worst = max(worst, self._measure(lib, f"batch rows 0..{min(input_ids.shape[0], 4) - 1} x {L}", input_ids[:4]))
         rep.update(max_abs_dlogit=worst, tol=self.selfcheck_tol, precision=self.precision)
         self._checked_min_len = L if self._checked_min_len is None else min(L, self._checked_min_len)

@@ -79,6 +79,12 @@ def test_arguments_and_errors(built_lib):
     out = net(torch.full((2, 128), 7, dtype=torch.int64).cuda())
     assert out.shape == (2, 2) and torch.isfinite(out).all()
     net.close()
+    small = SequenceCNNTransformer(vocab_size=12, max_len=16, num_encoder_layers=1, precision="fp16c")   # guarded by default:
+    out = small(torch.full((2, 128), 7, dtype=torch.int64).cuda())          # its seeded sample must respect max_len (8 * 16 tokens)
+    assert small.selfcheck_report["samples"][0]["sample"] == "synthetic 4 x 128" and torch.isfinite(out).all()
+    with pytest.raises(ValueError, match="precision must be"):
+        SequenceCNNTransformer(vocab_size=12, max_len=16, precision="fp8")
+    small.close()
 
 
 @pytest.mark.parametrize("seed,B,L", [(0, 2, 1000), (1, 2, 2055), (2, 2, 4101), (3, 2, 8193)])
