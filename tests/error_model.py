@@ -113,5 +113,29 @@ def main():
                 print(f"seed {seed}  {B} x {L}  {name:44s} max |dlogit| {err:.2e}   (max |logit| {ref.abs().max():.2f})", flush=True)
 
 
+def rank(L=2048, B=16, wseeds=(4, 6, 7, 1)):
+    """`python tests/error_model.py rank [L B]`: rms / max logit error over B reads of the compensated-weights mode with ONE more
+    operand (or a set) carried as hi + lo -- which activation rounding would be worth a lo term?  (Round 3: none alone; the error is
+    spread over LN1, y, z and ln_f: -10 % each, -35..-45 % for LN1 + y together, -50..-65 % with z as well.  A max over a few reads
+    is too noisy to rank by: removing one source can raise it.)"""
+    stat = lambda e: f"rms {e.pow(2).mean().sqrt().item():.2e} max {e.abs().max().item():.2e}"
+    for wseed in wseeds:
+        sd = ho.make_state_dict(wseed, head_scale=3.0)
+        ids, _ = ho.synthetic_batch(5, B, L - 1, seed=99 + wseed)
+        with torch.no_grad():
+            ref = forward(ids, sd, {})
+            base = {**ALL16, "w": "hh"}
+            cases = {"base (all 16-bit, weights hi + lo)": base, "LN1 hi + lo": {**base, "a_ln1": "hh"},
+                     "y hi + lo": {**base, "y": "hh", "a_y": "hh"}, "z hi + lo": {**base, "z": "hh"},
+                     "ln_f hi + lo, pool exact": {**base, "a_lnf": "hh", "pool": None},
+                     "LN1 + y": {**base, "a_ln1": "hh", "y": "hh", "a_y": "hh"},
+                     "LN1 + y + z": {**base, "a_ln1": "hh", "y": "hh", "a_y": "hh", "z": "hh"}}
+            for n, c in cases.items():
+                print(f"weights {wseed}  {B} x {L}  {n:36s} {stat(forward(ids, sd, c) - ref)}", flush=True)
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "rank":
+        rank(*(int(a) for a in sys.argv[2:4]))
+    else:
+        main()
