@@ -223,7 +223,7 @@ def main():
     ap.add_argument("--precision", default=os.environ.get("CLM_PRECISION", "fp16c"),
                     help="fp16c (default: the 16-bit-rate mode inside the reference's 1e-3 tolerance) | fp32 (exact) | "
                          "fp16 | bf16 (reduced precision, outside the tolerance)")
-    ap.add_argument("--chunk-reads", type=int, default=64)
+    ap.add_argument("--chunk-reads", type=int, default=256)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fp32-leg", action="store_true", help="skip the extra exact-fp32 timing (fp32_exact_reads_per_s)")
     ap.add_argument("--net", default="hyena", choices=["hyena", "transformer"],

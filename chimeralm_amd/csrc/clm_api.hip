@@ -106,14 +106,12 @@ struct clm_handle {
     std::vector<FilterSet> filters;
     uint64_t clock = 0;
     // workspace (one chunk of reads)
-    int ws_B = 0, ws_L = 0;
-    size_t ws_es_full = 0;        // activation element size the workspace holds at ws_L tokens (4 once the fp32 kernels may run at any length)
-    size_t ws_z_bytes = 0, ws_y_bytes = 0, ws_es = 0;   // ws_es: element size z / y were last written with
+    size_t ws_cap[12] = {};       // bytes of each workspace buffer (ensure_workspace: WS_H .. WS_EDGE_READ)
+    size_t ws_es = 0;             // element size z / y were last written with
     float* h = nullptr;
     void *z = nullptr, *y = nullptr, *u = nullptr;
     float *scores = nullptr, *stats = nullptr, *partial = nullptr, *pooled = nullptr, *lone_ws = nullptr;
     float2* gscratch = nullptr;                     // segment spectra of the long-read convolution
-    size_t gscratch_elems = 0;
     int last_B = 0, last_L = 0, last_Lp = 0;
     // debug / profiling
     int stop_layer = -1, stop_stage = -1;
@@ -272,18 +270,36 @@ void free_filters(clm_handle* h) {
     h->filters.clear();
 }
 
+// The per-chunk workspace: twelve buffers, each with its own capacity in bytes and grown on its own -- a call needs Bc x (its
+// own length) of each, and chunk_for() bounds that product whatever the read length, so a handle that has seen 256 x 8k-token and
+// 32 x 32k-token batches holds the larger of the two needs per buffer, not 256 x 32k (the round-2 shape bookkeeping did).
+enum { WS_H, WS_Z, WS_Y, WS_U, WS_SCORES, WS_STATS, WS_PARTIAL, WS_POOLED, WS_GSCRATCH, WS_IDS8, WS_LONE, WS_EDGE_READ, WS_N };
+static_assert(WS_N == sizeof(clm_handle::ws_cap) / sizeof(size_t), "one capacity per buffer");
+void** ws_slot(clm_handle* h, int i) {
+    switch (i) {
+        case WS_H: return (void**)&h->h;
+        case WS_Z: return &h->z;
+        case WS_Y: return &h->y;
+        case WS_U: return &h->u;
+        case WS_SCORES: return (void**)&h->scores;
+        case WS_STATS: return (void**)&h->stats;
+        case WS_PARTIAL: return (void**)&h->partial;
+        case WS_POOLED: return (void**)&h->pooled;
+        case WS_GSCRATCH: return (void**)&h->gscratch;
+        case WS_IDS8: return (void**)&h->ids8;
+        case WS_LONE: return (void**)&h->lone_ws;
+        default: return (void**)&h->edge_read;
+    }
+}
+
 void free_workspace(clm_handle* h) {
-    for (void* p : {(void*)h->h, h->z, h->y, h->u, (void*)h->scores, (void*)h->stats, (void*)h->partial,
-                    (void*)h->pooled, (void*)h->gscratch, (void*)h->ids8, (void*)h->lone_ws, (void*)h->edge_read})
-        if (p) (void)hipFree(p);
-    h->edge_read = nullptr;
-    h->gscratch = nullptr;
-    h->gscratch_elems = 0;
-    h->h = nullptr; h->z = h->y = h->u = nullptr;
-    h->scores = h->stats = h->partial = h->pooled = h->lone_ws = nullptr;
-    h->ids8 = nullptr;
-    h->ws_B = h->ws_L = 0;
-    h->ws_es_full = 0;
+    for (int i = 0; i < WS_N; ++i) {
+        void** p = ws_slot(h, i);
+        if (*p) (void)hipFree(*p);
+        *p = nullptr;
+        h->ws_cap[i] = 0;
+    }
+    h->ws_es = 0;
 }
 
 void free_packed(clm_handle* h) {
@@ -305,49 +321,37 @@ void free_packed(clm_handle* h) {
 const float* W(clm_handle* h, const std::string& key) { return h->w[key].d; }
 
 int ensure_workspace(clm_handle* h, int Bc, int L, hipStream_t st) {
-    // element size of z / y / u at full length: 4 when the exact-fp32 kernels may run reads of any length (fp32 handle, self-check
-    // referee pass, fallback); fp16c otherwise keeps 2-byte buffers with room for 4-byte reads below f16c_min_len
-    const size_t es_need = (h->cfg.precision == PREC_F32 || h->fallback32 || h->force_prec == PREC_F32) ? 4 : 2;
-    if (Bc <= h->ws_B && L <= h->ws_L && es_need <= h->ws_es_full) return CLM_OK;
-    HIPCHK(h, hipStreamSynchronize(st));
-    int nb = Bc > h->ws_B ? Bc : h->ws_B, nl = L > h->ws_L ? L : h->ws_L;
-    const size_t es = std::max(es_need, h->ws_es_full);
-    free_workspace(h);
-    const size_t Lp = (size_t)round_up(nl, 64);
-    size_t nl_es = (size_t)nl * es, Lp_es = Lp * es;
-    if (h->cfg.precision == PREC_F16C) {
-        const size_t ls = (size_t)std::min(nl, h->f16c_min_len - 1);
-        nl_es = std::max(nl_es, ls * 4);
-        Lp_es = std::max(Lp_es, (size_t)round_up((int)ls, 64) * 4);
-    }
-    const size_t n_h = (size_t)nb * nl * D * 4, n_z = (size_t)nb * D3 * Lp_es, n_y = (size_t)nb * D * Lp_es,
-                 n_u = (size_t)nb * DI * nl_es;
-    HIPCHK(h, hipMalloc((void**)&h->h, n_h));
-    HIPCHK(h, hipMalloc(&h->z, n_z));
-    HIPCHK(h, hipMalloc(&h->y, n_y));
-    HIPCHK(h, hipMalloc(&h->u, n_u));
-    HIPCHK(h, hipMalloc((void**)&h->scores, (size_t)nb * nl * 4));
-    HIPCHK(h, hipMalloc((void**)&h->stats, (size_t)nb * 2 * 4));
-    {   // pooling partials: [POOL_SPLIT][4][256] per read (fp32 path) or one POOL_PSTRIDE row per 128-token tile
-        const size_t per_read = std::max((size_t)POOL_SPLIT * 4 * D, (size_t)((nl + 127) / 128) * POOL_PSTRIDE);
-        HIPCHK(h, hipMalloc((void**)&h->partial, (size_t)nb * per_read * 4));
-    }
-    HIPCHK(h, hipMalloc((void**)&h->pooled, (size_t)nb * D * 4));
-    HIPCHK(h, hipMalloc((void**)&h->lone_ws, lone_token_ws_floats(nb) * 4));
-    HIPCHK(h, hipMalloc((void**)&h->ids8, (size_t)nb * Lp));
-    HIPCHK(h, hipMalloc((void**)&h->edge_read, (size_t)nb * D3 * sizeof(float2)));
+    const int prec = effective_prec(h, L);                   // (honours the self-check's referee pass and the fallback)
+    const size_t es = elem_size(prec), Lp = (size_t)round_up(L, 64), nb = (size_t)Bc, nl = (size_t)L;
+    size_t need[WS_N] = {};
+    need[WS_H] = nb * nl * D * 4;
+    need[WS_Z] = nb * D3 * Lp * es;
+    need[WS_Y] = nb * D * Lp * es;
+    need[WS_U] = (prec == PREC_F32 || h->force_generic) ? nb * DI * nl * es : 0;   // the 1024-wide fc1 output: unfused paths only
+    need[WS_SCORES] = nb * nl * 4;
+    need[WS_STATS] = nb * 2 * 4;
+    // pooling partials: [POOL_SPLIT][4][256] per read (fp32 path) or one POOL_PSTRIDE row per 128-token tile
+    need[WS_PARTIAL] = nb * std::max((size_t)POOL_SPLIT * 4 * D, (size_t)((nl + 127) / 128) * POOL_PSTRIDE) * 4;
+    need[WS_POOLED] = nb * D * 4;
+    need[WS_LONE] = lone_token_ws_floats((int)nb) * 4;
+    need[WS_IDS8] = nb * Lp;
+    need[WS_EDGE_READ] = nb * D3 * sizeof(float2);
+    if (conv_segments_for(L) > 1) need[WS_GSCRATCH] = ((nb + 1) / 2) * D * (size_t)conv_segments_for(L) * 16384 * sizeof(float2);
+    bool grow = false;
+    for (int i = 0; i < WS_N; ++i) grow |= need[i] > h->ws_cap[i];
     if (!h->edge_bnd) HIPCHK(h, hipMalloc((void**)&h->edge_bnd, (size_t)1024 * 2 * D3 * sizeof(float2)));   // >= any grid (one workgroup per CU)
-    if (conv_segments_for(nl) > 1) {
-        const size_t pairs = (size_t)(nb + 1) / 2, S = (size_t)conv_segments_for(nl);
-        h->gscratch_elems = pairs * D * S * 16384;
-        HIPCHK(h, hipMalloc((void**)&h->gscratch, h->gscratch_elems * sizeof(float2)));
+    if (!grow) return CLM_OK;
+    HIPCHK(h, hipStreamSynchronize(st));
+    for (int i = 0; i < WS_N; ++i) {
+        if (need[i] <= h->ws_cap[i]) continue;
+        void** p = ws_slot(h, i);
+        if (*p) HIPCHK(h, hipFree(*p));
+        *p = nullptr;
+        h->ws_cap[i] = 0;
+        HIPCHK(h, hipMalloc(p, need[i]));
+        h->ws_cap[i] = need[i];
+        if (i == WS_Z || i == WS_Y) HIPCHK(h, hipMemset(*p, 0, need[i]));   // padding columns [L, Lp) must never hold NaN garbage
     }
-    HIPCHK(h, hipMemset(h->z, 0, n_z));   // padding columns [L, Lp) must never hold NaN garbage
-    HIPCHK(h, hipMemset(h->y, 0, n_y));
-    h->ws_z_bytes = n_z; h->ws_y_bytes = n_y; h->ws_es = 0;
-    h->ws_B = nb;
-    h->ws_L = nl;
-    h->ws_es_full = es;
     return CLM_OK;
 }
 
@@ -506,6 +510,19 @@ int check_bad_ids(clm_handle* h) {
 
 bool stop_here(clm_handle* h, int layer, int stage) { return h->stop_layer == layer && h->stop_stage == stage; }
 
+// Reads pushed through all layers together: cfg.chunk_reads, capped by tokens so that a chunk's workspace stays bounded whatever
+// the read length -- 256 x 8,256 tokens in the 16-bit modes (z + y + h: 6.5 GB; measured round 3, same box: 7,976 / 8,047 / 8,164
+// reads/s at 64 / 128 / 256 reads per chunk: the ~26 small launches of a chunk, the persistent kernels' ramps and the head are paid
+// per chunk, and 288 GB of HBM have room), a quarter of that in exact fp32 (its 1024-wide fc1 output is 4 KiB per token, and the
+// proven size).  Even, so that a chunk boundary never splits a read pair of the packed transform.
+int chunk_for(const clm_handle* h, int L) {
+    const long long cap_tokens = effective_prec(h, L) == PREC_F32 ? 64LL * 8256 : 256LL * 8256;
+    long long c = cap_tokens / round_up(L, 64);
+    if (c > h->cfg.chunk_reads) c = h->cfg.chunk_reads;
+    if (c > 1) c &= ~1LL;
+    return c < 1 ? 1 : (int)c;
+}
+
 int forward_chunk(clm_handle* h, const void* ids, int ids_dtype, int64_t row_stride, int Bc, int L, float* logits,
                   hipStream_t st) {
     const int prec = effective_prec(h, L), Lp = round_up(L, 64);
@@ -521,8 +538,8 @@ int forward_chunk(clm_handle* h, const void* ids, int ids_dtype, int64_t row_str
     h->last_B = Bc; h->last_L = L; h->last_Lp = Lp;
     if (h->ws_es != elem_size(prec)) {   // fp16c: fp32 and fp16 chunks share z / y -- what one type left in the padding
         if (h->ws_es) {                  // columns may read as NaN in the other
-            HIPCHK(h, hipMemsetAsync(h->z, 0, h->ws_z_bytes, st));
-            HIPCHK(h, hipMemsetAsync(h->y, 0, h->ws_y_bytes, st));
+            HIPCHK(h, hipMemsetAsync(h->z, 0, h->ws_cap[WS_Z], st));
+            HIPCHK(h, hipMemsetAsync(h->y, 0, h->ws_cap[WS_Y], st));
         }
         h->ws_es = elem_size(prec);
     }
@@ -689,7 +706,7 @@ int clm_default_config(clm_config* c) {
     c->emb_dim = EMB; c->max_seq_len = 32770; c->head_hidden = HH; c->n_classes = NCLS;
     c->ln_eps = 1e-5f;
     c->precision = CLM_PREC_F32;
-    c->chunk_reads = 64;
+    c->chunk_reads = 256;
     return CLM_OK;
 }
 
@@ -860,7 +877,8 @@ int clm_reserve(clm_handle* h, int B, int L) {
     const ReversedFilter* kr = nullptr;
     int rc = ensure_filters(h, L, 0, &fs, &kr);
     if (rc) return rc;
-    int Bc = B < h->cfg.chunk_reads ? B : h->cfg.chunk_reads;
+    const int chunk = chunk_for(h, L);
+    int Bc = B < chunk ? B : chunk;
     return ensure_workspace(h, Bc, L, 0);
 }
 
@@ -876,7 +894,7 @@ int clm_forward(clm_handle* h, const void* ids, int ids_dtype, int64_t ids_row_s
     if (int rc = check_bad_ids(h)) return rc;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const size_t ies = ids_dtype == CLM_DT_I64 ? 8 : (ids_dtype == CLM_DT_I32 ? 4 : 1);
-    const int chunk = h->cfg.chunk_reads;
+    const int chunk = chunk_for(h, L);
     for (int b0 = 0; b0 < B; b0 += chunk) {
         int Bc = B - b0 < chunk ? B - b0 : chunk;
         const char* p = reinterpret_cast<const char*>(ids) + (size_t)b0 * ids_row_stride * ies;
@@ -977,10 +995,10 @@ int clm_selfcheck(clm_handle* h, const void* ids, int ids_dtype, int64_t ids_row
     const bool prof = h->prof;
     h->prof = false;                                            // not part of anybody's timed region
     const size_t ies = ids_dtype == CLM_DT_I64 ? 8 : (ids_dtype == CLM_DT_I32 ? 4 : 1);
-    const int chunk = h->cfg.chunk_reads;
     int rc = CLM_OK;
     for (int pass = 0; pass < 2 && !rc; ++pass) {
         h->force_prec = pass == 0 ? mode_prec : (int)PREC_F32;
+        const int chunk = chunk_for(h, L);
         for (int b0 = 0; b0 < B && !rc; b0 += chunk) {
             const int Bc = B - b0 < chunk ? B - b0 : chunk;
             const char* p = reinterpret_cast<const char*>(ids) + (size_t)b0 * ids_row_stride * ies;
@@ -1020,7 +1038,6 @@ int clm_set_short_read_len(clm_handle* h, int min_len) {
     if (!h || min_len < 1) return fail(h, CLM_E_INVALID, "clm_set_short_read_len: bad argument");
     if (h->cfg.precision != PREC_F16C) return fail(h, CLM_E_UNSUPPORTED, "clm_set_short_read_len: not a CLM_PREC_F16C handle");
     h->f16c_min_len = min_len;
-    h->ws_B = h->ws_L = 0;        // the workspace is sized for 4-byte activations below the switch: let the next forward re-derive it
     return CLM_OK;
 }
 

@@ -22,7 +22,7 @@ class EngineError(RuntimeError):
 class Engine:
     """One MI355X inference engine instance bound to `device` (e.g. "cuda:0")."""
 
-    def __init__(self, device: torch.device | str | int = "cuda:0", precision: str = "fp32", chunk_reads: int = 64):
+    def __init__(self, device: torch.device | str | int = "cuda:0", precision: str = "fp32", chunk_reads: int = 256):
         self._lib = N.load()
         self._h = N._H()
         device = torch.device(device if not isinstance(device, int) else f"cuda:{device}")

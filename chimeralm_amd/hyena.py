@@ -191,7 +191,7 @@ class HyenaDna(nn.Module):
     """
 
     def __init__(self, number_of_classes: int, head: nn.Module, backbone_name: str = "hyenadna-small-32k-seqlen", *,
-                 freeze_backbone: bool = False, precision: str = "fp16c", chunk_reads: int = 64,
+                 freeze_backbone: bool = False, precision: str = "fp16c", chunk_reads: int = 256,
                  selfcheck: bool | None = None, selfcheck_tol: float = 5e-4):
         super().__init__()
         if number_of_classes != 2:

@@ -13,7 +13,7 @@ from .hyena import BinarySequenceClassifier, HyenaDna
 
 class ChimeraLM:
     @classmethod
-    def new(cls, *, save_attention: bool = False, precision: str = "fp16c", chunk_reads: int = 64,
+    def new(cls, *, save_attention: bool = False, precision: str = "fp16c", chunk_reads: int = 256,
             selfcheck: bool | None = None, selfcheck_tol: float = 5e-4) -> ClassificationLit:
         """Randomly initialised model of the production architecture (lm.py:39-61).  `precision` / `selfcheck`: see
         `chimeralm_amd.hyena.HyenaDna` -- the default "fp16c" is measured against the exact-fp32 kernels on the loaded weights
@@ -35,7 +35,7 @@ class ChimeraLM:
 
     @classmethod
     def from_pretrained(cls, model_name: str = "yangliz5/chimeralm", *, save_attention: bool = False,
-                        precision: str = "fp16c", chunk_reads: int = 64, selfcheck: bool | None = None,
+                        precision: str = "fp16c", chunk_reads: int = 256, selfcheck: bool | None = None,
                         selfcheck_tol: float = 5e-4) -> ClassificationLit:
         """Released weights (lm.py:12-37).  `model_name` is a local directory / file holding `model.safetensors`
         or a Lightning `.ckpt`; a Hub repo id is resolved through the local HF cache only (no network here)."""

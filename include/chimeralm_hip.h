@@ -75,7 +75,8 @@ typedef struct clm_config {
     int32_t n_classes;     /* 2                                                             */
     float ln_eps;          /* 1e-5                                                          */
     int32_t precision;     /* CLM_PREC_*                                                    */
-    int32_t chunk_reads;   /* reads pushed through all layers together (workspace ~ chunk)  */
+    int32_t chunk_reads;   /* reads pushed through all layers together (default 256; the engine lowers it for long reads so that a
+                              chunk holds at most 256 x 8,256 tokens in the 16-bit modes, 64 x 8,256 in exact fp32: workspace ~ chunk) */
 } clm_config;
 
 int clm_abi_version(void);

@@ -464,11 +464,11 @@ def test_maximum_length_reads(engines, sd):
     _check(engines["fp16"], "fp16", ids, sd, ref=ref)
 
 
-@pytest.mark.parametrize("prec,B", [("fp16c", 256), ("fp16c", 32), ("fp16", 256)])
-def test_baseline_batch_size_independent_properties(sd, built_lib, prec, B):
-    """BASELINE.json's bench configurations AT SIZE and in the benched mode: 256 reads of 8192 bases + [SEP] in 64-read chunks
-    (C3: 8,192 convolution units per launch through the persistent XCD-ordered loop, 4,096 tail tiles) and the 32-read shard a
-    GPU gets in the 8-GPU run (C4).  The oracle is too slow for the whole batch; reads are independent units, so (a) two runs
+@pytest.mark.parametrize("prec,B,chunk", [("fp16c", 256, 256), ("fp16c", 256, 64), ("fp16c", 32, 256), ("fp16", 256, 64)])
+def test_baseline_batch_size_independent_properties(sd, built_lib, prec, B, chunk):
+    """BASELINE.json's bench configurations AT SIZE and in the benched mode: 256 reads of 8192 bases + [SEP] as ONE chunk (the
+    default since round 3: 32,768 convolution units per launch through the persistent XCD-ordered loop, 16,384 tail tiles, z alone
+    3.2 GB) and in 64-read chunks (C3 as benched in round 2), and the 32-read shard a GPU gets in the 8-GPU run (C4).  The oracle is too slow for the whole batch; reads are independent units, so (a) two runs
     are bit-identical, (b) reversing the batch reverses the logits (each read gets another pair partner in the packed FFT:
     equal up to rounding, not bitwise), (c) reads computed alone equal their rows of the full batch, (d) a sample of rows
     matches the oracle at the mode's bound (fp16c: GATE), (e) fp16c: the exact-fp32 kernels agree on a sample (clm_selfcheck)."""
@@ -476,7 +476,7 @@ def test_baseline_batch_size_independent_properties(sd, built_lib, prec, B):
 
     ids = _ids(B, 8193, seed=41)
     t = torch.from_numpy(ids).cuda()
-    e = Engine("cuda:0", precision=prec, chunk_reads=64)
+    e = Engine("cuda:0", precision=prec, chunk_reads=chunk)
     e.load_state_dict(sd)
     a = e.forward(t).cpu()
     assert torch.isfinite(a).all()
