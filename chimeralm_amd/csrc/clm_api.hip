@@ -816,8 +816,10 @@ int clm_finalize(clm_handle* h) {
         int rc;
         if ((rc = pack(p + "mixer.in_proj.weight", D3, D, &h->packed[i][0]))) return rc;
         if ((rc = pack(p + "mixer.out_proj.weight", D, D, &h->packed[i][1]))) return rc;
-        if ((rc = pack(p + "mlp.fc1.weight", DI, D, &h->packed[i][2]))) return rc;
-        if ((rc = pack(p + "mlp.fc2.weight", D, DI, &h->packed[i][3]))) return rc;
+        // (fp16c: the two MLP products run on plain fp16 weights -- tail16_kernel, MLP_PREC)
+        const int mlp_prec = prec == PREC_F16C ? (int)PREC_F16 : prec;
+        if ((rc = pack_as(mlp_prec, p + "mlp.fc1.weight", DI, D, &h->packed[i][2]))) return rc;
+        if ((rc = pack_as(mlp_prec, p + "mlp.fc2.weight", D, DI, &h->packed[i][3]))) return rc;
         LayerW& lw = h->lw[i];
         lw.ln1_g = W(h, p + "norm1.weight"); lw.ln1_b = W(h, p + "norm1.bias");
         lw.ln2_g = W(h, p + "norm2.weight"); lw.ln2_b = W(h, p + "norm2.bias");

@@ -113,7 +113,8 @@ __device__ __forceinline__ f32x2 gelu_tanh2(f32x2 x) {
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.7071067811865476f)); }
 
 // ---- kernel launchers (definitions in the .hip files); all are asynchronous on `st` --------------------
-// PREC_F16C ("fp16c"): fp16 activations x weights held as hi + lo, hi = fp16(w), lo = e4m3((w - hi) * 2^17): per 64-deep group
+// PREC_F16C ("fp16c"): fp16 activations x weights held as hi + lo (in_proj, out_proj, score layer; the MLP weights are plain fp16
+// since round 3: MLP_PREC, gemm_common.h), hi = fp16(w), lo = e4m3((w - hi) * 2^17): per 64-deep group
 // four fp16 MFMAs with hi and ONE block-scaled K = 64 fp8 MFMA with lo (the activation fragments' upper bytes, i.e. the halfs
 // truncated to e5m2, gathered in registers) into one fp32 accumulator.  The rounding of the packed weights is the one error of the fp16 mode that is coherent across tokens
 // (every token sees the same perturbed matrix, so the attention pooling cannot average it out): tests/error_model.py

@@ -624,6 +624,13 @@ __global__ __launch_bounds__(512) void tail16_kernel(TailArgs m, unsigned long l
     using elem = typename CT<PREC>::elem;
     using frag = u16x8;
     constexpr int BM = 128, NCH = DI / 256;
+    // fp16c: fc1 and fc2 run on PLAIN fp16 weights (packed as such, launch side: MLP_PREC).  The rounding of the MLP's weights
+    // does not show in the logits -- rms error over 16 reads with every weight as hi + lo against fc1 and fc2 rounded to fp16,
+    // five weight draws: 3.40 / 3.57, 2.29 / 2.13, 2.94 / 3.09, 1.67 / 1.79, 1.01 / 1.62 e-4, where out_proj or in_proj rounded
+    // alone give 4-19e-4 (tests/error_model.py, round 3) -- and the two products are 2/3 of a tile's weight bytes, lo MFMAs and
+    // operand conversions.
+    constexpr int PF = MLP_PREC<PREC>;
+    static_assert(std::is_same<typename CT<PF>::elem, elem>::value, "the MLP products read the same activation tiles");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     elem* As = reinterpret_cast<elem*>(smem);              // LN2(r) tile [128][RS16]      (aliases Ys during out_proj)
     elem* Hs = As + BM * RS16;                              // gelu(fc1) chunk [128][RS16]
@@ -708,7 +715,7 @@ __global__ __launch_bounds__(512) void tail16_kernel(TailArgs m, unsigned long l
             }
         }
     }
-    phase_km<PREC, D, D>(Ys, wo, 0, 0, w1, 0, 0, wave, lane, bs, acc2);   // (first fc1 set requested under the last set)
+    phase_km<PREC, D, D, PF>(Ys, wo, 0, 0, w1, 0, 0, wave, lane, bs, acc2);   // (first fc1 set requested under the last set)
     CLM_STAMP_AT(2);
     // ---- 2./3. LayerNorm-2 of r straight from the accumulators -> As (16-bit)
     ln_acc_to_tile<PREC>(acc2, P1, P2, m.ln_g, m.ln_b, m.eps, As, t0, L, wave, lrow, lhalf);
@@ -718,7 +725,7 @@ __global__ __launch_bounds__(512) void tail16_kernel(TailArgs m, unsigned long l
 #pragma unroll 1
     for (int j = 0; j < NCH; ++j) {
         zero_acc(acc1);
-        phase_tm<PREC, D, DI, true>(As, w1, j, 0, w2, 0, j, wave, lane, bs, acc1);
+        phase_tm<PF, D, DI, true>(As, w1, j, 0, w2, 0, j, wave, lane, bs, acc1);
         // GELU biases first, then the second fc2 half-set: it streams in while the workgroup is in its VALU-only GELU
         // phase and the L2 -> CU path is otherwise idle (the MFMA phases are bound by exactly that path)
         float4 b1v[4];
@@ -727,7 +734,7 @@ __global__ __launch_bounds__(512) void tail16_kernel(TailArgs m, unsigned long l
 #pragma unroll
             for (int q = 0; q < 4; ++q) b1v[q] = *reinterpret_cast<const float4*>(b1 + 8 * q);
         }
-        load_set<PREC, DI, 1>(w2, 0, j, 1, wave, lane, bs[1]);
+        load_set<PF, DI, 1>(w2, 0, j, 1, wave, lane, bs[1]);
         __builtin_amdgcn_sched_barrier(0);
         __syncthreads();
         CLM_STAMP_AT(5 + 3 * j);
@@ -754,8 +761,10 @@ __global__ __launch_bounds__(512) void tail16_kernel(TailArgs m, unsigned long l
         CLM_STAMP_AT(6 + 3 * j);
         // last slot: next fc1 set; on the last trip the first set of what follows (wrap-around keeps the prefetch unconditional)
         // (ZG: the in_proj stage starts with block ZG_ORDER[0])
-        phase_tm<PREC, DI, D, true, true>(Hs, w2, 0, j, (NEXT != NEXT_NONE && j + 1 == NCH) ? wn : w1,
-                                          j + 1 < NCH ? j + 1 : (ZG ? ZG_ORDER[0] : 0), 0, wave, lane, bs, acc2);
+        // (the successor's packing depends on j: its first set is addressed here, requested as raw fragments there)
+        const frag* nxt = (NEXT != NEXT_NONE && j + 1 == NCH) ? set_base<PREC, D>(wn, ZG ? ZG_ORDER[0] : 0, 0, 0, wave, lane)
+                                                              : set_base<PF, D>(w1, j + 1 < NCH ? j + 1 : 0, 0, 0, wave, lane);
+        phase_tm<PF, DI, D, true, true, NoHook, PREC_RAWNEXT>(Hs, w2, 0, j, nxt, 0, 0, wave, lane, bs, acc2);
         CLM_STAMP_AT(7 + 3 * j);
     }
     __syncthreads();                                       // As / Hs are dead: reuse them as the staging tiles
@@ -890,7 +899,8 @@ void launch_mlp16(int prec, float* h, const float* g, const float* bta, const vo
     MlpArgs m{h, g, bta, w1, w2, b1, b2, B, L, eps};
     constexpr size_t lds = (size_t)2 * 128 * RS16 * 2;
     dim3 grid((L + 127) / 128, B), block(512);
-    CLM_LAUNCH16(prec, mlp16_kernel, grid, block, lds, st, m);
+    // (fp16c: LayerNorm-2 + fc1 + GELU + fc2 is the plain fp16 kernel on fp16-packed weights, as inside tail16_kernel)
+    CLM_LAUNCH16(prec == PREC_F16C ? (int)PREC_F16 : prec, mlp16_kernel, grid, block, lds, st, m);
 }
 
 // developer stamps (CLM_STAMP=1): per-phase mean cycles of wave 0 over all workgroups, printed by clm_destroy

@@ -163,7 +163,19 @@ __device__ __forceinline__ void compute_km(const typename CT<PREC>::elem* Ys, in
 struct NoHook {
     __device__ __forceinline__ void operator()(int) const {}
 };
-template <int PREC, int K, int KN, bool ROWS_N, bool P1_LOADED = false, typename Hook = NoHook>
+// PRECN: the packing of the FOLLOWING phase's weights where it differs from this phase's (tail16_kernel in fp16c: the two MLP
+// products run on plain fp16 weights between compensated out_proj / in_proj products).  PRECN = PREC_RAWNEXT: `wnext` already
+// points at the lane's first fragment of the following set, whatever its packing, and all SETK fragments behind it are requested
+// (a set of either packing is SETK or fewer consecutive fragments 64 apart; the surplus ones of a compensated set are the next
+// set's first two: harmless) -- for a slot whose successor is only known at run time, without a branch around the request.
+constexpr int PREC_SAME = -1, PREC_RAWNEXT = -2;
+template <int PREC, int K>
+__device__ __forceinline__ const u16x8* set_base(const u16x8* wp, int nb, int kc, int part, int wave, int lane) {
+    constexpr int KSTEPS = 256 / CT<PREC>::MFMA_K, KSTEPS_ALL = K / CT<PREC>::MFMA_K;
+    constexpr int FR = CT<PREC>::MFMA_K == 16 ? WFR<PREC> : 1, KP = SETK / FR;
+    return wp + ((size_t)(nb * 8 + wave) * KSTEPS_ALL + kc * KSTEPS + part * KP) * (FR * 64) + lane;
+}
+template <int PREC, int K, int KN, bool ROWS_N, bool P1_LOADED = false, typename Hook = NoHook, int PRECN = PREC_SAME>
 __device__ __forceinline__ void phase_tm(const typename CT<PREC>::elem* As, const u16x8* wp, int nb, int kc,
                                          const u16x8* wnext, int nnb, int nkc, int wave, int lane,
                                          u16x8 (&bs)[2][1][SETK], f32x16 (&acc)[4], Hook hook = Hook(), int hook0 = 0) {
@@ -173,8 +185,11 @@ __device__ __forceinline__ void phase_tm(const typename CT<PREC>::elem* As, cons
         constexpr int p = decltype(pc)::value;
         if constexpr (p + 1 < NP) {
             if constexpr (!(P1_LOADED && p == 0)) load_set<PREC, K, 1>(wp, nb, kc, p + 1, wave, lane, bs[(p + 1) & 1]);
+        } else if constexpr (PRECN == PREC_RAWNEXT) {
+#pragma unroll
+            for (int ks = 0; ks < SETK; ++ks) bs[0][0][ks] = wnext[(size_t)ks * 64];
         } else {
-            load_set<PREC, KN, 1>(wnext, nnb, nkc, 0, wave, lane, bs[0]);
+            load_set<PRECN == PREC_SAME ? PREC : PRECN, KN, 1>(wnext, nnb, nkc, 0, wave, lane, bs[0]);
         }
         if constexpr (p % (NP / 2) == 0) hook(hook0 + p / (NP / 2));
         __builtin_amdgcn_sched_barrier(0);
@@ -183,7 +198,7 @@ __device__ __forceinline__ void phase_tm(const typename CT<PREC>::elem* As, cons
     });
 }
 // same over the k-major tile (out_proj); set 1 is always loaded by the caller
-template <int PREC, int K, int KN>
+template <int PREC, int K, int KN, int PRECN = PREC>
 __device__ __forceinline__ void phase_km(const typename CT<PREC>::elem* Ys, const u16x8* wp, int nb, int kc,
                                          const u16x8* wnext, int nnb, int nkc, int wave, int lane,
                                          u16x8 (&bs)[2][1][SETK], f32x16 (&acc)[4]) {
@@ -192,7 +207,7 @@ __device__ __forceinline__ void phase_km(const typename CT<PREC>::elem* Ys, cons
         constexpr int p = decltype(pc)::value;
         if constexpr (p > 0) {
             if constexpr (p + 1 < NP) load_set<PREC, K, 1>(wp, nb, kc, p + 1, wave, lane, bs[(p + 1) & 1]);
-            else load_set<PREC, KN, 1>(wnext, nnb, nkc, 0, wave, lane, bs[0]);
+            else load_set<PRECN, KN, 1>(wnext, nnb, nkc, 0, wave, lane, bs[0]);
             __builtin_amdgcn_sched_barrier(0);
         }
         compute_km<PREC>(Ys, p, lane, bs[p & 1], acc);

@@ -307,6 +307,9 @@ __device__ __forceinline__ void epilogue(const GemmArgs& a, f32x16 (&acc)[CT<PRE
 // one "set" of weight fragments: both column tiles of a wave x SETK fragments (16 bytes per lane each) = SETK k-steps,
 // or SETK / 2 k-steps of (hi, lo) pairs in the compensated mode; a 256-deep reduction chunk is NPARTS sets
 constexpr int SETK = 8;
+// the arithmetic of the two MLP products inside a kernel of mode PREC (see tail16_kernel): plain fp16 under fp16c
+template <int PREC>
+constexpr int MLP_PREC = PREC == PREC_F16C ? (int)PREC_F16 : PREC;
 template <int PREC>
 constexpr int KPS = SETK / WFR<PREC>;                       // k-steps per set
 template <int PREC>

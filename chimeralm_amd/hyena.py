@@ -176,7 +176,7 @@ class HyenaDna(nn.Module):
 
     Extra keyword-only arguments (engine knobs, absent in the reference):
     `precision` selects the arithmetic of the dense projections -- "fp32" (exact, the reference's), "fp16c" (fp16 activations x
-    weights held as fp16 hi + fp8 lo: 16-bit MFMA rate; measured 1.2e-4 .. 9.6e-4 from the fp32 reference on seeded weights,
+    in_proj / out_proj / score weights held as fp16 hi + fp8 lo, MLP weights plain fp16: 16-bit MFMA rate; measured 1.9e-4 .. 1.04e-3 from the fp32 reference on seeded weights,
     DESIGN.md section 2; reads below 2,048 tokens run in fp32 kernels), "fp16" / "bf16" (reduced precision, outside the
     reference's 1e-3 tolerance); `chunk_reads` the number of reads pushed through all layers together.
     `selfcheck` (default: on for "fp16c") -- the reference runs ONE precision, fp32, always (hyena.py:244-256); a 16-bit mode's

@@ -51,8 +51,9 @@ extern "C" {
 #define CLM_PREC_F32 0
 #define CLM_PREC_BF16 1
 #define CLM_PREC_F16 2
-/* F16C: fp16 activations x weights held as hi + lo, hi = fp16(w) and lo = e4m3((w - hi) * 2^17): per 64-deep group four fp16
- * MFMAs with hi and one block-scaled fp8 MFMA with lo (activations truncated to e5m2 in registers), one fp32 accumulator.  The mode
+/* F16C: fp16 activations; the weights of in_proj, out_proj and the score layer held as hi + lo, hi = fp16(w) and lo = e4m3((w - hi)
+ * * 2^17): per 64-deep group four fp16 MFMAs with hi and one block-scaled fp8 MFMA with lo (activations truncated to e5m2 in
+ * registers), one fp32 accumulator; the two MLP products on plain fp16 weights (their rounding does not show in the logits).  The mode
  * that runs at 16-bit MFMA rate AND stays within the reference's 1e-3 logit tolerance (weight rounding is the error
  * that attention pooling cannot average out, tests/error_model.py); z / y are stored as fp16 like CLM_PREC_F16. */
 #define CLM_PREC_F16C 3
