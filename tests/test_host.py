@@ -68,6 +68,10 @@ def test_no_cpu_path_and_loud_failure(built_lib):
 def test_product_package_never_imports_oracle():
     for f in (REPO / "chimeralm_amd").rglob("*.py"):
         assert "oracle" not in f.read_text(), f"{f} mentions the oracle: the product path must not use it"
+    # ... and nothing under tools/ imports it either (developer probes that need it live under tests/)
+    for f in (REPO / "tools").rglob("*.py"):
+        txt = f.read_text()
+        assert "from oracle" not in txt and "import oracle" not in txt, f"{f} imports the oracle: move it under tests/"
 
 
 def test_state_dict_keys_match_reference_checkpoint_layout():

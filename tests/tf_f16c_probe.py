@@ -1,4 +1,4 @@
-"""Developer probe (GPU): raw error of the transformer's fp16c / fp16 modes against the fp64 oracle, by weight scale and length."""
+"""Developer probe (GPU; test infrastructure: it imports the oracle; not collected by pytest): raw error of the transformer's fp16c / fp16 modes against the fp64 oracle, by weight scale and length."""
 import sys
 
 import numpy as np

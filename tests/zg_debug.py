@@ -1,8 +1,8 @@
 """Developer check of the gated z hand-over (GPU): z / y of the LAST block as the two hand-over forms leave them.
-    python tools/dev/zg_debug.py [B L precision]"""
+    python tests/zg_debug.py [B L precision]"""
 import os, sys
 from pathlib import Path
-sys.path.insert(0, str(Path(__file__).resolve().parent.parent.parent))
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 import numpy as np, torch
 from oracle import hyena_oracle as ho
 from chimeralm_amd.engine import Engine
