@@ -267,6 +267,29 @@ def test_determinism_and_chunk_invariance(sd, built_lib):
     e1.close(), e2.close()
 
 
+def test_token_capped_chunks_equal_small_chunks(sd, built_lib):
+    """The engine lowers `chunk_reads` for long reads so that a chunk holds at most 256 x 8,256 tokens (clm_api.hip, chunk_for):
+    110 reads of 20,000 tokens go through as chunks of 104 + 6 reads under the default of 256 and agree with chunks of 8 (the same
+    read pairs in the packed transform; not bitwise: where a workgroup's tile range starts inside a read, its first two tokens take
+    the gated hand-over's patch path, and the ranges follow the launch size); the workspace follows the capped chunk, not 256 reads."""
+    from chimeralm_amd.engine import Engine
+
+    ids = torch.from_numpy(_ids(110, 20000, seed=5)).cuda()
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    e1 = Engine("cuda:0", precision="fp16c")                  # default chunk_reads = 256
+    e1.load_state_dict(sd)
+    a = e1.forward(ids).cpu()
+    used = free0 - torch.cuda.mem_get_info()[0]
+    assert torch.isfinite(a).all()
+    # z + y + h + gscratch of 104 reads x 20,032 tokens: ~12 GB; 256 reads would be ~30 GB
+    assert used < 16 * 2 ** 30, f"workspace of {used / 2 ** 30:.1f} GiB: the chunk was not capped"
+    e2 = Engine("cuda:0", precision="fp16c", chunk_reads=8)
+    e2.load_state_dict(sd)
+    assert (a - e2.forward(ids).cpu()).abs().max() < 0.5 * GATE
+    e1.close(), e2.close()
+
+
 @pytest.mark.parametrize("L", [9000, 16385])
 def test_block0_id_table_long_reads(sd, built_lib, monkeypatch, L):
     """Same for the segmented kernel (L > 8193), incl. the dot-product path of the lone last token (16385)."""
