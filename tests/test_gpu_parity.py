@@ -547,6 +547,36 @@ def test_shape_churn_filter_cache_and_workspace_regrowth(sd, built_lib):
     e.close()
 
 
+def test_random_shapes_against_the_exact_kernels(sd, built_lib):
+    """Forty seeded (reads, tokens) shapes -- odd and even batches, lengths on and off the 64 / 128 / 8,192-token boundaries, padded
+    reads -- through ONE default fp16c engine (256-read chunks, gated hand-over, peeled last token where L = 128 k + 1): every
+    batch within the mode's regression bound of the exact-fp32 kernels of the same engine (`clm_selfcheck`) and label-identical
+    where decided.  A cheap sweep for indexing mistakes the hand-picked shapes above might miss."""
+    from chimeralm_amd.engine import Engine
+
+    e = Engine("cuda:0", precision="fp16c")
+    e.load_state_dict(sd)
+    e.set_f16c_min_len(1)                                     # the 16-bit kernels at every length
+    rng = np.random.default_rng(2026)
+    special = [127, 128, 129, 255, 257, 1025, 2049, 4097, 8191, 8192, 8193, 8194, 8257, 9000, 16384, 16385, 16386, 24577]
+    worst = 0.0
+    for k in range(40):
+        L = int(special[k]) if k < len(special) else int(rng.integers(2, 12000))
+        B = int(rng.integers(1, 9)) if L > 6000 else int(rng.integers(1, 40))
+        ids = _ids(B, L, seed=500 + k)
+        if k % 3 == 0 and L > 40:
+            ids[0, : L // 3] = 4                                # a left-padded read
+        t = torch.from_numpy(ids).cuda()
+        out = e.forward(t).cpu()
+        assert torch.isfinite(out).all(), (B, L)
+        diff, differ = e.selfcheck(t)
+        worst = max(worst, diff)
+        bound = RAW_FP16C_BOUND if L >= 1024 else 4e-3           # short reads: less to average over (section 2)
+        assert diff <= bound, f"{B} x {L}: |fp16c - exact fp32| = {diff:.2e}"
+    print(f"40 random shapes: worst |fp16c - exact fp32| = {worst:.2e}")
+    e.close()
+
+
 def test_collated_bam_batch_against_oracle(engines, sd, golden_dir):
     """configs[0] plumbing: real reads -> tokenizer -> collator (left pad) -> engine == oracle on the same batch."""
     from chimeralm_amd import bam, tokenizer as T
