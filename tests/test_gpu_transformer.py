@@ -149,3 +149,31 @@ def test_selfcheck_falls_back_to_fp32_and_the_abi_agrees(built_lib):
     assert guarded.selfcheck_report["fallback"] is False
     guarded.close()
     exact.close()
+
+
+def test_random_shapes_fp16c_against_the_exact_kernels(built_lib):
+    """Sixteen seeded (reads, tokens) shapes through one fp16c model against the exact-fp32 kernels of the same handle
+    (`clm_tf_selfcheck`): positions on and off the 128-row tile boundary, single-position reads, odd batches -- the two-plane
+    attention output and the two-pass out_proj must index them all."""
+    import ctypes as C
+
+    from chimeralm_amd import _native as N
+
+    sd = to.make_state_dict(5, to.PRODUCTION, scale=1.0)
+    net = _model(sd, "fp16c")
+    lib = N.load()
+    rng = np.random.default_rng(7)
+    lengths = [8, 15, 16, 1023, 1024, 1025, 1031, 2055, 4101] + [int(x) for x in rng.integers(8, 6000, size=7)]
+    worst = 0.0
+    for k, L in enumerate(lengths):
+        B = int(rng.integers(1, 6))
+        ids = torch.from_numpy(to.synthetic_ids(300 + k, B, L, pads=(L // 4 if k % 2 else 0))).cuda()
+        out = net(ids)
+        assert torch.isfinite(out).all()
+        diff, differ = C.c_float(), C.c_int()
+        assert lib.clm_tf_selfcheck(net._h, C.c_void_p(ids.data_ptr()), N.DT_I64, ids.stride(0), B, L, None, C.byref(diff),
+                                    C.byref(differ)) == 0
+        worst = max(worst, diff.value)
+        assert diff.value < (GATE if L >= 512 else 4e-3), f"{B} x {L}: |fp16c - exact fp32| = {diff.value:.2e}"
+    print(f"16 random shapes: worst |fp16c - exact fp32| = {worst:.2e}")
+    net.close()
