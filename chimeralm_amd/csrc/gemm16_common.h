@@ -243,19 +243,23 @@ __device__ __forceinline__ void ln_acc_to_tile(f32x16 (&acc2)[4], float* P1, flo
     for (int mt = 0; mt < 4; ++mt) mean[mt] = 0.f, rstd[mt] = 1.f;
     __syncthreads();
 #elif !defined(CLM_EXP_LN1X)     // the two-exchange form: mean first, then the deviations about it
+    // (the two half-waves of a wave hold the same tokens: their partial sums are added through one lane exchange before they go to
+    //  the table -- 8 partials per token instead of 16, half the table reads and adds of every thread.  Round 3, timing-only build
+    //  of the final kernel: the statistics are 14 % of the tail kernel, profiles/r03_timing_only.txt)
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) {
         float s = 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) s += acc2[mt][r];
-        P1[(wave * 2 + lhalf) * BM + mt * 32 + lrow] = s;
+        s += __shfl_xor(s, 32, 64);
+        if (lhalf == 0) P1[wave * BM + mt * 32 + lrow] = s;
     }
     __syncthreads();
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) {
         float s = 0.f;
 #pragma unroll
-        for (int w = 0; w < 16; ++w) s += P1[w * BM + mt * 32 + lrow];
+        for (int w = 0; w < 8; ++w) s += P1[w * BM + mt * 32 + lrow];
         mean[mt] = s * (1.0f / D);
         float v = 0.f;
 #pragma unroll
@@ -263,14 +267,15 @@ __device__ __forceinline__ void ln_acc_to_tile(f32x16 (&acc2)[4], float* P1, flo
             const float d = acc2[mt][r] - mean[mt];
             v += d * d;
         }
-        P2[(wave * 2 + lhalf) * BM + mt * 32 + lrow] = v;
+        v += __shfl_xor(v, 32, 64);
+        if (lhalf == 0) P2[wave * BM + mt * 32 + lrow] = v;
     }
     __syncthreads();
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) {
         float v = 0.f;
 #pragma unroll
-        for (int w = 0; w < 16; ++w) v += P2[w * BM + mt * 32 + lrow];
+        for (int w = 0; w < 8; ++w) v += P2[w * BM + mt * 32 + lrow];
         rstd[mt] = 1.0f / sqrtf(v * (1.0f / D) + eps);
     }
 #else
@@ -319,27 +324,34 @@ __device__ __forceinline__ void ln_acc_to_tile(f32x16 (&acc2)[4], float* P1, flo
 #endif
     const float* gp = g + wave * 32 + 4 * lhalf;
     const float* bp = bta + wave * 32 + 4 * lhalf;
+    // Rows beyond the read leave as zeros.  Only a read's last tile has any (none at all where the last token is peeled: 8k-bp
+    // reads), so the 64 selects per thread are kept off the common path by a uniform branch (timing-only build without them:
+    // -2 .. -4 % on the tail kernel).
+    auto write_tile = [&](auto masked) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const float4 g4 = *reinterpret_cast<const float4*>(gp + 8 * q);
-        const float4 b4 = *reinterpret_cast<const float4*>(bp + 8 * q);
+        for (int q = 0; q < 4; ++q) {
+            const float4 g4 = *reinterpret_cast<const float4*>(gp + 8 * q);
+            const float4 b4 = *reinterpret_cast<const float4*>(bp + 8 * q);
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt) {
-            const bool ok = t0 + mt * 32 + lrow < L;
-            const float y0 = ok ? (acc2[mt][4 * q + 0] - mean[mt]) * rstd[mt] * g4.x + b4.x : 0.f;
-            const float y1 = ok ? (acc2[mt][4 * q + 1] - mean[mt]) * rstd[mt] * g4.y + b4.y : 0.f;
-            const float y2 = ok ? (acc2[mt][4 * q + 2] - mean[mt]) * rstd[mt] * g4.z + b4.z : 0.f;
-            const float y3 = ok ? (acc2[mt][4 * q + 3] - mean[mt]) * rstd[mt] * g4.w + b4.w : 0.f;
-            if (KEEP) {
-                acc2[mt][4 * q + 0] = y0;
-                acc2[mt][4 * q + 1] = y1;
-                acc2[mt][4 * q + 2] = y2;
-                acc2[mt][4 * q + 3] = y3;
+            for (int mt = 0; mt < 4; ++mt) {
+                const bool ok = !decltype(masked)::value || t0 + mt * 32 + lrow < L;
+                const float y0 = ok ? (acc2[mt][4 * q + 0] - mean[mt]) * rstd[mt] * g4.x + b4.x : 0.f;
+                const float y1 = ok ? (acc2[mt][4 * q + 1] - mean[mt]) * rstd[mt] * g4.y + b4.y : 0.f;
+                const float y2 = ok ? (acc2[mt][4 * q + 2] - mean[mt]) * rstd[mt] * g4.z + b4.z : 0.f;
+                const float y3 = ok ? (acc2[mt][4 * q + 3] - mean[mt]) * rstd[mt] * g4.w + b4.w : 0.f;
+                if (KEEP) {
+                    acc2[mt][4 * q + 0] = y0;
+                    acc2[mt][4 * q + 1] = y1;
+                    acc2[mt][4 * q + 2] = y2;
+                    acc2[mt][4 * q + 3] = y3;
+                }
+                u16x4 pk = {to_bits<PREC>(y0), to_bits<PREC>(y1), to_bits<PREC>(y2), to_bits<PREC>(y3)};
+                *reinterpret_cast<u16x4*>(As + (mt * 32 + lrow) * RS16 + wave * 32 + 8 * q + 4 * lhalf) = pk;
             }
-            u16x4 pk = {to_bits<PREC>(y0), to_bits<PREC>(y1), to_bits<PREC>(y2), to_bits<PREC>(y3)};
-            *reinterpret_cast<u16x4*>(As + (mt * 32 + lrow) * RS16 + wave * 32 + 8 * q + 4 * lhalf) = pk;
         }
-    }
+    };
+    if (t0 + BM <= L) write_tile(std::false_type{});        // (uniform)
+    else write_tile(std::true_type{});
     __syncthreads();
 }
 
