@@ -60,6 +60,8 @@ SYMBOLS = {
     "clm_check": (C.c_int, [_H, C.c_void_p]),
     "clm_selfcheck": (C.c_int, [_H, C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_float),
                                 C.POINTER(C.c_int)]),
+    "clm_logit_deviation": (C.c_int, [C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_int, C.c_int, C.POINTER(C.c_float),
+                                      C.POINTER(C.c_int)]),
     "clm_set_fallback": (C.c_int, [_H, C.c_int]),
     "clm_effective_precision": (C.c_int, [_H, C.c_int]),
     "clm_set_short_read_len": (C.c_int, [_H, C.c_int]),

@@ -1015,14 +1015,27 @@ int clm_selfcheck(clm_handle* h, const void* ids, int ids_dtype, int64_t ids_row
     HIPCHK(h, hipStreamSynchronize(st));
     float worst = 0.f;
     int differ = 0;
-    for (int b = 0; b < B; ++b) {
-        const float* a = &host[(size_t)b * NCLS];
-        const float* r = &host[((size_t)h->sc_cap + b) * NCLS];
-        for (int c = 0; c < NCLS; ++c) {
-            const float d = std::fabs(a[c] - r[c]);
-            worst = (d > worst || d != d) ? (d != d ? INFINITY : d) : worst;   // NaN anywhere = infinitely wrong
+    (void)clm_logit_deviation(host.data(), host.data() + (size_t)h->sc_cap * NCLS, B, NCLS, &worst, &differ);
+    *max_abs_diff = worst;
+    if (labels_differ) *labels_differ = differ;
+    return CLM_OK;
+}
+
+int clm_logit_deviation(const float* a, const float* b, int B, int n_classes, float* max_abs_diff, int* labels_differ) {
+    if (!a || !b || !max_abs_diff || B < 0 || n_classes < 1) return CLM_E_INVALID;
+    float worst = 0.f;
+    int differ = 0;
+    for (int r = 0; r < B; ++r) {
+        const float *x = a + (size_t)r * n_classes, *y = b + (size_t)r * n_classes;
+        int ax = 0, ay = 0;
+        for (int c = 0; c < n_classes; ++c) {
+            const float d = std::fabs(x[c] - y[c]);
+            if (!(d <= 3.0e38f)) worst = INFINITY;             // NaN or inf anywhere = infinitely wrong, and it STAYS so
+            else if (d > worst) worst = d;
+            if (x[c] > x[ax]) ax = c;
+            if (y[c] > y[ay]) ay = c;
         }
-        differ += (a[1] > a[0]) != (r[1] > r[0]);
+        differ += ax != ay;
     }
     *max_abs_diff = worst;
     if (labels_differ) *labels_differ = differ;

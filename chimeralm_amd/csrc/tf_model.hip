@@ -487,7 +487,7 @@ struct clm_tf_handle {
     std::map<std::string, void*> packed;
     bool finalized = false;
     // workspace
-    size_t cap_rows = 0, cap_tok = 0;
+    size_t cap_rows = 0, cap_tok = 0, cap_B = 0;            // cap_B: reads `pooled` has rows for (it scales with B alone)
     size_t cap16[7] = {};                         // bytes of x1, x2, x3, hx, qkv, att, u
     unsigned char* ids8 = nullptr;
     void *x1 = nullptr, *x2 = nullptr, *x3 = nullptr, *hx = nullptr, *qkv = nullptr, *att = nullptr, *u = nullptr;
@@ -572,7 +572,7 @@ void tf_free_ws(clm_tf_handle* h) {
         if (p) (void)hipFree(p);
     h->ids8 = nullptr; h->x1 = h->x2 = h->x3 = h->hx = h->qkv = h->att = h->u = nullptr;
     h->h = h->scores = h->pooled = h->ws32 = nullptr;
-    h->cap_rows = h->cap_tok = h->cap_ws32 = 0;
+    h->cap_rows = h->cap_tok = h->cap_ws32 = h->cap_B = 0;
     for (size_t& c : h->cap16) c = 0;
 }
 
@@ -766,14 +766,20 @@ static int tf_run(clm_tf_handle* h, bool prec32, const void* ids, int ids_dtype,
                   float* logits_out, hipStream_t st) {
     const int L3 = L / 8;
     const size_t M = (size_t)B * L3, tok = (size_t)B * ((L + 63) / 64 * 64);
-    if (M > h->cap_rows || tok > h->cap_tok) {                // shared pieces: ids, residual stream, pooling
+    if (M > h->cap_rows || tok > h->cap_tok) {                // shared pieces: ids, residual stream, pooling scores
         TFCHK(h, hipDeviceSynchronize());
         tf_free_ws(h);
         TFCHK(h, hipMalloc((void**)&h->ids8, tok));
         TFCHK(h, hipMalloc((void**)&h->h, M * D * 4));
         TFCHK(h, hipMalloc((void**)&h->scores, M * 4));
-        TFCHK(h, hipMalloc((void**)&h->pooled, (size_t)B * D * 4));
         h->cap_rows = M; h->cap_tok = tok;
+    }
+    if ((size_t)B > h->cap_B) {                               // pooled [B][256]: its own capacity -- a batch of MORE, SHORTER reads fits
+        TFCHK(h, hipDeviceSynchronize());                     // cap_rows / cap_tok and must still regrow this one
+        if (h->pooled) (void)hipFree(h->pooled);
+        h->pooled = nullptr; h->cap_B = 0;
+        TFCHK(h, hipMalloc((void**)&h->pooled, (size_t)B * D * 4));
+        h->cap_B = (size_t)B;
     }
     if (prec32) {
         const size_t need = tf32_workspace_floats(B, L);
@@ -867,16 +873,7 @@ int clm_tf_selfcheck(clm_tf_handle* h, const void* ids, int ids_dtype, int64_t i
         TFCHK(h, hipMemcpyAsync(a.data(), lm, a.size() * 4, hipMemcpyDeviceToHost, st));
         TFCHK(h, hipMemcpyAsync(b.data(), lx, b.size() * 4, hipMemcpyDeviceToHost, st));
         TFCHK(h, hipStreamSynchronize(st));
-        for (int r = 0; r < B; ++r) {
-            int am = 0, bm = 0;
-            for (int c = 0; c < NCLS; ++c) {
-                const float d = std::fabs(a[(size_t)r * NCLS + c] - b[(size_t)r * NCLS + c]);
-                if (!(d <= diff)) diff = d;                    // NaN-propagating maximum
-                if (a[(size_t)r * NCLS + c] > a[(size_t)r * NCLS + am]) am = c;
-                if (b[(size_t)r * NCLS + c] > b[(size_t)r * NCLS + bm]) bm = c;
-            }
-            differ += am != bm;
-        }
+        (void)clm_logit_deviation(a.data(), b.data(), B, NCLS, &diff, &differ);   // (shared with clm_selfcheck: a non-finite logit is sticky +inf)
     }
     if (max_abs_diff_out) *max_abs_diff_out = diff;
     if (labels_differ_out) *labels_differ_out = differ;

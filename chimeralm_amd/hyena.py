@@ -181,9 +181,10 @@ class HyenaDna(nn.Module):
     reference's 1e-3 tolerance); `chunk_reads` the number of reads pushed through all layers together.
     `selfcheck` (default: on for "fp16c") -- the reference runs ONE precision, fp32, always (hyena.py:244-256); a 16-bit mode's
     distance from it depends on the weights, so it is MEASURED on the weights actually loaded: before the first batch after every
-    weight (re)load seeded synthetic samples of 4,097, 2,048, 1,024, 512 and 256 tokens and the first reads of that batch -- and
-    of any later batch less than half as long as every batch checked so far -- run through both the mode and the exact-fp32
-    kernels of the same engine (`clm_selfcheck`).  If the largest logit difference at the longest sample or on a batch exceeds
+    weight (re)load seeded synthetic samples of 4,097, 2,048, 1,024, 512 and 256 tokens and four reads spread over that batch --
+    and of every `selfcheck_every`-th later batch (64), and of any batch more than 1.5x shorter or longer than every batch checked
+    so far -- run through both the mode and the exact-fp32 kernels of the same engine (`clm_selfcheck`).  A sample, not a bound:
+    batches in between are not measured.  If the largest logit difference at the longest sample or on a batch exceeds
     `selfcheck_tol` (5e-4, half the tolerance) the engine falls back to exact fp32 for good (logged); otherwise the shortest
     sample length that still passes (with every longer one) becomes the length below which reads take the fp32 kernels inside
     the mode (`clm_set_short_read_len`; 2,048 unmeasured) -- the mode's error is a sum of per-token roundings that the pooling averages
@@ -192,7 +193,7 @@ class HyenaDna(nn.Module):
 
     def __init__(self, number_of_classes: int, head: nn.Module, backbone_name: str = "hyenadna-small-32k-seqlen", *,
                  freeze_backbone: bool = False, precision: str = "fp16c", chunk_reads: int = 256,
-                 selfcheck: bool | None = None, selfcheck_tol: float = 5e-4):
+                 selfcheck: bool | None = None, selfcheck_tol: float = 5e-4, selfcheck_every: int = 64):
         super().__init__()
         if number_of_classes != 2:
             raise NotImplementedError("the engine implements the binary (2-class) head only")
@@ -207,13 +208,16 @@ class HyenaDna(nn.Module):
         self.chunk_reads = chunk_reads
         self.selfcheck = (precision == "fp16c") if selfcheck is None else bool(selfcheck)
         self.selfcheck_tol = float(selfcheck_tol)
+        self.selfcheck_every = int(selfcheck_every)
         self.selfcheck_report: dict = {}
         if freeze_backbone:
             for p in self.backbone.parameters():
                 p.requires_grad = False
         self._engine: Engine | None = None
         self._engine_sig = None
-        self._checked_min_len: int | None = None          # shortest batch a self-check has covered since the last weight load
+        self._checked_min_len: int | None = None          # shortest / longest batch a self-check has covered since the last
+        self._checked_max_len: int | None = None          # weight load, and the batches that went by since the last check
+        self._batches_since_check = 0
 
     # -------------------------------------------------------------------------------- engine plumbing
     def _signature(self):
@@ -230,13 +234,22 @@ class HyenaDna(nn.Module):
         if sig != self._engine_sig:
             self._engine.load_state_dict(self.state_dict())
             self._engine_sig = sig
-            self._engine.set_fallback(False)               # new weights: the mode gets a new hearing
-            self._checked_min_len = None
+            self._engine.set_fallback(False)               # new weights: the mode gets a new hearing ...
+            if self.precision == "fp16c":
+                self._engine.set_f16c_min_len(2048)        # ... and the length switch its unmeasured default
+            self._checked_min_len = self._checked_max_len = None
+            self._batches_since_check = 0
             self.selfcheck_report = {}
         return self._engine
 
     # -------------------------------------------------------------------------------- the 16-bit mode on trial
     _SAMPLE_LENGTHS = (4097, 2048, 1024, 512, 256)       # descending: the mode's error grows like 1 / sqrt(L)
+    _BATCH_ROWS = 4                                       # reads of a batch that a check runs through both arithmetics
+
+    @staticmethod
+    def _sample_rows(B: int, n: int) -> list[int]:
+        """`n` rows spread evenly over a batch of B (not its first rows: a file sorted by anything would make those alike)."""
+        return list(range(B)) if B <= n else sorted({round(i * (B - 1) / (n - 1)) for i in range(n)})
 
     def _selfcheck(self, eng: Engine, input_ids: torch.Tensor) -> None:
         """See the class docstring.  Runs on torch's current stream and synchronises it (a few ms per sample)."""
@@ -251,33 +264,41 @@ class HyenaDna(nn.Module):
 
         if self._checked_min_len is None:                  # first batch since the weights were loaded
             g = torch.Generator().manual_seed(20240)
-            if f16c:
-                eng.set_f16c_min_len(1)                    # measure the 16-bit kernels themselves at every sample length
             min_ok = None
-            for Ls in self._SAMPLE_LENGTHS:
-                n = 4 if Ls >= 2048 else 8
-                ids = torch.randint(7, 11, (n, Ls), generator=g, dtype=torch.uint8)
-                ids[:, -1] = 1                              # [SEP]
-                ids[0, : Ls // 3] = 4                       # one read left-padded, as the collator pads
-                d = measure(f"synthetic {n} x {Ls}", ids.to(eng.device))
-                if d > self.selfcheck_tol:
-                    if min_ok is None:                      # not even the longest sample passes: the mode is off for good
-                        rep["max_abs_dlogit"] = d
-                    break
-                rep["max_abs_dlogit"] = max(rep.get("max_abs_dlogit", 0.0), d)
-                min_ok = Ls
-                if not f16c:
-                    break                                   # fp16 / bf16: one verdict, no length switch
-            if f16c:
+            try:
+                if f16c:
+                    eng.set_f16c_min_len(1)                # measure the 16-bit kernels themselves at every sample length
+                for Ls in self._SAMPLE_LENGTHS:
+                    n = 4 if Ls >= 2048 else 8
+                    ids = torch.randint(7, 11, (n, Ls), generator=g, dtype=torch.uint8)
+                    ids[:, -1] = 1                          # [SEP]
+                    ids[0, : Ls // 3] = 4                   # one read left-padded, as the collator pads
+                    d = measure(f"synthetic {n} x {Ls}", ids.to(eng.device))
+                    if not d <= self.selfcheck_tol:         # (NaN fails too)
+                        if min_ok is None:                  # not even the longest sample passes: the mode is off for good
+                            rep["max_abs_dlogit"] = d
+                        break
+                    rep["max_abs_dlogit"] = max(rep.get("max_abs_dlogit", 0.0), d)
+                    min_ok = Ls
+                    if not f16c:
+                        break                               # fp16 / bf16: one verdict, no length switch
+            finally:
+                # whatever happened in the loop (an engine error included) the handle never stays at "every length in 16 bits":
                 # reads shorter than the shortest sample length that passed (with every longer one) take the fp32 kernels
-                rep["f16c_min_len"] = min_ok if min_ok is not None else 2048
-                eng.set_f16c_min_len(rep["f16c_min_len"])
+                if f16c:
+                    rep["f16c_min_len"] = min_ok if min_ok is not None else 2048
+                    eng.set_f16c_min_len(rep["f16c_min_len"])
         if eng.effective_precision(L) != "fp32":
-            d = measure(f"batch rows 0..{min(B, 4) - 1} x {L}", input_ids[: min(B, 4)])
-            rep["max_abs_dlogit"] = max(rep.get("max_abs_dlogit", 0.0), d)
+            rows = self._sample_rows(B, self._BATCH_ROWS)
+            sample = input_ids[rows] if rows != list(range(len(rows))) else input_ids[: len(rows)]
+            d = measure(f"batch rows {rows} x {L}", sample)
+            rep["max_abs_dlogit"] = max(rep.get("max_abs_dlogit", 0.0), d) if d == d else float("inf")
         rep["tol"], rep["precision"] = self.selfcheck_tol, self.precision
         self._checked_min_len = L if self._checked_min_len is None else min(L, self._checked_min_len)
-        if rep.get("max_abs_dlogit", 0.0) > self.selfcheck_tol and not rep.get("fallback"):
+        self._checked_max_len = max(L, self._checked_max_len or 0)
+        self._batches_since_check = 0
+        rep["checks"] = rep.get("checks", 0) + 1
+        if not rep.get("max_abs_dlogit", 0.0) <= self.selfcheck_tol and not rep.get("fallback"):
             eng.set_fallback(True)
             rep["fallback"] = True
             import logging
@@ -290,13 +311,26 @@ class HyenaDna(nn.Module):
             warnings.warn(msg, RuntimeWarning, stacklevel=3)
         rep.setdefault("fallback", False)
 
-    def guard(self, eng: Engine, input_ids: torch.Tensor) -> None:
-        """Self-check of the 16-bit mode where one is due (first batch since a weight load; a batch less than half as long as
-        every batch checked so far).  `forward` calls it; loops that drive the engine directly (predict.run_predict_native) call
-        it with the batch's first reads."""
-        if self.selfcheck and self.precision != "fp32" and not self.selfcheck_report.get("fallback") and (
-                self._checked_min_len is None or 2 * input_ids.shape[1] < self._checked_min_len):
-            self._selfcheck(eng, input_ids)
+    def guard_due(self, n_tokens: int) -> bool:
+        """Is a self-check due for a batch of `n_tokens`-token reads?  The first batch since a weight load; a batch whose length
+        leaves the range already checked by more than a factor 1.5 in EITHER direction (the mode's error is neither monotone in
+        the length nor the same from batch to batch: profiles/r03_fp16c_margin.txt); and every `selfcheck_every`-th batch
+        (default 64: two passes over 4 reads, ~0.2 % of the time between two checks).  Counts the batch."""
+        if not self.selfcheck or self.precision == "fp32" or self.selfcheck_report.get("fallback"):
+            return False
+        if self._checked_min_len is None:
+            return True
+        self._batches_since_check += 1
+        return (3 * n_tokens < 2 * self._checked_min_len or 2 * n_tokens > 3 * self._checked_max_len
+                or (self.selfcheck_every > 0 and self._batches_since_check >= self.selfcheck_every))
+
+    def guard(self, eng: Engine, input_ids, n_tokens: int | None = None) -> None:
+        """Self-check of the 16-bit mode where one is due (`guard_due`).  `forward` calls it; loops that drive the engine directly
+        (predict.run_predict_native) call it with a CALLABLE that returns the batch's ids on the device, so that nothing is
+        copied for the batches -- almost all -- on which no check is due."""
+        L = int(n_tokens if n_tokens is not None else input_ids.shape[1])
+        if self.guard_due(L):
+            self._selfcheck(eng, input_ids() if callable(input_ids) else input_ids)
 
     def forward(self, input_ids: torch.Tensor, input_quals: torch.Tensor | None = None) -> torch.Tensor:
         """`input_quals` is accepted and ignored, exactly as the reference does (hyena.py:244-256)."""

@@ -7,7 +7,7 @@ buffer of the same shape), same `forward(input_ids, input_quals=None) -> logits 
 `ClassificationLit` reads.  The arithmetic runs in csrc/tf_model.hip + csrc/attention.hip behind the `clm_tf_*` C ABI; there is no
 CPU path.  Engine knobs absent in the reference: `precision` in {"fp32", "fp16c", "fp16", "bf16"} (fp32 = the reference's arithmetic;
 fp16c = fp16 activations x weights as fp16 hi + fp8 lo, the Hyena path's compensated mode) and `selfcheck` /
-`selfcheck_tol`: before the first batch after a weight load (and again for a batch less than half as long as any checked so far) the
+`selfcheck_tol`: before the first batch after a weight load (and again every `selfcheck_every`-th batch and for a batch more than 1.5x shorter or longer than any checked so far) the
 16-bit mode is measured against the exact-fp32 kernels of the same engine on seeded reads and on the batch's first reads
 (`clm_tf_selfcheck`); above the threshold the module falls back to fp32 for good and says so.  On by default for fp16c.
 """
@@ -41,7 +41,8 @@ class TransformerEngineError(RuntimeError):
 class SequenceCNNTransformer(nn.Module):
     def __init__(self, vocab_size: int, max_len: int, d_model: int = 256, cnn_kernel_size: int = 3, dropout: float = 0.1,
                  num_encoder_layers: int = 2, nhead: int = 8, dim_feedforward: int = 1024, number_of_classes: int = 2,
-                 padding_idx: int = 4, *, precision: str = "fp16", selfcheck: bool | None = None, selfcheck_tol: float = 5e-4):
+                 padding_idx: int = 4, *, precision: str = "fp16", selfcheck: bool | None = None, selfcheck_tol: float = 5e-4,
+                 selfcheck_every: int = 64):
         super().__init__()
         if (vocab_size, d_model, cnn_kernel_size, nhead, dim_feedforward, number_of_classes) != (12, 256, 3, 8, 1024, 2):
             raise NotImplementedError("the MI355X encoder implements the production shape: vocab 12, d_model 256, kernel 3, "
@@ -54,7 +55,10 @@ class SequenceCNNTransformer(nn.Module):
         self.selfcheck = (precision == "fp16c") if selfcheck is None else bool(selfcheck)
         self.selfcheck_tol = float(selfcheck_tol)
         self.selfcheck_report: dict = {}
+        self.selfcheck_every = int(selfcheck_every)
         self._checked_min_len: int | None = None
+        self._checked_max_len: int | None = None
+        self._batches_since_check = 0
         self.embedding = nn.Embedding(vocab_size, d_model, padding_idx=padding_idx)
         self.pos_encoder = _PosEnc(d_model, max_len)
         conv = lambda: nn.Conv1d(d_model, d_model, kernel_size=cnn_kernel_size, padding=1)  # noqa: E731
@@ -91,7 +95,7 @@ class SequenceCNNTransformer(nn.Module):
                 self._check(lib.clm_tf_load_weight(self._h, k.encode(), C.c_void_p(t.data_ptr()), N.DT_F32, shape, t.dim()))
             self._check(lib.clm_tf_finalize(self._h))
             self._check(lib.clm_tf_set_fallback(self._h, 0))
-            self._sig, self._checked_min_len, self.selfcheck_report = sig, None, {}
+            self._sig, self._checked_min_len, self._checked_max_len, self._batches_since_check, self.selfcheck_report = sig, None, None, 0, {}
         return lib
 
     # ------------------------------------------------------------------ the 16-bit mode on trial
@@ -105,12 +109,22 @@ class SequenceCNNTransformer(nn.Module):
             {"sample": name, "max_abs_dlogit": diff.value, "labels_differ": differ.value})
         return diff.value
 
+    def guard_due(self, n_tokens: int) -> bool:
+        """As `HyenaDna.guard_due`: the first batch since a weight load, a batch more than 1.5x shorter or longer than every batch
+        checked so far, and every `selfcheck_every`-th batch."""
+        if not self.selfcheck or self.precision == "fp32" or self.selfcheck_report.get("fallback"):
+            return False
+        if self._checked_min_len is None:
+            return True
+        self._batches_since_check += 1
+        return (3 * n_tokens < 2 * self._checked_min_len or 2 * n_tokens > 3 * self._checked_max_len
+                or (self.selfcheck_every > 0 and self._batches_since_check >= self.selfcheck_every))
+
     def guard(self, lib, input_ids: torch.Tensor) -> None:
         """Self-check of the 16-bit mode where one is due (see the module docstring)."""
         rep = self.selfcheck_report
         L = input_ids.shape[1]
-        if not self.selfcheck or self.precision == "fp32" or rep.get("fallback") or not (
-                self._checked_min_len is None or 2 * L < self._checked_min_len):
+        if not self.guard_due(L):
             return
         worst = rep.get("max_abs_dlogit", 0.0)
         if self._checked_min_len is None:                      # first batch since the weights were loaded: seeded reads
@@ -119,9 +133,13 @@ class SequenceCNNTransformer(nn.Module):
             ids = torch.randint(7, 11, (4, Ls), generator=g, dtype=torch.uint8)
             ids[0, : Ls // 3] = 4                              # one read left-padded, as the collator pads
             worst = max(worst, self._measure(lib, f"synthetic 4 x {Ls}", ids.to(input_ids.device)))
-        worst = max(worst, self._measure(lib, f"batch rows 0..{min(input_ids.shape[0], 4) - 1} x {L}", input_ids[:4]))
+        B = input_ids.shape[0]
+        rows = list(range(B)) if B <= 4 else sorted({round(i * (B - 1) / 3) for i in range(4)})   # spread over the batch
+        worst = max(worst, self._measure(lib, f"batch rows {rows} x {L}", input_ids[rows].contiguous()))
         rep.update(max_abs_dlogit=worst, tol=self.selfcheck_tol, precision=self.precision)
         self._checked_min_len = L if self._checked_min_len is None else min(L, self._checked_min_len)
+        self._checked_max_len = max(L, self._checked_max_len or 0)
+        self._batches_since_check = 0
         if not worst <= self.selfcheck_tol:                    # (NaN fails too)
             self._check(lib.clm_tf_set_fallback(self._h, 1))
             rep["fallback"] = True

@@ -143,6 +143,10 @@ int clm_selfcheck(clm_handle* h, const void* ids, int ids_dtype, int64_t ids_row
                   float* max_abs_diff, int* labels_differ);
 int clm_set_fallback(clm_handle* h, int on);
 int clm_effective_precision(const clm_handle* h, int L);
+/* The reduction both self-checks report (pure host arithmetic, no device needed): a, b = logits [B][n_classes] of the mode and of
+ * the referee; *max_abs_diff = the largest |a - b|, +inf as soon as ANY difference is not finite (and it stays +inf: a NaN in read
+ * 0 must not be overwritten by a finite difference of read 1); *labels_differ = reads whose argmax differs (may be NULL). */
+int clm_logit_deviation(const float* a, const float* b, int B, int n_classes, float* max_abs_diff, int* labels_differ);
 /* CLM_PREC_F16C only: reads shorter than `min_len` tokens run in the exact-fp32 kernels inside the mode (default 2,048: the
  * mode's error is a sum of per-token fp16 roundings that the attention pooling averages like 1 / sqrt(L); below some length it
  * no longer fits half the tolerance).  That length depends on the weights: the caller may MEASURE it with clm_selfcheck on reads

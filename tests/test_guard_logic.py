@@ -49,14 +49,66 @@ def test_all_samples_pass_lowers_the_switch_to_the_shortest_sample():
     net.guard(eng, _ids(6, 3000))
     rep = net.selfcheck_report
     assert rep["fallback"] is False and eng.fallback is False and rep["f16c_min_len"] == 256 == eng.min_len
-    assert [c[1] for c in eng.calls] == [4097, 2048, 1024, 512, 256, 3000]       # descending samples, then the batch's first rows
+    assert [c[1] for c in eng.calls] == [4097, 2048, 1024, 512, 256, 3000]       # descending samples, then four rows of the batch
     assert eng.calls[-1][0] == 4 and abs(rep["max_abs_dlogit"] - 4.9e-4) < 1e-12
     n = len(eng.calls)
-    net.guard(eng, _ids(6, 3000))                                                # checked once per weight load ...
-    net.guard(eng, _ids(6, 1600))
+    net.guard(eng, _ids(6, 3000))                                                # a length inside the checked range: nothing to do ...
+    net.guard(eng, _ids(6, 2200))
+    net.guard(eng, _ids(6, 4400))
     assert len(eng.calls) == n
-    net.guard(eng, _ids(2, 1400))                                                # ... and again for a batch less than half as long
+    net.guard(eng, _ids(2, 1400))                                                # ... a batch more than 1.5x SHORTER than any checked
     assert eng.calls[-1] == (2, 1400) and len(eng.calls) == n + 1
+    net.guard(eng, _ids(3, 4600))                                                # ... or more than 1.5x LONGER (the error is
+    assert eng.calls[-1] == (3, 4600) and len(eng.calls) == n + 2                #     not monotone in the length)
+    net.guard(eng, _ids(3, 2000))                                                # [1400, 4600] is covered now
+    assert len(eng.calls) == n + 2
+
+
+def test_periodic_recheck_and_rows_spread_over_the_batch():
+    net = lm.ChimeraLM.new(precision="fp16c", selfcheck_every=3).net
+    eng = StubEngine({4097: 2e-4, 2048: 3e-4, 1024: 7e-4})
+    seen = []
+    eng_selfcheck = eng.selfcheck
+    eng.selfcheck = lambda ids: (seen.append(ids.clone()), eng_selfcheck(ids))[1]
+    ids = torch.arange(40, dtype=torch.uint8)[:, None].repeat(1, 3000)            # row r holds the value r
+    net.guard(eng, ids)
+    assert seen[-1][:, 0].tolist() == [0, 13, 26, 39]                              # four rows spread over the batch, not rows 0..3
+    n = len(eng.calls)
+    net.guard(eng, ids), net.guard(eng, ids)
+    assert len(eng.calls) == n and net.selfcheck_report["checks"] == 1
+    net.guard(eng, ids)                                                            # the third batch since the last check
+    assert len(eng.calls) == n + 1 and net.selfcheck_report["checks"] == 2
+    eng.batch_err = 9e-4                                                           # the mode drifts above the threshold on LATER data
+    net.guard(eng, ids), net.guard(eng, ids)
+    assert eng.fallback is False
+    with pytest.warns(RuntimeWarning, match="falling back"):
+        net.guard(eng, ids)
+    assert eng.fallback is True and net.selfcheck_report["fallback"] is True
+
+
+def test_guard_takes_a_callable_and_only_calls_it_when_a_check_is_due():
+    net = _net()
+    eng = StubEngine({4097: 2e-4, 2048: 3e-4, 1024: 7e-4})
+    made = []
+    make = lambda: (made.append(1), _ids(5, 3000))[1]
+    net.guard(eng, make, n_tokens=3000)
+    assert len(made) == 1
+    for _ in range(10):
+        net.guard(eng, make, n_tokens=3000)
+    assert len(made) == 1                                                          # run_predict_native: no copy on the other batches
+
+
+def test_an_engine_error_inside_the_sample_loop_restores_the_length_switch():
+    net = _net()
+    eng = StubEngine({4097: 2e-4})
+    def boom(ids):
+        if ids.shape[1] == 2048:
+            raise RuntimeError("out of memory")
+        return (2e-4, 0)
+    eng.selfcheck = boom
+    with pytest.raises(RuntimeError):
+        net.guard(eng, _ids(4, 5000))
+    assert eng.min_len == 4097                                                     # never left at 1 (every length in 16 bits)
 
 
 def test_first_failing_sample_sets_the_switch_and_keeps_the_mode_for_longer_reads():

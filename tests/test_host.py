@@ -32,6 +32,36 @@ def test_abi_exports_every_header_symbol(built_lib):
     assert lib2.clm_profile_stage_name(2) == b"short_long_conv"
 
 
+def test_logit_deviation_keeps_a_non_finite_difference(built_lib):
+    """the self-checks' reduction (`clm_logit_deviation`, shared by clm_selfcheck and clm_tf_selfcheck; pure host
+    arithmetic) -- a NaN / inf in ANY read is +inf for good, whatever finite differences follow it."""
+    from chimeralm_amd import _native
+
+    lib = _native.load()
+
+    def dev(a, b):
+        a, b = np.ascontiguousarray(a, np.float32), np.ascontiguousarray(b, np.float32)
+        d, n = ctypes.c_float(-1.0), ctypes.c_int(-1)
+        fp = ctypes.POINTER(ctypes.c_float)
+        assert lib.clm_logit_deviation(a.ctypes.data_as(fp), b.ctypes.data_as(fp), a.shape[0], a.shape[1], ctypes.byref(d),
+                                       ctypes.byref(n)) == 0
+        return d.value, n.value
+
+    ref = np.array([[0.5, -0.5], [1.0, 2.0], [3.0, -1.0]], np.float32)
+    got = ref + np.array([[1e-4, 0], [0, -3e-4], [2e-4, 0]], np.float32)
+    d, n = dev(got, ref)
+    assert abs(d - 3e-4) < 1e-6 and n == 0
+    for bad in (np.nan, np.inf, -np.inf):
+        for row in range(3):                                  # row 0 is the case the old transformer reduction lost
+            g = got.copy()
+            g[row, 1] = bad
+            assert dev(g, ref)[0] == np.inf, (bad, row)
+    flipped = ref.copy()
+    flipped[1] = flipped[1, ::-1]
+    assert dev(flipped, ref) == (1.0, 1)
+    assert lib.clm_logit_deviation(None, None, 1, 2, None, None) == _native.E_INVALID
+
+
 def test_headers_are_plain_c_and_a_c_client_links(built_lib, tmp_path):
     """The boundary is a C ABI: both headers compile as strict C99 on their own, and the plain-C client of
     tests/c_abi/ (run on the GPU by tests/test_gpu_c_abi.py) compiles and links against the library with gcc."""
