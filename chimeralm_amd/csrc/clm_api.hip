@@ -41,11 +41,7 @@ struct FilterSet {
     float* ktime[NLAYER] = {};
     float2* kf[NLAYER] = {};
     float2* tw = nullptr;
-    float2* kf2[NLAYER] = {};     // 16384-point class only: even | odd bins of kf (split-transform kernel)
     float2* kfp[NLAYER] = {};     // 16384-point class only: kf lane-packed for the persistent kernel (launch_spectrum_lanepack)
-    float2* twM = nullptr;        //                          twiddles of the 8192-point passes
-    float2* kf16[NLAYER] = {};    // KEY_LONG, 16-bit modes: partition spectra of the 16,384-token segments (hyena_conv_seg16_kernel)
-    float2* twN = nullptr;        //                          exp(-2 pi i n / 32768), n < 16384: the split transform's twist
     std::vector<ReversedFilter> krev;
 };
 
@@ -96,8 +92,6 @@ struct clm_handle {
     float2* edge_bnd = nullptr;
     float2* edge_read = nullptr;
     int edge_read_cap = 0;
-    bool seg16 = false;           // CLM_SEG16=1: blocks 1..3 of long reads through the 16,384-token-segment kernel (hyena_conv_seg16_kernel:
-                                  // measured 15 % slower than the 8,192-token segments at 32k x 32, off by default; tests keep it correct)
     bool raw_z = false;           // CLM_RAW_Z=1: the fused in_proj stage writes x0 | x1 | v as before round 3 (A/B runs, tests)
     unsigned char* ids8 = nullptr;   // workspace: clamped ids [B][Lp]
     float* head_t[5] = {};
@@ -106,12 +100,13 @@ struct clm_handle {
     std::vector<FilterSet> filters;
     uint64_t clock = 0;
     // workspace (one chunk of reads)
-    size_t ws_cap[12] = {};       // bytes of each workspace buffer (ensure_workspace: WS_H .. WS_EDGE_READ)
+    size_t ws_cap[13] = {};       // bytes of each workspace buffer (ensure_workspace: WS_H .. WS_YLO)
     size_t ws_es = 0;             // element size z / y were last written with
     float* h = nullptr;
     void *z = nullptr, *y = nullptr, *u = nullptr;
     float *scores = nullptr, *stats = nullptr, *partial = nullptr, *pooled = nullptr, *lone_ws = nullptr;
     float2* gscratch = nullptr;                     // segment spectra of the long-read convolution
+    unsigned char* ylo = nullptr;                   // PREC_F16C: lo bytes of y [B][256][Lp] (round 4, clm_common.h lo8_pack4)
     int last_B = 0, last_L = 0, last_Lp = 0;
     // debug / profiling
     int stop_layer = -1, stop_stage = -1;
@@ -120,7 +115,6 @@ struct clm_handle {
     bool no_idconv = false;       // CLM_NO_IDCONV=1: run block 0's in_proj instead of the id-table convolution (A/B runs)
     int conv_flags = 0;           // CLM_CONV_ONESHOT=1 / CLM_CONV_NO_XCD=1: CONV_* switches of the convolution launchers (A/B runs, tests)
     bool no_lone_peel = false;    // CLM_NO_LONE_PEEL=1: keep the lone last token of 128 k + 1-token reads in a tile of its own (A/B runs)
-    bool split_conv = false;      // CLM_SPLIT_CONV=1: 8k reads through hyena_conv_eo_kernel (two 8192-point problems; measured slower, kept for A/B)
     bool force_generic = false;   // CLM_GENERIC_GEMM=1: route 16-bit modes through the generic kernels (A/B runs)
     bool prof = false;
     std::vector<ProfRec> recs;
@@ -245,12 +239,8 @@ void free_filter_set(FilterSet& f) {
     for (int i = 0; i < NLAYER; ++i) {
         if (f.ktime[i]) (void)hipFree(f.ktime[i]);
         if (f.kf[i]) (void)hipFree(f.kf[i]);
-        if (f.kf2[i]) (void)hipFree(f.kf2[i]);
-        f.kf2[i] = nullptr;
         if (f.kfp[i]) (void)hipFree(f.kfp[i]);
         f.kfp[i] = nullptr;
-        if (f.kf16[i]) (void)hipFree(f.kf16[i]);
-        f.kf16[i] = nullptr;
         for (auto& r : f.krev)
             if (r.p[i]) (void)hipFree(r.p[i]);
         f.ktime[i] = nullptr;
@@ -258,11 +248,7 @@ void free_filter_set(FilterSet& f) {
     }
     f.krev.clear();
     if (f.tw) (void)hipFree(f.tw);
-    if (f.twM) (void)hipFree(f.twM);
-    if (f.twN) (void)hipFree(f.twN);
     f.tw = nullptr;
-    f.twM = nullptr;
-    f.twN = nullptr;
 }
 
 void free_filters(clm_handle* h) {
@@ -273,7 +259,7 @@ void free_filters(clm_handle* h) {
 // The per-chunk workspace: twelve buffers, each with its own capacity in bytes and grown on its own -- a call needs Bc x (its
 // own length) of each, and chunk_for() bounds that product whatever the read length, so a handle that has seen 256 x 8k-token and
 // 32 x 32k-token batches holds the larger of the two needs per buffer, not 256 x 32k (the round-2 shape bookkeeping did).
-enum { WS_H, WS_Z, WS_Y, WS_U, WS_SCORES, WS_STATS, WS_PARTIAL, WS_POOLED, WS_GSCRATCH, WS_IDS8, WS_LONE, WS_EDGE_READ, WS_N };
+enum { WS_H, WS_Z, WS_Y, WS_U, WS_SCORES, WS_STATS, WS_PARTIAL, WS_POOLED, WS_GSCRATCH, WS_IDS8, WS_LONE, WS_EDGE_READ, WS_YLO, WS_N };
 static_assert(WS_N == sizeof(clm_handle::ws_cap) / sizeof(size_t), "one capacity per buffer");
 void** ws_slot(clm_handle* h, int i) {
     switch (i) {
@@ -288,6 +274,7 @@ void** ws_slot(clm_handle* h, int i) {
         case WS_GSCRATCH: return (void**)&h->gscratch;
         case WS_IDS8: return (void**)&h->ids8;
         case WS_LONE: return (void**)&h->lone_ws;
+        case WS_YLO: return (void**)&h->ylo;
         default: return (void**)&h->edge_read;
     }
 }
@@ -336,6 +323,7 @@ int ensure_workspace(clm_handle* h, int Bc, int L, hipStream_t st) {
     need[WS_LONE] = lone_token_ws_floats((int)nb) * 4;
     need[WS_IDS8] = nb * Lp;
     need[WS_EDGE_READ] = nb * D3 * sizeof(float2);
+    need[WS_YLO] = h->cfg.precision == PREC_F16C ? nb * D * Lp : 0;
     if (conv_segments_for(L) > 1) need[WS_GSCRATCH] = ((nb + 1) / 2) * D * (size_t)conv_segments_for(L) * 16384 * sizeof(float2);
     bool grow = false;
     for (int i = 0; i < WS_N; ++i) grow |= need[i] > h->ws_cap[i];
@@ -350,7 +338,7 @@ int ensure_workspace(clm_handle* h, int Bc, int L, hipStream_t st) {
         h->ws_cap[i] = 0;
         HIPCHK(h, hipMalloc(p, need[i]));
         h->ws_cap[i] = need[i];
-        if (i == WS_Z || i == WS_Y) HIPCHK(h, hipMemset(*p, 0, need[i]));   // padding columns [L, Lp) must never hold NaN garbage
+        if (i == WS_Z || i == WS_Y || i == WS_YLO) HIPCHK(h, hipMemset(*p, 0, need[i]));   // padding columns [L, Lp) must never hold NaN garbage
     }
     return CLM_OK;
 }
@@ -378,10 +366,6 @@ int ensure_filters(clm_handle* h, int L, hipStream_t st, FilterSet** out, const 
         HIPCHK(h, hipMalloc((void**)&scratch, (size_t)D * N * sizeof(double2)));
         HIPCHK(h, hipMalloc((void**)&f.tw, (size_t)(N / 2) * sizeof(float2)));
         launch_twiddles(f.tw, logn, st);
-        if (S == 1 && logn == 14 && h->split_conv) {
-            HIPCHK(h, hipMalloc((void**)&f.twM, (size_t)(N / 4) * sizeof(float2)));
-            launch_twiddles(f.twM, logn - 1, st);
-        }
         for (int i = 0; i < NLAYER; ++i) {
             HIPCHK(h, hipMalloc((void**)&f.ktime[i], (size_t)f.Lf * D * 4));
             HIPCHK(h, hipMalloc((void**)&f.kf[i], (size_t)D * f.KS * N * sizeof(float2)));
@@ -397,10 +381,6 @@ int ensure_filters(clm_handle* h, int L, hipStream_t st, FilterSet** out, const 
                     HIPCHK(h, hipMalloc((void**)&f.kfp[i], (size_t)D * N * sizeof(float2)));
                     launch_spectrum_lanepack(f.kf[i], f.kfp[i], 1, 0, st);
                 }
-                if (logn == 14 && h->split_conv) {
-                    HIPCHK(h, hipMalloc((void**)&f.kf2[i], (size_t)D * N * sizeof(float2)));
-                    launch_spectrum_split(f.kf[i], f.kf2[i], logn, st);
-                }
             } else {   // kf [256][KS][N], lane-packed for the segmented kernel: one launch per partition, through a temporary
                 float2* tmp = nullptr;
                 HIPCHK(h, hipMalloc((void**)&tmp, (size_t)D * N * sizeof(float2)));
@@ -412,32 +392,6 @@ int ensure_filters(clm_handle* h, int L, hipStream_t st, FilterSet** out, const 
                 HIPCHK(h, hipStreamSynchronize(st));
                 HIPCHK(h, hipFree(tmp));
             }
-        }
-        if (S > 1 && h->cfg.precision != CLM_PREC_F32 && h->seg16) {
-            // 16,384-token segments (hyena_conv_seg16_kernel): partition j = taps [16384 j, 16384 (j + 1)) below and partition j - 1
-            // above, as a 32768-point spectrum, split into even | odd bins, each lane-packed like a 16384-point spectrum
-            constexpr int N2 = 32768, M2 = 16384;
-            double2* scratch15 = nullptr;
-            float2 *tmp15 = nullptr, *tmp2 = nullptr;
-            HIPCHK(h, hipMalloc((void**)&scratch15, (size_t)D * N2 * sizeof(double2)));
-            HIPCHK(h, hipMalloc((void**)&tmp15, (size_t)D * N2 * sizeof(float2)));
-            HIPCHK(h, hipMalloc((void**)&tmp2, (size_t)D * N2 * sizeof(float2)));
-            HIPCHK(h, hipMalloc((void**)&f.twN, (size_t)M2 * sizeof(float2)));
-            launch_twiddles(f.twN, 15, st);
-            for (int i = 0; i < NLAYER; ++i) {
-                std::string p = "bb.layers." + std::to_string(i) + ".mixer.filter_fn.";
-                HIPCHK(h, hipMalloc((void**)&f.kf16[i], (size_t)D * 4 * M2 * sizeof(float2)));
-                for (int j = 0; j < 2; ++j) {
-                    launch_filter_spectrum(f.ktime[i], W(h, p + "bias"), tmp15, scratch15, f.Lf, 15, j * M2, M2, (j - 1) * M2, st);
-                    launch_spectrum_split(tmp15, tmp2, 15, st);
-                    for (int par = 0; par < 2; ++par)
-                        launch_spectrum_lanepack(tmp2 + (size_t)par * M2, f.kf16[i], 4, 2 * j + par, st, N2);
-                }
-            }
-            HIPCHK(h, hipStreamSynchronize(st));
-            HIPCHK(h, hipFree(scratch15));
-            HIPCHK(h, hipFree(tmp15));
-            HIPCHK(h, hipFree(tmp2));
         }
         HIPCHK(h, hipGetLastError());
         HIPCHK(h, hipStreamSynchronize(st));
@@ -555,7 +509,9 @@ int forward_chunk(clm_handle* h, const void* ids, int ids_dtype, int64_t row_str
     const bool peel = fuse_next && !h->no_lone_peel && L > 128 && L % 128 == 1;
     // ... and hands z over in the form the convolution reads: x0f and g = x1f * vf, filtered and gated by the in_proj stage itself
     // (two rows per channel instead of three; gemm16.hip inproj_blocks_gated)
-    const bool zgated = fuse_next && !h->raw_z && !h->split_conv;   // (the split-transform A/B kernel reads the raw rows)
+    const bool zgated = fuse_next && !h->raw_z;
+    // fp16c, round 4: y (every block) and the gated rows of z carry one lo byte per element next to the halfs
+    unsigned char* const ylo = (prec == PREC_F16C && tuned16) ? h->ylo : nullptr;
     if (zgated && tail16_grid(((peel ? L - 1 : L) + 127) / 128 * Bc) > 1024)
         return fail(h, CLM_E_UNSUPPORTED, "more than 1024 compute units: edge_bnd is sized for 1024 workgroups");
     const void* packed_score = alt32 ? h->packed_score32 : h->packed_score;
@@ -581,21 +537,14 @@ int forward_chunk(clm_handle* h, const void* ids, int ids_dtype, int64_t row_str
         if (stop_here(h, i, CLM_STAGE_INPROJ)) return CLM_OK;
         {
             StageTimer t(h, st, CLM_STAGE_CONV);
-            if (S == 1 && fs->logn == 14 && fs->kf2[i] && h->split_conv)
-                launch_hyena_conv_dif(prec, h->z, h->y, fs->kf2[i], fs->twM, fs->tw, fs->ktime[i], lw.short_w, lw.short_b, Bc, L,
-                                      Lp, idconv ? h->ids8 : nullptr, idconv ? h->ztab : nullptr, st);
-            else if (S == 1)
+            if (S == 1)
                 launch_hyena_conv(prec, h->z, h->y, fs->kf[i], fs->tw, fs->ktime[i], lw.short_w, lw.short_b, Bc, L, Lp,
                                   fs->logn, idconv ? h->ids8 : nullptr, idconv ? h->ztab : nullptr, st,
-                                  h->conv_flags | ((zgated && i > 0) ? CONV_GATED : 0), fs->kfp[i]);
-            else if (zgated && i > 0 && fs->kf16[i]) {   // long reads, blocks 1..3 of the fused 16-bit path: 16,384-token segments
-                const bool lone16 = kr && (L - 1) % 16384 == 0;
-                launch_hyena_conv_seg16(prec, h->z, h->y, fs->kf16[i], fs->tw, fs->twN, h->gscratch, Bc, L, Lp,
-                                        lone16 ? kr->p[i] : nullptr, lone16 ? kr->stride : 0, st, h->conv_flags);
-            } else
+                                  h->conv_flags | ((zgated && i > 0) ? CONV_GATED : 0), fs->kfp[i], ylo);
+            else
                 launch_hyena_conv_seg(prec, h->z, h->y, fs->kf[i], fs->KS, fs->tw, lw.short_w, lw.short_b, h->gscratch, Bc,
                                       L, Lp, S, kr ? kr->p[i] : nullptr, kr ? kr->stride : 0, idconv ? h->ids8 : nullptr,
-                                      idconv ? h->ztab : nullptr, st, h->conv_flags | ((zgated && i > 0) ? CONV_GATED : 0));
+                                      idconv ? h->ztab : nullptr, st, h->conv_flags | ((zgated && i > 0) ? CONV_GATED : 0), ylo);
         }
         if (stop_here(h, i, CLM_STAGE_CONV)) return CLM_OK;
         const bool stop_mid = stop_here(h, i, CLM_STAGE_OUTPROJ);
@@ -604,6 +553,7 @@ int forward_chunk(clm_handle* h, const void* ids, int ids_dtype, int64_t row_str
             TailArgs ta{h->y, h->h, lw.w_out, lw.w_fc1, lw.w_fc2, lw.b_out, lw.ln2_g, lw.ln2_b, lw.b_fc1, lw.b_fc2, Bc, L, Lp,
                         eps, peel ? L - 1 : L, (idpath && i == 0) ? h->ids8 : nullptr, W(h, "bb.embeddings.word_embeddings.weight"),
                         nullptr, nullptr, nullptr, nullptr, nullptr, spa};
+            ta.ylo = ylo;
             int next = NEXT_NONE;
             if (fuse_next && i + 1 < NLAYER) {
                 const LayerW& nx = h->lw[i + 1];
@@ -612,6 +562,7 @@ int forward_chunk(clm_handle* h, const void* ids, int ids_dtype, int64_t row_str
                 if (zgated) {
                     ta.zg = 1; ta.n_fir = h->fir[i + 1]; ta.edge_bnd = h->edge_bnd;
                     ta.edge_read = peel ? h->edge_read : nullptr;
+                    ta.zlo = ylo != nullptr;
                 }
             } else if (fuse_next) {
                 next = NEXT_SCORE;
@@ -638,6 +589,7 @@ int forward_chunk(clm_handle* h, const void* ids, int ids_dtype, int64_t row_str
                 }
                 la.ws = h->lone_ws;
                 la.B = Bc; la.L = L; la.Lp = Lp; la.ntiles = (L + 127) / 128; la.eps = eps;
+                la.ylo = ylo; la.zlo = ta.zlo;
                 launch_lone_token(prec, la, st);
             }
         } else {
@@ -736,9 +688,7 @@ int clm_create(const clm_config* cfg, int device, clm_handle** out) {
     h->no_lone_peel = std::getenv("CLM_NO_LONE_PEEL") && std::getenv("CLM_NO_LONE_PEEL")[0] == '1';
     if (std::getenv("CLM_CONV_ONESHOT") && std::getenv("CLM_CONV_ONESHOT")[0] == '1') h->conv_flags |= CONV_ONESHOT;
     if (std::getenv("CLM_CONV_NO_XCD") && std::getenv("CLM_CONV_NO_XCD")[0] == '1') h->conv_flags |= CONV_NO_XCD;
-    h->split_conv = std::getenv("CLM_SPLIT_CONV") && std::getenv("CLM_SPLIT_CONV")[0] == '1';
     h->raw_z = std::getenv("CLM_RAW_Z") && std::getenv("CLM_RAW_Z")[0] == '1';
-    h->seg16 = std::getenv("CLM_SEG16") && std::getenv("CLM_SEG16")[0] == '1';
     h->cfg = *cfg;
     h->device = device;
     if (hipHostMalloc((void**)&h->bad_ids, sizeof(int), hipHostMallocMapped) == hipSuccess) *h->bad_ids = 0;

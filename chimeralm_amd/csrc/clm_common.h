@@ -6,6 +6,8 @@
 
 #include <type_traits>
 
+#include "clm_lab.h"
+
 namespace clm {
 
 // model constants fixed by the reference (chimeralm/models/lm.py:19-31)
@@ -101,9 +103,7 @@ __device__ __forceinline__ float gelu_tanh(float x) {
 // two at a time: the element-wise part maps onto v_pk_mul_f32 / v_pk_fma_f32 / v_pk_add_f32
 using f32x2 = float __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ f32x2 gelu_tanh2(f32x2 x) {
-#ifdef CLM_EXP_NOGELU   // timing-only build: no transcendental
-    return x * 0.5f;
-#endif
+    if constexpr (lab::NOGELU) return x * 0.5f;
     f32x2 p = x * (GELU_A + GELU_B * (x * x));
     f32x2 d = {1.0f + __builtin_amdgcn_exp2f(p.x), 1.0f + __builtin_amdgcn_exp2f(p.y)};
     f32x2 r = {__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
@@ -111,6 +111,32 @@ __device__ __forceinline__ f32x2 gelu_tanh2(f32x2 x) {
 }
 // exact gelu (erf form): nn.GELU() of the head (hyena.py:38,47,162)
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.7071067811865476f)); }
+
+// ---- round 4: lo bytes of 16-bit activations (fp16c) -----------------------------------------------------------------------------
+// x = fp16(x) + lo, |lo| <= 2^-11 |x|: one e5m2 byte carries lo to 3 significant bits, i.e. x to ~15 bits instead of fp16's 11.
+// lo8 = e5m2(lo * LO2_SCALE); LO2_SCALE = 2^10 / 0.9155 -- the factor 1 / 0.9155 undoes the truncation bias of the weight bytes the
+// lo bytes meet in the MFMA (gemm_common.h mfma_lo2); readers that want the VALUE multiply by LO2_INV and never see it.  The scaled
+// lo cannot exceed 16384 * 1.1 < 57344 (e5m2's maximum) for any finite fp16(x): no saturation logic.
+constexpr float LO8_TRUNC_GAIN_V = 1.0f / 0.9155f;
+constexpr float LO2_SCALE = 1024.f * LO8_TRUNC_GAIN_V;
+constexpr float LO2_INV = 1.0f / LO2_SCALE;
+constexpr int LO2_E8M0 = 127 - 10;
+// (x - fp16(x)) of four values -> four e5m2 bytes (round to nearest even), hi halfs returned through `h`
+__device__ __forceinline__ unsigned lo8_pack4(float x0, float x1, float x2, float x3, u16x4& h) {
+    const _Float16 h0 = (_Float16)x0, h1 = (_Float16)x1, h2 = (_Float16)x2, h3 = (_Float16)x3;
+    h = u16x4{__builtin_bit_cast(unsigned short, h0), __builtin_bit_cast(unsigned short, h1), __builtin_bit_cast(unsigned short, h2),
+              __builtin_bit_cast(unsigned short, h3)};
+    int w = 0;
+    w = __builtin_amdgcn_cvt_pk_bf8_f32((x0 - (float)h0) * LO2_SCALE, (x1 - (float)h1) * LO2_SCALE, w, false);
+    w = __builtin_amdgcn_cvt_pk_bf8_f32((x2 - (float)h2) * LO2_SCALE, (x3 - (float)h3) * LO2_SCALE, w, true);
+    return (unsigned)w;
+}
+// four e5m2 lo bytes -> the four fp32 corrections (x - fp16(x), up to the lo's own rounding)
+__device__ __forceinline__ void lo8_unpack4(unsigned w, float (&d)[4]) {
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    const f2 a = __builtin_amdgcn_cvt_pk_f32_bf8((int)w, false), b = __builtin_amdgcn_cvt_pk_f32_bf8((int)w, true);
+    d[0] = a.x * LO2_INV, d[1] = a.y * LO2_INV, d[2] = b.x * LO2_INV, d[3] = b.y * LO2_INV;
+}
 
 // ---- kernel launchers (definitions in the .hip files); all are asynchronous on `st` --------------------
 // PREC_F16C ("fp16c"): fp16 activations x weights held as hi + lo (in_proj, out_proj, score layer; the MLP weights are plain fp16
@@ -194,6 +220,11 @@ struct TailArgs {
     float2* edge_bnd;         // [gridDim.x][2][768] raw in_proj rows (no bias): [w][0] = tokens 126, 127 of the tile before workgroup w's
                               // first tile, [w][1] = tokens 0, 1 of that first tile (launch_gated_patch recomputes those two tokens)
     float2* edge_read;        // [B][768] or null: raw rows of the last two tiled tokens of every read (the peeled lone token's history)
+    // Round 4, PREC_F16C: the 16-bit tensors either side of the convolution carry one lo byte per element (lo8_pack4): y to ~15 bits
+    // into out_proj (its lo plane is staged into a second LDS tile and enters through mfma_lo2), x0f / g to ~15 bits into the
+    // convolution.  tests/error_model.py: the fp16 rounding of y and z was 20-60 % of the mode's logit error variance.
+    const unsigned char* ylo; // [B][256][Lp] lo bytes of y, written by the convolution (null: y is plain fp16)
+    int zlo;                  // zg only: the gated in_proj stage also writes the lo bytes of x0f | g into rows 512.. of n_z ([2][256][Lp])
 };
 // tiles of the tail kernel are taken in CONTIGUOUS ranges per workgroup (the short filter's two-token history then comes from the
 // workgroup's own previous tile): range length for `total` tiles on `grid` workgroups
@@ -222,6 +253,8 @@ struct LoneTokenArgs {
     float* ws;                   // fp32 scratch, lone_token_ws_floats(B) floats: vectors handed from stage to stage
     int B, L, Lp, ntiles;
     float eps;
+    const unsigned char* ylo;    // round 4, PREC_F16C (see TailArgs): lo bytes of y (null: none); zlo: write the lo bytes of x0f | g too
+    int zlo;
 };
 size_t lone_token_ws_floats(int B);
 void launch_lone_token(int prec, const LoneTokenArgs& a, hipStream_t st);
@@ -261,24 +294,12 @@ void launch_hyena_conv(int prec, const void* z, void* y, const float2* kf, const
                        const float* short_w, const float* short_b, int B, int L, int Lp, int logn,
                        const unsigned char* ids8, const float* ztab, hipStream_t st, int flags = 0,
                        const float2* kf_packed = nullptr /*16384-point class: kf through launch_spectrum_lanepack(kf, ., 1, 0);
-                                                           without it the one-workgroup-per-unit kernel runs*/);
-// 8k reads (4098 .. 8193 tokens): the 16384-point convolution as two 8192-point problems (even / odd bins), two workgroups per CU.
-// kf2 [256][2][8192] from launch_spectrum_split(kf of the 16384-point class); twM = the 8192-point twiddle table, twN the 16384 one
-void launch_spectrum_split(const float2* kf, float2* kf2, int logn, hipStream_t st);
+                                                           without it the one-workgroup-per-unit kernel runs*/,
+                       unsigned char* ylo = nullptr /*PREC_F16C, round 4: [B][256][Lp] lo bytes of y (lo8_pack4); with it the gated
+                                                      rows of z are read as hi + lo too (rows 512.. of z: [2][256][Lp] bytes)*/);
 // partition spectrum j (natural order, src [256][16384]) -> slice j of the lane-packed [256][KS][16][512] quads of the
 // segmented kernel (hyena_conv_seg_kernel)
-// (src_stride: elements between the channels of `src`, default 16384)
-void launch_spectrum_lanepack(const float2* src, float2* dst, int KS, int j, hipStream_t st, size_t src_stride = 0);
-// long reads, 16,384-token segments through the split transform (hyena_conv_seg16_kernel): gated input, 16-bit modes only.
-// kf16 [256][2 partitions][2 parities][16384] lane-packed (launch_spectrum_lanepack with KS = 4, j = 2 * partition + parity, of the
-// even | odd halves launch_spectrum_split makes of a 32768-point partition spectrum); tw the 16384-point twiddles, twN
-// exp(-2 pi i n / 32768), n < 16384; gscratch [pairs][256][2][16384]
-int conv_segments16_for(int L);                   // 0 for L <= 8193, else ceil((L - 1) / 16384)
-void launch_hyena_conv_seg16(int prec, const void* z, void* y, const float2* kf16, const float2* tw, const float2* twN,
-                             float2* gscratch, int B, int L, int Lp, const float* krev, int krev_stride, hipStream_t st, int flags = 0);
-void launch_hyena_conv_dif(int prec, const void* z, void* y, const float2* kf2, const float2* twM, const float2* twN,
-                           const float* ktime, const float* short_w, const float* short_b, int B, int L, int Lp,
-                           const unsigned char* ids8, const float* ztab, hipStream_t st);
+void launch_spectrum_lanepack(const float2* src, float2* dst, int KS, int j, hipStream_t st);
 void launch_ztab(const float* emb, const float* g, const float* bta, const float* w, const float* bias, float* ztab,
                  float eps, hipStream_t st);
 
@@ -289,7 +310,7 @@ void launch_hyena_conv_seg(int prec, const void* z, void* y, const float2* kf, i
                            const float* short_b, float2* gscratch, int B, int L, int Lp, int S,
                            const float* krev /*null unless conv_lone_tail(L)*/, int krev_stride,
                            const unsigned char* ids8 /*16-bit modes, block 0: as launch_hyena_conv*/, const float* ztab,
-                           hipStream_t st, int flags = 0);
+                           hipStream_t st, int flags = 0, unsigned char* ylo = nullptr /*as launch_hyena_conv*/);
 
 // head (head.hip)
 void launch_softmax_stats(const float* scores, float* stats /*[B][2] = max, sum*/, int B, int L, hipStream_t st);

@@ -1,0 +1,53 @@
+// clm_lab.h -- the ONE place where timing-only builds touch the kernels.
+//
+// The product build (python -m chimeralm_amd.build) never defines CLM_LAB: every switch below is then a compile-time `false`
+// and the branches it guards are dead code that does not reach the object file.  tools/build_variant.sh NAME -DCLM_LAB -DCLM_EXP_x
+// builds a library in which ONE kind of work is removed (results WRONG by construction, instruction stream otherwise the same);
+// tools/abn.sh alternates it with the product build on one box.  What those builds measured is in profiles/r03_timing_only.txt
+// and DESIGN.md section 4.9.
+#pragma once
+
+namespace clm {
+namespace lab {
+#if defined(CLM_LAB) && defined(CLM_EXP_A0)
+constexpr bool A0 = true;          // every A fragment of a weight set is its first one: one LDS read per set instead of 16
+#else
+constexpr bool A0 = false;
+#endif
+#if defined(CLM_LAB) && defined(CLM_EXP_NOLO)
+constexpr bool NOLO = true;        // no lo half in the compensated products: what the fp8 MFMAs + the byte gathers cost
+#else
+constexpr bool NOLO = false;
+#endif
+#if defined(CLM_LAB) && defined(CLM_EXP_NOLN)
+constexpr bool NOLN = true;        // no LayerNorm statistics (one barrier kept: it orders earlier LDS reads before the tile writes)
+#else
+constexpr bool NOLN = false;
+#endif
+#if defined(CLM_LAB) && defined(CLM_EXP_NOW)
+constexpr bool NOW = true;         // only the first weight set of a column block is ever loaded: no weight stream at all
+#else
+constexpr bool NOW = false;
+#endif
+#if defined(CLM_LAB) && defined(CLM_EXP_W0)
+constexpr bool W0 = true;          // every weight set is the wave's first one: weights from the L1
+#else
+constexpr bool W0 = false;
+#endif
+#if defined(CLM_LAB) && defined(CLM_EXP_NOGELU)
+constexpr bool NOGELU = true;      // no transcendental in the MLP's GELU
+#else
+constexpr bool NOGELU = false;
+#endif
+#if defined(CLM_LAB) && defined(CLM_EXP_NOZSTORE)
+constexpr bool NOZSTORE = true;    // z is never written (one lane keeps the data alive)
+#else
+constexpr bool NOZSTORE = false;
+#endif
+#if defined(CLM_LAB) && defined(CLM_EXP_NOFIR)
+constexpr bool NOFIR = true;       // no short filter, no lane exchange in the gated in_proj epilogue
+#else
+constexpr bool NOFIR = false;
+#endif
+}  // namespace lab
+}  // namespace clm

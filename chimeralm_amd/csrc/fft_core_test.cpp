@@ -115,177 +115,6 @@ static double test_conv(int L, unsigned seed) {
     return max_err / max_ref;
 }
 
-// Split-transform form used for 8k reads (hyena_conv_dif_kernel): the N = 2M point transform of an input whose upper half is
-// zero (but for the one element at M when L == M + 1) is two independent M-point problems, the even and the odd bins,
-//     X[2j] = DFT_M(x_lo + x_hi)[j],   X[2j+1] = DFT_M((x_lo - x_hi) w_N^n)[j],
-//     y[n]  = IDFT_M(X_e K_e)[n] + w_N^-n IDFT_M(X_o K_o)[n]  (n < M),   y[M] = IDFT_M(X_e K_e)[0] - IDFT_M(X_o K_o)[0],
-// each run through the UN-PRUNED generic passes of the M-point plan (half the LDS of the N-point transform).
-template <int LOGM>
-static double test_conv_split(int L, unsigned seed) {
-    using P = Plan<LOGM>;
-    using TL = TwLayout<LOGM>;
-    constexpr int M = P::N, N = 2 * M, NT = P::NT, LAST = P::LAST;
-    if (!(L >= 1 && L <= M + 1)) {
-        std::printf("bad L\n");
-        std::exit(2);
-    }
-    std::mt19937 rng(seed);
-    std::normal_distribution<double> nd;
-    std::vector<double> g0(L), g1(L), k(L);
-    for (int t = 0; t < L; ++t) g0[t] = nd(rng), g1[t] = nd(rng), k[t] = nd(rng) * std::exp(-3.0 * t / L);
-    std::vector<cd> kf(N);
-    for (int t = 0; t < L; ++t) kf[t] = k[t];
-    fft_ref(kf, false);
-    std::vector<float2> kf2(N), twM(M / 2), twN(M);
-    for (int s = 0; s < 2; ++s)
-        for (int j = 0; j < M; ++j) kf2[size_t(s) * M + j] = make_float2(float(kf[2 * j + s].real() / N), float(kf[2 * j + s].imag() / N));
-    for (int m = 0; m < M / 2; ++m) twM[m] = make_float2(float(std::cos(2 * M_PI * m / M)), float(-std::sin(2 * M_PI * m / M)));
-    for (int n = 0; n < M; ++n) twN[n] = make_float2(float(std::cos(2 * M_PI * n / N)), float(-std::sin(2 * M_PI * n / N)));
-    std::vector<Cx2> wall(size_t(NT) * TL::TOTAL);
-    for (int tid = 0; tid < NT; ++tid) {
-        Cx2* w = &wall[size_t(tid) * TL::TOTAL];
-        int ns = 16;
-        for (int p = 1; p <= P::NPASS - 2; ++p, ns *= 16) pass_twiddles<LOGM, 16, false>(w + TL::fwd(p), tid, ns, twM.data());
-        pass_twiddles<LOGM, LAST, false>(w + TL::fwd_last(), tid, ns, twM.data());
-        ns = LAST;
-        for (int p = 1; p <= P::NPASS - 1; ++p, ns *= 16) pass_twiddles<LOGM, 16, true>(w + TL::inv(p), tid, ns, twM.data());
-    }
-    std::vector<Cx2> regs(size_t(NT) * 16), kv(size_t(NT) * 16);
-    auto R = [&](int tid) { return &regs[size_t(tid) * 16]; };
-    auto W = [&](int tid) { return &wall[size_t(tid) * TL::TOTAL]; };
-    std::vector<float> bre(padded_size(M)), bim(padded_size(M)), ore(M + 1, 0.f), oim(M + 1, 0.f);
-    const bool tail = L == M + 1;
-    float re0[2] = {0.f, 0.f}, im0[2] = {0.f, 0.f};
-    for (int s = 0; s < 2; ++s) {
-        for (int n = 0; n < M; ++n) {
-            float xr = n < L ? float(g0[n]) : 0.f, xi = n < L ? float(g1[n]) : 0.f;
-            if (tail && n == 0) xr += (s ? -1.f : 1.f) * float(g0[M]), xi += (s ? -1.f : 1.f) * float(g1[M]);
-            if (s) {
-                const float wr = twN[n].x, wi = twN[n].y, tr = xr * wr - xi * wi, ti = xr * wi + xi * wr;
-                xr = tr, xi = ti;
-            }
-            bre[pad_index(n)] = xr, bim[pad_index(n)] = xi;
-        }
-        int Ns = 1;
-        for (int p = 0; p < P::NPASS - 1; ++p) {
-            for (int tid = 0; tid < NT; ++tid) pass_load<LOGM, 16>(bre.data(), bim.data(), R(tid), tid);
-            for (int tid = 0; tid < NT; ++tid) pass_compute_w<LOGM, 16, false>(R(tid), tid, p > 0, W(tid) + TL::fwd(p > 0 ? p : 1));
-            for (int tid = 0; tid < NT; ++tid) pass_store<LOGM, 16>(bre.data(), bim.data(), R(tid), tid, Ns);
-            Ns *= 16;
-        }
-        for (int tid = 0; tid < NT; ++tid) spectrum_fetch<LOGM, LAST>(&kv[size_t(tid) * 16], tid, kf2.data() + size_t(s) * M);
-        for (int tid = 0; tid < NT; ++tid) pass_load<LOGM, LAST>(bre.data(), bim.data(), R(tid), tid);
-        for (int tid = 0; tid < NT; ++tid) pass_compute_w<LOGM, LAST, false>(R(tid), tid, true, W(tid) + TL::fwd_last());
-        for (int tid = 0; tid < NT; ++tid) spectrum_multiply_and_first_inverse_v<LOGM, LAST>(R(tid), tid, &kv[size_t(tid) * 16]);
-        for (int tid = 0; tid < NT; ++tid) pass_store<LOGM, LAST>(bre.data(), bim.data(), R(tid), tid, 1);
-        Ns = LAST;
-        for (int p = 1; p <= P::NPASS - 1; ++p) {
-            for (int tid = 0; tid < NT; ++tid) pass_load<LOGM, 16>(bre.data(), bim.data(), R(tid), tid);
-            for (int tid = 0; tid < NT; ++tid) pass_compute_w<LOGM, 16, true>(R(tid), tid, true, W(tid) + TL::inv(p));
-            for (int tid = 0; tid < NT; ++tid) pass_store<LOGM, 16>(bre.data(), bim.data(), R(tid), tid, Ns);
-            Ns *= 16;
-        }
-        re0[s] = bre[pad_index(0)], im0[s] = bim[pad_index(0)];
-        for (int n = 0; n < M; ++n) {
-            const float a = bre[pad_index(n)], b = bim[pad_index(n)];
-            if (!s) ore[n] = a, oim[n] = b;
-            else ore[n] += a * twN[n].x + b * twN[n].y, oim[n] += b * twN[n].x - a * twN[n].y;   // conj(w_N^n) * r_o
-        }
-    }
-    ore[M] = re0[0] - re0[1], oim[M] = im0[0] - im0[1];
-    double max_err = 0, max_ref = 0;
-    for (int t = 0; t < L; ++t) {
-        double r0 = 0, r1 = 0;
-        for (int q = 0; q <= t; ++q) r0 += k[q] * g0[t - q], r1 += k[q] * g1[t - q];
-        double y0 = ore[t], y1 = oim[t];
-        if (t == 0 && tail) {
-            y0 -= double(float(k[L - 1])) * double(float(g0[L - 1]));
-            y1 -= double(float(k[L - 1])) * double(float(g1[L - 1]));
-        }
-        max_err = std::fmax(max_err, std::fmax(std::fabs(y0 - r0), std::fabs(y1 - r1)));
-        max_ref = std::fmax(max_ref, std::fmax(std::fabs(r0), std::fabs(r1)));
-    }
-    return max_err / max_ref;
-}
-
-// the same split-transform convolution through the seven passes of Split13 (radix 16, 8, 8, 8 | 8, 8, 16), as the kernel runs it
-template <int J>
-static void split13_run_pass(std::vector<float>& bre, std::vector<float>& bim, std::vector<Cx2>& regs, const float2* twM, const float2* kfs) {
-    constexpr int NT = Plan<13>::NT;
-    for (int tid = 0; tid < NT; ++tid) split13_compute<J>(bre.data(), bim.data(), &regs[size_t(tid) * 16], tid, twM, kfs);
-    for (int tid = 0; tid < NT; ++tid) split13_store<J>(bre.data(), bim.data(), &regs[size_t(tid) * 16], tid);
-}
-static double test_conv_split13(int L, unsigned seed) {
-    constexpr int M = 8192, N = 2 * M, NT = Plan<13>::NT;
-    std::mt19937 rng(seed);
-    std::normal_distribution<double> nd;
-    std::vector<double> g0(L), g1(L), k(L);
-    for (int t = 0; t < L; ++t) g0[t] = nd(rng), g1[t] = nd(rng), k[t] = nd(rng) * std::exp(-3.0 * t / L);
-    std::vector<cd> kf(N);
-    for (int t = 0; t < L; ++t) kf[t] = k[t];
-    fft_ref(kf, false);
-    std::vector<float2> kf2(N), twM(M / 2), twN(M);
-    for (int s = 0; s < 2; ++s)
-        for (int j = 0; j < M; ++j) kf2[size_t(s) * M + j] = make_float2(float(kf[2 * j + s].real() / N), float(kf[2 * j + s].imag() / N));
-    for (int m = 0; m < M / 2; ++m) twM[m] = make_float2(float(std::cos(2 * M_PI * m / M)), float(-std::sin(2 * M_PI * m / M)));
-    for (int n = 0; n < M; ++n) twN[n] = make_float2(float(std::cos(2 * M_PI * n / N)), float(-std::sin(2 * M_PI * n / N)));
-    std::vector<Cx2> regs(size_t(NT) * 16);
-    std::vector<float> bre(padded_size(M)), bim(padded_size(M)), ore(M + 1, 0.f), oim(M + 1, 0.f);
-    const bool tail = L == M + 1;
-    float re0[2] = {0.f, 0.f}, im0[2] = {0.f, 0.f};
-    for (int s = 0; s < 2; ++s) {
-        for (int n = 0; n < M; ++n) {
-            float xr = n < L ? float(g0[n]) : 0.f, xi = n < L ? float(g1[n]) : 0.f;
-            if (tail && n == 0) xr += (s ? -1.f : 1.f) * float(g0[M]), xi += (s ? -1.f : 1.f) * float(g1[M]);
-            if (s) {
-                const float wr = twN[n].x, wi = twN[n].y, tr = xr * wr - xi * wi, ti = xr * wi + xi * wr;
-                xr = tr, xi = ti;
-            }
-            bre[pad_index(n)] = xr, bim[pad_index(n)] = xi;
-        }
-        const float2* kfs = kf2.data() + size_t(s) * M;
-        split13_run_pass<0>(bre, bim, regs, twM.data(), kfs);
-        split13_run_pass<1>(bre, bim, regs, twM.data(), kfs);
-        split13_run_pass<2>(bre, bim, regs, twM.data(), kfs);
-        split13_run_pass<3>(bre, bim, regs, twM.data(), kfs);
-        split13_run_pass<4>(bre, bim, regs, twM.data(), kfs);
-        split13_run_pass<5>(bre, bim, regs, twM.data(), kfs);
-        split13_run_pass<6>(bre, bim, regs, twM.data(), kfs);
-        re0[s] = bre[pad_index(0)], im0[s] = bim[pad_index(0)];
-        for (int n = 0; n < M; ++n) {
-            const float a = bre[pad_index(n)], b = bim[pad_index(n)];
-            if (!s) ore[n] = a, oim[n] = b;
-            else ore[n] += a * twN[n].x + b * twN[n].y, oim[n] += b * twN[n].x - a * twN[n].y;
-        }
-    }
-    ore[M] = re0[0] - re0[1], oim[M] = im0[0] - im0[1];
-    double max_err = 0, max_ref = 0;
-    for (int t = 0; t < L; ++t) {
-        double r0 = 0, r1 = 0;
-        for (int q = 0; q <= t; ++q) r0 += k[q] * g0[t - q], r1 += k[q] * g1[t - q];
-        double y0 = ore[t], y1 = oim[t];
-        if (t == 0 && tail) {
-            y0 -= double(float(k[L - 1])) * double(float(g0[L - 1]));
-            y1 -= double(float(k[L - 1])) * double(float(g1[L - 1]));
-        }
-        max_err = std::fmax(max_err, std::fmax(std::fabs(y0 - r0), std::fabs(y1 - r1)));
-        max_ref = std::fmax(max_ref, std::fmax(std::fabs(r0), std::fabs(r1)));
-    }
-    return max_err / max_ref;
-}
-
-template <int LOGM>
-static int run_split(unsigned seed) {
-    constexpr int M = 1 << LOGM;
-    int fails = 0;
-    for (int L : {M + 1, M, M - 5, M / 2 + 2}) {
-        double e = test_conv_split<LOGM>(L, seed + L);
-        std::printf("split LOGM=%d L=%d rel_err=%.3e\n", LOGM, L, e);
-        if (!(e < 2e-5)) ++fails;
-    }
-    return fails;
-}
-
 template <int LOGN>
 static int run(unsigned seed) {
     constexpr int N = 1 << LOGN;
@@ -308,14 +137,6 @@ int main() {
     fails += run<12>(5);
     fails += run<13>(6);
     fails += run<14>(7);
-    fails += run_split<13>(8);      // 8k reads: two 8192-point problems instead of one 16384-point transform
-    fails += run_split<14>(9);      // long reads: 16384-token segments through two 16384-point problems
-    fails += run_split<10>(10);
-    for (int L : {8193, 8192, 8187, 4098}) {
-        const double e = test_conv_split13(L, 11 + L);
-        std::printf("split13 (16,8,8,8 | 8,8,16) L=%d rel_err=%.3e\n", L, e);
-        if (!(e < 2e-5)) ++fails;
-    }
     std::printf(fails ? "FAIL %d\n" : "ALL OK\n", fails);
     return fails ? 1 : 0;
 }

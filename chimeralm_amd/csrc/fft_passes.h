@@ -182,56 +182,6 @@ CLM_HD void spectrum_multiply_and_first_inverse_v(Cx2* v, int tid, const Cx2* kv
     }
 }
 
-// ---- split-transform plan for M = 8192 (hyena_conv_eo_kernel) ---------------------------------------------------------------
-// An UN-PRUNED 8192-point circular convolution in seven passes: forward radix 16, 8, 8, 8 -- the last one fused with the
-// spectrum product and the first inverse pass (radix 8, Ns = 1) -- then inverse radix 8, 8, 16.  No radix-2 pass: the radix-8
-// passes need two twiddles per thread where Plan<13>'s radix-2 pass needs eight.  Pass j (0..6): radix, sub-transform size of
-// its OUTPUT layout (the Ns of pass_store), whether it is an inverse pass.
-struct Split13 {
-    static constexpr int LOGM = 13, NPASS = 7;
-    static CLM_HDC int radix(int j) { return (j == 0 || j == 6) ? 16 : 8; }
-    static CLM_HDC int ns(int j) { return j == 0 ? 1 : j == 1 ? 16 : j == 2 ? 128 : j == 3 ? 1 : j == 4 ? 8 : j == 5 ? 64 : 512; }
-    static CLM_HDC int ns_fwd_last() { return 1024; }          // twiddle stage of pass 3's forward half
-};
-// "load + compute" half of pass J on the buffer (re, im): everything between the barrier that completed the previous store
-// and the barrier before this pass's store.  kfs: the M spectrum bins of this sub-problem (pass 3 only).
-template <int J>
-CLM_HD void split13_compute(const float* re, const float* im, Cx2* v, int tid, const float2* tw, const float2* kfs) {
-    constexpr int L = Split13::LOGM;
-    if constexpr (J == 0) {
-        pass_load<L, 16>(re, im, v, tid);
-        pass_compute_w<L, 16, false>(v, tid, false, v);
-    } else if constexpr (J == 1 || J == 2) {
-        Cx2 w[PassGeom<L, 8>::NP];
-        pass_twiddles<L, 8, false>(w, tid, Split13::ns(J), tw);
-        pass_load<L, 8>(re, im, v, tid);
-        pass_compute_w<L, 8, false>(v, tid, true, w);
-    } else if constexpr (J == 3) {
-        Cx2 w[PassGeom<L, 8>::NP], kv[16];
-        pass_twiddles<L, 8, false>(w, tid, Split13::ns_fwd_last(), tw);
-        spectrum_fetch<L, 8>(kv, tid, kfs);
-        pass_load<L, 8>(re, im, v, tid);
-        pass_compute_w<L, 8, false>(v, tid, true, w);
-        spectrum_multiply_and_first_inverse_v<L, 8>(v, tid, kv);
-    } else if constexpr (J == 4 || J == 5) {
-        Cx2 w[PassGeom<L, 8>::NP];
-        pass_twiddles<L, 8, true>(w, tid, Split13::ns(J), tw);
-        pass_load<L, 8>(re, im, v, tid);
-        pass_compute_w<L, 8, true>(v, tid, true, w);
-    } else {
-        Cx2 w[PassGeom<L, 16>::NP];
-        pass_twiddles<L, 16, true>(w, tid, Split13::ns(J), tw);
-        pass_load<L, 16>(re, im, v, tid);
-        pass_compute_w<L, 16, true>(v, tid, true, w);
-    }
-}
-template <int J>
-CLM_HD void split13_store(float* re, float* im, const Cx2* v, int tid) {
-    constexpr int L = Split13::LOGM;
-    if constexpr (J == 0 || J == 6) pass_store<L, 16>(re, im, v, tid, Split13::ns(J));
-    else pass_store<L, 8>(re, im, v, tid, Split13::ns(J));
-}
-
 // Twiddle register layout of a whole convolution (forward passes 1..NPASS-1, inverse passes 1..NPASS-1), in pairs:
 template <int LOGN>
 struct TwLayout {

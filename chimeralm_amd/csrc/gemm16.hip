@@ -200,17 +200,25 @@ __device__ __forceinline__ void zg_fir_inplace(f32x16 (&a)[4], const float4 f, f
 }
 
 // the wave's 128 tokens x 32 channels in `a` -> 16-bit -> row `row0 + lrow` of z (through the wave-private staging tile)
-template <int PREC>
+// LO (fp16c, round 4): the values' lo bytes (lo8_pack4) follow through the SAME staging tile once the halfs have left it (LDS
+// operations of one wave execute in order) into row `row0 + lrow` of the lo planes in rows 512.. of z ([2][256][Lp] bytes).
+template <int PREC, bool LO = false>
 __device__ __forceinline__ void zg_store_rows(const f32x16 (&a)[4], typename CT<PREC>::elem* zs, void* zout, int b, int row0,
                                               int t0, int Lp, int lane) {
     using elem = typename CT<PREC>::elem;
     const int lrow = lane & 31, lhalf = lane >> 5;
+    unsigned lo4[LO ? 16 : 1];
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            u16x4 pk = {to_bits<PREC>(a[mt][4 * q + 0]), to_bits<PREC>(a[mt][4 * q + 1]), to_bits<PREC>(a[mt][4 * q + 2]),
-                        to_bits<PREC>(a[mt][4 * q + 3])};
+            u16x4 pk;
+            if constexpr (LO) {
+                lo4[4 * mt + q] = lo8_pack4(a[mt][4 * q + 0], a[mt][4 * q + 1], a[mt][4 * q + 2], a[mt][4 * q + 3], pk);
+            } else {
+                pk = u16x4{to_bits<PREC>(a[mt][4 * q + 0]), to_bits<PREC>(a[mt][4 * q + 1]), to_bits<PREC>(a[mt][4 * q + 2]),
+                           to_bits<PREC>(a[mt][4 * q + 3])};
+            }
             *reinterpret_cast<u16x4*>(zs + lrow * RSOUT + mt * 32 + 8 * q + 4 * lhalf) = pk;
         }
     __builtin_amdgcn_sched_barrier(0);
@@ -221,14 +229,30 @@ __device__ __forceinline__ void zg_store_rows(const f32x16 (&a)[4], typename CT<
     for (int i = 0; i < 8; ++i) {
         const int row = i * 4 + (lane >> 4);
         const uint4 v = *reinterpret_cast<const uint4*>(zs + row * RSOUT + col8);
-#ifdef CLM_EXP_NOZSTORE   // timing-only build: z is never written (one lane keeps the data alive)
-        if (in_row && v.x == 0x12345678u)
-#else
-        if (in_row)
-#endif
-            *reinterpret_cast<uint4*>(zg + (size_t)row * Lp + col8) = v;
+        if (in_row && (!lab::NOZSTORE || v.x == 0x12345678u)) *reinterpret_cast<uint4*>(zg + (size_t)row * Lp + col8) = v;
     }
     __builtin_amdgcn_sched_barrier(0);
+    if constexpr (LO) {
+        constexpr int RS8 = 144;                            // bytes per staged lo row: 128 + 16 (16-byte aligned rows)
+        unsigned char* z8 = reinterpret_cast<unsigned char*>(zs);
+        static_assert(32 * RS8 <= 32 * RSOUT * (int)sizeof(elem), "the lo rows fit the staging tile");
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) *reinterpret_cast<unsigned*>(z8 + lrow * RS8 + mt * 32 + 8 * q + 4 * lhalf) = lo4[4 * mt + q];
+        __builtin_amdgcn_sched_barrier(0);
+        // rows 512.. of the read's z block: [2][256][Lp] bytes; row0 < 256: x0f (plane 0), row0 >= 256: g (plane 1) -- i.e. byte row row0
+        unsigned char* zl = reinterpret_cast<unsigned char*>(reinterpret_cast<elem*>(zout) + ((size_t)b * D3 + 2 * D) * Lp) + (size_t)row0 * Lp + t0;
+        const int col16 = (lane & 7) * 16;
+        const bool in_row8 = t0 + col16 < Lp;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = i * 8 + (lane >> 3);
+            const uint4 v = *reinterpret_cast<const uint4*>(z8 + row * RS8 + col16);
+            if (in_row8) *reinterpret_cast<uint4*>(zl + (size_t)row * Lp + col16) = v;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
 }
 
 template <int PREC, typename Hook>
@@ -268,9 +292,7 @@ __device__ __forceinline__ void inproj_blocks_gated(const typename CT<PREC>::ele
         if (gt.tail_bnd && lhalf) m.edge_bnd[((size_t)(gt.w + 1) * 2 + 0) * D3 + q * 256 + c] = tl;
         if (gt.head_bnd && !lhalf) m.edge_bnd[((size_t)gt.w * 2 + 1) * D3 + q * 256 + c] = hd;
         if (gt.read_tail && lhalf) m.edge_read[(size_t)b * D3 + q * 256 + c] = tl;
-#ifndef CLM_EXP_NOFIR     // timing-only build: no filter, no lane exchange
-        zg_fir_inplace<PREC>(acc, firq, p2, p3, lane);
-#endif
+        if constexpr (!lab::NOFIR) zg_fir_inplace<PREC>(acc, firq, p2, p3, lane);
         // x1f waits for vf through a whole MFMA phase in which both accumulators, two weight sets and the fragment ring are live
         // (hipcc spilled 8 .. 26 of its registers to scratch, behind vmcnt waits): its upper half (tokens 64 .. 127) waits in the
         // wave's staging tile instead -- unused until g is staged -- as eight conflict-free 16-byte rows per lane
@@ -296,9 +318,9 @@ __device__ __forceinline__ void inproj_blocks_gated(const typename CT<PREC>::ele
                 accv[2 + (k >> 2)][4 * (k & 3) + 3] *= x.w;
             }
             asm volatile("" ::: "memory");
-            zg_store_rows<PREC>(accv, zs, m.n_z, b, 256 + wave * 32, t0, m.Lp, lane);
+            zg_store_rows<PREC, PREC == PREC_F16C>(accv, zs, m.n_z, b, 256 + wave * 32, t0, m.Lp, lane);
         } else {
-            zg_store_rows<PREC>(accx, zs, m.n_z, b, wave * 32, t0, m.Lp, lane);
+            zg_store_rows<PREC, PREC == PREC_F16C>(accx, zs, m.n_z, b, wave * 32, t0, m.Lp, lane);
         }
     });
 }
@@ -323,6 +345,13 @@ __global__ __launch_bounds__(256) void gated_patch_kernel(TailArgs m, int tiles_
     const unsigned g = (unsigned)from_float<T>(zf[1][0] * zf[2][0]).bits | ((unsigned)from_float<T>(zf[1][1] * zf[2][1]).bits << 16);
     *reinterpret_cast<unsigned*>(z + (size_t)c * m.Lp) = x0;
     *reinterpret_cast<unsigned*>(z + (size_t)(256 + c) * m.Lp) = g;
+    if (m.zlo) {                                             // fp16c: the two tokens' lo bytes (rows 512.. of z: [2][256][Lp] bytes)
+        unsigned char* zl = reinterpret_cast<unsigned char*>(reinterpret_cast<T*>(m.n_z) + ((size_t)b * D3 + 2 * D) * m.Lp) + t0;
+        u16x4 hb;
+        const unsigned l = lo8_pack4(zf[0][0], zf[0][1], zf[1][0] * zf[2][0], zf[1][1] * zf[2][1], hb);
+        *reinterpret_cast<unsigned short*>(zl + (size_t)c * m.Lp) = (unsigned short)(l & 0xffffu);
+        *reinterpret_cast<unsigned short*>(zl + (size_t)(256 + c) * m.Lp) = (unsigned short)(l >> 16);
+    }
 }
 
 __global__ __launch_bounds__(256) void fir_table_kernel(const float* __restrict__ sw, const float* __restrict__ sb,
@@ -452,9 +481,13 @@ __global__ __launch_bounds__(512) void mlp16_kernel(MlpArgs m) {
 
 // Scores and the online-softmax pooling partial of one staged ln_f tile.  On entry bs[0] / bs[1] hold the two half-sets
 // of attention.0.weight; P / E / V: [8][128] + [128] + [4][256] floats of LDS behind the tile.
-template <int PREC>
+// LO2 (fp16c in the fused tail kernel): `Al` holds the lo bytes of the ln_f tile (ln_acc_to_tile<.., LO>): the score product gets
+// the activations' lo term and the pooled vector is summed from hi + lo -- ln_f's fp16 rounding was a fifth of the mode's logit
+// error (round 4, tests/error_model.py).
+template <int PREC, bool LO2 = false>
 __device__ __forceinline__ void score_pool_tile(const ScorePoolArgs& m, const typename CT<PREC>::elem* As, float* P, int b,
-                                                int tile, int tid, u16x8 (&bs)[2][1][SETK], f32x16 (&acc)[4]) {
+                                                int tile, int tid, u16x8 (&bs)[2][1][SETK], f32x16 (&acc)[4],
+                                                const unsigned char* Al = nullptr) {
     using elem = typename CT<PREC>::elem;
     constexpr int BM = 128;
     float* E = P + 8 * BM;
@@ -463,7 +496,7 @@ __device__ __forceinline__ void score_pool_tile(const ScorePoolArgs& m, const ty
     zero_acc(acc);
     {   // rows = features (register quads), lane = token; the last slot re-requests set 0 (unconditional prefetch, unused)
         const u16x8* wsp = reinterpret_cast<const u16x8*>(m.w1);
-        phase_tm<PREC, D, D, true, true>(As, wsp, 0, 0, wsp, 0, 0, wave, lane, bs, acc);
+        phase_tm<PREC, D, D, true, true, NoHook, PREC_SAME, LO2>(As, wsp, 0, 0, wsp, 0, 0, wave, lane, bs, acc, NoHook(), 0, Al);
     }
     {
         float4 b1v[4], w2v[4];
@@ -520,8 +553,15 @@ __device__ __forceinline__ void score_pool_tile(const ScorePoolArgs& m, const ty
             elem lo, hi;
             lo.bits = (unsigned short)(pk & 0xffffu);
             hi.bits = (unsigned short)(pk >> 16);
-            a0 = fmaf(e, to_float(lo), a0);
-            a1 = fmaf(e, to_float(hi), a1);
+            float v0 = to_float(lo), v1 = to_float(hi);
+            if constexpr (LO2) {                            // channels 2 c2, 2 c2 + 1: adjacent bytes of the lo row
+                typedef float f2 __attribute__((ext_vector_type(2)));
+                const int l8 = *reinterpret_cast<const unsigned short*>(Al + t * RSL + (lo_pos(2 * c2) ^ lo_swz(t)));
+                const f2 d = __builtin_amdgcn_cvt_pk_f32_bf8(l8, false);
+                v0 = fmaf(d.x, LO2_INV, v0), v1 = fmaf(d.y, LO2_INV, v1);
+            }
+            a0 = fmaf(e, v0, a0);
+            a1 = fmaf(e, v1, a1);
         }
         V[g * D + 2 * c2] = a0;
         V[g * D + 2 * c2 + 1] = a1;
@@ -592,6 +632,35 @@ __device__ __forceinline__ void tail_load_y_piece(const TailArgs& m, uint4 (&yx)
 #pragma unroll
     for (int i = 4 * half; i < 4 * half + 4; ++i)
         yx[i] = *reinterpret_cast<const uint4*>(src + (size_t)((tid >> 4) + 32 * i) * m.Lp + tkc);
+}
+// Round 4 (fp16c): the y tile's lo bytes, [256 channels][128 tokens] in HBM as y itself.  A thread takes 4 channels x 16 tokens
+// (channels 4 cg .., cg = 8 wave + (tid & 7); tokens 16 tp .., tp = (tid >> 3) & 7: eight lanes cover one 128-byte line of a row) ...
+__device__ __forceinline__ void tail_load_ylo(const TailArgs& m, uint4 (&yl)[4], int b, int t0, int tid) {
+    const int cg = (tid >> 6) * 8 + (tid & 7), tk = ((tid >> 3) & 7) * 16, tkc = t0 + tk < m.Lp ? tk : 0;   // clamped, masked at the LDS store
+    const unsigned char* src = m.ylo + ((size_t)b * D + 4 * cg) * m.Lp + t0 + tkc;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) yl[r] = *reinterpret_cast<const uint4*>(src + (size_t)r * m.Lp);
+}
+// ... and turns them into the token-major lo tile the MFMA reads (RSL, lo_pos, lo_swz): per token quad a 4 x 4 byte transpose in
+// registers (8 v_perm_b32), then one dword (4 consecutive channels) per token.
+__device__ __forceinline__ void tail_stage_ylo(unsigned char* Aly, const uint4 (&yl)[4], int t0, int Lp, int tid) {
+    const int cg = (tid >> 6) * 8 + (tid & 7), tk = ((tid >> 3) & 7) * 16;
+    const bool in_row = t0 + tk < Lp;
+    unsigned char* dst = Aly + tk * RSL;
+    const int col = lo_pos(4 * cg) ^ lo_swz(tk);           // (16 tokens = one swizzle group)
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        const unsigned d0 = a == 0 ? yl[0].x : a == 1 ? yl[0].y : a == 2 ? yl[0].z : yl[0].w;
+        const unsigned d1 = a == 0 ? yl[1].x : a == 1 ? yl[1].y : a == 2 ? yl[1].z : yl[1].w;
+        const unsigned d2 = a == 0 ? yl[2].x : a == 1 ? yl[2].y : a == 2 ? yl[2].z : yl[2].w;
+        const unsigned d3 = a == 0 ? yl[3].x : a == 1 ? yl[3].y : a == 2 ? yl[3].z : yl[3].w;
+        const unsigned x0 = __builtin_amdgcn_perm(d1, d0, 0x05010400u), x1 = __builtin_amdgcn_perm(d1, d0, 0x07030602u);
+        const unsigned y0 = __builtin_amdgcn_perm(d3, d2, 0x05010400u), y1 = __builtin_amdgcn_perm(d3, d2, 0x07030602u);
+        const unsigned o[4] = {__builtin_amdgcn_perm(y0, x0, 0x05040100u), __builtin_amdgcn_perm(y0, x0, 0x07060302u),
+                               __builtin_amdgcn_perm(y1, x1, 0x05040100u), __builtin_amdgcn_perm(y1, x1, 0x07060302u)};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) *reinterpret_cast<unsigned*>(dst + (4 * a + e) * RSL + col) = in_row ? o[e] : 0u;
+    }
 }
 // PIECES: how many of the four residual pieces the hooks request.  fp16c: none -- with all four (64 registers) plus the y
 // pieces (32) live next to the accumulators and the weight sets, hipcc spilled one piece AS IT LOADED it (four times
@@ -667,10 +736,17 @@ __global__ __launch_bounds__(512) void tail16_kernel(TailArgs m, unsigned long l
     // was measured too: 2 % slower -- the phases are latency-bound per CU, not a chip-wide bandwidth burst.)
     float4 hv[4][4];                                       // residual in accumulator layout: token mt*32+lrow, 4 features
     uint4 yx[8];                                           // y tile pieces of this thread
+    // fp16c, round 4: y comes as hi + lo bytes; the lo plane is staged into a token-major tile behind the y tile (under As / Hs,
+    // dead during out_proj) and adds the activations' lo term to out_proj (compute_km LO2)
+    constexpr bool LOY = PREC == PREC_F16C;
+    uint4 yl[LOY ? 4 : 1];
+    unsigned char* Aly = smem + (size_t)D * RSKM * 2;
+    static_assert((size_t)D * RSKM * 2 % 16 == 0 && (size_t)D * RSKM * 2 + 128 * RSL <= (size_t)2 * BM * RS16 * 2, "y lo tile fits behind the y tile");
     tail_load_resid(m, hv, tile_begin / tiles_x, (tile_begin % tiles_x) * BM, (int)threadIdx.x >> 6, (int)threadIdx.x & 31,
                     ((int)threadIdx.x >> 5) & 1);
     tail_load_y_piece<elem>(m, yx, 0, tile_begin / tiles_x, (tile_begin % tiles_x) * BM, threadIdx.x);
     tail_load_y_piece<elem>(m, yx, 1, tile_begin / tiles_x, (tile_begin % tiles_x) * BM, threadIdx.x);
+    if constexpr (LOY) tail_load_ylo(m, yl, tile_begin / tiles_x, (tile_begin % tiles_x) * BM, threadIdx.x);
 #pragma unroll 1
     for (int tile = tile_begin; tile < tile_end; ++tile) {
     // the thread index is made opaque once per trip: every address below is re-derived inside the trip instead of being
@@ -695,6 +771,7 @@ __global__ __launch_bounds__(512) void tail16_kernel(TailArgs m, unsigned long l
         for (int i = 0; i < 8; ++i)
             *reinterpret_cast<uint4*>(Ys + ((tid >> 4) + 32 * i) * RSKM + tk) = in_row ? yx[i] : make_uint4(0, 0, 0, 0);
     }
+    if constexpr (LOY) tail_stage_ylo(Aly, yl, t0, Lp, tid);
     __syncthreads();
     CLM_STAMP_AT(1);
     // ---- 1. r = h + b_out + out_proj(y) (kept in acc2): the accumulators START from the residual rows, so their 64 registers
@@ -715,7 +792,7 @@ __global__ __launch_bounds__(512) void tail16_kernel(TailArgs m, unsigned long l
             }
         }
     }
-    phase_km<PREC, D, D, PF>(Ys, wo, 0, 0, w1, 0, 0, wave, lane, bs, acc2);   // (first fc1 set requested under the last set)
+    phase_km<PREC, D, D, PF, LOY>(Ys, wo, 0, 0, w1, 0, 0, wave, lane, bs, acc2, Aly);   // (first fc1 set requested under the last set)
     CLM_STAMP_AT(2);
     // ---- 2./3. LayerNorm-2 of r straight from the accumulators -> As (16-bit)
     ln_acc_to_tile<PREC>(acc2, P1, P2, m.ln_g, m.ln_b, m.eps, As, t0, L, wave, lrow, lhalf);
@@ -814,14 +891,19 @@ __global__ __launch_bounds__(512) void tail16_kernel(TailArgs m, unsigned long l
         tail_load_resid(m, hv, nb_, nt0, wave, lrow, lhalf);
         tail_load_y_piece<elem>(m, yx, 0, nb_, nt0, tid);
         tail_load_y_piece<elem>(m, yx, 1, nb_, nt0, tid);
+        if constexpr (LOY) tail_load_ylo(m, yl, nb_, nt0, tid);
     }
     // ---- 6. what follows, on the tile still in registers
     if constexpr (NEXT != NEXT_NONE) {
         load_set<PREC, D, 1>(wn, ZG ? ZG_ORDER[0] : 0, 0, 1, wave, lane, bs[1]);
         __builtin_amdgcn_sched_barrier(0);
         // (the first barrier inside orders the staging reads above before the As writes)
-        ln_acc_to_tile<PREC>(acc2, P1, P2, NEXT == NEXT_SCORE ? m.sp.ln_g : m.n_g, NEXT == NEXT_SCORE ? m.sp.ln_b : m.n_b,
-                             m.eps, As, t0, L, wave, lrow, lhalf);
+        // (fp16c, score variant: the ln_f tile as hi + lo -- the lo tile sits in the Hs region, behind the 8.5 KiB of P / E / V)
+        constexpr bool LOF = PREC == PREC_F16C && NEXT == NEXT_SCORE;
+        unsigned char* Alf = reinterpret_cast<unsigned char*>(Hs) + 16384;
+        static_assert(16384 >= (8 * 128 + 128 + 4 * D) * 4 && 16384 + 128 * RSL <= 128 * RS16 * 2, "lo tile of ln_f fits the Hs region");
+        ln_acc_to_tile<PREC, false, LOF>(acc2, P1, P2, NEXT == NEXT_SCORE ? m.sp.ln_g : m.n_g, NEXT == NEXT_SCORE ? m.sp.ln_b : m.n_b,
+                                         m.eps, As, t0, L, wave, lrow, lhalf, Alf);
         CLM_STAMP_AT(19);
         if constexpr (NEXT == NEXT_INPROJ) {
             // bs[1] is re-requested by the block loop (same addresses, L2-resident): keeps the loop identical to in_proj16
@@ -843,12 +925,14 @@ __global__ __launch_bounds__(512) void tail16_kernel(TailArgs m, unsigned long l
                                                         STAMP ? stamps + (size_t)tile * TAIL_NSTAMP : nullptr});
 #pragma unroll
             for (int mt = PIECES; mt < 4; ++mt) tail_load_resid_piece(m, hv[mt], mt, nb_, nt0, wave, lrow, lhalf);
+            if constexpr (LOY) tail_load_ylo(m, yl, nb_, nt0, tid);
         } else {
-            score_pool_tile<PREC>(m.sp, As, reinterpret_cast<float*>(Hs), b, tile % tiles_x, tid, bs, acc1);
+            score_pool_tile<PREC, LOF>(m.sp, As, reinterpret_cast<float*>(Hs), b, tile % tiles_x, tid, bs, acc1, Alf);
             // (requested before the score stage these 96 registers spill through its erf epilogue: one launch in four)
             tail_load_resid(m, hv, nb_, nt0, wave, lrow, lhalf);
             tail_load_y_piece<elem>(m, yx, 0, nb_, nt0, tid);
             tail_load_y_piece<elem>(m, yx, 1, nb_, nt0, tid);
+            if constexpr (LOY) tail_load_ylo(m, yl, nb_, nt0, tid);
         }
         CLM_STAMP_AT(20);
     }

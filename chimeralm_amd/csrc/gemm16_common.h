@@ -13,6 +13,17 @@ constexpr int RS16 = 264;     // row stride (elements) of token-major LDS tiles:
 constexpr int RSKM = 160;     // row stride of the k-major (channel-major) tile: 320 B = 256 B + 64 B, so the four
                               // rows of a transposing read land on four different 64-byte bank groups
 constexpr int RSOUT = 136;    // row stride of the wave-private output staging tile: 272 B (16-byte aligned rows)
+// Round 4, the lo tile of a compensated ACTIVATION operand (gemm_common.h lo8_pack4 / mfma_lo2): token-major, one e5m2 byte per
+// feature, row stride 272 B = 256 + 16 (like RS16: a 16-lane group's 16-byte reads fall on 16 different bank groups).  Inside a
+// row the 32 bytes a lane feeds the K = 64 MFMA of the 64-deep group g = k >> 6 for its k-half h = (k >> 3) & 1 lie together, in
+// the k order of the fp16 fragments (byte 8 s + j = k-step s = (k >> 4) & 3, element j = k & 7): two 16-byte reads per row tile.
+// Rows are XOR-swizzled in units of the 32-byte chunks by the row's 16-row group (lo_swz): the writers own either 32 consecutive
+// rows per wave (LayerNorm: rows r and r + 16 would meet in one bank) or 16 consecutive tokens per lane (the y tile's staging:
+// lanes 16 rows apart would all meet in one), the MFMA readers 16 consecutive rows per 16-lane group -- for whom the swizzle is a
+// per-lane constant plus compile-time terms: chunk (g, h) of row 32 mt + lrow lies at 64 (g ^ mt) + 32 (h ^ (lrow >> 4)).
+constexpr int RSL = 272;
+__host__ __device__ constexpr int lo_pos(int k) { return (k & ~63) + 32 * ((k >> 3) & 1) + 8 * ((k >> 4) & 3) + (k & 7); }
+__host__ __device__ constexpr int lo_swz(int row) { return ((row >> 4) & 7) << 5; }
 
 template <int PREC>
 __device__ __forceinline__ unsigned short to_bits(float v) {
@@ -22,20 +33,18 @@ __device__ __forceinline__ unsigned short to_bits(float v) {
 // acc[mt] += A-tile(token-major LDS) x weight set `part` (k-steps [part * KPS, (part + 1) * KPS) of the 256-deep chunk).
 // ROWS_N: accumulator rows are output features (lane = token).  Compensated mode: the set holds (hi, lo) pairs and every
 // A fragment feeds two MFMAs -- half the LDS bytes per MFMA of the plain modes.
-template <int PREC, bool ROWS_N, int AHEAD = 4>
+// LO2 (fp16c only): the activations' lo tile `Al` (RSL, lo_pos) adds a third term per row tile and 64-deep group.
+template <int PREC, bool ROWS_N, int AHEAD = 4, bool LO2 = false>
 __device__ __forceinline__ void compute_tm(const typename CT<PREC>::elem* As, int part, int lrow, int lhalf,
-                                           const u16x8 (&src)[1][SETK], f32x16 (&acc)[4]) {
+                                           const u16x8 (&src)[1][SETK], f32x16 (&acc)[4], const unsigned char* Al = nullptr) {
+    static_assert(!LO2 || PREC == PREC_F16C, "activation lo tiles exist in the compensated mode only");
     // Explicitly software-pipelined over the 4*KPS (k-step, row tile) items: the A fragment of item i + AHEAD is requested
     // before the MFMA(s) of item i (ring of AHEAD + 1 fragments), and that order is pinned with sched_group_barrier.  Left to
     // itself hipcc serialises `ds_read -> s_waitcnt lgkmcnt(0) -> mfma` wherever registers are tight (fc1: both accumulators
     // and two half-sets live), and every MFMA then pays a full LDS latency: fc1 ran at half the rate of fc2.
     constexpr int FR = WFR<PREC>, KP = KPS<PREC>, NI = 4 * KP, R = AHEAD + 1;
     const typename CT<PREC>::elem* a0 = As + lrow * RS16 + part * KP * 16 + lhalf * 8;
-#ifdef CLM_EXP_A0       // timing-only build: every A fragment of a set is its first one (one LDS read per set instead of 16)
-#define CLM_A_OFF(x) 0
-#else
-#define CLM_A_OFF(x) (x)
-#endif
+#define CLM_A_OFF(x) (lab::A0 ? 0 : (x))
     if constexpr (PREC == PREC_F16C) {
         // Compensated mode.  Items run ROW-TILE major (mt = i >> 2, k-step = i & 3): a row tile's four activation fragments feed
         // four fp16 MFMAs with the hi fragments and, their upper bytes gathered as e5m2 as they pass (8 registers, two v_perm_b32
@@ -50,6 +59,17 @@ __device__ __forceinline__ void compute_tm(const typename CT<PREC>::elem* As, in
 #pragma unroll
             for (int r = 0; r < 8; ++r) w8[r] = (int)lo32[r];
         }
+        // LO2: the set's four hi fragments truncated to e5m2 (their upper bytes) are the weight operand of the activations' lo term
+        i32x8 w8h = {0, 0, 0, 0, 0, 0, 0, 0}, alo = {0, 0, 0, 0, 0, 0, 0, 0};
+        const unsigned char* al0 = LO2 ? Al + lrow * RSL + 32 * (lhalf ^ (lrow >> 4)) : nullptr;   // (lo_swz: + 64 (part ^ mt) below)
+        if constexpr (LO2) {
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                int w0, w1;
+                frag_to_e5m2t(src[0][ks], w0, w1);
+                w8h[2 * ks] = w0, w8h[2 * ks + 1] = w1;
+            }
+        }
 #pragma unroll
         for (int i = 0; i < AHEAD; ++i) afc[i % R] = *reinterpret_cast<const u16x8*>(a0 + CLM_A_OFF((i >> 2) * 32 * RS16 + (i & 3) * 16));
 #pragma unroll
@@ -59,24 +79,38 @@ __device__ __forceinline__ void compute_tm(const typename CT<PREC>::elem* As, in
                 afc[n % R] = *reinterpret_cast<const u16x8*>(a0 + CLM_A_OFF((n >> 2) * 32 * RS16 + (n & 3) * 16));
             }
             const int mt = i >> 2, ks = i & 3;
+            if constexpr (LO2) {
+                if (ks == 0) {                            // the row tile's 32 lo bytes: needed three MFMAs from now
+                    typedef int i32x4 __attribute__((ext_vector_type(4)));
+                    const i32x4 p0 = *reinterpret_cast<const i32x4*>(al0 + mt * 32 * RSL + 64 * (part ^ mt)),
+                                p1 = *reinterpret_cast<const i32x4*>(al0 + mt * 32 * RSL + 64 * (part ^ mt) + 16);
+                    alo = i32x8{p0[0], p0[1], p0[2], p0[3], p1[0], p1[1], p1[2], p1[3]};
+                }
+            }
             if (ROWS_N) acc[mt] = mfma<PREC>(src[0][ks], afc[i % R], acc[mt]);
             else acc[mt] = mfma<PREC>(afc[i % R], src[0][ks], acc[mt]);
-#ifndef CLM_EXP_NOLO    // timing-only build without the lo half: what the lo MFMA + the byte gathers cost
-            int w0, w1;
-            frag_to_e5m2t(afc[i % R], w0, w1);
-            a8[2 * ks] = w0, a8[2 * ks + 1] = w1;
-            if (ks == 3) acc[mt] = mfma_lo8<ROWS_N>(w8, a8, acc[mt]);
-#endif
+            if constexpr (!lab::NOLO) {
+                int w0, w1;
+                frag_to_e5m2t(afc[i % R], w0, w1);
+                a8[2 * ks] = w0, a8[2 * ks + 1] = w1;
+                if (ks == 3) acc[mt] = mfma_lo8<ROWS_N>(w8, a8, acc[mt]);
+            }
+            if constexpr (LO2) {
+                if (ks == 3) acc[mt] = mfma_lo2<ROWS_N>(w8h, alo, acc[mt]);
+            }
         }
+        if constexpr (LO2) __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);
         __builtin_amdgcn_sched_group_barrier(0x100, AHEAD, 0);
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
             if (i + AHEAD < NI) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            if (LO2 && (i & 3) == 0) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-#ifndef CLM_EXP_NOLO
-            __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
-            if ((i & 3) == 3) __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-#endif
+            if constexpr (!lab::NOLO) {
+                __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+                if ((i & 3) == 3) __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            }
+            if (LO2 && (i & 3) == 3) __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
         }
         return;
     }
@@ -105,9 +139,10 @@ __device__ __forceinline__ void compute_tm(const typename CT<PREC>::elem* As, in
 
 // Same, A operand taken from the k-major tile Ys[k][token] with the transposing read: a 16-lane group reads a
 // 4(k) x 16(token) block and lane i receives token i's four k values (cdna_hip_programming.md T10).
-template <int PREC>
+template <int PREC, bool LO2 = false>
 __device__ __forceinline__ void compute_km(const typename CT<PREC>::elem* Ys, int part, int lane,
-                                           const u16x8 (&src)[1][SETK], f32x16 (&acc)[4]) {
+                                           const u16x8 (&src)[1][SETK], f32x16 (&acc)[4], const unsigned char* Al = nullptr) {
+    static_assert(!LO2 || PREC == PREC_F16C, "activation lo tiles exist in the compensated mode only");
     constexpr int FR = WFR<PREC>, KP = KPS<PREC>;
     const int li = lane & 15, g1 = (lane >> 4) & 1, h = lane >> 5, q = li >> 2, p = li & 3;
     const typename CT<PREC>::elem* base = Ys + (8 * h + q) * RSKM + 16 * g1 + 4 * p;
@@ -119,8 +154,26 @@ __device__ __forceinline__ void compute_km(const typename CT<PREC>::elem* Ys, in
             for (int r = 0; r < 8; ++r) w8[r] = (int)lo32[r];
         }
         i32x8 a8 = {0, 0, 0, 0, 0, 0, 0, 0};
+        // LO2 (the y tile's lo bytes, token-major like every lo tile): as compute_tm
+        i32x8 w8h = {0, 0, 0, 0, 0, 0, 0, 0};
+        const unsigned char* al0 = LO2 ? Al + (lane & 31) * RSL + 32 * (h ^ ((lane >> 4) & 1)) : nullptr;
+        if constexpr (LO2) {
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                int w0, w1;
+                frag_to_e5m2t(src[0][ks], w0, w1);
+                w8h[2 * ks] = w0, w8h[2 * ks + 1] = w1;
+            }
+        }
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) {
+            i32x8 alo = {0, 0, 0, 0, 0, 0, 0, 0};
+            if constexpr (LO2) {
+                typedef int i32x4 __attribute__((ext_vector_type(4)));
+                const i32x4 q0 = *reinterpret_cast<const i32x4*>(al0 + mt * 32 * RSL + 64 * (part ^ mt)),
+                            q1 = *reinterpret_cast<const i32x4*>(al0 + mt * 32 * RSL + 64 * (part ^ mt) + 16);
+                alo = i32x8{q0[0], q0[1], q0[2], q0[3], q1[0], q1[1], q1[2], q1[3]};
+            }
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
                 const typename CT<PREC>::elem* p0 = base + ((part * KP + ks) * 16) * RSKM + mt * 32;
@@ -134,6 +187,7 @@ __device__ __forceinline__ void compute_km(const typename CT<PREC>::elem* Ys, in
                 a8[2 * ks] = w0, a8[2 * ks + 1] = w1;
             }
             acc[mt] = mfma_lo8<true>(w8, a8, acc[mt]);
+            if constexpr (LO2) acc[mt] = mfma_lo2<true>(w8h, alo, acc[mt]);
         }
         return;
     }
@@ -175,10 +229,11 @@ __device__ __forceinline__ const u16x8* set_base(const u16x8* wp, int nb, int kc
     constexpr int FR = CT<PREC>::MFMA_K == 16 ? WFR<PREC> : 1, KP = SETK / FR;
     return wp + ((size_t)(nb * 8 + wave) * KSTEPS_ALL + kc * KSTEPS + part * KP) * (FR * 64) + lane;
 }
-template <int PREC, int K, int KN, bool ROWS_N, bool P1_LOADED = false, typename Hook = NoHook, int PRECN = PREC_SAME>
+template <int PREC, int K, int KN, bool ROWS_N, bool P1_LOADED = false, typename Hook = NoHook, int PRECN = PREC_SAME, bool LO2 = false>
 __device__ __forceinline__ void phase_tm(const typename CT<PREC>::elem* As, const u16x8* wp, int nb, int kc,
                                          const u16x8* wnext, int nnb, int nkc, int wave, int lane,
-                                         u16x8 (&bs)[2][1][SETK], f32x16 (&acc)[4], Hook hook = Hook(), int hook0 = 0) {
+                                         u16x8 (&bs)[2][1][SETK], f32x16 (&acc)[4], Hook hook = Hook(), int hook0 = 0,
+                                         const unsigned char* Al = nullptr /*LO2: the activations' lo tile*/) {
     constexpr int NP = NPARTS<PREC>;
     const int lrow = lane & 31, lhalf = lane >> 5;
     static_for<0, NP>([&](auto pc) {
@@ -193,15 +248,15 @@ __device__ __forceinline__ void phase_tm(const typename CT<PREC>::elem* As, cons
         }
         if constexpr (p % (NP / 2) == 0) hook(hook0 + p / (NP / 2));
         __builtin_amdgcn_sched_barrier(0);
-        compute_tm<PREC, ROWS_N>(As, p, lrow, lhalf, bs[p & 1], acc);
+        compute_tm<PREC, ROWS_N, 4, LO2>(As, p, lrow, lhalf, bs[p & 1], acc, Al);
         __builtin_amdgcn_sched_barrier(0);
     });
 }
 // same over the k-major tile (out_proj); set 1 is always loaded by the caller
-template <int PREC, int K, int KN, int PRECN = PREC>
+template <int PREC, int K, int KN, int PRECN = PREC, bool LO2 = false>
 __device__ __forceinline__ void phase_km(const typename CT<PREC>::elem* Ys, const u16x8* wp, int nb, int kc,
                                          const u16x8* wnext, int nnb, int nkc, int wave, int lane,
-                                         u16x8 (&bs)[2][1][SETK], f32x16 (&acc)[4]) {
+                                         u16x8 (&bs)[2][1][SETK], f32x16 (&acc)[4], const unsigned char* Al = nullptr) {
     constexpr int NP = NPARTS<PREC>;
     static_for<0, NP>([&](auto pc) {
         constexpr int p = decltype(pc)::value;
@@ -210,7 +265,7 @@ __device__ __forceinline__ void phase_km(const typename CT<PREC>::elem* Ys, cons
             else load_set<PRECN, KN, 1>(wnext, nnb, nkc, 0, wave, lane, bs[0]);
             __builtin_amdgcn_sched_barrier(0);
         }
-        compute_km<PREC>(Ys, p, lane, bs[p & 1], acc);
+        compute_km<PREC, LO2>(Ys, p, lane, bs[p & 1], acc, Al);
         __builtin_amdgcn_sched_barrier(0);
     });
 }
@@ -232,17 +287,23 @@ __device__ __forceinline__ void zero_acc(f32x16 (&acc)[4]) {
 //  layer's bias where possible: measured in tail16_kernel, 1.572 vs 1.573 ms per launch -- not kept.  The statistics and the
 //  affine step on register pairs (v_pk_*_f32, half the arithmetic instructions but 190 more v_mov for splats and pairs):
 //  1.568 vs 1.578 ms in the in_proj variant, 1.431 vs 1.422 in the score variant -- not kept either.)
-template <int PREC, bool KEEP = false>
+// LO (fp16c): the normalised values also leave their lo bytes in `Al` (RSL, lo_pos; gemm_common.h lo8_pack4) -- the operand tile of
+// the product that follows is then carried to ~15 bits instead of fp16's 11.
+template <int PREC, bool KEEP = false, bool LO = false>
 __device__ __forceinline__ void ln_acc_to_tile(f32x16 (&acc2)[4], float* P1, float* P2, const float* __restrict__ g,
                                                const float* __restrict__ bta, float eps, typename CT<PREC>::elem* As,
-                                               int t0, int L, int wave, int lrow, int lhalf) {
+                                               int t0, int L, int wave, int lrow, int lhalf, unsigned char* Al = nullptr) {
+    static_assert(!LO || PREC == PREC_F16C, "activation lo tiles exist in the compensated mode only");
     constexpr int BM = 128;
     float mean[4], rstd[4];
-#ifdef CLM_EXP_NOLN     // timing-only build (tools/build_variant.sh): no statistics; one barrier kept (orders earlier LDS reads before As)
+    if constexpr (lab::NOLN) {
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt) mean[mt] = 0.f, rstd[mt] = 1.f;
-    __syncthreads();
-#elif !defined(CLM_EXP_LN1X)     // the two-exchange form: mean first, then the deviations about it
+        for (int mt = 0; mt < 4; ++mt) mean[mt] = 0.f, rstd[mt] = 1.f;
+        __syncthreads();
+    } else {
+    // the two-exchange form: mean first, then the deviations about it.  (ONE exchange -- every lane leaves the sum of its 16 values
+    // and their squared deviations about its own mean, combined exactly after Chan et al. -- was built and MEASURED SLOWER in round 3:
+    // 22.76 vs 22.45 ms of tail kernel per step; the statistics cost VALU + LDS instructions, not barriers.  DESIGN.md section 4.9.)
     // (the two half-waves of a wave hold the same tokens: their partial sums are added through one lane exchange before they go to
     //  the table -- 8 partials per token instead of 16, half the table reads and adds of every thread.  Round 3, timing-only build
     //  of the final kernel: the statistics are 14 % of the tail kernel, profiles/r03_timing_only.txt)
@@ -278,50 +339,7 @@ __device__ __forceinline__ void ln_acc_to_tile(f32x16 (&acc2)[4], float* P1, flo
         for (int w = 0; w < 8; ++w) v += P2[w * BM + mt * 32 + lrow];
         rstd[mt] = 1.0f / sqrtf(v * (1.0f / D) + eps);
     }
-#else
-    // A/B build (-DCLM_EXP_LN1X), MEASURED SLOWER in round 3 and therefore not the default: ONE exchange instead of two -- every
-    // lane leaves the sum of its 16 values AND their squared deviations about ITS OWN mean; the 16 partials of a token combine
-    // exactly (Chan et al.):  mean = sum_w s_w / 256,  M2 = sum_w [ m2_w + 16 (s_w / 16 - mean)^2 ]  (no E[x^2] - mean^2
-    // cancellation; no spills with the row tiles kept apart by sched_barrier -- the first attempt, DESIGN.md section 4.3, spilled
-    // 110+ registers).  Same box, tail kernel per step: 22.45 ms two exchanges, 22.76 ms one: the statistics cost 10 % of the kernel
-    // (timing-only build without them) as VALU + LDS instructions, not as barriers -- the saved barrier buys less than the
-    // combination's extra arithmetic and the doubled table reads per exchange cost.
-#pragma unroll
-    for (int mt = 0; mt < 4; ++mt) {
-        float s = 0.f;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) s += acc2[mt][r];
-        const float mu = s * (1.0f / 16.0f);
-        float v = 0.f;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const float d = acc2[mt][r] - mu;
-            v = fmaf(d, d, v);
-        }
-        P1[(wave * 2 + lhalf) * BM + mt * 32 + lrow] = s;
-        P2[(wave * 2 + lhalf) * BM + mt * 32 + lrow] = v;
     }
-    __syncthreads();
-#pragma unroll
-    for (int mt = 0; mt < 4; ++mt) {
-        float sw[16];
-        float s = 0.f;
-#pragma unroll
-        for (int w = 0; w < 16; ++w) {
-            sw[w] = P1[w * BM + mt * 32 + lrow];
-            s += sw[w];
-        }
-        mean[mt] = s * (1.0f / D);
-        float v = 0.f;
-#pragma unroll
-        for (int w = 0; w < 16; ++w) {
-            const float d = sw[w] * (1.0f / 16.0f) - mean[mt];
-            v += fmaf(16.0f * d, d, P2[w * BM + mt * 32 + lrow]);
-        }
-        rstd[mt] = 1.0f / sqrtf(v * (1.0f / D) + eps);
-        __builtin_amdgcn_sched_barrier(0);
-    }
-#endif
     const float* gp = g + wave * 32 + 4 * lhalf;
     const float* bp = bta + wave * 32 + 4 * lhalf;
     // Rows beyond the read leave as zeros.  Only a read's last tile has any (none at all where the last token is peeled: 8k-bp
@@ -345,8 +363,16 @@ __device__ __forceinline__ void ln_acc_to_tile(f32x16 (&acc2)[4], float* P1, flo
                     acc2[mt][4 * q + 2] = y2;
                     acc2[mt][4 * q + 3] = y3;
                 }
-                u16x4 pk = {to_bits<PREC>(y0), to_bits<PREC>(y1), to_bits<PREC>(y2), to_bits<PREC>(y3)};
-                *reinterpret_cast<u16x4*>(As + (mt * 32 + lrow) * RS16 + wave * 32 + 8 * q + 4 * lhalf) = pk;
+                if constexpr (LO) {
+                    u16x4 pk;
+                    const unsigned lo4 = lo8_pack4(y0, y1, y2, y3, pk);
+                    *reinterpret_cast<u16x4*>(As + (mt * 32 + lrow) * RS16 + wave * 32 + 8 * q + 4 * lhalf) = pk;
+                    // features wave * 32 + 8 q + 4 lhalf + {0..3}: one dword of the lo row (lo_pos is contiguous over 4-aligned j)
+                    *reinterpret_cast<unsigned*>(Al + (mt * 32 + lrow) * RSL + ((lo_pos(wave * 32 + 8 * q) + 4 * lhalf) ^ lo_swz(mt * 32 + lrow))) = lo4;
+                } else {
+                    u16x4 pk = {to_bits<PREC>(y0), to_bits<PREC>(y1), to_bits<PREC>(y2), to_bits<PREC>(y3)};
+                    *reinterpret_cast<u16x4*>(As + (mt * 32 + lrow) * RS16 + wave * 32 + 8 * q + 4 * lhalf) = pk;
+                }
             }
         }
     };

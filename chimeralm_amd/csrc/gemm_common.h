@@ -59,13 +59,33 @@ __device__ __forceinline__ f32x16 mfma_lo8(i32x8 w8, i32x8 a8, f32x16 c) {
 // (Also measured and not kept, round 3: the lo product in the 4/6-bit class of the scaled MFMA -- e2m1 activations x e2m3
 //  weights with a block scale run it in 32 cycles instead of 64, tools/micro/mfma_fp6_lo.cpp -- tail 22.8 -> 22.2 ms per step
 //  against 20.45 here: the four conversions per fragment, not the MFMA cycles, were what the lo half cost.)
-constexpr float LO8_TRUNC_GAIN = 1.0f / 0.9155f;
+constexpr float LO8_TRUNC_GAIN = LO8_TRUNC_GAIN_V;
 __device__ __forceinline__ void frag_to_e5m2t(u16x8 af, int& w0, int& w1) {
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
     const u32x4 d = __builtin_bit_cast(u32x4, af);
     const unsigned d0 = d[0], d1 = d[1], d2 = d[2], d3 = d[3];   // (scalars first: bit_cast of a vector ELEMENT reads element 0, hipcc 7.2)
     w0 = (int)__builtin_amdgcn_perm(d1, d0, 0x07050301u);         // bytes 1, 3 of d0 then of d1: the upper bytes of halfs 0..3
     w1 = (int)__builtin_amdgcn_perm(d3, d2, 0x07050301u);
+}
+
+// ---- round 4: the lo half of an ACTIVATION operand ------------------------------------------------------------------------------
+// With the weights compensated, what is left of the fp16c mode's error is the fp16 rounding of the GEMM activation operands (and of
+// z / y in HBM): token-random, 2^-12 relative per element (tests/error_model.py).  The producer of an operand
+// tile (LayerNorm from the accumulators; the convolution for y) has the fp32 value in registers, so it also leaves
+//     lo8 = e5m2((x - fp16(x)) * 2^10 / 0.9155)          one byte per element, in a second tile
+// and the product gets a third term per 64-deep group:  acc += lo8(x) . e5m2_trunc(w_hi)  on the same K = 64 block-scaled MFMA
+// (block scale 2^-10).  The weight operand of that term needs no storage and no load: the upper bytes of the fp16 hi fragments a
+// wave already holds ARE e5m2 numbers (frag_to_e5m2t: two v_perm per fragment, once per weight set); their truncation bias (0.9155,
+// see LO8_TRUNC_GAIN) is folded into the producer's scale.  2^10: x - fp16(x) is at most 2^-11 |x|, and |x| < 65504, so the scaled
+// lo never exceeds 16384 < 57344 = the e5m2 maximum -- no saturation logic; fp16 values down to 2^-4 keep a NORMAL lo (relative
+// precision 2^-3 on a 2^-12 term), smaller ones lose it to e5m2's subnormals, where the absolute error is below 2^-27.
+// (LO2_SCALE, lo8_pack4, lo8_unpack4: clm_common.h -- the convolution kernels write y's and read z's lo bytes with them.)
+// acc += lo8(activations) . e5m2_trunc(w_hi): `w8h` the lane's 32 truncated weight bytes (frag_to_e5m2t of the set's four hi
+// fragments), `alo` its 32 activation lo bytes, both in the k order of the fp16 fragments (byte 8 s + j = k-step s, element j)
+template <bool W_IS_A>
+__device__ __forceinline__ f32x16 mfma_lo2(i32x8 w8h, i32x8 alo, f32x16 c) {
+    if (W_IS_A) return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(w8h, alo, c, 1 /*e5m2*/, 1 /*e5m2*/, 0, 127, 0, LO2_E8M0);
+    return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(alo, w8h, c, 1, 1, 0, LO2_E8M0, 0, 127);
 }
 
 template <int PREC>
@@ -319,16 +339,14 @@ __device__ __forceinline__ void load_set(const typename CT<PREC>::frag* wp, int 
                                          typename CT<PREC>::frag (&dst)[NT][SETK]) {
     constexpr int KSTEPS = 256 / CT<PREC>::MFMA_K, KSTEPS_ALL = K / CT<PREC>::MFMA_K;
     constexpr int FR = CT<PREC>::MFMA_K == 16 ? WFR<PREC> : 1, KP = SETK / FR;
-#ifdef CLM_EXP_NOW   // timing-only build: only the first set of a column block is ever loaded -- no weight stream at all, wrong results
-    if (kc != 0 || part != 0) return;
-#endif
+    if constexpr (lab::NOW) {
+        if (kc != 0 || part != 0) return;
+    }
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
         const typename CT<PREC>::frag* p =
             wp + ((size_t)(nb * 8 + wave * NT + nt) * KSTEPS_ALL + kc * KSTEPS + part * KP) * (FR * 64) + lane;
-#ifdef CLM_EXP_W0   // timing-only build (tools/build_variant.sh): every set is the wave's first one -- weights from the L1, wrong results
-        p = wp + (size_t)(wave * NT + nt) * KSTEPS_ALL * (FR * 64) + lane;
-#endif
+        if constexpr (lab::W0) p = wp + (size_t)(wave * NT + nt) * KSTEPS_ALL * (FR * 64) + lane;
 #pragma unroll
         for (int ks = 0; ks < SETK; ++ks)
             if (PREC != PREC_F16C || ks < 6) dst[nt][ks] = p[(size_t)ks * 64];     // compensated mode: slots 6, 7 are unused

@@ -219,6 +219,49 @@ __device__ __forceinline__ void store8<f16_t>(f16_t* p, const float* v) {
     *reinterpret_cast<u16x8*>(p) = o;
 }
 
+// ---- round 4 (fp16c): lo bytes next to the 16-bit rows of z and y (clm_common.h lo8_pack4) --------------------------------------
+// z: the gated in_proj stage leaves the lo bytes of x0f | g in rows 512.. of the read's z block, as [2][256][Lp] bytes.
+template <typename T>
+__device__ __forceinline__ const unsigned char* zlo_row(const T* zb /* z + b * 768 * Lp */, int which /*0: x0f, 1: g*/, int c, int Lp) {
+    return reinterpret_cast<const unsigned char*>(zb + (size_t)2 * D * Lp) + (size_t)(which * D + c) * Lp;
+}
+// o[0..7] += the corrections of 8 lo bytes
+__device__ __forceinline__ void add_lo8(const uint2 lo, float* o) {
+    float d[4];
+    lo8_unpack4(lo.x, d);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] += d[e];
+    lo8_unpack4(lo.y, d);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[4 + e] += d[e];
+}
+__device__ __forceinline__ float lo1b(unsigned byte) { return __builtin_amdgcn_cvt_f32_bf8((int)byte, 0) * LO2_INV; }
+__device__ __forceinline__ float lo1(const unsigned char* row, int t) { return lo1b(row[t]); }
+// 8 values -> 8 halfs at p and their 8 lo bytes at lo
+__device__ __forceinline__ void store8_hilo(f16_t* p, unsigned char* lo, const float* v) {
+    u16x4 h0, h1;
+    const unsigned l0 = lo8_pack4(v[0], v[1], v[2], v[3], h0), l1 = lo8_pack4(v[4], v[5], v[6], v[7], h1);
+    *reinterpret_cast<u16x8*>(p) = u16x8{h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
+    *reinterpret_cast<uint2*>(lo) = make_uint2(l0, l1);
+}
+__device__ __forceinline__ void store1_hilo(f16_t* p, unsigned char* lo, float v) {
+    u16x4 h;
+    const unsigned l = lo8_pack4(v, 0.f, 0.f, 0.f, h);
+    p->bits = h[0];
+    *lo = (unsigned char)(l & 0xffu);
+}
+// the kernels' y stores: plain, or hi + lo when LO (fp16c; T = f16_t then)
+template <typename T, bool LO>
+__device__ __forceinline__ void ystore8(T* p, unsigned char* lo, const float* v) {
+    if constexpr (LO) store8_hilo(p, lo, v);
+    else store8<T>(p, v);
+}
+template <typename T, bool LO>
+__device__ __forceinline__ void ystore1(T* p, unsigned char* lo, float v) {
+    if constexpr (LO) store1_hilo(p, lo, v);
+    else *p = from_float<T>(v);
+}
+
 template <typename T>
 __device__ __forceinline__ void load2(const T* p, float* o);
 template <>
@@ -380,11 +423,14 @@ constexpr int CONV_NSTAMP = 16;
 // in_proj output is one of 16 precomputed rows (ztab, fp32): the kernel reads the ids (1 byte per token, shared by all 256
 // channel workgroups of a read) and looks x0 / x1 / v up instead of reading z -- in_proj of block 0 is never launched.
 // GATED: z holds x0f (row c) and g = x1f * vf (row 256 + c), filtered and gated by the producer (see hyena_conv_pers_kernel).
-template <int LOGN, typename T, bool STAMP = false, bool IDS = false, bool GATED = false>
+// LO (fp16c, T = f16_t): y leaves as hi + lo bytes (ylo [B][256][Lp]); GATED: x0f and g are read as hi + lo (zlo_row).
+template <int LOGN, typename T, bool STAMP = false, bool IDS = false, bool GATED = false, bool LO = false>
 __global__ __launch_bounds__(Plan<LOGN>::NT) void hyena_conv_kernel(
     const T* __restrict__ z, T* __restrict__ y, const float2* __restrict__ kf, const float2* __restrict__ tw,
     const float* __restrict__ ktime, const float* __restrict__ short_w, const float* __restrict__ short_b, int B, int L,
-    int Lp, unsigned long long* stamps, const unsigned char* __restrict__ ids8, const float* __restrict__ ztab) {
+    int Lp, unsigned long long* stamps, const unsigned char* __restrict__ ids8, const float* __restrict__ ztab,
+    unsigned char* __restrict__ ylo) {
+    static_assert(!LO || std::is_same<T, f16_t>::value, "lo bytes exist in the compensated fp16 mode only");
 #define CLM_STAMP_AT(k)                                                                                   \
     do {                                                                                                  \
         if (STAMP && threadIdx.x == 0)                                                                    \
@@ -446,18 +492,23 @@ __global__ __launch_bounds__(Plan<LOGN>::NT) void hyena_conv_kernel(
     float x0At = 0.f, gAt = 0.f, x0Bt = 0.f, gBt = 0.f;
     if constexpr (GATED) {
         uint4 gr[CH][2][2];                                  // [chunk][read][x0f, g]
+        uint2 grl[LO ? CH : 1][2][2];                        // LO: their lo bytes
         T gtl[2][2];
+        float gtll[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
 #pragma unroll
         for (int rd = 0; rd < 2; ++rd)
 #pragma unroll
             for (int a2 = 0; a2 < 2; ++a2) {
                 const T* row = (rd == 0 ? zA : zB) + (size_t)(a2 * D + c) * Lp;
+                const unsigned char* rowl = zlo_row(rd == 0 ? zA : zB, a2, c, Lp);
 #pragma unroll
                 for (int ch = 0; ch < CH; ++ch) {
-                    const int t0 = 8 * (tid + ch * NT);
-                    gr[ch][rd][a2] = *reinterpret_cast<const uint4*>(row + ((t0 < HALF && t0 < L) ? t0 : 0));
+                    const int t0 = 8 * (tid + ch * NT), tc = (t0 < HALF && t0 < L) ? t0 : 0;
+                    gr[ch][rd][a2] = *reinterpret_cast<const uint4*>(row + tc);
+                    if constexpr (LO) grl[ch][rd][a2] = *reinterpret_cast<const uint2*>(rowl + tc);
                 }
                 gtl[rd][a2] = row[(tail && tid == TAIL_TID) ? HALF : 0];
+                if constexpr (LO) gtll[rd][a2] = lo1(rowl, (tail && tid == TAIL_TID) ? HALF : 0);
             }
 #pragma unroll
         for (int ch = 0; ch < CH; ++ch) {
@@ -468,6 +519,12 @@ __global__ __launch_bounds__(Plan<LOGN>::NT) void hyena_conv_kernel(
                 cvt8<T>(gr[ch][1][0], x0B[ch]);
                 cvt8<T>(gr[ch][0][1], gA);
                 cvt8<T>(gr[ch][1][1], gB);
+                if constexpr (LO) {
+                    add_lo8(grl[ch][0][0], x0A[ch]);
+                    add_lo8(grl[ch][1][0], x0B[ch]);
+                    add_lo8(grl[ch][0][1], gA);
+                    add_lo8(grl[ch][1][1], gB);
+                }
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     gA[e] = (t0 + e < L) ? gA[e] : 0.f;
@@ -478,10 +535,10 @@ __global__ __launch_bounds__(Plan<LOGN>::NT) void hyena_conv_kernel(
             }
         }
         if (tail && tid == TAIL_TID) {
-            x0At = to_float(gtl[0][0]);
-            gAt = to_float(gtl[0][1]);
-            x0Bt = to_float(gtl[1][0]);
-            gBt = hasB ? to_float(gtl[1][1]) : 0.f;
+            x0At = to_float(gtl[0][0]) + gtll[0][0];
+            gAt = to_float(gtl[0][1]) + gtll[0][1];
+            x0Bt = to_float(gtl[1][0]) + gtll[1][0];
+            gBt = hasB ? to_float(gtl[1][1]) + gtll[1][1] : 0.f;
         }
     } else {
     Raw<T> raw[IDS ? 1 : CH][2][IDS ? 1 : 3];
@@ -636,6 +693,8 @@ __global__ __launch_bounds__(Plan<LOGN>::NT) void hyena_conv_kernel(
     // ---------------------------------------------------------------- phase C: gate with x0, store
     T* yA = y + ((size_t)bA * D + c) * Lp;
     T* yB = y + ((size_t)(hasB ? bB : bA) * D + c) * Lp;
+    unsigned char* ylA = LO ? ylo + ((size_t)bA * D + c) * Lp : nullptr;
+    unsigned char* ylB = LO ? ylo + ((size_t)(hasB ? bB : bA) * D + c) * Lp : nullptr;
 #pragma unroll
     for (int ch = 0; ch < CH; ++ch) {
         const int t0 = 8 * (tid + ch * NT);
@@ -654,13 +713,13 @@ __global__ __launch_bounds__(Plan<LOGN>::NT) void hyena_conv_kernel(
                 oA[e] = ok ? oA[e] * x0A[ch][e] : 0.f;
                 oB[e] = ok ? oB[e] * x0B[ch][e] : 0.f;
             }
-            store8<T>(yA + t0, oA);
-            if (hasB) store8<T>(yB + t0, oB);
+            ystore8<T, LO>(yA + t0, ylA + t0, oA);
+            if (hasB) ystore8<T, LO>(yB + t0, ylB + t0, oB);
         }
     }
     if (tail && tid == TAIL_TID) {
-        yA[HALF] = from_float<T>(bre[pad_index(HALF)] * x0At);
-        if (hasB) yB[HALF] = from_float<T>(bim[pad_index(HALF)] * x0Bt);
+        ystore1<T, LO>(yA + HALF, ylA + HALF, bre[pad_index(HALF)] * x0At);
+        if (hasB) ystore1<T, LO>(yB + HALF, ylB + HALF, bim[pad_index(HALF)] * x0Bt);
     }
     CLM_STAMP_AT(11);
     if (STAMP && threadIdx.x == 0)
@@ -681,7 +740,7 @@ __global__ __launch_bounds__(Plan<LOGN>::NT) void hyena_conv_kernel(
 // Units are taken round-robin by gridDim.x = #CUs workgroups; LOGN = 14 (reads of 4098 .. 8193 tokens) only.
 // GATED (the fused tail kernel's hand-over, gemm16.hip inproj_blocks_gated): z row c holds x0f, row 256 + c holds g = x1f * vf --
 // already filtered and gated by the producer -- so phase A is a load + convert of ONE row and phase C a multiply with one row.
-template <typename T, bool IDS, bool GATED = false>
+template <typename T, bool IDS, bool GATED = false, bool LO = false>
 struct ConvGateRaw {                                   // x1 / v rows of one unit, both reads (IDS: the token ids instead)
     Raw<T> r[GATED ? 1 : 2][2][GATED ? 1 : 2];         // [chunk][read][x1, v]
     T ztail[2][2];
@@ -690,13 +749,17 @@ struct ConvGateRaw {                                   // x1 / v rows of one uni
     unsigned char idt[2];
     uint4 g[2][2];                                     // GATED: 8 samples of g per [chunk][read]
     T gtail[2];
+    uint2 gl[2][2];                                    // GATED + LO: their lo bytes
+    unsigned char gltail[2];
 };
 
-template <typename T, bool IDS, bool GATED = false>
+// LO (fp16c): as hyena_conv_kernel -- y leaves as hi + lo bytes, the gated rows are read as hi + lo.
+template <typename T, bool IDS, bool GATED = false, bool LO = false>
 __global__ __launch_bounds__(Plan<14>::NT) void hyena_conv_pers_kernel(
     const T* __restrict__ z, T* __restrict__ y, const float2* __restrict__ kf /*lane-packed*/, const float2* __restrict__ tw,
     const float* __restrict__ ktime, const float* __restrict__ short_w, const float* __restrict__ short_b, int B, int L,
-    int Lp, const unsigned char* __restrict__ ids8, const float* __restrict__ ztab, int use_xcd) {
+    int Lp, const unsigned char* __restrict__ ids8, const float* __restrict__ ztab, int use_xcd, unsigned char* __restrict__ ylo) {
+    static_assert(!LO || std::is_same<T, f16_t>::value, "lo bytes exist in the compensated fp16 mode only");
     constexpr int LOGN = 14;
     using P = Plan<LOGN>;
     using TL = TwLayout<LOGN>;
@@ -742,7 +805,7 @@ __global__ __launch_bounds__(Plan<14>::NT) void hyena_conv_pers_kernel(
     }
     static_assert(!(GATED && IDS), "block 0 looks its rows up by token id: nothing to hand over");
     // requests of the gate rows (x1, v) of unit u: no control flow between the loads (all in flight together)
-    auto request_gate = [&](int q, ConvGateRaw<T, IDS, GATED>& g, int ltid) {
+    auto request_gate = [&](int q, ConvGateRaw<T, IDS, GATED, LO>& g, int ltid) {
         int c, pair;
         unit_of(q, c, pair);
         const int bA = 2 * pair, bB = (2 * pair + 1 < B) ? 2 * pair + 1 : bA;
@@ -750,12 +813,15 @@ __global__ __launch_bounds__(Plan<14>::NT) void hyena_conv_pers_kernel(
 #pragma unroll
             for (int rd = 0; rd < 2; ++rd) {
                 const T* row = z + ((size_t)(rd == 0 ? bA : bB) * D3 + D + c) * Lp;
+                const unsigned char* rowl = zlo_row(z + (size_t)(rd == 0 ? bA : bB) * D3 * Lp, 1, c, Lp);
 #pragma unroll
                 for (int ch = 0; ch < CH; ++ch) {
                     const int t0 = 8 * (ltid + ch * NT);
                     g.g[ch][rd] = *reinterpret_cast<const uint4*>(row + (t0 < L ? t0 : 0));      // clamped, never out of the row
+                    if constexpr (LO) g.gl[ch][rd] = *reinterpret_cast<const uint2*>(rowl + (t0 < L ? t0 : 0));
                 }
                 g.gtail[rd] = row[(tail && ltid == TAIL_TID) ? HALF : 0];
+                if constexpr (LO) g.gltail[rd] = rowl[(tail && ltid == TAIL_TID) ? HALF : 0];
             }
         } else if constexpr (IDS) {
 #pragma unroll
@@ -788,7 +854,7 @@ __global__ __launch_bounds__(Plan<14>::NT) void hyena_conv_pers_kernel(
         }
     };
 
-    ConvGateRaw<T, IDS, GATED> cur;
+    ConvGateRaw<T, IDS, GATED, LO> cur;
     request_gate(first < n_mine ? first : 0, cur, tid);
 
 #pragma unroll 1
@@ -830,6 +896,10 @@ __global__ __launch_bounds__(Plan<14>::NT) void hyena_conv_pers_kernel(
                     float gA[8], gB[8];
                     cvt8<T>(cur.g[ch][0], gA);
                     cvt8<T>(cur.g[ch][1], gB);
+                    if constexpr (LO) {
+                        add_lo8(cur.gl[ch][0], gA);
+                        add_lo8(cur.gl[ch][1], gB);
+                    }
                     if constexpr (!FULL) {
 #pragma unroll
                         for (int e = 0; e < 8; ++e) {
@@ -841,8 +911,10 @@ __global__ __launch_bounds__(Plan<14>::NT) void hyena_conv_pers_kernel(
                     lds_store8(bim + pad_index(t0), gB);
                 }
                 if (tail && ltid == TAIL_TID) {
-                    gtail[0] = to_float(cur.gtail[0]);
-                    gtail[1] = hasB ? to_float(cur.gtail[1]) : 0.f;
+                    float l0 = 0.f, l1 = 0.f;
+                    if constexpr (LO) l0 = lo1b(cur.gltail[0]), l1 = lo1b(cur.gltail[1]);
+                    gtail[0] = to_float(cur.gtail[0]) + l0;
+                    gtail[1] = hasB ? to_float(cur.gtail[1]) + l1 : 0.f;
                 }
             } else {
 #pragma unroll
@@ -940,18 +1012,23 @@ __global__ __launch_bounds__(Plan<14>::NT) void hyena_conv_pers_kernel(
         // ---- requests that have the last pass to land: x0 rows of this unit, gate rows of this workgroup's next unit
         Raw<T> x0r[CH][2];
         T x0tail[2];
+        uint2 x0l[CH][2];                                // GATED + LO: the lo bytes of x0f
+        unsigned char x0ltail[2] = {0, 0};
         const T* zA = z + (size_t)bA * D3 * Lp;
         const T* zB = z + (size_t)(hasB ? bB : bA) * D3 * Lp;
         if constexpr (GATED) {                           // (x0f: no history needed -- only the 16-byte vector of Raw<T> is used)
 #pragma unroll
             for (int rd = 0; rd < 2; ++rd) {
                 const T* row = (rd == 0 ? zA : zB) + (size_t)c * Lp;
+                const unsigned char* rowl = zlo_row(rd == 0 ? zA : zB, 0, c, Lp);
 #pragma unroll
                 for (int ch = 0; ch < CH; ++ch) {
                     const int t0 = 8 * (ltid + ch * NT);
                     x0r[ch][rd].d = *reinterpret_cast<const uint4*>(row + (t0 < L ? t0 : 0));
+                    if constexpr (LO) x0l[ch][rd] = *reinterpret_cast<const uint2*>(rowl + (t0 < L ? t0 : 0));
                 }
                 x0tail[rd] = row[(tail && ltid == TAIL_TID) ? HALF : 0];
+                if constexpr (LO) x0ltail[rd] = rowl[(tail && ltid == TAIL_TID) ? HALF : 0];
             }
         } else if constexpr (!IDS) {
 #pragma unroll
@@ -965,7 +1042,7 @@ __global__ __launch_bounds__(Plan<14>::NT) void hyena_conv_pers_kernel(
                 x0tail[rd] = row[(tail && ltid == TAIL_TID) ? HALF : 0];
             }
         }
-        ConvGateRaw<T, IDS, GATED> nxt;
+        ConvGateRaw<T, IDS, GATED, LO> nxt;
         {
             const int un = u + stride;
             request_gate(un < n_mine ? un : u, nxt, ltid);       // clamped: unconditional loads
@@ -981,6 +1058,8 @@ __global__ __launch_bounds__(Plan<14>::NT) void hyena_conv_pers_kernel(
             constexpr bool FULL = decltype(fullc)::value;
             T* yA = y + ((size_t)bA * D + c) * Lp;
             T* yB = y + ((size_t)(hasB ? bB : bA) * D + c) * Lp;
+            unsigned char* ylA = LO ? ylo + ((size_t)bA * D + c) * Lp : nullptr;
+            unsigned char* ylB = LO ? ylo + ((size_t)(hasB ? bB : bA) * D + c) * Lp : nullptr;
 #pragma unroll
             for (int ch = 0; ch < CH; ++ch) {
                 const int t0 = 8 * (ltid + ch * NT);
@@ -989,6 +1068,10 @@ __global__ __launch_bounds__(Plan<14>::NT) void hyena_conv_pers_kernel(
                 if constexpr (GATED) {
                     cvt8<T>(x0r[ch][0].d, x0a);
                     cvt8<T>(x0r[ch][1].d, x0b);
+                    if constexpr (LO) {
+                        add_lo8(x0l[ch][0], x0a);
+                        add_lo8(x0l[ch][1], x0b);
+                    }
                 } else if constexpr (IDS) {
                     float xa3[3][10], xb3[3][10];
                     // opaque copies: otherwise the 40 extracted ids (common subexpressions with phase A) are kept across the
@@ -1020,16 +1103,17 @@ __global__ __launch_bounds__(Plan<14>::NT) void hyena_conv_pers_kernel(
                         oA[e] = ok ? oA[e] * x0a[e] : 0.f;
                         oB[e] = ok ? oB[e] * x0b[e] : 0.f;
                     }
-                    store8<T>(yA + t0, oA);
-                    if (hasB) store8<T>(yB + t0, oB);
+                    ystore8<T, LO>(yA + t0, ylA + t0, oA);
+                    if (hasB) ystore8<T, LO>(yB + t0, ylB + t0, oB);
                 }
                 if (ch == CH - 1 && tail && ltid == TAIL_TID) {     // token HALF: x0 from x[8], x[9] of this chunk and z[HALF]
-                    const float za = IDS ? zt[cur.idt[0] & 15] : to_float(x0tail[0]);
-                    const float zb = IDS ? zt[cur.idt[1] & 15] : to_float(x0tail[1]);
+                    float za = IDS ? zt[cur.idt[0] & 15] : to_float(x0tail[0]);
+                    float zb = IDS ? zt[cur.idt[1] & 15] : to_float(x0tail[1]);
+                    if constexpr (GATED && LO) za += lo1b(x0ltail[0]), zb += lo1b(x0ltail[1]);
                     const float x0At = GATED ? za : sb[0] + sw[0][0] * xa[8] + sw[0][1] * xa[9] + sw[0][2] * za;
                     const float x0Bt = GATED ? zb : sb[0] + sw[0][0] * xb[8] + sw[0][1] * xb[9] + sw[0][2] * zb;
-                    yA[HALF] = from_float<T>(bre[pad_index(HALF)] * x0At);
-                    if (hasB) yB[HALF] = from_float<T>(bim[pad_index(HALF)] * x0Bt);
+                    ystore1<T, LO>(yA + HALF, ylA + HALF, bre[pad_index(HALF)] * x0At);
+                    if (hasB) ystore1<T, LO>(yB + HALF, ylB + HALF, bim[pad_index(HALF)] * x0Bt);
                 }
             }
         };
@@ -1040,13 +1124,13 @@ __global__ __launch_bounds__(Plan<14>::NT) void hyena_conv_pers_kernel(
     }
 }
 
-template <typename T, bool IDS, bool GATED = false>
+template <typename T, bool IDS, bool GATED = false, bool LO = false>
 static void launch_conv_pers_inst(const void* z, void* y, const float2* kf, const float2* tw, const float* ktime,
                                   const float* short_w, const float* short_b, int B, int L, int Lp, const unsigned char* ids8,
-                                  const float* ztab, int use_xcd, hipStream_t st) {
+                                  const float* ztab, int use_xcd, hipStream_t st, unsigned char* ylo = nullptr) {
     using P = Plan<14>;
     constexpr size_t lds = (size_t)2 * padded_size(P::N) * sizeof(float) + 256;
-    auto kern = hyena_conv_pers_kernel<T, IDS, GATED>;
+    auto kern = hyena_conv_pers_kernel<T, IDS, GATED, LO>;
     static bool attr_done = false;
     if (!attr_done) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -1060,276 +1144,14 @@ static void launch_conv_pers_inst(const void* z, void* y, const float2* kf, cons
     const int n_units = ((B + 1) / 2) * D;
     dim3 grid(n_units < cus ? n_units : cus), block(P::NT);
     hipLaunchKernelGGL(kern, grid, block, lds, st, reinterpret_cast<const T*>(z), reinterpret_cast<T*>(y), kf, tw, ktime, short_w,
-                       short_b, B, L, Lp, ids8, ztab, use_xcd);
+                       short_b, B, L, Lp, ids8, ztab, use_xcd, ylo);
 }
 
-// ================================================================================================ 8k reads: split transform
-// Reads of 4098 .. 8193 tokens need the 16384-point transform, whose LDS buffer (147 KiB) leaves ONE workgroup per CU, and in
-// hyena_conv_kernel all eight waves move through the passes together: the LDS-bound exchange (store) phases and the
-// VALU-bound load + butterfly phases run strictly one after the other (stamps: eight exchanges of 4-5.7k cycles, of which
-// ~2k are LDS time and ~2.2k VALU time).
-// The transform of a half-zero input, of which only half the output is wanted, is two INDEPENDENT half-size problems
-// (decimation in frequency into the even and the odd bins; fft_core_test.cpp test_conv_split13 emulates this kernel's passes):
-//     X[2j]   = DFT_M(x_lo + x_hi)[j]                     y[n] = IDFT_M(X_e K_e)[n] + w_N^-n IDFT_M(X_o K_o)[n],  n < M
-//     X[2j+1] = DFT_M((x_lo - x_hi) w_N^n)[j]             y[M] = IDFT_M(X_e K_e)[0] - IDFT_M(X_o K_o)[0]
-// with M = N/2 = 8192 and x_hi = the one element at index M (L == M + 1) or nothing.  The two problems live side by side in
-// the same 147 KiB and are run by the two HALVES of the workgroup (waves 0-3: even bins, waves 4-7: odd bins; one wave of each
-// on every SIMD), the odd half one phase BEHIND the even half: in every barrier interval one half is in a load + butterfly
-// phase and the other in a store phase, so the VALU and the LDS pipe of the CU work at the same time instead of in turn.  The
-// zero padding is never transformed (no pruned first / last passes needed), and phase A / C stay those of the one-shot kernel.
-// MEASURED SLOWER than hyena_conv_kernel and therefore OFF by default (CLM_SPLIT_CONV=1 selects it; tests keep it correct):
-// same box, 8k x 256, convolution stage of a step: 13.5 ms one-shot kernel, 15.4 ms this kernel.  A SIMD needs TWO waves in
-// VALU code to reach its packed-fp32 issue rate (a lone wave issues every 4 cycles); with one half of the workgroup storing
-// while the other computes, every butterfly phase runs at half rate and takes as long as the one-shot kernel's (which moves
-// twice the data with two waves per SIMD), and the store intervals come on top.  Two earlier forms were dropped for the same
-// reason plus register pressure (convolution stage 13.0 ms one-shot on that box): the two problems one after the other in
-// 256-thread workgroups, two per CU, even result held in registers: 14.1 ms unrolled (57 KB of code, 25-36 spilled dwords),
-// 18.2 ms with the two trips rolled (85 spilled dwords).  Overlapping the LDS and VALU phases needs four waves per SIMD, i.e.
-// 16 points per thread instead of 32 -- a different pass geometry, not built.
-// A third form, built, measured and REMOVED (round 2): one workgroup keeps TWO units in registers (2 x 64 data registers per
-// thread), half a pass apart, and time-shares the one LDS buffer -- every wave issues the LDS instructions of one unit's
-// exchange and the butterflies of the other unit in the same barrier interval (no wave specialisation, so both waves of a
-// SIMD are in VALU code together), barriers waiting for LDS traffic only, ds / VALU instructions interleaved 2 : 10 with
-// sched_group_barrier (a wave stalls at issue with 15 LDS instructions outstanding).  Bit-identical results; 1.04 ms per launch
-// against 0.80 for hyena_conv_pers_kernel.  A timing-only build of just its transform passes (no gating, no global traffic):
-// 0.66 ms interleaved, 0.72 ms with each exchange issued in a row -- against ~0.60 ms for the same passes run one unit at a
-// time.  LDS transfers and packed-fp32 VALU work of the SAME waves do not overlap to any useful degree on this CU (both move
-// through the SIMD's register file), so the 2 x 64 registers and the second barrier pair per pass buy nothing.
-// exp(-2 pi i e / 16384), e = 0..7: the within-chunk factors of w_N^n (literals: folded into the unrolled code)
-#define CLM_DIF_WC                                                                                                          \
-    {{1.0f, -0.0f}, {0.99999992646f, -3.8349518757e-4f}, {0.99999970586f, -7.6699031874e-4f}, {0.99999933819f, -1.1504853371e-3f}, \
-     {0.99999882345f, -1.5339801863e-3f}, {0.99999816164f, -1.9174748099e-3f}, {0.99999735277f, -2.3009691514e-3f},          \
-     {0.99999639683f, -2.6844631547e-3f}}
-
-template <typename T, bool IDS>
-__global__ __launch_bounds__(512) void hyena_conv_eo_kernel(
-    const T* __restrict__ z, T* __restrict__ y, const float2* __restrict__ kf2 /*[256][2][M]: even | odd bins of kf*/,
-    const float2* __restrict__ twM /*exp(-2 pi i m / M), m < M/2*/, const float2* __restrict__ twN /*exp(-2 pi i n / 2M), n < M*/,
-    const float* __restrict__ ktime, const float* __restrict__ short_w, const float* __restrict__ short_b, int B, int L, int Lp,
-    const unsigned char* __restrict__ ids8, const float* __restrict__ ztab) {
-    constexpr int M = 8192, NT = 512, CH = M / 8 / NT;          // 2 chunks of 8 tokens per thread in phases A and C
-    static_assert(Plan<Split13::LOGM>::N == M && Plan<Split13::LOGM>::NT == NT / 2 && CH == 2, "two 256-thread halves");
-    constexpr float DIF_WC[8][2] = CLM_DIF_WC;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    float* ere = reinterpret_cast<float*>(smem);              // even problem: read A of the pair = real parts, read B = imaginary
-    float* eim = ere + padded_size(M);
-    float* ore = eim + padded_size(M);                        // odd problem
-    float* oim = ore + padded_size(M);
-    float* gtail = oim + padded_size(M);                      // g[M], x0[M] of both reads (L == M + 1)
-    float* zt = gtail + 4;                                    // IDS: [3][16] rows x0 | x1 | v of this channel
-
-    const int tid = threadIdx.x;
-    const int c = blockIdx.y, pair = blockIdx.x;
-    const int bA = 2 * pair, bB = 2 * pair + 1;
-    const bool hasB = bB < B;
-    const T* zA = z + (size_t)bA * D3 * Lp;
-    const T* zB = z + (size_t)(hasB ? bB : bA) * D3 * Lp;
-    const bool tail = (L == M + 1);
-    float sw[3][3], sb[3];
-#pragma unroll
-    for (int q = 0; q < 3; ++q) {
-#pragma unroll
-        for (int e = 0; e < 3; ++e) sw[q][e] = short_w[(q * D + c) * 3 + e];
-        sb[q] = short_b[q * D + c];
-    }
-    float2 wb[CH];                                            // w_N^t0 of this thread's chunks
-#pragma unroll
-    for (int ch = 0; ch < CH; ++ch) wb[ch] = twN[8 * (tid + ch * NT)];
-
-    // ---------------------------------------------------------------- phase A: load, short filter, gate (as hyena_conv_kernel)
-    constexpr int TAIL_TID = M / 8 - 1 - (CH - 1) * NT;       // owner of tokens [M-8, M): also computes token M
-    Raw<T> raw[IDS ? 1 : CH][2][IDS ? 1 : 3];
-    T ztail[2][3];
-    uint2 idd[CH][2];
-    unsigned short idp[CH][2];
-    unsigned char idt[2] = {0, 0};
-    if constexpr (IDS) {
-        if (tid < 48) zt[tid] = ztab[(size_t)(tid & 15) * D3 + (tid >> 4) * D + c];
-#pragma unroll
-        for (int rd = 0; rd < 2; ++rd) {
-            const unsigned char* ir = ids8 + (size_t)(rd == 0 ? bA : (hasB ? bB : bA)) * Lp;
-#pragma unroll
-            for (int ch = 0; ch < CH; ++ch) {
-                const int t0 = 8 * (tid + ch * NT);
-                const bool valid = t0 < L;
-                idd[ch][rd] = *reinterpret_cast<const uint2*>(ir + (valid ? t0 : 0));
-                idp[ch][rd] = *reinterpret_cast<const unsigned short*>(ir + ((valid && t0 > 0) ? t0 - 2 : 0));
-            }
-            idt[rd] = ir[(tail && tid == TAIL_TID) ? M : 0];
-        }
-        __syncthreads();                                      // zt visible
-    } else {
-#pragma unroll
-        for (int rd = 0; rd < 2; ++rd) {
-            const T* zr = rd == 0 ? zA : zB;
-#pragma unroll
-            for (int a3 = 0; a3 < 3; ++a3) {
-                const T* row = zr + (size_t)(a3 * D + c) * Lp;
-#pragma unroll
-                for (int ch = 0; ch < CH; ++ch) {
-                    const int t0 = 8 * (tid + ch * NT);
-                    raw_load(raw[ch][rd][a3], row, t0, t0 < L);
-                }
-                ztail[rd][a3] = row[(tail && tid == TAIL_TID) ? M : 0];
-            }
-        }
-    }
-    float x0A[CH][8], x0B[CH][8];
-#pragma unroll
-    for (int ch = 0; ch < CH; ++ch) {
-        const int t0 = 8 * (tid + ch * NT);
-        const bool valid = t0 < L;
-        float xa[3][10], xb[3][10], gA[8], gB[8], x1[8], v[8], x1b[8], vb[8];
-        if constexpr (IDS) {
-            ids_decode<true>(idd[ch][0], idp[ch][0], t0, valid, zt, xa);
-            ids_decode<true>(idd[ch][1], idp[ch][1], t0, valid && hasB, zt, xb);
-        } else {
-#pragma unroll
-            for (int a3 = 0; a3 < 3; ++a3) {
-                raw_decode(raw[ch][0][a3], t0, valid, xa[a3]);
-                raw_decode(raw[ch][1][a3], t0, valid && hasB, xb[a3]);
-            }
-        }
-        fir3_pair(xa[0], xb[0], sw[0][0], sw[0][1], sw[0][2], sb[0], x0A[ch], x0B[ch]);
-        fir3_pair(xa[1], xb[1], sw[1][0], sw[1][1], sw[1][2], sb[1], x1, x1b);
-        fir3_pair(xa[2], xb[2], sw[2][0], sw[2][1], sw[2][2], sb[2], v, vb);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            gA[e] = (t0 + e < L) ? v[e] * x1[e] : 0.f;
-            gB[e] = (hasB && t0 + e < L) ? vb[e] * x1b[e] : 0.f;
-        }
-        lds_store8(ere + pad_index(t0), gA);                  // even problem: x_lo as it is
-        lds_store8(eim + pad_index(t0), gB);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {                         // odd problem: x_lo w_N^n
-            const float wr = wb[ch].x * DIF_WC[e][0] - wb[ch].y * DIF_WC[e][1];
-            const float wi = wb[ch].x * DIF_WC[e][1] + wb[ch].y * DIF_WC[e][0];
-            const float xr = gA[e] * wr - gB[e] * wi, xi = gA[e] * wi + gB[e] * wr;
-            gA[e] = xr, gB[e] = xi;
-        }
-        lds_store8(ore + pad_index(t0), gA);
-        lds_store8(oim + pad_index(t0), gB);
-        if (ch == CH - 1 && tail && tid == TAIL_TID) {        // token M: taps are x[8], x[9] of this chunk and z[M]
-            float ta[3], tb[3];
-#pragma unroll
-            for (int a3 = 0; a3 < 3; ++a3) {
-                const float za = IDS ? zt[a3 * 16 + (idt[0] & 15)] : to_float(ztail[0][a3]);
-                const float zb = IDS ? zt[a3 * 16 + (idt[1] & 15)] : to_float(ztail[1][a3]);
-                ta[a3] = sb[a3] + sw[a3][0] * xa[a3][8] + sw[a3][1] * xa[a3][9] + sw[a3][2] * za;
-                tb[a3] = sb[a3] + sw[a3][0] * xb[a3][8] + sw[a3][1] * xb[a3][9] + sw[a3][2] * zb;
-            }
-            gtail[0] = ta[1] * ta[2];
-            gtail[1] = hasB ? tb[1] * tb[2] : 0.f;
-            gtail[2] = ta[0];
-            gtail[3] = hasB ? tb[0] : 0.f;
-        }
-    }
-    __syncthreads();
-    if (tail && tid == 0) {             // x_hi = the element at index M joins element 0 of both problems, with opposite signs
-        ere[0] += gtail[0], eim[0] += gtail[1];               // (w_N^0 = 1)
-        ore[0] -= gtail[0], oim[0] -= gtail[1];
-    }
-    __syncthreads();
-
-    // ---------------------------------------------------------------- the two 8192-point problems, one phase apart
-    {
-        const int half = tid >> 8, gtid = tid & 255;          // wave-uniform: waves 0-3 even bins, waves 4-7 odd bins
-        float* bre = half ? ore : ere;
-        float* bim = half ? oim : eim;
-        const float2* kfs = kf2 + ((size_t)c * 2 + half) * M;
-        Cx2 v[16];
-        static_for<0, 2 * Split13::NPASS + 1>([&](auto kc) {
-            constexpr int k = decltype(kc)::value;
-            if (half == 0) {
-                if constexpr (k < 2 * Split13::NPASS) {
-                    if constexpr (k % 2 == 0) split13_compute<k / 2>(bre, bim, v, gtid, twM, kfs);
-                    else split13_store<k / 2>(bre, bim, v, gtid);
-                }
-            } else {
-                if constexpr (k >= 1) {
-                    if constexpr ((k - 1) % 2 == 0) split13_compute<(k - 1) / 2>(bre, bim, v, gtid, twM, kfs);
-                    else split13_store<(k - 1) / 2>(bre, bim, v, gtid);
-                }
-            }
-            __syncthreads();
-        });
-    }
-
-    // ---------------------------------------------------------------- phase C: combine, gate with x0, store
-    T* yA = y + ((size_t)bA * D + c) * Lp;
-    T* yB = y + ((size_t)(hasB ? bB : bA) * D + c) * Lp;
-#pragma unroll
-    for (int ch = 0; ch < CH; ++ch) {
-        const int t0 = 8 * (tid + ch * NT);
-        if (t0 < Lp) {
-            float eA[8], eB[8], oA[8], oB[8];
-            lds_load8(ere + pad_index(t0), eA);
-            lds_load8(eim + pad_index(t0), eB);
-            lds_load8(ore + pad_index(t0), oA);
-            lds_load8(oim + pad_index(t0), oB);
-            if (tail && t0 == 0) {      // token M: y[M] = (r_e[0] - r_o[0]) x0[M]; the one wrapped product k[L-1] g[L-1] on output 0
-                yA[M] = from_float<T>((eA[0] - oA[0]) * gtail[2]);
-                if (hasB) yB[M] = from_float<T>((eB[0] - oB[0]) * gtail[3]);
-                const float kl = ktime[(size_t)(L - 1) * D + c];
-                eA[0] -= kl * gtail[0];
-                eB[0] -= kl * gtail[1];
-            }
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {                     // r_e + conj(w_N^n) r_o, then the gate
-                const float wr = wb[ch].x * DIF_WC[e][0] - wb[ch].y * DIF_WC[e][1];
-                const float wi = wb[ch].x * DIF_WC[e][1] + wb[ch].y * DIF_WC[e][0];
-                const bool ok = t0 + e < L;
-                const float a = eA[e] + (oA[e] * wr + oB[e] * wi), b = eB[e] + (oB[e] * wr - oA[e] * wi);
-                eA[e] = ok ? a * x0A[ch][e] : 0.f;
-                eB[e] = ok ? b * x0B[ch][e] : 0.f;
-            }
-            store8<T>(yA + t0, eA);
-            if (hasB) store8<T>(yB + t0, eB);
-        }
-    }
-}
-
-// kf2[c][s][j] = kf[c][2 j + s]: the even and the odd bins of the N-point filter spectrum as two contiguous M-point spectra
-__global__ __launch_bounds__(256) void spectrum_split_kernel(const float2* __restrict__ kf, float2* __restrict__ kf2, int N) {
-    const int i = blockIdx.x * 256 + threadIdx.x, c = blockIdx.y;
-    if (i < N) kf2[(size_t)c * N + (size_t)(i & 1) * (N / 2) + (i >> 1)] = kf[(size_t)c * N + i];
-}
-void launch_spectrum_split(const float2* kf, float2* kf2, int logn, hipStream_t st) {
-    const int N = 1 << logn;
-    hipLaunchKernelGGL(spectrum_split_kernel, dim3((N + 255) / 256, D), dim3(256), 0, st, kf, kf2, N);
-}
-
-template <typename T, bool IDS>
-static void launch_conv_eo_inst(const void* z, void* y, const float2* kf2, const float2* twM, const float2* twN, const float* ktime,
-                                 const float* short_w, const float* short_b, int B, int L, int Lp, const unsigned char* ids8,
-                                 const float* ztab, hipStream_t st) {
-    constexpr size_t lds = (size_t)4 * padded_size(8192) * sizeof(float) + 256;     // both problems + tail slots + the 3x16 id table
-    static_assert(lds <= 160 * 1024, "LDS");
-    auto kern = hyena_conv_eo_kernel<T, IDS>;
-    static bool attr_done = false;
-    if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_done = true;
-    }
-    dim3 grid((B + 1) / 2, D), block(512);
-    hipLaunchKernelGGL(kern, grid, block, lds, st, reinterpret_cast<const T*>(z), reinterpret_cast<T*>(y), kf2, twM, twN, ktime,
-                       short_w, short_b, B, L, Lp, ids8, ztab);
-}
-
-void launch_hyena_conv_dif(int prec, const void* z, void* y, const float2* kf2, const float2* twM, const float2* twN,
-                           const float* ktime, const float* short_w, const float* short_b, int B, int L, int Lp,
-                           const unsigned char* ids8, const float* ztab, hipStream_t st) {
-    const bool ids = ids8 != nullptr && ztab != nullptr;
-    if (prec == PREC_F32)
-        launch_conv_eo_inst<float, false>(z, y, kf2, twM, twN, ktime, short_w, short_b, B, L, Lp, nullptr, nullptr, st);
-    else if (prec == PREC_BF16) {
-        if (ids) launch_conv_eo_inst<bf16_t, true>(z, y, kf2, twM, twN, ktime, short_w, short_b, B, L, Lp, ids8, ztab, st);
-        else launch_conv_eo_inst<bf16_t, false>(z, y, kf2, twM, twN, ktime, short_w, short_b, B, L, Lp, nullptr, nullptr, st);
-    } else {
-        if (ids) launch_conv_eo_inst<f16_t, true>(z, y, kf2, twM, twN, ktime, short_w, short_b, B, L, Lp, ids8, ztab, st);
-        else launch_conv_eo_inst<f16_t, false>(z, y, kf2, twM, twN, ktime, short_w, short_b, B, L, Lp, nullptr, nullptr, st);
-    }
-}
+// (Round 2 built the 16384-point convolution of 8k reads as two 8192-point problems over the even / odd bins -- hyena_conv_eo_kernel --
+//  and round 3 the same decomposition for 16,384-token segments of long reads -- hyena_conv_seg16_kernel.  Both were correct and both
+//  MEASURED SLOWER than the kernels in this file (8k: 15.4 vs 13.5 ms per batch; 32k: 2.18 vs 1.90 ms per launch at 4.7 instead of
+//  5.8 GB); they were removed in round 4.  The numbers and the reasons are in DESIGN.md section 4.6 / 8 and profiles/r03_seg16.txt;
+//  the code is in the history at commit 8ca4f7f.)
 
 typedef unsigned v4u32 __attribute__((vector_size(16)));   // the type the buffer builtins take and return
 // buffer descriptor over [p, p + bytes): every input wave-uniform, made provably so with readfirstlane
@@ -1343,12 +1165,11 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, size_
 // Partition spectrum j of every channel from natural bin order (src [256][N]) into the lane-packed layout the segmented kernel
 // reads (dst [256][KS][16][512] quads): quad (e, t) = (re, re, im, im) of bins t + 512 ka and t + 512 (ka + 1),
 // ka = 2 (e / 4) + 8 (e % 4) -- the two butterflies thread t holds in pair e of the last forward pass (radix 4, 512 threads).
-__global__ __launch_bounds__(512) void spectrum_lanepack_kernel(const float2* __restrict__ src, float4* __restrict__ dst, int KS, int j,
-                                                                size_t src_stride) {
+__global__ __launch_bounds__(512) void spectrum_lanepack_kernel(const float2* __restrict__ src, float4* __restrict__ dst, int KS, int j) {
     constexpr int N = 16384, NT = 512, LAST = Plan<14>::LAST;
     static_assert(LAST == 4 && Plan<14>::NT == NT, "pair geometry of the 16384-point plan");
     const int c = blockIdx.x, t = threadIdx.x;
-    const float2* s = src + (size_t)c * src_stride;
+    const float2* s = src + (size_t)c * N;
     float4* d = dst + ((size_t)c * KS + j) * (N / 2);
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
@@ -1357,9 +1178,8 @@ __global__ __launch_bounds__(512) void spectrum_lanepack_kernel(const float2* __
         d[e * NT + t] = make_float4(a.x, b.x, a.y, b.y);
     }
 }
-void launch_spectrum_lanepack(const float2* src, float2* dst, int KS, int j, hipStream_t st, size_t src_stride) {
-    hipLaunchKernelGGL(spectrum_lanepack_kernel, dim3(D), dim3(512), 0, st, src, reinterpret_cast<float4*>(dst), KS, j,
-                       src_stride ? src_stride : (size_t)16384);
+void launch_spectrum_lanepack(const float2* src, float2* dst, int KS, int j, hipStream_t st) {
+    hipLaunchKernelGGL(spectrum_lanepack_kernel, dim3(D), dim3(512), 0, st, src, reinterpret_cast<float4*>(dst), KS, j);
 }
 
 // ================================================================================================ long reads
@@ -1378,13 +1198,16 @@ void launch_spectrum_lanepack(const float2* src, float2* dst, int KS, int j, hip
 // +25 % of the kernel at 32769 tokens, +50 % at 16385).
 // IDS (16-bit modes, block 0): x0 | x1 | v looked up in ztab by token id, as in hyena_conv_kernel.
 // GATED: z holds x0f / g, filtered and gated by the producer (see hyena_conv_pers_kernel).
-template <typename T, bool LONE, bool IDS, bool GATED = false>
+// LO (fp16c): as hyena_conv_kernel -- y leaves as hi + lo bytes, the gated rows are read as hi + lo.
+template <typename T, bool LONE, bool IDS, bool GATED = false, bool LO = false>
 __global__ __launch_bounds__(Plan<14>::NT) void hyena_conv_seg_kernel(
     const T* __restrict__ z, T* __restrict__ y, const float2* __restrict__ kf /*[256][KS][N] lane-packed (launch_spectrum_lanepack), KS >= S partitions stored*/,
     int KS, const float2* __restrict__ tw, const float* __restrict__ short_w, const float* __restrict__ short_b,
     float2* __restrict__ gscratch /*[pairs][256][S][N]*/, int B, int L, int Lp, int S,
     const float* __restrict__ krev /*[256][krev_stride], LONE only*/, int krev_stride,
-    const unsigned char* __restrict__ ids8 /*[B][Lp], IDS only*/, const float* __restrict__ ztab /*[16][768]*/, int use_xcd) {
+    const unsigned char* __restrict__ ids8 /*[B][Lp], IDS only*/, const float* __restrict__ ztab /*[16][768]*/, int use_xcd,
+    unsigned char* __restrict__ ylo) {
+    static_assert(!LO || std::is_same<T, f16_t>::value, "lo bytes exist in the compensated fp16 mode only");
     constexpr int LOGN = 14;
     using P = Plan<LOGN>;
     using TL = TwLayout<LOGN>;
@@ -1405,6 +1228,8 @@ __global__ __launch_bounds__(Plan<14>::NT) void hyena_conv_seg_kernel(
     const T* zB = z + (size_t)(hasB ? bB : bA) * D3 * Lp;
     T* yA = y + ((size_t)bA * D + c) * Lp;
     T* yB = y + ((size_t)(hasB ? bB : bA) * D + c) * Lp;
+    unsigned char* ylA = LO ? ylo + ((size_t)bA * D + c) * Lp : nullptr;
+    unsigned char* ylB = LO ? ylo + ((size_t)(hasB ? bB : bA) * D + c) * Lp : nullptr;
     const float2* kfc = kf + (size_t)c * KS * N;
     float2* gs = gscratch + ((size_t)pair * D + c) * S * N;
     const float* kr = LONE ? krev + (size_t)c * krev_stride : nullptr;
@@ -1448,13 +1273,16 @@ __global__ __launch_bounds__(Plan<14>::NT) void hyena_conv_seg_kernel(
         static_assert(!(GATED && (IDS || std::is_same<T, float>::value)), "the gated hand-over exists in the fused 16-bit path only");
         if constexpr (GATED) {
             uint4 gr[CH][2];
+            uint2 grl[CH][2];
 #pragma unroll
             for (int rd = 0; rd < 2; ++rd) {
                 const T* row = (rd == 0 ? zA : zB) + (size_t)(D + c) * Lp;
+                const unsigned char* rowl = zlo_row(rd == 0 ? zA : zB, 1, c, Lp);
 #pragma unroll
                 for (int ch = 0; ch < CH; ++ch) {
                     const int t0 = seg0 + 8 * (ltid + ch * NT);
                     gr[ch][rd] = *reinterpret_cast<const uint4*>(row + (t0 < L ? t0 : 0));
+                    if constexpr (LO) grl[ch][rd] = *reinterpret_cast<const uint2*>(rowl + (t0 < L ? t0 : 0));
                 }
             }
 #pragma unroll
@@ -1463,6 +1291,10 @@ __global__ __launch_bounds__(Plan<14>::NT) void hyena_conv_seg_kernel(
                 float gA[8], gB[8];
                 cvt8<T>(gr[ch][0], gA);
                 cvt8<T>(gr[ch][1], gB);
+                if constexpr (LO) {
+                    add_lo8(grl[ch][0], gA);
+                    add_lo8(grl[ch][1], gB);
+                }
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     gA[e] = (t0 + e < L) ? gA[e] : 0.f;
@@ -1686,6 +1518,7 @@ __global__ __launch_bounds__(Plan<14>::NT) void hyena_conv_seg_kernel(
         pass_store<LOGN, LAST>(bre, bim, v, ltid, 1);
         __syncthreads();
         Raw<T> x0r[CH][2];
+        uint2 x0l[CH][2];
         {
             int Ns = LAST;
 #pragma unroll
@@ -1695,10 +1528,12 @@ __global__ __launch_bounds__(Plan<14>::NT) void hyena_conv_seg_kernel(
 #pragma unroll
                         for (int rd = 0; rd < 2; ++rd) {
                             const T* row = (rd == 0 ? zA : zB) + (size_t)c * Lp;
+                            const unsigned char* rowl = zlo_row(rd == 0 ? zA : zB, 0, c, Lp);
 #pragma unroll
                             for (int ch = 0; ch < CH; ++ch) {
                                 const int t0 = seg0 + 8 * (ltid + ch * NT);
                                 x0r[ch][rd].d = *reinterpret_cast<const uint4*>(row + (t0 < L ? t0 : 0));
+                                if constexpr (LO) x0l[ch][rd] = *reinterpret_cast<const uint2*>(rowl + (t0 < L ? t0 : 0));
                             }
                         }
                     } else if constexpr (!IDS && !std::is_same<T, float>::value) {
@@ -1736,6 +1571,10 @@ __global__ __launch_bounds__(Plan<14>::NT) void hyena_conv_seg_kernel(
             if constexpr (GATED) {
                 cvt8<T>(x0r[ch][0].d, x0A);
                 cvt8<T>(x0r[ch][1].d, x0B);
+                if constexpr (LO) {
+                    add_lo8(x0l[ch][0], x0A);
+                    add_lo8(x0l[ch][1], x0B);
+                }
             } else if constexpr (std::is_same<T, float>::value) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) x0A[e] = 0.f, x0B[e] = 0.f;
@@ -1771,8 +1610,8 @@ __global__ __launch_bounds__(Plan<14>::NT) void hyena_conv_seg_kernel(
                 oB[e] = ok ? oB[e] * x0B[e] : 0.f;
             }
             if (t0 < Lp) {
-                store8<T>(yA + t0, oA);
-                if (hasB) store8<T>(yB + t0, oB);
+                ystore8<T, LO>(yA + t0, ylA + t0, oA);
+                if (hasB) ystore8<T, LO>(yB + t0, ylB + t0, oB);
             }
         }
         __syncthreads();   // the LDS buffer is refilled by the next segment
@@ -1794,7 +1633,10 @@ __global__ __launch_bounds__(Plan<14>::NT) void hyena_conv_seg_kernel(
             // short filter of the one token t (t >= 2 here) on row a3 of read rd: from z, or from the id table
             auto filt = [&](int rd, int a3) {
                 if constexpr (GATED) {        // a3 = 0: x0f; a3 = 1: g (called as filt(., 2) * filt(., 1): the v slot counts as 1)
-                    return a3 == 2 ? 1.0f : to_float(((rd == 0 ? zA : zB) + (size_t)(a3 * D + c) * Lp)[t]);
+                    if (a3 == 2) return 1.0f;
+                    float v1 = to_float(((rd == 0 ? zA : zB) + (size_t)(a3 * D + c) * Lp)[t]);
+                    if constexpr (LO) v1 += lo1(zlo_row(rd == 0 ? zA : zB, a3, c, Lp), t);
+                    return v1;
                 } else if constexpr (IDS) {
                     const unsigned char* ir = rd == 0 ? irA : irB;
                     const float* r = zt + a3 * 16;
@@ -1804,24 +1646,24 @@ __global__ __launch_bounds__(Plan<14>::NT) void hyena_conv_seg_kernel(
                                             sb[a3]);
                 }
             };
-            yA[t] = from_float<T>(fmaf(filt(0, 2) * filt(0, 1), k0, sa) * filt(0, 0));
-            if (hasB) yB[t] = from_float<T>(fmaf(filt(1, 2) * filt(1, 1), k0, sbb) * filt(1, 0));
+            ystore1<T, LO>(yA + t, ylA + t, fmaf(filt(0, 2) * filt(0, 1), k0, sa) * filt(0, 0));
+            if (hasB) ystore1<T, LO>(yB + t, ylB + t, fmaf(filt(1, 2) * filt(1, 1), k0, sbb) * filt(1, 0));
         }
         for (int t = L + tid; t < Lp; t += NT) {             // padding columns stay zero
-            yA[t] = from_float<T>(0.f);
-            if (hasB) yB[t] = from_float<T>(0.f);
+            ystore1<T, LO>(yA + t, ylA + t, 0.f);
+            if (hasB) ystore1<T, LO>(yB + t, ylB + t, 0.f);
         }
     }
 }
 
-template <typename T, bool LONE, bool IDS, bool GATED = false>
+template <typename T, bool LONE, bool IDS, bool GATED = false, bool LO = false>
 static void launch_conv_seg_inst(const void* z, void* y, const float2* kf, int KS, const float2* tw, const float* short_w,
                               const float* short_b, float2* gscratch, int B, int L, int Lp, int S,
                               const float* krev, int krev_stride, const unsigned char* ids8, const float* ztab,
-                              int use_xcd, hipStream_t st) {
+                              int use_xcd, hipStream_t st, unsigned char* ylo = nullptr) {
     using P = Plan<14>;
     constexpr size_t lds = (size_t)2 * padded_size(P::N) * sizeof(float) + 256;   // + the 3x16 id table
-    auto kern = hyena_conv_seg_kernel<T, LONE, IDS, GATED>;
+    auto kern = hyena_conv_seg_kernel<T, LONE, IDS, GATED, LO>;
     static bool attr_done = false;
     if (!attr_done) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1831,23 +1673,24 @@ static void launch_conv_seg_inst(const void* z, void* y, const float2* kf, int K
     static_assert(D % XCDS == 0, "channels split evenly over the XCDs");
     dim3 grid(((B + 1) / 2) * D), block(P::NT);
     hipLaunchKernelGGL(kern, grid, block, lds, st, reinterpret_cast<const T*>(z), reinterpret_cast<T*>(y), kf, KS, tw,
-                       short_w, short_b, gscratch, B, L, Lp, S, krev, krev_stride, ids8, ztab, use_xcd);
+                       short_w, short_b, gscratch, B, L, Lp, S, krev, krev_stride, ids8, ztab, use_xcd, ylo);
 }
-template <typename T>
+// LO: fp16c (T = f16_t) with a lo plane for y -- the gated rows then carry lo bytes too
+template <typename T, bool LO = false>
 static void launch_conv_seg_t(const void* z, void* y, const float2* kf, int KS, const float2* tw, const float* short_w,
                               const float* short_b, float2* gscratch, int B, int L, int Lp, int S, const float* krev,
                               int krev_stride, const unsigned char* ids8, const float* ztab, int use_xcd, hipStream_t st,
-                              bool gated) {
+                              bool gated, unsigned char* ylo = nullptr) {
 #define CLM_SEG(LONE, IDS)                                                                                               \
-    launch_conv_seg_inst<T, LONE, IDS>(z, y, kf, KS, tw, short_w, short_b, gscratch, B, L, Lp, S, krev, krev_stride, ids8, ztab, use_xcd, st)
+    launch_conv_seg_inst<T, LONE, IDS, false, LO>(z, y, kf, KS, tw, short_w, short_b, gscratch, B, L, Lp, S, krev, krev_stride, ids8, ztab, use_xcd, st, ylo)
     if constexpr (std::is_same<T, float>::value) {           // fp32 mode never takes the id path
         if (krev) CLM_SEG(true, false);
         else CLM_SEG(false, false);
     } else {
         const bool ids = ids8 != nullptr && ztab != nullptr;
         if (gated && !ids) {
-            if (krev) launch_conv_seg_inst<T, true, false, true>(z, y, kf, KS, tw, short_w, short_b, gscratch, B, L, Lp, S, krev, krev_stride, nullptr, nullptr, use_xcd, st);
-            else launch_conv_seg_inst<T, false, false, true>(z, y, kf, KS, tw, short_w, short_b, gscratch, B, L, Lp, S, krev, krev_stride, nullptr, nullptr, use_xcd, st);
+            if (krev) launch_conv_seg_inst<T, true, false, true, LO>(z, y, kf, KS, tw, short_w, short_b, gscratch, B, L, Lp, S, krev, krev_stride, nullptr, nullptr, use_xcd, st, ylo);
+            else launch_conv_seg_inst<T, false, false, true, LO>(z, y, kf, KS, tw, short_w, short_b, gscratch, B, L, Lp, S, krev, krev_stride, nullptr, nullptr, use_xcd, st, ylo);
             return;
         }
         if (krev && ids) CLM_SEG(true, true);
@@ -1860,348 +1703,18 @@ static void launch_conv_seg_t(const void* z, void* y, const float2* kf, int KS, 
 
 void launch_hyena_conv_seg(int prec, const void* z, void* y, const float2* kf, int KS, const float2* tw, const float* short_w,
                            const float* short_b, float2* gscratch, int B, int L, int Lp, int S, const float* krev,
-                           int krev_stride, const unsigned char* ids8, const float* ztab, hipStream_t st, int flags) {
+                           int krev_stride, const unsigned char* ids8, const float* ztab, hipStream_t st, int flags,
+                           unsigned char* ylo) {
     const int use_xcd = !(flags & CONV_NO_XCD);
     const bool gated = (flags & CONV_GATED) != 0;
-    if (prec == PREC_F32)
+    if (prec == PREC_F16C && ylo)
+        launch_conv_seg_t<f16_t, true>(z, y, kf, KS, tw, short_w, short_b, gscratch, B, L, Lp, S, krev, krev_stride, ids8, ztab, use_xcd, st, gated, ylo);
+    else if (prec == PREC_F32)
         launch_conv_seg_t<float>(z, y, kf, KS, tw, short_w, short_b, gscratch, B, L, Lp, S, krev, krev_stride, nullptr, nullptr, use_xcd, st, false);
     else if (prec == PREC_BF16)
         launch_conv_seg_t<bf16_t>(z, y, kf, KS, tw, short_w, short_b, gscratch, B, L, Lp, S, krev, krev_stride, ids8, ztab, use_xcd, st, gated);
     else
         launch_conv_seg_t<f16_t>(z, y, kf, KS, tw, short_w, short_b, gscratch, B, L, Lp, S, krev, krev_stride, ids8, ztab, use_xcd, st, gated);
-}
-
-// ================================================================================================ long reads, 16,384-token segments
-// Round 3.  hyena_conv_seg_kernel moves 5.8 GB per 32 x 32,769 launch where 1.6 GB are algorithmic: S = 4
-// segments of 8,192 tokens mean S (S - 1) / 2 = 6 spectral products per unit, each re-reading a 128 KB segment spectrum from the
-// global scratch, and three spectra written -- and the kernel runs at the 3 TB/s that traffic gets through the fabric.  With
-// segments of M = 16,384 tokens a 32k-bp read has TWO (a 16k-bp read one: no product at all), i.e. ONE product per unit.  The
-// transform of such a segment has 2 M = 32,768 points and does not fit the LDS -- but its input is half zero and only half of its
-// output is wanted, so it is two independent M-point problems over the even and the odd bins (the decomposition of
-// hyena_conv_eo_kernel, emulated on the host by fft_core_test.cpp test_conv_split13):
-//     X[2j]   = DFT_M(x)[j]                        y[n] = IDFT_M(X_e K_e)[n] + w_N^-n IDFT_M(X_o K_o)[n],   n < M,  N = 2 M
-//     X[2j+1] = DFT_M(x w_N^n)[j]
-// run ONE AFTER THE OTHER in the one 147 KiB buffer: the even problem's result waits in 64 registers per thread through the odd
-// problem's passes (no spill: the pass twiddles are requested pass group by pass group and the spectra of the product in quarters,
-// as in hyena_conv_seg_kernel).  Neither problem is pruned (all M inputs, all M outputs), so a segment costs four full M-point
-// transforms where two 8,192-token segments cost four pruned ones (+ ~15 % butterfly work) -- against 1.5 MB -> 0.9 MB of traffic
-// per unit.  Partition spectra: K'_j = spectrum_N([taps of partition j | taps of partition j - 1]) as in the 8k-segment kernel,
-// split into even / odd bins and lane-packed (kf16 [256][2 partitions][2][M quads]).  GATED input only (the fused tail kernel's
-// hand-over: blocks 1..3 of the 16-bit path); block 0 (token ids), fp32 and the raw-row A/B path keep hyena_conv_seg_kernel.
-// MEASURED SLOWER and therefore OFF by default (CLM_SEG16=1 selects it; tests keep it correct): same box, 32 x 32,769 tokens in
-// fp16c, convolution launches of blocks 1..3: 2.18 ms against 1.90 ms for hyena_conv_seg_kernel (1,717 vs 1,797 reads/s).  The
-// 5.8 GB the 8,192-token segments move do not bound them: a unit is four transform pipelines either way (here un-pruned, there
-// pruned), each with its exposed row / twiddle / spectrum requests -- what hyena_conv_pers_kernel hides with its next-unit
-// prefetches -- and halving the scratch traffic buys less than the pruned first / last passes and the 64 registers of the
-// waiting even result cost.
-// LONE: L = S2 * M + 1 (16,385, 32,769): the last output as a dot product with the reversed filter, as in the 8k-segment kernel.
-constexpr int SEG16_LEN = 16384;
-#define CLM_DIF_WC15                                                                                                        \
-    {{1.0f, -0.0f}, {0.99999998162f, -1.9174759731e-4f}, {0.99999992647f, -3.8349518757e-4f}, {0.99999983455f, -5.7524276373e-4f}, \
-     {0.99999970586f, -7.6699031874e-4f}, {0.99999954041f, -9.5873784555e-4f}, {0.99999933819f, -1.1504853371e-3f},          \
-     {0.99999909921f, -1.3422327864e-3f}}
-
-template <typename T, bool LONE>
-__global__ __launch_bounds__(Plan<14>::NT) void hyena_conv_seg16_kernel(
-    const T* __restrict__ z /*gated: row c = x0f, row 256 + c = g*/, T* __restrict__ y,
-    const float2* __restrict__ kf16 /*[256][2][2][M] lane-packed quads: partition j, parity*/, const float2* __restrict__ tw /*M-point*/,
-    const float2* __restrict__ twN /*exp(-2 pi i n / 2M), n < M*/, float2* __restrict__ gscratch /*[pairs][256][2][M]: segment 0's spectra*/,
-    int B, int L, int Lp, int S2, const float* __restrict__ krev, int krev_stride, int use_xcd) {
-    constexpr int LOGN = 14;
-    using P = Plan<LOGN>;
-    using TL = TwLayout<LOGN>;
-    constexpr int M = P::N, NT = P::NT, LAST = P::LAST, CH = M / 8 / NT;
-    static_assert(M == SEG16_LEN && CH == 4 && NT == 512, "four 8-token chunks per thread");
-    constexpr float WC[8][2] = CLM_DIF_WC15;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    float* bre = reinterpret_cast<float*>(smem);
-    float* bim = bre + padded_size(M);
-
-    const int tid = threadIdx.x;
-    const int pairs = (B + 1) / 2, xcd = blockIdx.x % XCDS, slot = blockIdx.x / XCDS;
-    const int c = use_xcd ? XCDS * (slot / pairs) + xcd : (int)blockIdx.x / pairs, pair = use_xcd ? slot % pairs : (int)blockIdx.x % pairs;
-    const int bA = 2 * pair, bB = 2 * pair + 1;
-    const bool hasB = bB < B;
-    const T* zA = z + (size_t)bA * D3 * Lp;
-    const T* zB = z + (size_t)(hasB ? bB : bA) * D3 * Lp;
-    T* yA = y + ((size_t)bA * D + c) * Lp;
-    T* yB = y + ((size_t)(hasB ? bB : bA) * D + c) * Lp;
-    const float* kr = LONE ? krev + (size_t)c * krev_stride : nullptr;
-    float dotA = 0.f, dotB = 0.f;
-    // buffer descriptors (uniform): this unit's two scratch spectra (even | odd of segment 0), this channel's four packed spectra
-    const __amdgpu_buffer_rsrc_t g_rs = make_rsrc(gscratch + ((size_t)pair * D + c) * 2 * M, (size_t)2 * M * sizeof(float2));
-    const __amdgpu_buffer_rsrc_t k_rs = make_rsrc(kf16 + (size_t)c * 4 * M, (size_t)4 * M * sizeof(float2));
-    using G = PassGeom<LOGN, LAST>;
-    static_assert(G::NP * LAST == 16 && sizeof(Cx2) == 16, "16 full pairs per thread");
-
-#pragma unroll 1
-    for (int m = 0; m < S2; ++m) {
-        const int seg0 = m * M;
-        int ltid = tid;                    // laundered once per segment (see hyena_conv_seg_kernel)
-        asm volatile("" : "+v"(ltid));
-        const int loff = ltid * (int)sizeof(Cx2);
-        auto quad = [&](const __amdgpu_buffer_rsrc_t& rs, int idx /*spectrum index inside the resource*/, int e) -> Cx2 {
-            const v4u32 r = __builtin_amdgcn_raw_buffer_load_b128(rs, loff, (idx * (M / 2) + NT * e) * (int)sizeof(Cx2), 0);
-            const unsigned r0 = r[0], r1 = r[1], r2 = r[2], r3 = r[3];
-            return Cx2{make_v2(__uint_as_float(r0), __uint_as_float(r1)), make_v2(__uint_as_float(r2), __uint_as_float(r3))};
-        };
-        auto quad_w = [&](const __amdgpu_buffer_rsrc_t& rs, int idx, int e, Cx2 val) {
-            v4u32 r;
-            r[0] = __float_as_uint(val.re.x), r[1] = __float_as_uint(val.re.y);
-            r[2] = __float_as_uint(val.im.x), r[3] = __float_as_uint(val.im.y);
-            __builtin_amdgcn_raw_buffer_store_b128(r, rs, loff, (idx * (M / 2) + NT * e) * (int)sizeof(Cx2), 0);
-        };
-        float ye[CH][2][8];                // the even problem's result (read A | read B), held through the odd problem
-        float2 wb[CH];                     // w_N^tl of this thread's chunks
-#pragma unroll
-        for (int ch = 0; ch < CH; ++ch) wb[ch] = twN[8 * (ltid + ch * NT)];
-
-#pragma unroll 1
-        for (int par = 0; par < 2; ++par) {                  // 0: even bins, 1: odd bins -- a rolled loop: ONE copy of the seven passes
-            const int PAR = __builtin_amdgcn_readfirstlane(par);
-            asm volatile("" : "+v"(ltid));                   // (per problem: no pass address is carried from the even to the odd one)
-            // ---- phase A: the segment's g rows -> LDS (odd problem: times w_N^n)
-            {
-                uint4 gr[CH][2];
-#pragma unroll
-                for (int rd = 0; rd < 2; ++rd) {
-                    const T* row = (rd == 0 ? zA : zB) + (size_t)(D + c) * Lp;
-#pragma unroll
-                    for (int ch = 0; ch < CH; ++ch) {
-                        const int t0 = seg0 + 8 * (ltid + ch * NT);
-                        gr[ch][rd] = *reinterpret_cast<const uint4*>(row + (t0 < L ? t0 : 0));
-                    }
-                }
-#pragma unroll
-                for (int ch = 0; ch < CH; ++ch) {
-                    const int tl = 8 * (ltid + ch * NT), t0 = seg0 + tl;
-                    float gA[8], gB[8];
-                    cvt8<T>(gr[ch][0], gA);
-                    cvt8<T>(gr[ch][1], gB);
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        gA[e] = (t0 + e < L) ? gA[e] : 0.f;
-                        gB[e] = (hasB && t0 + e < L) ? gB[e] : 0.f;
-                    }
-                    if (LONE && PAR == 0) {        // this segment's share of the last output's dot product
-                        float kk[8];
-                        load8<float>(kr + t0, kk);
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) dotA = fmaf(gA[e], kk[e], dotA), dotB = fmaf(gB[e], kk[e], dotB);
-                    }
-                    if (PAR == 1) {
-                        // (opaque copy of the chunk's base twist: shared with phase C, hipcc computes all 64 twist values of the
-                        //  thread once, above the loop, and keeps them -- in scratch)
-                        float wbx = wb[ch].x, wby = wb[ch].y;
-                        asm volatile("" : "+v"(wbx), "+v"(wby));
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) {
-                            const float wr = wbx * WC[e][0] - wby * WC[e][1], wi = wbx * WC[e][1] + wby * WC[e][0];
-                            const float xr = gA[e] * wr - gB[e] * wi, xi = gA[e] * wi + gB[e] * wr;
-                            gA[e] = xr, gB[e] = xi;
-                        }
-                    }
-                    lds_store8(bre + pad_index(tl), gA);
-                    lds_store8(bim + pad_index(tl), gB);
-                }
-            }
-            Cx2 wall[TL::TOTAL];
-            {
-                int ns = 16;
-#pragma unroll
-                for (int p = 1; p <= P::NPASS - 2; ++p) {
-                    pass_twiddles<LOGN, 16, false>(wall + TL::fwd(p), ltid, ns, tw);
-                    ns *= 16;
-                }
-                pass_twiddles<LOGN, LAST, false>(wall + TL::fwd_last(), ltid, ns, tw);
-            }
-            __syncthreads();
-            // ---- forward transform: all M inputs (no pruned pass)
-            Cx2 v[16];
-            {
-                int Ns = 1;
-#pragma unroll
-                for (int p = 0; p < P::NPASS - 1; ++p) {
-                    pass_load<LOGN, 16>(bre, bim, v, ltid);
-                    pass_compute_w<LOGN, 16, false>(v, ltid, p > 0, wall + (p > 0 ? TL::fwd(p) : 0));
-                    __syncthreads();
-                    pass_store<LOGN, 16>(bre, bim, v, ltid, Ns);
-                    __syncthreads();
-                    Ns *= 16;
-                }
-            }
-            // ---- last forward pass, spectrum product, first inverse butterfly
-            {
-                pass_load<LOGN, LAST>(bre, bim, v, ltid);
-                pass_compute_w<LOGN, LAST, false>(v, ltid, true, wall + TL::fwd_last());
-                if (m + 1 < S2) {              // segment 0 of two: keep its spectrum for segment 1 (uniform branch)
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) quad_w(g_rs, PAR, e, v[e]);
-                }
-                // x K'_0 of this parity, a quarter of the pairs at a time (all 16 quads at once are 64 registers next to the 64 of
-                // the spectrum and the 64 of the waiting even result: spills)
-#pragma unroll
-                for (int qtr = 0; qtr < 4; ++qtr) {
-                    Cx2 kb[4];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) kb[e] = quad(k_rs, PAR, 4 * qtr + e);
-                    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        Cx2& acc = v[4 * qtr + e];
-                        acc = Cx2::mul(acc, kb[e]);
-                        asm volatile("" : "+v"(acc.re), "+v"(acc.im));
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-            }
-            if (m > 0) {                       // + G_0 K'_1, a quarter of the pairs per step (registers: 2 x 16 at a time)
-#pragma unroll
-                for (int qtr = 0; qtr < 4; ++qtr) {
-                    Cx2 ga[4], kb[4];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        ga[e] = quad(g_rs, PAR, 4 * qtr + e);
-                        kb[e] = quad(k_rs, 2 + PAR, 4 * qtr + e);
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        Cx2& acc = v[4 * qtr + e];
-                        acc = Cx2::add(acc, Cx2::mul(ga[e], kb[e]));
-                        asm volatile("" : "+v"(acc.re), "+v"(acc.im));
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-            }
-            {
-                int ns = LAST;
-#pragma unroll
-                for (int p = 1; p <= P::NPASS - 1; ++p) {
-                    pass_twiddles<LOGN, 16, true>(wall + TL::inv(p), ltid, ns, tw);
-                    ns *= 16;
-                }
-            }
-#pragma unroll
-            for (int p = 0; p < G::NP; ++p) Dft<LAST, true>::run(v + p * LAST);
-            __syncthreads();
-            pass_store<LOGN, LAST>(bre, bim, v, ltid, 1);
-            __syncthreads();
-            // ---- inverse passes: all M outputs
-            uint4 x0r[CH][2];
-            {
-                int Ns = LAST;
-#pragma unroll
-                for (int p = 1; p <= P::NPASS - 1; ++p) {
-                    {
-                        if (PAR == 1 && p == P::NPASS - 1) {   // x0f rows of this segment: the last pass to land
-#pragma unroll
-                            for (int rd = 0; rd < 2; ++rd) {
-                                const T* row = (rd == 0 ? zA : zB) + (size_t)c * Lp;
-#pragma unroll
-                                for (int ch = 0; ch < CH; ++ch) {
-                                    const int t0 = seg0 + 8 * (ltid + ch * NT);
-                                    x0r[ch][rd] = *reinterpret_cast<const uint4*>(row + (t0 < L ? t0 : 0));
-                                }
-                            }
-                        }
-                    }
-                    pass_load<LOGN, 16>(bre, bim, v, ltid);
-                    pass_compute_w<LOGN, 16, true>(v, ltid, true, wall + TL::inv(p));
-                    __syncthreads();
-                    pass_store<LOGN, 16>(bre, bim, v, ltid, Ns);
-                    __syncthreads();
-                    Ns *= 16;
-                }
-            }
-            if (PAR == 0) {                    // the even result waits in registers; the buffer goes to the odd problem
-#pragma unroll
-                for (int ch = 0; ch < CH; ++ch) {
-                    const int tl = 8 * (ltid + ch * NT);
-                    lds_load8(bre + pad_index(tl), ye[ch][0]);
-                    lds_load8(bim + pad_index(tl), ye[ch][1]);
-                }
-                __syncthreads();
-            } else {
-                // ---- phase C: y = (r_e + conj(w_N^n) r_o) * x0f
-#pragma unroll
-                for (int ch = 0; ch < CH; ++ch) {
-                    const int tl = 8 * (ltid + ch * NT), t0 = seg0 + tl;
-                    float oA[8], oB[8], x0a[8], x0b[8];
-                    lds_load8(bre + pad_index(tl), oA);
-                    lds_load8(bim + pad_index(tl), oB);
-                    cvt8<T>(x0r[ch][0], x0a);
-                    cvt8<T>(x0r[ch][1], x0b);
-                    float wbx = wb[ch].x, wby = wb[ch].y;
-                    asm volatile("" : "+v"(wbx), "+v"(wby));
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        const float wr = wbx * WC[e][0] - wby * WC[e][1], wi = wbx * WC[e][1] + wby * WC[e][0];
-                        const bool ok = t0 + e < L;
-                        const float a = ye[ch][0][e] + (oA[e] * wr + oB[e] * wi), b = ye[ch][1][e] + (oB[e] * wr - oA[e] * wi);
-                        oA[e] = ok ? a * x0a[e] : 0.f;
-                        oB[e] = ok ? b * x0b[e] : 0.f;
-                    }
-                    if (t0 < Lp) {
-                        store8<T>(yA + t0, oA);
-                        if (hasB) store8<T>(yB + t0, oB);
-                    }
-                }
-                __syncthreads();   // the LDS buffer is refilled by the next segment
-            }
-        }
-    }
-    if constexpr (LONE) {
-        const float a = wave_sum(dotA), b = wave_sum(dotB);
-        if ((tid & 63) == 0) {
-            bre[tid >> 6] = a;
-            bim[tid >> 6] = b;
-        }
-        __syncthreads();
-        if (tid == 0) {
-            const int t = L - 1;
-            float sa = 0.f, sbb = 0.f;
-#pragma unroll
-            for (int w = 0; w < NT / 64; ++w) sa += bre[w], sbb += bim[w];
-            const float k0 = kr[t];                          // tap 0 (+ skip term)
-            auto at = [&](int rd, int row) { return to_float(((rd == 0 ? zA : zB) + (size_t)(row * D + c) * Lp)[t]); };
-            yA[t] = from_float<T>(fmaf(at(0, 1), k0, sa) * at(0, 0));
-            if (hasB) yB[t] = from_float<T>(fmaf(at(1, 1), k0, sbb) * at(1, 0));
-        }
-        for (int t = L + tid; t < Lp; t += NT) {             // padding columns stay zero
-            yA[t] = from_float<T>(0.f);
-            if (hasB) yB[t] = from_float<T>(0.f);
-        }
-    }
-}
-
-int conv_segments16_for(int L) { return L <= SEG_LEN + 1 ? 0 : (L - 1 + SEG16_LEN - 1) / SEG16_LEN; }
-
-template <typename T, bool LONE>
-static void launch_conv_seg16_inst(const void* z, void* y, const float2* kf16, const float2* tw, const float2* twN, float2* gscratch,
-                                   int B, int L, int Lp, int S2, const float* krev, int krev_stride, int use_xcd, hipStream_t st) {
-    using P = Plan<14>;
-    constexpr size_t lds = (size_t)2 * padded_size(P::N) * sizeof(float) + 256;
-    auto kern = hyena_conv_seg16_kernel<T, LONE>;
-    static bool attr_done = false;
-    if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_done = true;
-    }
-    dim3 grid(((B + 1) / 2) * D), block(P::NT);
-    hipLaunchKernelGGL(kern, grid, block, lds, st, reinterpret_cast<const T*>(z), reinterpret_cast<T*>(y), kf16, tw, twN, gscratch, B, L,
-                       Lp, S2, krev, krev_stride, use_xcd);
-}
-void launch_hyena_conv_seg16(int prec, const void* z, void* y, const float2* kf16, const float2* tw, const float2* twN,
-                             float2* gscratch, int B, int L, int Lp, const float* krev, int krev_stride, hipStream_t st, int flags) {
-    const int use_xcd = !(flags & CONV_NO_XCD), S2 = conv_segments16_for(L);
-    if (prec == PREC_BF16) {
-        if (krev) launch_conv_seg16_inst<bf16_t, true>(z, y, kf16, tw, twN, gscratch, B, L, Lp, S2, krev, krev_stride, use_xcd, st);
-        else launch_conv_seg16_inst<bf16_t, false>(z, y, kf16, tw, twN, gscratch, B, L, Lp, S2, nullptr, 0, use_xcd, st);
-    } else {
-        if (krev) launch_conv_seg16_inst<f16_t, true>(z, y, kf16, tw, twN, gscratch, B, L, Lp, S2, krev, krev_stride, use_xcd, st);
-        else launch_conv_seg16_inst<f16_t, false>(z, y, kf16, tw, twN, gscratch, B, L, Lp, S2, nullptr, 0, use_xcd, st);
-    }
 }
 
 // ztab[id][n] = in_proj(LN1(embedding[id]))[n] of block 0, fp32: one workgroup per token id
@@ -2280,44 +1793,46 @@ void conv_dump_stamps() {
         if (k != 6) std::fprintf(stderr, "  %-14s %9.0f  %5.1f %%\n", names[k], sum[k] / (n ? n : 1), 100.0 * sum[k] / (n ? n : 1) / tot);
 }
 
-template <int LOGN, typename T>
+// one launch site = one static: the dynamic-LDS attribute is set once per kernel instantiation
+#define CLM_CONV_LAUNCH(KERN, ...)                                                                                                 \
+    do {                                                                                                                           \
+        auto kern_ = KERN;                                                                                                         \
+        static bool done_ = false;                                                                                                 \
+        if (!done_) {                                                                                                              \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern_), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+            done_ = true;                                                                                                          \
+        }                                                                                                                          \
+        hipLaunchKernelGGL(kern_, grid, block, lds, st, __VA_ARGS__);                                                              \
+    } while (0)
+
+// LO: fp16c (T = f16_t) with a lo plane for y -- the gated rows then carry lo bytes too
+template <int LOGN, typename T, bool LO = false>
 static void launch_conv_t(const void* z, void* y, const float2* kf, const float2* tw, const float* ktime,
                           const float* short_w, const float* short_b, int B, int L, int Lp, const unsigned char* ids8,
-                          const float* ztab, hipStream_t st, bool gated) {
+                          const float* ztab, hipStream_t st, bool gated, unsigned char* ylo = nullptr) {
     using P = Plan<LOGN>;
     constexpr size_t lds = (size_t)2 * padded_size(P::N) * sizeof(float) + 256;   // + g[N/2] pair + the 3x16 id table
     dim3 grid((B + 1) / 2, D), block(P::NT);
+    const T* zt = reinterpret_cast<const T*>(z);
+    T* yt = reinterpret_cast<T*>(y);
+    unsigned long long* const no_stamps = nullptr;
+    const unsigned char* const no_ids = nullptr;
+    const float* const no_tab = nullptr;
     if constexpr (!std::is_same<T, float>::value) {
         if (gated && !ids8) {
-            auto kern = hyena_conv_kernel<LOGN, T, false, false, true>;
-            static bool g_attr_done = false;
-            if (!g_attr_done) {
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-                g_attr_done = true;
-            }
-            hipLaunchKernelGGL(kern, grid, block, lds, st, reinterpret_cast<const T*>(z), reinterpret_cast<T*>(y), kf, tw, ktime,
-                               short_w, short_b, B, L, Lp, (unsigned long long*)nullptr, (const unsigned char*)nullptr,
-                               (const float*)nullptr);
+            CLM_CONV_LAUNCH((hyena_conv_kernel<LOGN, T, false, false, true, LO>), zt, yt, kf, tw, ktime, short_w, short_b, B, L, Lp,
+                            no_stamps, no_ids, no_tab, ylo);
             return;
         }
         if (ids8) {
-            auto kern = hyena_conv_kernel<LOGN, T, false, true>;
-            static bool ids_attr_done = false;
-            if (!ids_attr_done) {
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-                ids_attr_done = true;
-            }
-            hipLaunchKernelGGL(kern, grid, block, lds, st, (const T*)nullptr, reinterpret_cast<T*>(y), kf, tw, ktime, short_w,
-                               short_b, B, L, Lp, (unsigned long long*)nullptr, ids8, ztab);
+            CLM_CONV_LAUNCH((hyena_conv_kernel<LOGN, T, false, true, false, LO>), (const T*)nullptr, yt, kf, tw, ktime, short_w, short_b,
+                            B, L, Lp, no_stamps, ids8, ztab, ylo);
             return;
         }
     }
-    if constexpr (LOGN == 14 && std::is_same<T, f16_t>::value) {
+    if constexpr (LOGN == 14 && std::is_same<T, f16_t>::value && !LO) {
         static const bool stamp = std::getenv("CLM_STAMP") && std::getenv("CLM_STAMP")[0] == '1';
         if (stamp) {
-            auto kern = hyena_conv_kernel<LOGN, T, true>;
-            static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), true);
-            (void)once;
             const size_t wgs = (size_t)grid.x * grid.y;
             if (wgs > s_conv_stamp_wgs) {
                 if (s_conv_stamp_buf) (void)hipFree(s_conv_stamp_buf);
@@ -2325,28 +1840,22 @@ static void launch_conv_t(const void* z, void* y, const float2* kf, const float2
                 s_conv_stamp_wgs = wgs;
             }
             (void)hipMemsetAsync(s_conv_stamp_buf, 0, wgs * CONV_NSTAMP * 8, st);
-            hipLaunchKernelGGL(kern, grid, block, lds, st, reinterpret_cast<const T*>(z), reinterpret_cast<T*>(y), kf, tw, ktime,
-                               short_w, short_b, B, L, Lp, s_conv_stamp_buf, (const unsigned char*)nullptr, (const float*)nullptr);
+            CLM_CONV_LAUNCH((hyena_conv_kernel<LOGN, T, true>), zt, yt, kf, tw, ktime, short_w, short_b, B, L, Lp, s_conv_stamp_buf,
+                            no_ids, no_tab, (unsigned char*)nullptr);
             return;
         }
     }
-    auto kern = hyena_conv_kernel<LOGN, T, false>;
-    static bool attr_done = false;
-    if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)lds);
-        attr_done = true;
-    }
-    hipLaunchKernelGGL(kern, grid, block, lds, st, reinterpret_cast<const T*>(z), reinterpret_cast<T*>(y), kf, tw,
-                       ktime, short_w, short_b, B, L, Lp, (unsigned long long*)nullptr, (const unsigned char*)nullptr,
-                       (const float*)nullptr);
+    CLM_CONV_LAUNCH((hyena_conv_kernel<LOGN, T, false, false, false, LO>), zt, yt, kf, tw, ktime, short_w, short_b, B, L, Lp, no_stamps,
+                    no_ids, no_tab, ylo);
 }
 
 template <int LOGN>
 static void launch_conv_p(int prec, const void* z, void* y, const float2* kf, const float2* tw, const float* ktime,
                           const float* short_w, const float* short_b, int B, int L, int Lp, const unsigned char* ids8,
-                          const float* ztab, hipStream_t st, bool gated) {
-    if (prec == PREC_F32)
+                          const float* ztab, hipStream_t st, bool gated, unsigned char* ylo) {
+    if (prec == PREC_F16C && ylo)
+        launch_conv_t<LOGN, f16_t, true>(z, y, kf, tw, ktime, short_w, short_b, B, L, Lp, ids8, ztab, st, gated, ylo);
+    else if (prec == PREC_F32)
         launch_conv_t<LOGN, float>(z, y, kf, tw, ktime, short_w, short_b, B, L, Lp, nullptr, nullptr, st, false);
     else if (prec == PREC_BF16)
         launch_conv_t<LOGN, bf16_t>(z, y, kf, tw, ktime, short_w, short_b, B, L, Lp, ids8, ztab, st, gated);
@@ -2356,12 +1865,14 @@ static void launch_conv_p(int prec, const void* z, void* y, const float2* kf, co
 
 void launch_hyena_conv(int prec, const void* z, void* y, const float2* kf, const float2* tw, const float* ktime,
                        const float* short_w, const float* short_b, int B, int L, int Lp, int logn,
-                       const unsigned char* ids8, const float* ztab, hipStream_t st, int flags, const float2* kf_packed) {
+                       const unsigned char* ids8, const float* ztab, hipStream_t st, int flags, const float2* kf_packed,
+                       unsigned char* ylo) {
     // 16384-point class, 16-bit activations: persistent workgroups with next-unit requests (CONV_ONESHOT: one workgroup per
     // unit -- A/B runs; the developer stamps live in that kernel only)
     static const bool stamp = std::getenv("CLM_STAMP") && std::getenv("CLM_STAMP")[0] == '1';
     const bool ids = ids8 != nullptr && ztab != nullptr;
     const bool gated = (flags & CONV_GATED) != 0 && !ids;
+    const bool lo = prec == PREC_F16C && ylo != nullptr;
     if (logn == 14 && prec != PREC_F32 && !(flags & CONV_ONESHOT) && !(stamp && !gated) && kf_packed) {
         kf = kf_packed;
         const int xcd = !(flags & CONV_NO_XCD);
@@ -2369,6 +1880,10 @@ void launch_hyena_conv(int prec, const void* z, void* y, const float2* kf, const
             if (ids) launch_conv_pers_inst<bf16_t, true>(nullptr, y, kf, tw, ktime, short_w, short_b, B, L, Lp, ids8, ztab, xcd, st);
             else if (gated) launch_conv_pers_inst<bf16_t, false, true>(z, y, kf, tw, ktime, short_w, short_b, B, L, Lp, nullptr, nullptr, xcd, st);
             else launch_conv_pers_inst<bf16_t, false>(z, y, kf, tw, ktime, short_w, short_b, B, L, Lp, nullptr, nullptr, xcd, st);
+        } else if (lo) {
+            if (ids) launch_conv_pers_inst<f16_t, true, false, true>(nullptr, y, kf, tw, ktime, short_w, short_b, B, L, Lp, ids8, ztab, xcd, st, ylo);
+            else if (gated) launch_conv_pers_inst<f16_t, false, true, true>(z, y, kf, tw, ktime, short_w, short_b, B, L, Lp, nullptr, nullptr, xcd, st, ylo);
+            else launch_conv_pers_inst<f16_t, false, false, true>(z, y, kf, tw, ktime, short_w, short_b, B, L, Lp, nullptr, nullptr, xcd, st, ylo);
         } else {
             if (ids) launch_conv_pers_inst<f16_t, true>(nullptr, y, kf, tw, ktime, short_w, short_b, B, L, Lp, ids8, ztab, xcd, st);
             else if (gated) launch_conv_pers_inst<f16_t, false, true>(z, y, kf, tw, ktime, short_w, short_b, B, L, Lp, nullptr, nullptr, xcd, st);
@@ -2377,7 +1892,7 @@ void launch_hyena_conv(int prec, const void* z, void* y, const float2* kf, const
         return;
     }
 #define CLM_CONV_CASE(n) \
-    case n: launch_conv_p<n>(prec, z, y, kf, tw, ktime, short_w, short_b, B, L, Lp, ids8, ztab, st, gated); break;
+    case n: launch_conv_p<n>(prec, z, y, kf, tw, ktime, short_w, short_b, B, L, Lp, ids8, ztab, st, gated, ylo); break;
     switch (logn) {
         CLM_CONV_CASE(8)
         CLM_CONV_CASE(9)

@@ -81,7 +81,11 @@ __global__ __launch_bounds__(LT_THREADS) void lone_stage_kernel(LoneTokenArgs a)
     const int b = blockIdx.y, n0 = blockIdx.x * LT_ROWS, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, t = a.L - 1;
     float* ws = a.ws + (size_t)b * WS_STRIDE;
     if constexpr (STAGE == LS_OUT) {            // r = h + out_proj(y)
-        if (tid < D) vin[tid] = to_float(reinterpret_cast<const T*>(a.y)[((size_t)b * D + tid) * a.Lp + t]);
+        if (tid < D) {
+            float yv = to_float(reinterpret_cast<const T*>(a.y)[((size_t)b * D + tid) * a.Lp + t]);
+            if (a.ylo) yv += __builtin_amdgcn_cvt_f32_bf8((int)a.ylo[((size_t)b * D + tid) * a.Lp + t], 0) * LO2_INV;   // (fp16c: hi + lo)
+            vin[tid] = yv;
+        }
         __syncthreads();
         const float4 x[1] = {*reinterpret_cast<const float4*>(vin + 4 * lane)};
         // incoming residual row: block 0 of the id path reads the embedding table, else the residual stream
@@ -123,8 +127,16 @@ __global__ __launch_bounds__(LT_THREADS) void lone_stage_kernel(LoneTokenArgs a)
                 zf[q] = fmaf(f.z, vin[q * LT_ROWS + tid], fmaf(f.y, hist.y, fmaf(f.x, hist.x, f.w)));
             }
             T* z = reinterpret_cast<T*>(a.n_z) + (size_t)b * D3 * a.Lp + t;
+            const float gv = zf[1] * zf[2];
             z[(size_t)c * a.Lp] = from_float<T>(zf[0]);
-            z[(size_t)(D + c) * a.Lp] = from_float<T>(zf[1] * zf[2]);
+            z[(size_t)(D + c) * a.Lp] = from_float<T>(gv);
+            if (a.zlo) {                                    // fp16c: the lo bytes of x0f | g, rows 512.. of z as [2][256][Lp] bytes
+                unsigned char* zl = reinterpret_cast<unsigned char*>(reinterpret_cast<T*>(a.n_z) + ((size_t)b * D3 + 2 * D) * a.Lp) + t;
+                u16x4 hb;
+                const unsigned l = lo8_pack4(zf[0], gv, 0.f, 0.f, hb);
+                zl[(size_t)c * a.Lp] = (unsigned char)(l & 0xffu);
+                zl[(size_t)(D + c) * a.Lp] = (unsigned char)((l >> 8) & 0xffu);
+            }
         }
     } else if constexpr (STAGE == LS_ATT) {     // ln_f; attention.0 + GELU(erf) -> ws.u[0..255]; ln_f row = this token's pooling vector
         const float4 x[1] = {layer_norm_quad(ws + WS_H, a.n_g, a.n_b, a.eps, lane)};

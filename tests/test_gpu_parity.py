@@ -362,28 +362,6 @@ def test_lone_last_token_is_peeled_off_the_tile_kernels(sd, built_lib, monkeypat
     e0.close(), e1.close()
 
 
-@pytest.mark.parametrize("prec,B,L", [("fp32", 3, 8193), ("fp16c", 3, 8193), ("fp16", 5, 6000), ("fp16c", 2, 4098)])
-def test_split_transform_convolution_kernel(sd, built_lib, monkeypatch, prec, B, L):
-    """CLM_SPLIT_CONV=1: reads of 4098..8193 tokens through hyena_conv_eo_kernel (the 16384-point convolution as two 8192-point
-    problems run by the two halves of the workgroup).  Measured slower than the one-shot kernel and off by default; kept
-    correct: oracle parity, and agreement with the default kernel to fp32 rounding of the two transform orders."""
-    from chimeralm_amd.engine import Engine
-
-    ids = _ids(B, L, seed=71, pads=3)
-    t = torch.from_numpy(ids).cuda()
-    monkeypatch.setenv("CLM_RAW_Z", "1")                 # the split kernel reads the raw x0 | x1 | v rows: compare like with like
-    e0 = Engine("cuda:0", precision=prec, chunk_reads=4)
-    monkeypatch.setenv("CLM_SPLIT_CONV", "1")
-    e1 = Engine("cuda:0", precision=prec, chunk_reads=4)
-    monkeypatch.delenv("CLM_SPLIT_CONV")
-    monkeypatch.delenv("CLM_RAW_Z")
-    e0.load_state_dict(sd), e1.load_state_dict(sd)
-    a, b = e0.forward(t).cpu(), e1.forward(t).cpu()
-    assert (a - b).abs().max() < (2e-5 if prec == "fp32" else 3e-4)
-    _check(e1, prec, ids, sd)
-    e0.close(), e1.close()
-
-
 @pytest.mark.parametrize("prec,B,L,env", [("fp16c", 5, 8193, "CLM_CONV_ONESHOT"), ("fp16c", 3, 6000, "CLM_CONV_ONESHOT"),
                                           ("bf16", 4, 4098, "CLM_CONV_ONESHOT"), ("fp16c", 5, 8193, "CLM_CONV_NO_XCD"),
                                           ("fp16c", 3, 20000, "CLM_CONV_NO_XCD")])
@@ -448,34 +426,6 @@ def test_long_reads_segmented_convolution(engines, sd, prec, B, L):
     """L > 8193: partitioned convolution over 8192-token segments (2 and 3 segments, odd batch, a last segment of 1, 2 and 8 tokens;
     lengths S*8192 + 1 take the dot-product path for the lone last token: 16385 in fp32, 24577 in fp16 with an odd batch)."""
     _check(engines[prec], prec, _ids(B, L, seed=21, pads=5), sd)
-
-
-@pytest.mark.parametrize("prec,B,L", [("fp16c", 3, 20000), ("fp16c", 2, 16385), ("fp16c", 2, 32769), ("fp16", 3, 9000),
-                                      ("fp16c", 1, 24577), ("bf16", 2, 16384)])
-def test_long_reads_16k_segments_equal_8k_segments(sd, built_lib, monkeypatch, prec, B, L):
-    """Round 3, CLM_SEG16=1: blocks 1..3 of reads beyond 8,193 tokens through hyena_conv_seg16_kernel -- segments of 16,384
-    tokens, each a 32,768-point convolution computed as two 16,384-point problems over the even and the odd bins, one after the
-    other in the one LDS buffer (one spectral product per unit at 32k where the 8,192-token segments need six).  MEASURED SLOWER
-    than the 8,192-token-segment kernel (2.18 vs 1.90 ms per 32 x 32,769 launch: four un-pruned transforms per 16k tokens against
-    four pruned ones, and the segmented kernel is not traffic-bound) and off by default; kept correct: the same operator by
-    another transform -- logits agree with the default kernel to fp32-rounding-level differences in y that flip a few 16-bit
-    roundings -- and it stands against the oracle.  One segment (9,000 / 16,384 / 16,385 tokens) and two (20,000 / 24,577 /
-    32,769), the dot-product tail (16,385, 32,769), a lone read, odd batches."""
-    from chimeralm_amd.engine import Engine
-
-    ids = _ids(B, L, seed=141, pads=5)
-    t = torch.from_numpy(ids).cuda()
-    monkeypatch.setenv("CLM_SEG16", "1")
-    e0 = Engine("cuda:0", precision=prec, chunk_reads=4)
-    monkeypatch.delenv("CLM_SEG16")
-    e1 = Engine("cuda:0", precision=prec, chunk_reads=4)
-    e0.load_state_dict(sd), e1.load_state_dict(sd)
-    a, b = e0.forward(t).cpu(), e1.forward(t).cpu()
-    assert torch.equal(a, e0.forward(t).cpu())                  # deterministic
-    assert (a - b).abs().max() < 0.4 * TOL[prec]
-    ea = _check(e0, prec, ids, sd)
-    print(f"{prec} {B} x {L}: |16k segments - oracle| {ea:.2e}  |16k - 8k segments| {(a - b).abs().max():.2e}")
-    e0.close(), e1.close()
 
 
 def test_maximum_length_reads(engines, sd):

@@ -41,7 +41,6 @@ def test_hot_kernels_have_no_scratch_in_their_loops():
         (r"hyena_conv_kernelILi13ENS_5f16_tELb0ELb0E", 0),       # 4k reads
         (r"hyena_conv_seg_kernelINS_5f16_tELb1ELb0E", 64),       # long reads (was 324 before the buffer addressing)
         (r"hyena_conv_seg_kernelINS_5f16_tELb0ELb0E", 0),
-        (r"hyena_conv_seg16_kernelINS_5f16_tE", 96),              # opt-in 16k segments (CLM_SEG16=1): 40 / 84 (was 1024 at first)
         (r"enc_ffn16_kernelILi[123]E", 0),                        # transformer layer kernel, all three 16-bit modes
         (r"conv3_relu_pool_kernelILi[123]E", 0),
         (r"attention_fwd_kernelILi2ELb[01]E", 0),                 # fp16 attention, one plane and hi + lo planes

@@ -1,6 +1,7 @@
 #!/bin/bash
 # Build a variant of the engine library with extra compiler flags (timing-only experiments, A/B candidates):
 #   tools/build_variant.sh NAME [-DFLAG ...]   ->  chimeralm_amd/csrc/libclm_NAME.so   (run with CLM_LIB=<that path>, tools/ab.sh)
+# Timing-only switches live in chimeralm_amd/csrc/clm_lab.h and need -DCLM_LAB next to the switch: e.g. `-DCLM_LAB -DCLM_EXP_NOLN`.
 set -e
 R=$(cd "$(dirname "$0")/.." && pwd); C=$R/chimeralm_amd/csrc; name=$1; shift
 T=$(mktemp -d)
