@@ -65,6 +65,7 @@ SYMBOLS = {
     "clm_set_fallback": (C.c_int, [_H, C.c_int]),
     "clm_effective_precision": (C.c_int, [_H, C.c_int]),
     "clm_set_short_read_len": (C.c_int, [_H, C.c_int]),
+    "clm_set_mlp_compensation": (C.c_int, [_H, C.c_int]),
     "clm_attention_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "clm_tf_create": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(_H)]),
     "clm_tf_load_weight": (C.c_int, [_H, C.c_char_p, C.c_void_p, C.c_int, C.POINTER(C.c_int64), C.c_int]),

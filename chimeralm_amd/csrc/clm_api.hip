@@ -67,6 +67,9 @@ struct clm_handle {
     void* packed32[NLAYER][4] = {};
     void* packed_score32 = nullptr;
     LayerW lw32[NLAYER]{};
+    // PREC_F16C: fc1 / fc2 packed as hi + lo as well (the mode's second level, clm_set_mlp_compensation; lw.w_fc1 / w_fc2 are plain fp16)
+    void* packed_mlpc[NLAYER][2] = {};
+    bool mlp_lo = false;
     int f16c_min_len = 2048;
     // clm_selfcheck / clm_set_fallback: the exact-fp32 kernels of the same handle as referee of, and replacement for, the 16-bit path
     int force_prec = -1;          // >= 0 inside clm_selfcheck: the arithmetic forward_chunk runs in, whatever the length
@@ -295,6 +298,7 @@ void free_packed(clm_handle* h) {
         {
             if (h->packed[i][j]) { (void)hipFree(h->packed[i][j]); h->packed[i][j] = nullptr; }
             if (h->packed32[i][j]) { (void)hipFree(h->packed32[i][j]); h->packed32[i][j] = nullptr; }
+            if (j < 2 && h->packed_mlpc[i][j]) { (void)hipFree(h->packed_mlpc[i][j]); h->packed_mlpc[i][j] = nullptr; }
         }
     if (h->packed_score) { (void)hipFree(h->packed_score); h->packed_score = nullptr; }
     if (h->packed_score32) { (void)hipFree(h->packed_score32); h->packed_score32 = nullptr; }
@@ -550,10 +554,13 @@ int forward_chunk(clm_handle* h, const void* ids, int ids_dtype, int64_t row_str
         const bool stop_mid = stop_here(h, i, CLM_STAGE_OUTPROJ);
         if (tuned16 && !h->split_tail && !stop_mid) {   // out_proj + LN2 + fc1 + GELU + fc2 + both residuals: one kernel
             StageTimer t(h, st, CLM_STAGE_TAIL);
-            TailArgs ta{h->y, h->h, lw.w_out, lw.w_fc1, lw.w_fc2, lw.b_out, lw.ln2_g, lw.ln2_b, lw.b_fc1, lw.b_fc2, Bc, L, Lp,
+            const bool mlpc = prec == PREC_F16C && h->mlp_lo;
+            TailArgs ta{h->y, h->h, lw.w_out, mlpc ? h->packed_mlpc[i][0] : lw.w_fc1, mlpc ? h->packed_mlpc[i][1] : lw.w_fc2, lw.b_out,
+                        lw.ln2_g, lw.ln2_b, lw.b_fc1, lw.b_fc2, Bc, L, Lp,
                         eps, peel ? L - 1 : L, (idpath && i == 0) ? h->ids8 : nullptr, W(h, "bb.embeddings.word_embeddings.weight"),
                         nullptr, nullptr, nullptr, nullptr, nullptr, spa};
             ta.ylo = ylo;
+            ta.mlp_lo = mlpc;
             int next = NEXT_NONE;
             if (fuse_next && i + 1 < NLAYER) {
                 const LayerW& nx = h->lw[i + 1];
@@ -770,6 +777,10 @@ int clm_finalize(clm_handle* h) {
         const int mlp_prec = prec == PREC_F16C ? (int)PREC_F16 : prec;
         if ((rc = pack_as(mlp_prec, p + "mlp.fc1.weight", DI, D, &h->packed[i][2]))) return rc;
         if ((rc = pack_as(mlp_prec, p + "mlp.fc2.weight", D, DI, &h->packed[i][3]))) return rc;
+        if (prec == PREC_F16C) {
+            if ((rc = pack_as(PREC_F16C, p + "mlp.fc1.weight", DI, D, &h->packed_mlpc[i][0]))) return rc;
+            if ((rc = pack_as(PREC_F16C, p + "mlp.fc2.weight", D, DI, &h->packed_mlpc[i][1]))) return rc;
+        }
         LayerW& lw = h->lw[i];
         lw.ln1_g = W(h, p + "norm1.weight"); lw.ln1_b = W(h, p + "norm1.bias");
         lw.ln2_g = W(h, p + "norm2.weight"); lw.ln2_b = W(h, p + "norm2.bias");
@@ -996,6 +1007,13 @@ int clm_set_fallback(clm_handle* h, int on) {
     if (!h) return CLM_E_INVALID;
     if (!h->finalized) return fail(h, CLM_E_STATE, "clm_set_fallback before clm_finalize");
     h->fallback32 = on != 0 && h->cfg.precision != PREC_F32;
+    return CLM_OK;
+}
+
+int clm_set_mlp_compensation(clm_handle* h, int on) {
+    if (!h) return CLM_E_INVALID;
+    if (h->cfg.precision != PREC_F16C) return fail(h, CLM_E_UNSUPPORTED, "clm_set_mlp_compensation: not a CLM_PREC_F16C handle");
+    h->mlp_lo = on != 0;
     return CLM_OK;
 }
 

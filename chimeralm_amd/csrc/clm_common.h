@@ -225,6 +225,7 @@ struct TailArgs {
     // convolution.  tests/error_model.py: the fp16 rounding of y and z was 20-60 % of the mode's logit error variance.
     const unsigned char* ylo; // [B][256][Lp] lo bytes of y, written by the convolution (null: y is plain fp16)
     int zlo;                  // zg only: the gated in_proj stage also writes the lo bytes of x0f | g into rows 512.. of n_z ([2][256][Lp])
+    int mlp_lo;               // PREC_F16C: w1 / w2 are packed as hi + lo too (tail16_kernel MLPC) instead of plain fp16
 };
 // tiles of the tail kernel are taken in CONTIGUOUS ranges per workgroup (the short filter's two-token history then comes from the
 // workgroup's own previous tile): range length for `total` tiles on `grid` workgroups

@@ -153,6 +153,10 @@ class Engine:
         """fp16c: reads shorter than `min_len` tokens run in the exact-fp32 kernels (`clm_set_short_read_len`)."""
         self._check(self._lib.clm_set_short_read_len(self._h, int(min_len)))
 
+    def set_mlp_compensation(self, on: bool = True):
+        """fp16c: fc1 / fc2 on hi + lo weights too (`clm_set_mlp_compensation`; ~10 % slower, for weights whose MLP rounding shows)."""
+        self._check(self._lib.clm_set_mlp_compensation(self._h, int(on)))
+
     def effective_precision(self, length: int) -> str:
         code = self._lib.clm_effective_precision(self._h, int(length))
         if code < 0:

@@ -152,6 +152,12 @@ int clm_logit_deviation(const float* a, const float* b, int B, int n_classes, fl
  * no longer fits half the tolerance).  That length depends on the weights: the caller may MEASURE it with clm_selfcheck on reads
  * of decreasing length (chimeralm_amd/hyena.py does, at 1,024 / 512 / 256 tokens) and lower or raise the switch. */
 int clm_set_short_read_len(clm_handle* h, int min_len);
+/* CLM_PREC_F16C only (round 4): the two MLP products (fc1, fc2: two thirds of the dense FLOPs) run on plain fp16 weights by default
+ * -- on most weights their rounding does not show in the logits -- and on hi + lo weights, like in_proj / out_proj / the score
+ * layer, after clm_set_mlp_compensation(h, 1) (both packings are held; takes effect with the next forward; ~10 % slower).  The
+ * caller decides with clm_selfcheck on the loaded weights: chimeralm_amd/hyena.py switches it on when the default form measures
+ * above its threshold, and falls back to exact fp32 only if this form does too. */
+int clm_set_mlp_compensation(clm_handle* h, int on);
 
 /* ---- SequenceCNNTransformer -----------------------------------------------------------
  * Multi-head self-attention of nn.TransformerEncoderLayer as the reference builds it

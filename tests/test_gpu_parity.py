@@ -437,17 +437,20 @@ def test_maximum_length_reads(engines, sd):
     _check(engines["fp16"], "fp16", ids, sd, ref=ref)
 
 
-@pytest.mark.parametrize("prec,B,chunk", [("fp16c", 256, 256), ("fp16c", 256, 64), ("fp16c", 32, 256), ("fp16", 256, 64)])
-def test_baseline_batch_size_independent_properties(sd, built_lib, prec, B, chunk):
+@pytest.mark.parametrize("prec,B,chunk,L", [("fp16c", 256, 256, 8193), ("fp16c", 256, 64, 8193), ("fp16c", 32, 256, 8193),
+                                            ("fp16", 256, 64, 8193), ("fp16c", 4, 256, 32769), ("fp16c", 32, 256, 32769)])
+def test_baseline_batch_size_independent_properties(sd, built_lib, prec, B, chunk, L):
     """BASELINE.json's bench configurations AT SIZE and in the benched mode: 256 reads of 8192 bases + [SEP] as ONE chunk (the
     default since round 3: 32,768 convolution units per launch through the persistent XCD-ordered loop, 16,384 tail tiles, z alone
     3.2 GB) and in 64-read chunks (C3 as benched in round 2), and the 32-read shard a GPU gets in the 8-GPU run (C4).  The oracle is too slow for the whole batch; reads are independent units, so (a) two runs
     are bit-identical, (b) reversing the batch reverses the logits (each read gets another pair partner in the packed FFT:
     equal up to rounding, not bitwise), (c) reads computed alone equal their rows of the full batch, (d) a sample of rows
-    matches the oracle at the mode's bound (fp16c: GATE), (e) fp16c: the exact-fp32 kernels agree on a sample (clm_selfcheck)."""
+    matches the oracle at the mode's bound (fp16c: GATE), (e) fp16c: the exact-fp32 kernels agree on a sample (clm_selfcheck).
+    Round 4 (VERDICT r03 missing #6): C5 at ITS sizes too -- 32 reads of 32,768 bases + [SEP] (segmented convolution with the
+    dot-product tail, token-capped chunks of 64 reads) and the 4-read shard a GPU gets in the 8-GPU run; two oracle rows there."""
     from chimeralm_amd.engine import Engine
 
-    ids = _ids(B, 8193, seed=41)
+    ids = _ids(B, L, seed=41)
     t = torch.from_numpy(ids).cuda()
     e = Engine("cuda:0", precision=prec, chunk_reads=chunk)
     e.load_state_dict(sd)
@@ -456,15 +459,18 @@ def test_baseline_batch_size_independent_properties(sd, built_lib, prec, B, chun
     assert torch.equal(a, e.forward(t).cpu())                                   # (a)
     r = e.forward(torch.flip(t, dims=[0]).contiguous()).cpu()
     assert (torch.flip(r, dims=[0]) - a).abs().max() < 0.5 * TOL[prec]           # (b)
-    pick = [0, B // 4 - 1, B // 4, B - B // 5, B - 1]
+    pick = sorted({0, max(B // 4 - 1, 0), B // 4, B - max(B // 5, 1), B - 1})
     solo = e.forward(t[pick].contiguous()).cpu()
     assert (solo - a[pick]).abs().max() < 0.5 * TOL[prec]                        # (c)
-    ref = ho.forward(torch.from_numpy(ids[pick[:3]].astype(np.int64)), sd)       # (d)
-    assert (a[pick[:3]] - ref).abs().max() <= TOL[prec]
+    n_ref = 3 if L <= 8193 else 2                                                # (the oracle takes ~10 s per 32k-token read)
+    ref = ho.forward(torch.from_numpy(ids[pick[:n_ref]].astype(np.int64)), sd)   # (d)
+    err = (a[pick[:n_ref]] - ref).abs().max()
+    print(f"{prec} {B} x {L} (chunk {chunk}): |logits - oracle| on rows {pick[:n_ref]} = {err:.2e}")
+    assert err <= TOL[prec]
     decided = (ref[:, 0] - ref[:, 1]).abs() > MARGIN[prec]
-    assert torch.equal(a[pick[:3]].argmax(1)[decided], ref.argmax(1)[decided])
+    assert torch.equal(a[pick[:n_ref]].argmax(1)[decided], ref.argmax(1)[decided])
     if prec == "fp16c":                                                          # (e)
-        diff, _ = e.selfcheck(t[B - 8:].contiguous())
+        diff, _ = e.selfcheck(t[max(B - 8, 0):].contiguous())
         assert 0 < diff <= GATE
     e.close()
 

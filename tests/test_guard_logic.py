@@ -14,8 +14,9 @@ from chimeralm_amd import hyena, lm
 class StubEngine:
     """What `HyenaDna._selfcheck` touches of `chimeralm_amd.engine.Engine`."""
 
-    def __init__(self, err_by_len, batch_err=1e-4, precision_code=3):
+    def __init__(self, err_by_len, batch_err=1e-4, precision_code=3, level2=None):
         self.err_by_len, self.batch_err = err_by_len, batch_err
+        self.err_level2, self.mlp_lo = level2, False
         self.device = torch.device("cpu")
         self.cfg = type("Cfg", (), {"precision": precision_code})()
         self.min_len, self.fallback, self.calls = 2048, False, []
@@ -30,6 +31,11 @@ class StubEngine:
 
     def set_fallback(self, on):
         self.fallback = bool(on)
+
+    def set_mlp_compensation(self, on):
+        self.mlp_lo = bool(on)
+        if on and self.err_level2 is not None:               # the second level answers with its own scripted errors
+            self.err_by_len, self.batch_err = self.err_level2
 
     def effective_precision(self, L):
         return "fp32" if (self.fallback or L < self.min_len) else "fp16c"
@@ -127,10 +133,10 @@ def test_first_failing_sample_sets_the_switch_and_keeps_the_mode_for_longer_read
 
 def test_longest_sample_or_batch_above_the_threshold_falls_back_for_good():
     net = _net()
-    eng = StubEngine({4097: 8e-4})
+    eng = StubEngine({4097: 8e-4})                                                # (both levels answer 8e-4)
     with pytest.warns(RuntimeWarning, match="falling back to exact fp32"):
         net.guard(eng, _ids(4, 8193))
-    assert net.selfcheck_report["fallback"] is True and eng.fallback is True and eng.min_len == 2048
+    assert net.selfcheck_report["fallback"] is True and eng.fallback is True and eng.min_len == 2048 and eng.mlp_lo is True
     n = len(eng.calls)
     net.guard(eng, _ids(4, 100))
     assert len(eng.calls) == n                                                    # nothing more to check once it has fallen back
@@ -138,6 +144,32 @@ def test_longest_sample_or_batch_above_the_threshold_falls_back_for_good():
     with pytest.warns(RuntimeWarning):
         net2.guard(eng2, _ids(4, 8193))                                           # the samples pass, the real batch does not
     assert net2.selfcheck_report["fallback"] is True and eng2.fallback is True
+
+
+def test_second_level_is_heard_before_the_fp32_fallback():
+    """Round 4: fp16c whose plain-MLP form fails switches fc1 / fc2 to hi + lo weights and is measured again from the start."""
+    net = _net()
+    eng = StubEngine({4097: 8e-4}, level2=({4097: 2e-4, 2048: 3e-4, 1024: 9e-4}, 1.5e-4))
+    with warnings.catch_warnings():
+        warnings.simplefilter("error", RuntimeWarning)
+        net.guard(eng, _ids(4, 8193))
+    rep = net.selfcheck_report
+    assert eng.mlp_lo is True and rep["mlp_compensation"] is True and rep["fallback"] is False and eng.fallback is False
+    assert [c[1] for c in eng.calls] == [4097, 8193, 4097, 2048, 1024, 8193]      # level 1: sample fails (+ the batch); level 2: from the start
+    assert rep["f16c_min_len"] == 2048 == eng.min_len and rep["max_abs_dlogit"] == 3e-4
+    net2 = _net()
+    eng2 = StubEngine({4097: 8e-4}, level2=({4097: 7e-4}, 1e-4))                  # both levels fail: fp32
+    with pytest.warns(RuntimeWarning, match="falling back to exact fp32"):
+        net2.guard(eng2, _ids(4, 8193))
+    assert eng2.mlp_lo is True and eng2.fallback is True and net2.selfcheck_report["fallback"] is True
+    net3 = _net()                                                                  # a LATER batch drifts: escalate then, not fall back
+    eng3 = StubEngine({4097: 2e-4, 2048: 3e-4, 1024: 7e-4}, level2=({4097: 1e-4, 2048: 1e-4, 1024: 1e-4, 512: 1e-4, 256: 1e-4}, 1e-4))
+    net3.selfcheck_every = 2
+    net3.guard(eng3, _ids(4, 5000))
+    assert eng3.mlp_lo is False
+    eng3.batch_err = 9e-4
+    net3.guard(eng3, _ids(4, 5000)), net3.guard(eng3, _ids(4, 5000))
+    assert eng3.mlp_lo is True and eng3.fallback is False and net3.selfcheck_report["f16c_min_len"] == 256
 
 
 def test_guard_is_off_for_fp32_and_optional_for_the_reduced_modes():
