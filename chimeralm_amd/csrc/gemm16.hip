@@ -200,25 +200,17 @@ __device__ __forceinline__ void zg_fir_inplace(f32x16 (&a)[4], const float4 f, f
 }
 
 // the wave's 128 tokens x 32 channels in `a` -> 16-bit -> row `row0 + lrow` of z (through the wave-private staging tile)
-// LO (fp16c, round 4): the values' lo bytes (lo8_pack4) follow through the SAME staging tile once the halfs have left it (LDS
-// operations of one wave execute in order) into row `row0 + lrow` of the lo planes in rows 512.. of z ([2][256][Lp] bytes).
-template <int PREC, bool LO = false>
+template <int PREC>
 __device__ __forceinline__ void zg_store_rows(const f32x16 (&a)[4], typename CT<PREC>::elem* zs, void* zout, int b, int row0,
                                               int t0, int Lp, int lane) {
     using elem = typename CT<PREC>::elem;
     const int lrow = lane & 31, lhalf = lane >> 5;
-    unsigned lo4[LO ? 16 : 1];
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            u16x4 pk;
-            if constexpr (LO) {
-                lo4[4 * mt + q] = lo8_pack4(a[mt][4 * q + 0], a[mt][4 * q + 1], a[mt][4 * q + 2], a[mt][4 * q + 3], pk);
-            } else {
-                pk = u16x4{to_bits<PREC>(a[mt][4 * q + 0]), to_bits<PREC>(a[mt][4 * q + 1]), to_bits<PREC>(a[mt][4 * q + 2]),
-                           to_bits<PREC>(a[mt][4 * q + 3])};
-            }
+            u16x4 pk = {to_bits<PREC>(a[mt][4 * q + 0]), to_bits<PREC>(a[mt][4 * q + 1]), to_bits<PREC>(a[mt][4 * q + 2]),
+                        to_bits<PREC>(a[mt][4 * q + 3])};
             *reinterpret_cast<u16x4*>(zs + lrow * RSOUT + mt * 32 + 8 * q + 4 * lhalf) = pk;
         }
     __builtin_amdgcn_sched_barrier(0);
@@ -232,27 +224,6 @@ __device__ __forceinline__ void zg_store_rows(const f32x16 (&a)[4], typename CT<
         if (in_row && (!lab::NOZSTORE || v.x == 0x12345678u)) *reinterpret_cast<uint4*>(zg + (size_t)row * Lp + col8) = v;
     }
     __builtin_amdgcn_sched_barrier(0);
-    if constexpr (LO) {
-        constexpr int RS8 = 144;                            // bytes per staged lo row: 128 + 16 (16-byte aligned rows)
-        unsigned char* z8 = reinterpret_cast<unsigned char*>(zs);
-        static_assert(32 * RS8 <= 32 * RSOUT * (int)sizeof(elem), "the lo rows fit the staging tile");
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) *reinterpret_cast<unsigned*>(z8 + lrow * RS8 + mt * 32 + 8 * q + 4 * lhalf) = lo4[4 * mt + q];
-        __builtin_amdgcn_sched_barrier(0);
-        // rows 512.. of the read's z block: [2][256][Lp] bytes; row0 < 256: x0f (plane 0), row0 >= 256: g (plane 1) -- i.e. byte row row0
-        unsigned char* zl = reinterpret_cast<unsigned char*>(reinterpret_cast<elem*>(zout) + ((size_t)b * D3 + 2 * D) * Lp) + (size_t)row0 * Lp + t0;
-        const int col16 = (lane & 7) * 16;
-        const bool in_row8 = t0 + col16 < Lp;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int row = i * 8 + (lane >> 3);
-            const uint4 v = *reinterpret_cast<const uint4*>(z8 + row * RS8 + col16);
-            if (in_row8) *reinterpret_cast<uint4*>(zl + (size_t)row * Lp + col16) = v;
-        }
-        __builtin_amdgcn_sched_barrier(0);
-    }
 }
 
 template <int PREC, typename Hook>
@@ -318,11 +289,211 @@ __device__ __forceinline__ void inproj_blocks_gated(const typename CT<PREC>::ele
                 accv[2 + (k >> 2)][4 * (k & 3) + 3] *= x.w;
             }
             asm volatile("" ::: "memory");
-            zg_store_rows<PREC, PREC == PREC_F16C>(accv, zs, m.n_z, b, 256 + wave * 32, t0, m.Lp, lane);
+            zg_store_rows<PREC>(accv, zs, m.n_z, b, 256 + wave * 32, t0, m.Lp, lane);
         } else {
-            zg_store_rows<PREC, PREC == PREC_F16C>(accx, zs, m.n_z, b, wave * 32, t0, m.Lp, lane);
+            zg_store_rows<PREC>(accx, zs, m.n_z, b, wave * 32, t0, m.Lp, lane);
         }
     });
+}
+
+// ---- fp16c (round 4): the gated in_proj stage with the LayerNorm-1 tile as hi + lo bytes and z leaving as hi + lo -------------------
+// `Al` = the lo tile of the LayerNorm-1 output (ln_acc_to_tile<.., LO>): every product gets the activations' lo term (compute_tm
+// LO2: 16 more live registers).  The v block therefore runs in TWO 64-token halves -- x1f stays whole in its accumulator (no
+// stash in LDS: the lo tile took that space), v's accumulator is 32 registers at a time, and v's weights stream twice (+1/13 of a
+// tile's weight bytes).  Each half of g leaves as soon as it exists: halfs through the wave's staging tile as whole 128-byte lines
+// per channel row, then the values' lo bytes (lo8_pack4) through the same tile (LDS operations of one wave execute in order)
+// into the lo planes in rows 512.. of z ([2][256][Lp] bytes: byte row c = x0f, 256 + c = g).
+constexpr int ZG_WAVE_BYTES = 4608;                       // wave tile of the LO form: 32 rows x (64 halfs + 8)
+
+// short filter on the row tiles [MT0, MT0 + NMT): p2 / p3 = raw tokens -2, -1 of the range on entry, of the NEXT range on return
+template <int MT0, int NMT>
+__device__ __forceinline__ void zg_fir_range(f32x16 (&a)[4], const float4 f, float& p2, float& p3, int lane) {
+    const int lhalf = lane >> 5, paddr = (lane ^ 32) << 2;
+    constexpr int NP = 4 * NMT;
+    float e2[NP], e3[NP];
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+        const float s2 = a[MT0 + (i >> 2)][4 * (i & 3) + 2], s3 = a[MT0 + (i >> 2)][4 * (i & 3) + 3];   // (scalars first: see zg_fir_inplace)
+        e2[i] = __int_as_float(__builtin_amdgcn_ds_bpermute(paddr, __float_as_int(s2)));
+        e3[i] = __int_as_float(__builtin_amdgcn_ds_bpermute(paddr, __float_as_int(s3)));
+    }
+    float r2[NP], r3[NP];
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+        r2[i] = lhalf ? e2[i] : (i ? e2[i ? i - 1 : 0] : p2);
+        r3[i] = lhalf ? e3[i] : (i ? e3[i ? i - 1 : 0] : p3);
+    }
+    p2 = e2[NP - 1], p3 = e3[NP - 1];                        // (what the lhalf = 0 lanes of the next range need; unused by the others)
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+        const int mt = MT0 + (i >> 2), q = 4 * (i & 3);
+        const float z0 = a[mt][q], z1 = a[mt][q + 1], z2 = a[mt][q + 2], z3 = a[mt][q + 3];
+        a[mt][q + 0] = fmaf(f.z, z0, fmaf(f.y, r3[i], fmaf(f.x, r2[i], f.w)));
+        a[mt][q + 1] = fmaf(f.z, z1, fmaf(f.y, z0, fmaf(f.x, r3[i], f.w)));
+        a[mt][q + 2] = fmaf(f.z, z2, fmaf(f.y, z1, fmaf(f.x, z0, f.w)));
+        a[mt][q + 3] = fmaf(f.z, z3, fmaf(f.y, z2, fmaf(f.x, z1, f.w)));
+    }
+}
+
+// tokens [64 hf, 64 hf + 64) of the wave's 32 channels: halfs to byte-row-free z row `row0 + lrow`, lo bytes to lo-plane row `row0 + lrow`
+template <int HF>
+__device__ __forceinline__ void zg_store_half(const f32x16 (&a)[4], f16_t* zs, void* zout, int b, int row0, int t0, int Lp, int lane_in) {
+    constexpr int RSH = 72, RS8 = 80;                        // staged rows: 64 halfs + 8; 64 lo bytes + 16 (16-byte aligned rows)
+    static_assert(32 * RSH * 2 <= ZG_WAVE_BYTES && 32 * RS8 <= ZG_WAVE_BYTES, "both stagings fit the wave's tile");
+    // (an opaque copy of the lane per call: the four calls of a tile share most of their address terms, and shared terms are
+    //  computed once, early, and SPILLED across the MFMA phases in between -- ten dwords per tile before this line)
+    int lane = lane_in;
+    asm volatile("" : "+v"(lane));
+    const int lrow = lane & 31, lhalf = lane >> 5;
+    unsigned lo4[8];
+#pragma unroll
+    for (int m2 = 0; m2 < 2; ++m2)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int mt = 2 * HF + m2;
+            u16x4 pk;
+            lo4[4 * m2 + q] = lo8_pack4(a[mt][4 * q + 0], a[mt][4 * q + 1], a[mt][4 * q + 2], a[mt][4 * q + 3], pk);
+            *reinterpret_cast<u16x4*>(zs + lrow * RSH + m2 * 32 + 8 * q + 4 * lhalf) = pk;
+        }
+    __builtin_amdgcn_sched_barrier(0);
+    f16_t* zg = reinterpret_cast<f16_t*>(zout) + ((size_t)b * D3 + row0) * Lp + t0 + 64 * HF;
+    const bool in_row = t0 + 64 * HF < Lp;                   // Lp is a multiple of 64: the whole half in or out (uniform)
+    {
+        const int col8 = (lane & 7) * 8;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = i * 8 + (lane >> 3);
+            const uint4 v = *reinterpret_cast<const uint4*>(zs + row * RSH + col8);
+            if (in_row && (!lab::NOZSTORE || v.x == 0x12345678u)) *reinterpret_cast<uint4*>(zg + (size_t)row * Lp + col8) = v;
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    unsigned char* z8 = reinterpret_cast<unsigned char*>(zs);
+#pragma unroll
+    for (int m2 = 0; m2 < 2; ++m2)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) *reinterpret_cast<unsigned*>(z8 + lrow * RS8 + m2 * 32 + 8 * q + 4 * lhalf) = lo4[4 * m2 + q];
+    __builtin_amdgcn_sched_barrier(0);
+    unsigned char* zl = reinterpret_cast<unsigned char*>(reinterpret_cast<f16_t*>(zout) + ((size_t)b * D3 + 2 * D) * Lp) + (size_t)row0 * Lp + t0 + 64 * HF;
+    {
+        const int col16 = (lane & 3) * 16;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int row = i * 16 + (lane >> 2);
+            const uint4 v = *reinterpret_cast<const uint4*>(z8 + row * RS8 + col16);
+            if (in_row) *reinterpret_cast<uint4*>(zl + (size_t)row * Lp + col16) = v;
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+template <typename Hook>
+__device__ __forceinline__ void inproj_blocks_gated_lo(const f16_t* As, const unsigned char* Al, unsigned char* Zs, float* halo,
+                                                       const u16x8* wp, const TailArgs& m, const GatedTile gt, int b, int t0, int wave,
+                                                       int lane, u16x8 (&bs)[2][1][SETK], f32x16 (&accv)[4], f32x16 (&accx)[4],
+                                                       Hook hook) {
+    constexpr int PREC = PREC_F16C, K = D;
+    const int lrow = lane & 31, lhalf = lane >> 5;
+    f16_t* zs = reinterpret_cast<f16_t*>(Zs + wave * ZG_WAVE_BYTES);
+    float4 firq = make_float4(0.f, 0.f, 0.f, 0.f);
+    // raw-row bookkeeping of one block q: history of the tile's first tokens in, the tile's last / first raw tokens out
+    auto history = [&](int q, int c, float* hs, float& p2, float& p3) {
+        if (gt.fresh) {                                      // uniform; one tile in 16 .. 64
+            p2 = p3 = -m.n_bias[q * 256 + c];
+        } else {
+            const float2 hv2 = *reinterpret_cast<const float2*>(hs);
+            p2 = hv2.x, p3 = hv2.y;
+        }
+    };
+    auto leave_tail = [&](int q, int c, float* hs, const float2 tl) {       // raw tokens 126, 127
+        if (lhalf) *reinterpret_cast<float2*>(hs) = tl;      // (same wave, after the read in history(): LDS operations of a wave are in order)
+        if (gt.tail_bnd && lhalf) m.edge_bnd[((size_t)(gt.w + 1) * 2 + 0) * D3 + q * 256 + c] = tl;
+        if (gt.read_tail && lhalf) m.edge_read[(size_t)b * D3 + q * 256 + c] = tl;
+    };
+    auto leave_head = [&](int q, int c, const float2 hd) {                  // raw tokens 0, 1
+        if (gt.head_bnd && !lhalf) m.edge_bnd[((size_t)gt.w * 2 + 1) * D3 + q * 256 + c] = hd;
+    };
+    // ---- x1 (block 1), all four row tiles, stays in accx
+    {
+        constexpr int q = 1;
+        zero_acc(accx);
+        int lrow_e = lrow;                                   // opaque copy: addresses formed here, not kept across the MFMA phase
+        asm volatile("" : "+v"(lrow_e));
+        const int c = wave * 32 + lrow_e;
+        auto hook2 = [&](int step) {
+            if (step == 0) firq = m.n_fir[c * 3 + q];
+            hook(step);
+        };
+        phase_tm<PREC, K, K, false, false, decltype(hook2), PREC_SAME, true>(As, wp, q, 0, wp, 2, 0, wave, lane, bs, accx, hook2, 0, Al);
+        float* hs = halo + ((wave * 3 + q) * 32 + lrow_e) * 2;
+        float p2, p3;
+        history(q, c, hs, p2, p3);
+        leave_tail(q, c, hs, make_float2(accx[3][14], accx[3][15]));
+        leave_head(q, c, make_float2(accx[0][0], accx[0][1]));
+        if constexpr (!lab::NOFIR) zg_fir_inplace<PREC>(accx, firq, p2, p3, lane);
+        // x1f is COMPLETE here: left alone hipcc sinks the filter arithmetic of the upper row tiles to their first use, behind
+        // both halves of v, and carries the 16 lane-exchange results through those MFMA phases instead -- nine of them in scratch
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+            asm volatile("" : "+v"(accx[mt][0]), "+v"(accx[mt][1]), "+v"(accx[mt][2]), "+v"(accx[mt][3]), "+v"(accx[mt][4]), "+v"(accx[mt][5]),
+                              "+v"(accx[mt][6]), "+v"(accx[mt][7]), "+v"(accx[mt][8]), "+v"(accx[mt][9]), "+v"(accx[mt][10]),
+                              "+v"(accx[mt][11]), "+v"(accx[mt][12]), "+v"(accx[mt][13]), "+v"(accx[mt][14]), "+v"(accx[mt][15]));
+    }
+    // ---- v (block 2) in two halves of two row tiles: g = x1f * vf leaves half by half
+    {
+        constexpr int q = 2;
+        int lrow_e = lrow;
+        asm volatile("" : "+v"(lrow_e));
+        const int c = wave * 32 + lrow_e;
+        float* hs = halo + ((wave * 3 + q) * 32 + lrow_e) * 2;
+        float p2, p3;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) accv[0][r] = 0.f, accv[1][r] = 0.f;
+        auto hook2 = [&](int step) {
+            if (step == 2) firq = m.n_fir[c * 3 + q];
+            hook(step);
+        };
+        phase_tm<PREC, K, K, false, false, decltype(hook2), PREC_SAME, true, 0, 2>(As, wp, q, 0, wp, q, 0, wave, lane, bs, accv, hook2, 2, Al);
+        history(q, c, hs, p2, p3);
+        leave_head(q, c, make_float2(accv[0][0], accv[0][1]));
+        if constexpr (!lab::NOFIR) zg_fir_range<0, 2>(accv, firq, p2, p3, lane);
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) accv[mt][r] *= accx[mt][r];
+        zg_store_half<0>(accv, zs, m.n_z, b, 256 + wave * 32, t0, m.Lp, lane);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) accv[2][r] = 0.f, accv[3][r] = 0.f;
+        phase_tm<PREC, K, K, false, false, NoHook, PREC_SAME, true, 2, 2>(As, wp, q, 0, wp, 0, 0, wave, lane, bs, accv, NoHook(), 0, Al);
+        leave_tail(q, c, hs, make_float2(accv[3][14], accv[3][15]));
+        if constexpr (!lab::NOFIR) zg_fir_range<2, 2>(accv, firq, p2, p3, lane);
+#pragma unroll
+        for (int mt = 2; mt < 4; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) accv[mt][r] *= accx[mt][r];
+        zg_store_half<1>(accv, zs, m.n_z, b, 256 + wave * 32, t0, m.Lp, lane);
+    }
+    // ---- x0 (block 0), all four row tiles, in accx (x1f is dead)
+    {
+        constexpr int q = 0;
+        zero_acc(accx);
+        int lrow_e = lrow;
+        asm volatile("" : "+v"(lrow_e));
+        const int c = wave * 32 + lrow_e;
+        auto hook2 = [&](int step) {
+            if (step == 4) firq = m.n_fir[c * 3 + q];
+            hook(step);
+        };
+        phase_tm<PREC, K, K, false, false, decltype(hook2), PREC_SAME, true>(As, wp, q, 0, wp, ZG_ORDER[0], 0, wave, lane, bs, accx, hook2, 4, Al);
+        float* hs = halo + ((wave * 3 + q) * 32 + lrow_e) * 2;
+        float p2, p3;
+        history(q, c, hs, p2, p3);
+        leave_tail(q, c, hs, make_float2(accx[3][14], accx[3][15]));
+        leave_head(q, c, make_float2(accx[0][0], accx[0][1]));
+        if constexpr (!lab::NOFIR) zg_fir_inplace<PREC>(accx, firq, p2, p3, lane);
+        zg_store_half<0>(accx, zs, m.n_z, b, wave * 32, t0, m.Lp, lane);
+        zg_store_half<1>(accx, zs, m.n_z, b, wave * 32, t0, m.Lp, lane);
+    }
 }
 
 // Tokens 0, 1 of the first tile of every workgroup range that starts inside a read (inproj_blocks_gated computed them without
@@ -903,10 +1074,14 @@ __global__ __launch_bounds__(512) void tail16_kernel(TailArgs m, unsigned long l
         load_set<PREC, D, 1>(wn, ZG ? ZG_ORDER[0] : 0, 0, 1, wave, lane, bs[1]);
         __builtin_amdgcn_sched_barrier(0);
         // (the first barrier inside orders the staging reads above before the As writes)
-        // (fp16c, score variant: the ln_f tile as hi + lo -- the lo tile sits in the Hs region, behind the 8.5 KiB of P / E / V)
-        constexpr bool LOF = PREC == PREC_F16C && NEXT == NEXT_SCORE;
-        unsigned char* Alf = reinterpret_cast<unsigned char*>(Hs) + 16384;
+        // fp16c, round 4: the normalised tile as hi + lo bytes.  Score variant: the lo tile sits in the Hs region behind the 8.5 KiB
+        // of P / E / V.  Gated in_proj variant: at the head of the Hs region; the eight 6-KiB wave tiles of the stage (x1f stash,
+        // z staging) follow it, over the rest of Hs and the by then dead LayerNorm tables.
+        constexpr bool LOF = PREC == PREC_F16C && (NEXT == NEXT_SCORE || ZG);
+        unsigned char* Alf = reinterpret_cast<unsigned char*>(Hs) + (NEXT == NEXT_SCORE ? 16384 : 0);
         static_assert(16384 >= (8 * 128 + 128 + 4 * D) * 4 && 16384 + 128 * RSL <= 128 * RS16 * 2, "lo tile of ln_f fits the Hs region");
+        static_assert((size_t)128 * RSL + 8 * ZG_WAVE_BYTES <= (size_t)128 * RS16 * 2 + (size_t)2 * 16 * 128 * 4,
+                      "LayerNorm-1 lo tile + the gated stage's wave tiles fit Hs + the (by then dead) LayerNorm tables");
         ln_acc_to_tile<PREC, false, LOF>(acc2, P1, P2, NEXT == NEXT_SCORE ? m.sp.ln_g : m.n_g, NEXT == NEXT_SCORE ? m.sp.ln_b : m.n_b,
                                          m.eps, As, t0, L, wave, lrow, lhalf, Alf);
         CLM_STAMP_AT(19);
@@ -921,9 +1096,12 @@ __global__ __launch_bounds__(512) void tail16_kernel(TailArgs m, unsigned long l
                 const GatedTile gt{tile == tile_begin || tx == 0, tile == tile_begin && tx != 0,
                                    tile + 1 == tile_end && tile + 1 < total && (tile + 1) % tiles_x != 0,
                                    tx == tiles_x - 1 && m.edge_read != nullptr, (int)blockIdx.x};
-                inproj_blocks_gated<PREC>(As, Hs, Bt + BT_NB, wn, m, gt, b, t0, wave, lane, bs, acc1, acc2,
-                                          ResidHook<elem, PIECES>{m, hv, yx, nb_, nt0, wave, lrow, lhalf, tid,
-                                                                  STAMP ? stamps + (size_t)tile * TAIL_NSTAMP : nullptr});
+                const ResidHook<elem, PIECES> rhook{m, hv, yx, nb_, nt0, wave, lrow, lhalf, tid,
+                                                    STAMP ? stamps + (size_t)tile * TAIL_NSTAMP : nullptr};
+                if constexpr (PREC == PREC_F16C)
+                    inproj_blocks_gated_lo(As, Alf, Alf + 128 * RSL, Bt + BT_NB, wn, m, gt, b, t0, wave, lane, bs, acc1, acc2, rhook);
+                else
+                    inproj_blocks_gated<PREC>(As, Hs, Bt + BT_NB, wn, m, gt, b, t0, wave, lane, bs, acc1, acc2, rhook);
             } else
             inproj_blocks<PREC>(As, Hs, wn, Bt + BT_NB, m.n_z, b, t0, Lp, wave, lane, bs, acc1,
                                 ResidHook<elem, PIECES>{m, hv, yx, nb_, nt0, wave, lrow, lhalf, tid,

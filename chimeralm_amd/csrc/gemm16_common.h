@@ -34,10 +34,13 @@ __device__ __forceinline__ unsigned short to_bits(float v) {
 // ROWS_N: accumulator rows are output features (lane = token).  Compensated mode: the set holds (hi, lo) pairs and every
 // A fragment feeds two MFMAs -- half the LDS bytes per MFMA of the plain modes.
 // LO2 (fp16c only): the activations' lo tile `Al` (RSL, lo_pos) adds a third term per row tile and 64-deep group.
-template <int PREC, bool ROWS_N, int AHEAD = 4, bool LO2 = false>
+// MT0, NMT (fp16c only): the row tiles [MT0, MT0 + NMT) of the 128-token tile instead of all four (the gated in_proj stage runs its
+// v block in two 64-token halves: half the accumulator registers at a time).
+template <int PREC, bool ROWS_N, int AHEAD = 4, bool LO2 = false, int MT0 = 0, int NMT = 4>
 __device__ __forceinline__ void compute_tm(const typename CT<PREC>::elem* As, int part, int lrow, int lhalf,
                                            const u16x8 (&src)[1][SETK], f32x16 (&acc)[4], const unsigned char* Al = nullptr) {
     static_assert(!LO2 || PREC == PREC_F16C, "activation lo tiles exist in the compensated mode only");
+    static_assert((MT0 == 0 && NMT == 4) || PREC == PREC_F16C, "row-tile ranges are implemented for the compensated mode");
     // Explicitly software-pipelined over the 4*KPS (k-step, row tile) items: the A fragment of item i + AHEAD is requested
     // before the MFMA(s) of item i (ring of AHEAD + 1 fragments), and that order is pinned with sched_group_barrier.  Left to
     // itself hipcc serialises `ds_read -> s_waitcnt lgkmcnt(0) -> mfma` wherever registers are tight (fc1: both accumulators
@@ -51,6 +54,7 @@ __device__ __forceinline__ void compute_tm(const typename CT<PREC>::elem* As, in
         // per fragment: gemm_common.h frag_to_e5m2t), ONE K = 64 fp8 MFMA with the lo bytes -- half the cycles of the four fp16
         // lo MFMAs it replaces, 2.9e-6 instead of 8.3e-5 rms on a 64-deep product (tools/micro/mfma_fp8_lo.cpp).
         static_assert(KP == 4 && NI == 16, "a set is one 64-deep group");
+        constexpr int NIR = 4 * NMT;                          // items of this call: (row tile, k-step), row-tile major
         u16x8 afc[R];
         i32x8 a8 = {0, 0, 0, 0, 0, 0, 0, 0};          // the row tile's 32 e5m2 bytes, gathered fragment by fragment (frag_to_e5m2t)
         i32x8 w8;
@@ -71,14 +75,14 @@ __device__ __forceinline__ void compute_tm(const typename CT<PREC>::elem* As, in
             }
         }
 #pragma unroll
-        for (int i = 0; i < AHEAD; ++i) afc[i % R] = *reinterpret_cast<const u16x8*>(a0 + CLM_A_OFF((i >> 2) * 32 * RS16 + (i & 3) * 16));
+        for (int i = 0; i < AHEAD; ++i) afc[i % R] = *reinterpret_cast<const u16x8*>(a0 + CLM_A_OFF((MT0 + (i >> 2)) * 32 * RS16 + (i & 3) * 16));
 #pragma unroll
-        for (int i = 0; i < NI; ++i) {
-            if (i + AHEAD < NI) {
+        for (int i = 0; i < NIR; ++i) {
+            if (i + AHEAD < NIR) {
                 const int n = i + AHEAD;
-                afc[n % R] = *reinterpret_cast<const u16x8*>(a0 + CLM_A_OFF((n >> 2) * 32 * RS16 + (n & 3) * 16));
+                afc[n % R] = *reinterpret_cast<const u16x8*>(a0 + CLM_A_OFF((MT0 + (n >> 2)) * 32 * RS16 + (n & 3) * 16));
             }
-            const int mt = i >> 2, ks = i & 3;
+            const int mt = MT0 + (i >> 2), ks = i & 3;
             if constexpr (LO2) {
                 if (ks == 0) {                            // the row tile's 32 lo bytes: needed three MFMAs from now
                     typedef int i32x4 __attribute__((ext_vector_type(4)));
@@ -102,8 +106,8 @@ __device__ __forceinline__ void compute_tm(const typename CT<PREC>::elem* As, in
         if constexpr (LO2) __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);
         __builtin_amdgcn_sched_group_barrier(0x100, AHEAD, 0);
 #pragma unroll
-        for (int i = 0; i < NI; ++i) {
-            if (i + AHEAD < NI) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        for (int i = 0; i < NIR; ++i) {
+            if (i + AHEAD < NIR) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
             if (LO2 && (i & 3) == 0) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
             if constexpr (!lab::NOLO) {
@@ -229,7 +233,8 @@ __device__ __forceinline__ const u16x8* set_base(const u16x8* wp, int nb, int kc
     constexpr int FR = CT<PREC>::MFMA_K == 16 ? WFR<PREC> : 1, KP = SETK / FR;
     return wp + ((size_t)(nb * 8 + wave) * KSTEPS_ALL + kc * KSTEPS + part * KP) * (FR * 64) + lane;
 }
-template <int PREC, int K, int KN, bool ROWS_N, bool P1_LOADED = false, typename Hook = NoHook, int PRECN = PREC_SAME, bool LO2 = false>
+template <int PREC, int K, int KN, bool ROWS_N, bool P1_LOADED = false, typename Hook = NoHook, int PRECN = PREC_SAME, bool LO2 = false,
+          int MT0 = 0, int NMT = 4>
 __device__ __forceinline__ void phase_tm(const typename CT<PREC>::elem* As, const u16x8* wp, int nb, int kc,
                                          const u16x8* wnext, int nnb, int nkc, int wave, int lane,
                                          u16x8 (&bs)[2][1][SETK], f32x16 (&acc)[4], Hook hook = Hook(), int hook0 = 0,
@@ -248,7 +253,7 @@ __device__ __forceinline__ void phase_tm(const typename CT<PREC>::elem* As, cons
         }
         if constexpr (p % (NP / 2) == 0) hook(hook0 + p / (NP / 2));
         __builtin_amdgcn_sched_barrier(0);
-        compute_tm<PREC, ROWS_N, 4, LO2>(As, p, lrow, lhalf, bs[p & 1], acc, Al);
+        compute_tm<PREC, ROWS_N, 4, LO2, MT0, NMT>(As, p, lrow, lhalf, bs[p & 1], acc, Al);
         __builtin_amdgcn_sched_barrier(0);
     });
 }
