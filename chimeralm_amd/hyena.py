@@ -180,17 +180,17 @@ class HyenaDna(nn.Module):
     DESIGN.md section 2; reads below 2,048 tokens run in fp32 kernels), "fp16" / "bf16" (reduced precision, outside the
     reference's 1e-3 tolerance); `chunk_reads` the number of reads pushed through all layers together.
     `selfcheck` (default: on for "fp16c") -- the reference runs ONE precision, fp32, always (hyena.py:244-256); a 16-bit mode's
-    distance from it depends on the weights, so it is MEASURED on the weights actually loaded: before the first batch after every
-    weight (re)load seeded synthetic samples of 4,097, 2,048, 1,024, 512 and 256 tokens and four reads spread over that batch --
-    and of every `selfcheck_every`-th later batch (64), and of any batch more than 1.5x shorter or longer than every batch checked
-    so far -- run through both the mode and the exact-fp32 kernels of the same engine (`clm_selfcheck`).  A sample, not a bound:
-    batches in between are not measured.  fp16c has two levels: its MLP products run on plain fp16 weights (fast; enough on most
-    weights) and, if that form measures above the threshold, on hi + lo weights like the other projections (`clm_set_mlp_compensation`,
-    ~10 % slower) -- only if that form fails too does the engine fall back to exact fp32.  If the largest logit difference at the longest sample or on a batch exceeds
-    `selfcheck_tol` (5e-4, half the tolerance) the engine falls back to exact fp32 for good (logged); otherwise the shortest
-    sample length that still passes (with every longer one) becomes the length below which reads take the fp32 kernels inside
-    the mode (`clm_set_short_read_len`; 2,048 unmeasured) -- the mode's error is a sum of per-token roundings that the pooling averages
-    like 1 / sqrt(L), so where that switch belongs is a property of the weights.  `selfcheck_report` holds what was measured.
+    distance from it depends on the weights, so it is MEASURED on the weights actually loaded (`clm_selfcheck`: the same reads
+    through the mode and through the exact-fp32 kernels of the same engine).  Before the first batch after every weight (re)load:
+    seeded synthetic samples of 4,097, 2,048, 1,024, 512 and 256 tokens -- the shortest one that still stays within
+    `selfcheck_tol` (5e-4, half the tolerance; with every longer one) becomes the length below which reads take the fp32 kernels
+    inside the mode (`clm_set_short_read_len`; 4,098 if not even the longest sample passes) -- and four reads spread over that
+    batch.  Later: four reads of every `selfcheck_every`-th batch (64) and of any batch more than 1.5x shorter or longer than every
+    batch checked so far.  A sample, not a bound: batches in between are not measured.  A BATCH above the threshold moves fp16c to
+    its second level -- its MLP products run on plain fp16 weights (fast; enough on most weights) and then on hi + lo weights like
+    the other projections (`clm_set_mlp_compensation`, ~10 % slower), heard again from the start -- and only if that form fails on
+    the batch too does the engine fall back to exact fp32 for good (logged, RuntimeWarning).  `selfcheck_report` holds what was
+    measured.
     """
 
     def __init__(self, number_of_classes: int, head: nn.Module, backbone_name: str = "hyenadna-small-32k-seqlen", *,
@@ -283,18 +283,20 @@ class HyenaDna(nn.Module):
                     ids[0, : Ls // 3] = 4                   # one read left-padded, as the collator pads
                     d = measure(f"synthetic {n} x {Ls}", ids.to(eng.device))
                     if not d <= self.selfcheck_tol:
-                        if min_ok is None:                  # not even the longest sample passes: this form of the mode is off
+                        if not f16c:                        # fp16 / bf16 have no length switch: the sample IS the verdict
                             worst = max(worst, d)
-                        break
+                        break                               # fp16c: a failing sample moves the switch (below), it does not end the mode
                     worst = max(worst, d)
                     min_ok = Ls
                     if not f16c:
                         break                               # fp16 / bf16: one verdict, no length switch
             finally:
                 # whatever happened in the loop (an engine error included) the handle never stays at "every length in 16 bits":
-                # reads shorter than the shortest sample length that passed (with every longer one) take the fp32 kernels
+                # reads shorter than the shortest sample length that passed (with every longer one) take the fp32 kernels; if not
+                # even the longest sample passed, everything up to its length does -- longer reads are judged by the rows of their
+                # own batches (next lines; the error falls with the length)
                 if f16c:
-                    rep["f16c_min_len"] = min_ok if min_ok is not None else 2048
+                    rep["f16c_min_len"] = min_ok if min_ok is not None else self._SAMPLE_LENGTHS[0] + 1
                     eng.set_f16c_min_len(rep["f16c_min_len"])
         if eng.effective_precision(L) != "fp32":
             rows = self._sample_rows(B, self._BATCH_ROWS)

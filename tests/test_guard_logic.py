@@ -131,12 +131,24 @@ def test_first_failing_sample_sets_the_switch_and_keeps_the_mode_for_longer_read
     assert [c[1] for c in eng2.calls] == [4097, 2048]                             # the 3,000-token batch itself runs in fp32: nothing to measure
 
 
-def test_longest_sample_or_batch_above_the_threshold_falls_back_for_good():
+def test_a_failing_longest_sample_moves_the_switch_above_it_and_the_batch_decides():
     net = _net()
-    eng = StubEngine({4097: 8e-4})                                                # (both levels answer 8e-4)
+    eng = StubEngine({4097: 8e-4})                                                # the longest sample fails, the 8,193-token batch does not
+    with warnings.catch_warnings():
+        warnings.simplefilter("error", RuntimeWarning)
+        net.guard(eng, _ids(4, 8193))
+    rep = net.selfcheck_report
+    assert rep["fallback"] is False and eng.fallback is False and eng.mlp_lo is False
+    assert rep["f16c_min_len"] == 4098 == eng.min_len and rep["max_abs_dlogit"] == 1e-4   # reads up to 4,097 tokens: fp32 kernels
+    assert [c[1] for c in eng.calls] == [4097, 8193]
+
+
+def test_batch_above_the_threshold_at_both_levels_falls_back_for_good():
+    net = _net()
+    eng = StubEngine({4097: 8e-4}, batch_err=8e-4)                                # (both levels answer 8e-4)
     with pytest.warns(RuntimeWarning, match="falling back to exact fp32"):
         net.guard(eng, _ids(4, 8193))
-    assert net.selfcheck_report["fallback"] is True and eng.fallback is True and eng.min_len == 2048 and eng.mlp_lo is True
+    assert net.selfcheck_report["fallback"] is True and eng.fallback is True and eng.min_len == 4098 and eng.mlp_lo is True
     n = len(eng.calls)
     net.guard(eng, _ids(4, 100))
     assert len(eng.calls) == n                                                    # nothing more to check once it has fallen back
@@ -149,7 +161,7 @@ def test_longest_sample_or_batch_above_the_threshold_falls_back_for_good():
 def test_second_level_is_heard_before_the_fp32_fallback():
     """Round 4: fp16c whose plain-MLP form fails switches fc1 / fc2 to hi + lo weights and is measured again from the start."""
     net = _net()
-    eng = StubEngine({4097: 8e-4}, level2=({4097: 2e-4, 2048: 3e-4, 1024: 9e-4}, 1.5e-4))
+    eng = StubEngine({4097: 8e-4}, batch_err=8e-4, level2=({4097: 2e-4, 2048: 3e-4, 1024: 9e-4}, 1.5e-4))
     with warnings.catch_warnings():
         warnings.simplefilter("error", RuntimeWarning)
         net.guard(eng, _ids(4, 8193))
@@ -158,7 +170,7 @@ def test_second_level_is_heard_before_the_fp32_fallback():
     assert [c[1] for c in eng.calls] == [4097, 8193, 4097, 2048, 1024, 8193]      # level 1: sample fails (+ the batch); level 2: from the start
     assert rep["f16c_min_len"] == 2048 == eng.min_len and rep["max_abs_dlogit"] == 3e-4
     net2 = _net()
-    eng2 = StubEngine({4097: 8e-4}, level2=({4097: 7e-4}, 1e-4))                  # both levels fail: fp32
+    eng2 = StubEngine({4097: 8e-4}, batch_err=8e-4, level2=({4097: 7e-4}, 7e-4))  # both levels fail on the batch: fp32
     with pytest.warns(RuntimeWarning, match="falling back to exact fp32"):
         net2.guard(eng2, _ids(4, 8193))
     assert eng2.mlp_lo is True and eng2.fallback is True and net2.selfcheck_report["fallback"] is True
