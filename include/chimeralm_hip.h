@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define CLM_ABI_VERSION 2
+#define CLM_ABI_VERSION 3
 
 /* error codes */
 #define CLM_OK 0
