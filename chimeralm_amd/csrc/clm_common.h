@@ -122,20 +122,25 @@ constexpr float LO2_SCALE = 1024.f * LO8_TRUNC_GAIN_V;
 constexpr float LO2_INV = 1.0f / LO2_SCALE;
 constexpr int LO2_E8M0 = 127 - 10;
 // (x - fp16(x)) of four values -> four e5m2 bytes (round to nearest even), hi halfs returned through `h`
+// (written so that hipcc emits, per pair, ONE v_cvt_pk_f16_f32 for the halfs and two mixed-precision FMAs on them -- the half is
+//  an operand of v_fma_mix_f32, not converted back first: (x - h) S = fma(h, -S, x S); 12 instructions per four values where
+//  the plain form took 20, and every LayerNorm tile, z row and y row of fp16c pays them per element)
 __device__ __forceinline__ unsigned lo8_pack4(float x0, float x1, float x2, float x3, u16x4& h) {
-    const _Float16 h0 = (_Float16)x0, h1 = (_Float16)x1, h2 = (_Float16)x2, h3 = (_Float16)x3;
-    h = u16x4{__builtin_bit_cast(unsigned short, h0), __builtin_bit_cast(unsigned short, h1), __builtin_bit_cast(unsigned short, h2),
-              __builtin_bit_cast(unsigned short, h3)};
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    const h2 a = __builtin_convertvector(f2{x0, x1}, h2), b = __builtin_convertvector(f2{x2, x3}, h2);
+    h = u16x4{__builtin_bit_cast(unsigned short, a[0]), __builtin_bit_cast(unsigned short, a[1]), __builtin_bit_cast(unsigned short, b[0]),
+              __builtin_bit_cast(unsigned short, b[1])};
     int w = 0;
-    w = __builtin_amdgcn_cvt_pk_bf8_f32((x0 - (float)h0) * LO2_SCALE, (x1 - (float)h1) * LO2_SCALE, w, false);
-    w = __builtin_amdgcn_cvt_pk_bf8_f32((x2 - (float)h2) * LO2_SCALE, (x3 - (float)h3) * LO2_SCALE, w, true);
+    w = __builtin_amdgcn_cvt_pk_bf8_f32(fmaf((float)a[0], -LO2_SCALE, x0 * LO2_SCALE), fmaf((float)a[1], -LO2_SCALE, x1 * LO2_SCALE), w, false);
+    w = __builtin_amdgcn_cvt_pk_bf8_f32(fmaf((float)b[0], -LO2_SCALE, x2 * LO2_SCALE), fmaf((float)b[1], -LO2_SCALE, x3 * LO2_SCALE), w, true);
     return (unsigned)w;
 }
 // four e5m2 lo bytes -> the four fp32 corrections (x - fp16(x), up to the lo's own rounding)
 __device__ __forceinline__ void lo8_unpack4(unsigned w, float (&d)[4]) {
     typedef float f2 __attribute__((ext_vector_type(2)));
     const f2 a = __builtin_amdgcn_cvt_pk_f32_bf8((int)w, false), b = __builtin_amdgcn_cvt_pk_f32_bf8((int)w, true);
-    d[0] = a.x * LO2_INV, d[1] = a.y * LO2_INV, d[2] = b.x * LO2_INV, d[3] = b.y * LO2_INV;
+    d[0] = a.x * LO2_INV, d[1] = a.y * LO2_INV, d[2] = b.x * LO2_INV, d[3] = b.y * LO2_INV;   // (folds into the caller's FMAs)
 }
 
 // ---- kernel launchers (definitions in the .hip files); all are asynchronous on `st` --------------------

@@ -727,7 +727,7 @@ __device__ __forceinline__ void score_pool_tile(const ScorePoolArgs& m, const ty
             float v0 = to_float(lo), v1 = to_float(hi);
             if constexpr (LO2) {                            // channels 2 c2, 2 c2 + 1: adjacent bytes of the lo row
                 typedef float f2 __attribute__((ext_vector_type(2)));
-                const int l8 = *reinterpret_cast<const unsigned short*>(Al + t * RSL + (lo_pos(2 * c2) ^ lo_swz(t)));
+                const int l8 = *reinterpret_cast<const unsigned short*>(Al + t * RSL + lo_pos(2 * c2));
                 const f2 d = __builtin_amdgcn_cvt_pk_f32_bf8(l8, false);
                 v0 = fmaf(d.x, LO2_INV, v0), v1 = fmaf(d.y, LO2_INV, v1);
             }
@@ -804,21 +804,23 @@ __device__ __forceinline__ void tail_load_y_piece(const TailArgs& m, uint4 (&yx)
     for (int i = 4 * half; i < 4 * half + 4; ++i)
         yx[i] = *reinterpret_cast<const uint4*>(src + (size_t)((tid >> 4) + 32 * i) * m.Lp + tkc);
 }
-// Round 4 (fp16c): the y tile's lo bytes, [256 channels][128 tokens] in HBM as y itself.  A thread takes 4 channels x 16 tokens
-// (channels 4 cg .., cg = 8 wave + (tid & 7); tokens 16 tp .., tp = (tid >> 3) & 7: eight lanes cover one 128-byte line of a row) ...
+// Round 4 (fp16c): the y tile's lo bytes, [256 channels][128 tokens] in HBM as y itself.  A thread takes 4 channels x 16 tokens:
+// channels 4 cg .., cg = its LANE, tokens 16 tp .., tp = its wave -- so that the 32 lanes of a ds_write_b32 group write 32
+// different 4-channel columns of one token row, i.e. 32 different banks (lo_pos is a bit permutation of cg).  (The coalesced
+// assignment -- eight lanes per 128-byte line of a row -- made those writes 4-way conflicted; the loads here touch 64 lines per
+// instruction, 16 bytes each, which the other seven waves complete: 4 instructions per thread and tile, a tile ahead of their use.)
 __device__ __forceinline__ void tail_load_ylo(const TailArgs& m, uint4 (&yl)[4], int b, int t0, int tid) {
-    const int cg = (tid >> 6) * 8 + (tid & 7), tk = ((tid >> 3) & 7) * 16, tkc = t0 + tk < m.Lp ? tk : 0;   // clamped, masked at the LDS store
+    const int cg = tid & 63, tk = (tid >> 6) * 16, tkc = t0 + tk < m.Lp ? tk : 0;   // clamped, masked at the LDS store
     const unsigned char* src = m.ylo + ((size_t)b * D + 4 * cg) * m.Lp + t0 + tkc;
 #pragma unroll
     for (int r = 0; r < 4; ++r) yl[r] = *reinterpret_cast<const uint4*>(src + (size_t)r * m.Lp);
 }
-// ... and turns them into the token-major lo tile the MFMA reads (RSL, lo_pos, lo_swz): per token quad a 4 x 4 byte transpose in
+// ... and turns them into the token-major lo tile the MFMA reads (RSL, lo_pos): per token quad a 4 x 4 byte transpose in
 // registers (8 v_perm_b32), then one dword (4 consecutive channels) per token.
 __device__ __forceinline__ void tail_stage_ylo(unsigned char* Aly, const uint4 (&yl)[4], int t0, int Lp, int tid) {
-    const int cg = (tid >> 6) * 8 + (tid & 7), tk = ((tid >> 3) & 7) * 16;
+    const int cg = tid & 63, tk = (tid >> 6) * 16;
     const bool in_row = t0 + tk < Lp;
-    unsigned char* dst = Aly + tk * RSL;
-    const int col = lo_pos(4 * cg) ^ lo_swz(tk);           // (16 tokens = one swizzle group)
+    unsigned char* dst = Aly + tk * RSL + lo_pos(4 * cg);
 #pragma unroll
     for (int a = 0; a < 4; ++a) {
         const unsigned d0 = a == 0 ? yl[0].x : a == 1 ? yl[0].y : a == 2 ? yl[0].z : yl[0].w;
@@ -830,7 +832,7 @@ __device__ __forceinline__ void tail_stage_ylo(unsigned char* Aly, const uint4 (
         const unsigned o[4] = {__builtin_amdgcn_perm(y0, x0, 0x05040100u), __builtin_amdgcn_perm(y0, x0, 0x07060302u),
                                __builtin_amdgcn_perm(y1, x1, 0x05040100u), __builtin_amdgcn_perm(y1, x1, 0x07060302u)};
 #pragma unroll
-        for (int e = 0; e < 4; ++e) *reinterpret_cast<unsigned*>(dst + (4 * a + e) * RSL + col) = in_row ? o[e] : 0u;
+        for (int e = 0; e < 4; ++e) *reinterpret_cast<unsigned*>(dst + (4 * a + e) * RSL) = in_row ? o[e] : 0u;
     }
 }
 // PIECES: how many of the four residual pieces the hooks request.  fp16c: none -- with all four (64 registers) plus the y

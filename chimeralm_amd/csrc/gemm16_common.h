@@ -17,13 +17,14 @@ constexpr int RSOUT = 136;    // row stride of the wave-private output staging t
 // feature, row stride 272 B = 256 + 16 (like RS16: a 16-lane group's 16-byte reads fall on 16 different bank groups).  Inside a
 // row the 32 bytes a lane feeds the K = 64 MFMA of the 64-deep group g = k >> 6 for its k-half h = (k >> 3) & 1 lie together, in
 // the k order of the fp16 fragments (byte 8 s + j = k-step s = (k >> 4) & 3, element j = k & 7): two 16-byte reads per row tile.
-// Rows are XOR-swizzled in units of the 32-byte chunks by the row's 16-row group (lo_swz): the writers own either 32 consecutive
-// rows per wave (LayerNorm: rows r and r + 16 would meet in one bank) or 16 consecutive tokens per lane (the y tile's staging:
-// lanes 16 rows apart would all meet in one), the MFMA readers 16 consecutive rows per 16-lane group -- for whom the swizzle is a
-// per-lane constant plus compile-time terms: chunk (g, h) of row 32 mt + lrow lies at 64 (g ^ mt) + 32 (h ^ (lrow >> 4)).
+// No swizzle on top of that, on purpose: ds_read_b128 is served in the lane groups {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31} (+ 32) over 64
+// banks, and with a row stride of 68 dwords the 16 rows of such a group fall on 16 different 16-byte bank groups exactly when
+// all lanes read the SAME chunk -- an XOR swizzle by the row's 16-row group (tried first, to spread the writers) made every one of
+// the 160 lo reads of a tile 2-way conflicted: +5k LDS cycles per tile, SQ_LDS_BANK_CONFLICT 69 M -> 170 M per launch.  The
+// LayerNorm writer's 16 ds_write_b32 per lane are 4-way conflicted instead (all 32 lanes of a group write the same in-chunk dword:
+// 8 reachable banks; +768 LDS cycles per tile), which is the cheaper end (tools/dev/lds_lo_sim.py).
 constexpr int RSL = 272;
 __host__ __device__ constexpr int lo_pos(int k) { return (k & ~63) + 32 * ((k >> 3) & 1) + 8 * ((k >> 4) & 3) + (k & 7); }
-__host__ __device__ constexpr int lo_swz(int row) { return ((row >> 4) & 7) << 5; }
 
 template <int PREC>
 __device__ __forceinline__ unsigned short to_bits(float v) {
@@ -65,7 +66,7 @@ __device__ __forceinline__ void compute_tm(const typename CT<PREC>::elem* As, in
         }
         // LO2: the set's four hi fragments truncated to e5m2 (their upper bytes) are the weight operand of the activations' lo term
         i32x8 w8h = {0, 0, 0, 0, 0, 0, 0, 0}, alo = {0, 0, 0, 0, 0, 0, 0, 0};
-        const unsigned char* al0 = LO2 ? Al + lrow * RSL + 32 * (lhalf ^ (lrow >> 4)) : nullptr;   // (lo_swz: + 64 (part ^ mt) below)
+        const unsigned char* al0 = LO2 ? Al + lrow * RSL + 64 * part + 32 * lhalf : nullptr;
         if constexpr (LO2) {
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
@@ -86,8 +87,7 @@ __device__ __forceinline__ void compute_tm(const typename CT<PREC>::elem* As, in
             if constexpr (LO2) {
                 if (ks == 0) {                            // the row tile's 32 lo bytes: needed three MFMAs from now
                     typedef int i32x4 __attribute__((ext_vector_type(4)));
-                    const i32x4 p0 = *reinterpret_cast<const i32x4*>(al0 + mt * 32 * RSL + 64 * (part ^ mt)),
-                                p1 = *reinterpret_cast<const i32x4*>(al0 + mt * 32 * RSL + 64 * (part ^ mt) + 16);
+                    const i32x4 p0 = *reinterpret_cast<const i32x4*>(al0 + mt * 32 * RSL), p1 = *reinterpret_cast<const i32x4*>(al0 + mt * 32 * RSL + 16);
                     alo = i32x8{p0[0], p0[1], p0[2], p0[3], p1[0], p1[1], p1[2], p1[3]};
                 }
             }
@@ -160,7 +160,7 @@ __device__ __forceinline__ void compute_km(const typename CT<PREC>::elem* Ys, in
         i32x8 a8 = {0, 0, 0, 0, 0, 0, 0, 0};
         // LO2 (the y tile's lo bytes, token-major like every lo tile): as compute_tm
         i32x8 w8h = {0, 0, 0, 0, 0, 0, 0, 0};
-        const unsigned char* al0 = LO2 ? Al + (lane & 31) * RSL + 32 * (h ^ ((lane >> 4) & 1)) : nullptr;
+        const unsigned char* al0 = LO2 ? Al + (lane & 31) * RSL + 64 * part + 32 * h : nullptr;
         if constexpr (LO2) {
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
@@ -174,8 +174,7 @@ __device__ __forceinline__ void compute_km(const typename CT<PREC>::elem* Ys, in
             i32x8 alo = {0, 0, 0, 0, 0, 0, 0, 0};
             if constexpr (LO2) {
                 typedef int i32x4 __attribute__((ext_vector_type(4)));
-                const i32x4 q0 = *reinterpret_cast<const i32x4*>(al0 + mt * 32 * RSL + 64 * (part ^ mt)),
-                            q1 = *reinterpret_cast<const i32x4*>(al0 + mt * 32 * RSL + 64 * (part ^ mt) + 16);
+                const i32x4 q0 = *reinterpret_cast<const i32x4*>(al0 + mt * 32 * RSL), q1 = *reinterpret_cast<const i32x4*>(al0 + mt * 32 * RSL + 16);
                 alo = i32x8{q0[0], q0[1], q0[2], q0[3], q1[0], q1[1], q1[2], q1[3]};
             }
 #pragma unroll
@@ -373,7 +372,7 @@ __device__ __forceinline__ void ln_acc_to_tile(f32x16 (&acc2)[4], float* P1, flo
                     const unsigned lo4 = lo8_pack4(y0, y1, y2, y3, pk);
                     *reinterpret_cast<u16x4*>(As + (mt * 32 + lrow) * RS16 + wave * 32 + 8 * q + 4 * lhalf) = pk;
                     // features wave * 32 + 8 q + 4 lhalf + {0..3}: one dword of the lo row (lo_pos is contiguous over 4-aligned j)
-                    *reinterpret_cast<unsigned*>(Al + (mt * 32 + lrow) * RSL + ((lo_pos(wave * 32 + 8 * q) + 4 * lhalf) ^ lo_swz(mt * 32 + lrow))) = lo4;
+                    *reinterpret_cast<unsigned*>(Al + (mt * 32 + lrow) * RSL + lo_pos(wave * 32 + 8 * q) + 4 * lhalf) = lo4;
                 } else {
                     u16x4 pk = {to_bits<PREC>(y0), to_bits<PREC>(y1), to_bits<PREC>(y2), to_bits<PREC>(y3)};
                     *reinterpret_cast<u16x4*>(As + (mt * 32 + lrow) * RS16 + wave * 32 + 8 * q + 4 * lhalf) = pk;
