@@ -52,7 +52,7 @@ STAGE_FLOPS_PER_TOKEN = {"ln1_in_proj": 2 * D * 3 * D, "out_proj": 2 * D * D, "l
 TAIL_BYTES_PER_TOKEN = {"out_proj_ln2_mlp": {2: D * 2 + 2 * D * 4, 4: D * 4 + 2 * D * 4},
                         "ln2_mlp": {2: 2 * D * 4, 4: 2 * D * 4},
                         "ln1_in_proj": {2: D * 4 + 3 * D * 2, 4: D * 4 + 3 * D * 4}}
-Z_ROWS = 3 if os.environ.get("CLM_RAW_Z") == "1" else 2   # rows per channel the fused in_proj stage hands the convolution (gated: x0f, g)
+Z_ROWS = 3 if "raw_z" in os.environ.get("CLM_DEBUG", "").split(",") else 2   # rows per channel the fused in_proj stage hands the convolution (gated: x0f, g)
 
 
 def stage_bytes_per_token(stage: str, es: int) -> float:

@@ -16,6 +16,23 @@
 
 using namespace clm;
 
+namespace clm {
+// "name" present in the comma-separated CLM_DEBUG list?  Read from the environment at every call (handles created one after the other
+// in one process may differ); the per-launch users cache their answer.
+bool debug_flag(const char* name) {
+    const char* e = std::getenv("CLM_DEBUG");
+    if (!e) return false;
+    const size_t n = std::strlen(name);
+    for (const char* p = e; *p;) {
+        const char* q = std::strchr(p, ',');
+        const size_t len = q ? (size_t)(q - p) : std::strlen(p);
+        if (len == n && std::strncmp(p, name, n) == 0) return true;
+        p += len + (q ? 1 : 0);
+    }
+    return false;
+}
+}  // namespace clm
+
 namespace {
 
 struct Tensor {
@@ -95,7 +112,7 @@ struct clm_handle {
     float2* edge_bnd = nullptr;
     float2* edge_read = nullptr;
     int edge_read_cap = 0;
-    bool raw_z = false;           // CLM_RAW_Z=1: the fused in_proj stage writes x0 | x1 | v as before round 3 (A/B runs, tests)
+    bool raw_z = false;           // CLM_DEBUG=raw_z: the fused in_proj stage writes x0 | x1 | v as before round 3 (A/B runs, tests)
     unsigned char* ids8 = nullptr;   // workspace: clamped ids [B][Lp]
     float* head_t[5] = {};
     LayerW lw[NLAYER]{};
@@ -113,12 +130,12 @@ struct clm_handle {
     int last_B = 0, last_L = 0, last_Lp = 0;
     // debug / profiling
     int stop_layer = -1, stop_stage = -1;
-    bool split_tail = false;      // CLM_SPLIT_TAIL=1: separate out_proj16 + mlp16 kernels instead of the fused tail (A/B runs)
-    bool no_fuse_next = false;    // CLM_NO_FUSE_NEXT=1: separate in_proj / score kernels instead of fusing them into the tail
-    bool no_idconv = false;       // CLM_NO_IDCONV=1: run block 0's in_proj instead of the id-table convolution (A/B runs)
-    int conv_flags = 0;           // CLM_CONV_ONESHOT=1 / CLM_CONV_NO_XCD=1: CONV_* switches of the convolution launchers (A/B runs, tests)
-    bool no_lone_peel = false;    // CLM_NO_LONE_PEEL=1: keep the lone last token of 128 k + 1-token reads in a tile of its own (A/B runs)
-    bool force_generic = false;   // CLM_GENERIC_GEMM=1: route 16-bit modes through the generic kernels (A/B runs)
+    bool split_tail = false;      // CLM_DEBUG=split_tail: separate out_proj16 + mlp16 kernels instead of the fused tail (A/B runs)
+    bool no_fuse_next = false;    // CLM_DEBUG=no_fuse_next: separate in_proj / score kernels instead of fusing them into the tail
+    bool no_idconv = false;       // CLM_DEBUG=no_idconv: run block 0's in_proj instead of the id-table convolution (A/B runs)
+    int conv_flags = 0;           // CLM_DEBUG=conv_oneshot / conv_no_xcd: CONV_* switches of the convolution launchers (A/B runs, tests)
+    bool no_lone_peel = false;    // CLM_DEBUG=no_lone_peel: keep the lone last token of 128 k + 1-token reads in a tile of its own (A/B runs)
+    bool force_generic = false;   // CLM_DEBUG=generic_gemm: route 16-bit modes through the generic kernels (A/B runs)
     bool prof = false;
     std::vector<ProfRec> recs;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> free_events;
@@ -531,7 +548,7 @@ int forward_chunk(clm_handle* h, const void* ids, int ids_dtype, int64_t row_str
     for (int i = 0; i < NLAYER; ++i) {
         const LayerW& lw = alt32 ? h->lw32[i] : h->lw[i];
         // block 0 in the 16-bit modes: its in_proj output is a function of the token id alone, the convolution looks it
-        // up (ztab), single-shot and segmented kernel alike -- unless a debug stop asks for z itself or CLM_NO_IDCONV=1
+        // up (ztab), single-shot and segmented kernel alike -- unless a debug stop asks for z itself or CLM_DEBUG=no_idconv
         const bool idconv = i == 0 && (idpath || (tuned16 && !h->no_idconv && !stop_here(h, 0, CLM_STAGE_INPROJ)));
         if (!idconv && !(fuse_next && i > 0)) {
             StageTimer t(h, st, CLM_STAGE_INPROJ);
@@ -688,19 +705,20 @@ int clm_create(const clm_config* cfg, int device, clm_handle** out) {
     if (std::string(prop.gcnArchName).rfind("gfx950", 0) != 0)
         return fail(nullptr, CLM_E_UNSUPPORTED, std::string("this engine is built for gfx950 (MI355X) only, found ") + prop.gcnArchName);
     clm_handle* h = new clm_handle();
-    h->force_generic = std::getenv("CLM_GENERIC_GEMM") && std::getenv("CLM_GENERIC_GEMM")[0] == '1';
-    h->no_fuse_next = std::getenv("CLM_NO_FUSE_NEXT") && std::getenv("CLM_NO_FUSE_NEXT")[0] == '1';
-    h->no_idconv = std::getenv("CLM_NO_IDCONV") && std::getenv("CLM_NO_IDCONV")[0] == '1';
-    h->split_tail = std::getenv("CLM_SPLIT_TAIL") && std::getenv("CLM_SPLIT_TAIL")[0] == '1';
-    h->no_lone_peel = std::getenv("CLM_NO_LONE_PEEL") && std::getenv("CLM_NO_LONE_PEEL")[0] == '1';
-    if (std::getenv("CLM_CONV_ONESHOT") && std::getenv("CLM_CONV_ONESHOT")[0] == '1') h->conv_flags |= CONV_ONESHOT;
-    if (std::getenv("CLM_CONV_NO_XCD") && std::getenv("CLM_CONV_NO_XCD")[0] == '1') h->conv_flags |= CONV_NO_XCD;
-    h->raw_z = std::getenv("CLM_RAW_Z") && std::getenv("CLM_RAW_Z")[0] == '1';
+    // developer switches (A/B runs, tests): ONE variable, CLM_DEBUG, a comma-separated list read when a handle is created
+    // (clm_common.h debug_flag) -- no product behaviour hangs on the environment
+    h->force_generic = debug_flag("generic_gemm");     // 16-bit modes through the generic kernels
+    h->no_fuse_next = debug_flag("no_fuse_next");      // separate in_proj / score kernels instead of fusing them into the tail
+    h->no_idconv = debug_flag("no_idconv");            // block 0's in_proj instead of the id-table convolution
+    h->split_tail = debug_flag("split_tail");          // separate out_proj16 + mlp16 kernels instead of the fused tail
+    h->no_lone_peel = debug_flag("no_lone_peel");      // the lone last token of 128 k + 1-token reads in a tile of its own
+    if (debug_flag("conv_oneshot")) h->conv_flags |= CONV_ONESHOT;
+    if (debug_flag("conv_no_xcd")) h->conv_flags |= CONV_NO_XCD;
+    h->raw_z = debug_flag("raw_z");                    // the fused in_proj stage writes x0 | x1 | v as before round 3
     h->cfg = *cfg;
     h->device = device;
     if (hipHostMalloc((void**)&h->bad_ids, sizeof(int), hipHostMallocMapped) == hipSuccess) *h->bad_ids = 0;
     else h->bad_ids = nullptr;
-    if (const char* e = std::getenv("CLM_F16C_MIN_LEN")) h->f16c_min_len = std::max(1, std::atoi(e));   // developer knob (1 = never fp32)
     *out = h;
     return CLM_OK;
 }

@@ -129,11 +129,14 @@ __device__ __forceinline__ unsigned lo8_pack4(float x0, float x1, float x2, floa
     typedef _Float16 h2 __attribute__((ext_vector_type(2)));
     typedef float f2 __attribute__((ext_vector_type(2)));
     const h2 a = __builtin_convertvector(f2{x0, x1}, h2), b = __builtin_convertvector(f2{x2, x3}, h2);
-    h = u16x4{__builtin_bit_cast(unsigned short, a[0]), __builtin_bit_cast(unsigned short, a[1]), __builtin_bit_cast(unsigned short, b[0]),
-              __builtin_bit_cast(unsigned short, b[1])};
+    // (elements to scalars FIRST: __builtin_bit_cast straight from a vector element reads element 0 with hipcc 7.2 -- DESIGN.md
+    //  section 4.7; the first version of this function wrote half 0 into every odd slot, which tools/micro/mfma_lo2.cpp caught)
+    const _Float16 h0 = a[0], h1 = a[1], h2_ = b[0], h3 = b[1];
+    h = u16x4{__builtin_bit_cast(unsigned short, h0), __builtin_bit_cast(unsigned short, h1), __builtin_bit_cast(unsigned short, h2_),
+              __builtin_bit_cast(unsigned short, h3)};
     int w = 0;
-    w = __builtin_amdgcn_cvt_pk_bf8_f32(fmaf((float)a[0], -LO2_SCALE, x0 * LO2_SCALE), fmaf((float)a[1], -LO2_SCALE, x1 * LO2_SCALE), w, false);
-    w = __builtin_amdgcn_cvt_pk_bf8_f32(fmaf((float)b[0], -LO2_SCALE, x2 * LO2_SCALE), fmaf((float)b[1], -LO2_SCALE, x3 * LO2_SCALE), w, true);
+    w = __builtin_amdgcn_cvt_pk_bf8_f32(fmaf((float)h0, -LO2_SCALE, x0 * LO2_SCALE), fmaf((float)h1, -LO2_SCALE, x1 * LO2_SCALE), w, false);
+    w = __builtin_amdgcn_cvt_pk_bf8_f32(fmaf((float)h2_, -LO2_SCALE, x2 * LO2_SCALE), fmaf((float)h3, -LO2_SCALE, x3 * LO2_SCALE), w, true);
     return (unsigned)w;
 }
 // four e5m2 lo bytes -> the four fp32 corrections (x - fp16(x), up to the lo's own rounding)
@@ -142,6 +145,9 @@ __device__ __forceinline__ void lo8_unpack4(unsigned w, float (&d)[4]) {
     const f2 a = __builtin_amdgcn_cvt_pk_f32_bf8((int)w, false), b = __builtin_amdgcn_cvt_pk_f32_bf8((int)w, true);
     d[0] = a.x * LO2_INV, d[1] = a.y * LO2_INV, d[2] = b.x * LO2_INV, d[3] = b.y * LO2_INV;   // (folds into the caller's FMAs)
 }
+
+// developer switches: is `name` in the comma-separated environment variable CLM_DEBUG?  (clm_api.hip; A/B runs and tests only)
+bool debug_flag(const char* name);
 
 // ---- kernel launchers (definitions in the .hip files); all are asynchronous on `st` --------------------
 // PREC_F16C ("fp16c"): fp16 activations x weights held as hi + lo (in_proj, out_proj, score layer; the MLP weights are plain fp16
@@ -266,7 +272,7 @@ size_t lone_token_ws_floats(int B);
 void launch_lone_token(int prec, const LoneTokenArgs& a, hipStream_t st);
 // out_proj + LN2 + MLP (+ what follows on the same tile: NEXT_*), 16-bit modes (gemm16.hip)
 void launch_tail16(int prec, const TailArgs& m, int next, hipStream_t st);
-void tail16_dump_stamps();   // developer build only (CLM_STAMP=1)
+void tail16_dump_stamps();   // developer build only (CLM_DEBUG=stamp)
 void conv_dump_stamps();
 size_t packed_weight_bytes(int prec, int n, int k);
 // pack W [n][k] fp32 (device) into MFMA fragment order of the compute dtype
@@ -291,7 +297,7 @@ void launch_twiddles(float2* tw, int logn, hipStream_t st);   // tw[m] = exp(-2 
 // y = ((causal_conv(v*x1, k) + D*(v*x1)) * x0)   with (x0,x1,v) = short_filter(z)    [B,256,Lp]; D lives in kf
 // ids8/ztab non-null (16-bit modes, block 0): x0|x1|v come from the 16-row table ztab[id][768] via the token ids
 // ids8 [B][Lp] instead of z (in_proj of block 0 is not launched)
-// flags (A/B switches of the engine, CLM_CONV_ONESHOT=1 / CLM_CONV_NO_XCD=1 at clm_create):
+// flags (A/B switches of the engine, CLM_DEBUG=conv_oneshot / conv_no_xcd at clm_create):
 constexpr int CONV_ONESHOT = 1;   // 16384-point class, 16-bit: one workgroup per unit (hyena_conv_kernel) instead of the persistent kernel
 constexpr int CONV_NO_XCD = 2;    // units in plain order instead of all read pairs of a channel on one XCD
 constexpr int CONV_GATED = 4;     // z holds x0f (row c) and g = x1f * vf (row 256 + c), filtered and gated by the fused tail kernel

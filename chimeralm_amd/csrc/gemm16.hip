@@ -773,7 +773,7 @@ __global__ __launch_bounds__(512) void score_pool16_kernel(ScorePoolArgs m) {
 // out_proj16 + mlp16 kernels this removes one write and two reads of the fp32 residual stream (3 KiB of 6.5 KiB per
 // token), both latency-bound row phases of the MLP kernel, and one launch.
 
-// STAMP: developer build (CLM_STAMP=1) that records s_memtime at the phase boundaries of wave 0 of every workgroup into
+// STAMP: developer build (CLM_DEBUG=stamp) that records s_memtime at the phase boundaries of wave 0 of every workgroup into
 // a side buffer nothing else reads; the product instantiation (STAMP = false) contains no stamp.
 // NEXT: what follows the block on the same tile while it is still on chip -- the residual stream is then read once and
 // written once per block, and the separate in_proj / score launches (latency-bound on their own) disappear.
@@ -1172,7 +1172,7 @@ void launch_mlp16(int prec, float* h, const float* g, const float* bta, const vo
     CLM_LAUNCH16(prec == PREC_F16C ? (int)PREC_F16 : prec, mlp16_kernel, grid, block, lds, st, m);
 }
 
-// developer stamps (CLM_STAMP=1): per-phase mean cycles of wave 0 over all workgroups, printed by clm_destroy
+// developer stamps (CLM_DEBUG=stamp): per-phase mean cycles of wave 0 over all workgroups, printed by clm_destroy
 static unsigned long long* s_stamp_buf = nullptr;
 static size_t s_stamp_wgs = 0;
 void tail16_dump_stamps() {
@@ -1256,7 +1256,7 @@ void launch_tail16(int prec, const TailArgs& m, int next, hipStream_t st) {
     const int total = ((m.Lmain + 127) / 128) * m.B;
     dim3 grid(tail16_grid(total)), block(512);                 // persistent: one workgroup per CU (LDS-limited anyway)
     const bool zg = m.zg != 0 && next == NEXT_INPROJ;
-    static const bool stamp = std::getenv("CLM_STAMP") && std::getenv("CLM_STAMP")[0] == '1';
+    static const bool stamp = debug_flag("stamp");
     if (stamp && prec == PREC_F16C && next == NEXT_INPROJ) {   // developer build: the in_proj variant of the benched mode, stamped
         const size_t wgs = (size_t)total;
         if (wgs > s_stamp_wgs) {

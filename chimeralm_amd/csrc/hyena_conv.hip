@@ -417,7 +417,7 @@ __device__ __forceinline__ void lds_load8(const float* src, float* v) {
 //   phase B  forward passes; last forward pass fused with the spectrum product and the first inverse pass;
 //            inverse passes (the filter spectrum bins are fetched one pass ahead)
 //   phase C  LDS -> * x0 -> y
-// STAMP: developer build (CLM_STAMP=1, 16384-point f16 instantiation only) recording s_memtime at phase boundaries.
+// STAMP: developer build (CLM_DEBUG=stamp, 16384-point f16 instantiation only) recording s_memtime at phase boundaries.
 constexpr int CONV_NSTAMP = 16;
 // IDS: first block only.  The residual stream entering block 0 is the embedding row of the token id, so the block's
 // in_proj output is one of 16 precomputed rows (ztab, fp32): the kernel reads the ids (1 byte per token, shared by all 256
@@ -1253,6 +1253,27 @@ __global__ __launch_bounds__(Plan<14>::NT) void hyena_conv_seg_kernel(
     // buffer descriptors of this unit's spectrum scratch and this channel's partition spectra (uniform: blockIdx + arguments)
     const __amdgpu_buffer_rsrc_t g_rs = make_rsrc(gs, (size_t)S * N * sizeof(float2));
     const __amdgpu_buffer_rsrc_t k_rs = make_rsrc(kfc, (size_t)KS * N * sizeof(float2));
+    // GATED (round 4): the g rows of segment m + 1 are requested before the last inverse pass of segment m and
+    // consumed in its phase A -- the HBM round trip that opened every segment (the prefetch that took the 8k kernel from 0.81 to
+    // 0.57 ms) -- unconditionally: the last segment re-requests itself (a conditional request makes the waitcnt pass drain to zero)
+    uint4 gcur[GATED ? CH : 1][2];
+    uint2 glcur[(GATED && LO) ? CH : 1][2];
+    auto request_g = [&](int mseg, uint4 (&g)[GATED ? CH : 1][2], uint2 (&gl)[(GATED && LO) ? CH : 1][2], int ltid_) {
+        if constexpr (GATED) {
+#pragma unroll
+            for (int rd = 0; rd < 2; ++rd) {
+                const T* row = (rd == 0 ? zA : zB) + (size_t)(D + c) * Lp;
+                const unsigned char* rowl = zlo_row(rd == 0 ? zA : zB, 1, c, Lp);
+#pragma unroll
+                for (int ch = 0; ch < CH; ++ch) {
+                    const int t0 = mseg * SEG_LEN + 8 * (ltid_ + ch * NT);
+                    g[ch][rd] = *reinterpret_cast<const uint4*>(row + (t0 < L ? t0 : 0));
+                    if constexpr (LO) gl[ch][rd] = *reinterpret_cast<const uint2*>(rowl + (t0 < L ? t0 : 0));
+                }
+            }
+        }
+    };
+    request_g(0, gcur, glcur, tid);
 #pragma unroll 1
     for (int m = 0; m < S; ++m) {
         const int seg0 = m * SEG_LEN;
@@ -1272,28 +1293,15 @@ __global__ __launch_bounds__(Plan<14>::NT) void hyena_conv_seg_kernel(
         unsigned short idp[CH][2];                           //      and the two before it
         static_assert(!(GATED && (IDS || std::is_same<T, float>::value)), "the gated hand-over exists in the fused 16-bit path only");
         if constexpr (GATED) {
-            uint4 gr[CH][2];
-            uint2 grl[CH][2];
-#pragma unroll
-            for (int rd = 0; rd < 2; ++rd) {
-                const T* row = (rd == 0 ? zA : zB) + (size_t)(D + c) * Lp;
-                const unsigned char* rowl = zlo_row(rd == 0 ? zA : zB, 1, c, Lp);
-#pragma unroll
-                for (int ch = 0; ch < CH; ++ch) {
-                    const int t0 = seg0 + 8 * (ltid + ch * NT);
-                    gr[ch][rd] = *reinterpret_cast<const uint4*>(row + (t0 < L ? t0 : 0));
-                    if constexpr (LO) grl[ch][rd] = *reinterpret_cast<const uint2*>(rowl + (t0 < L ? t0 : 0));
-                }
-            }
 #pragma unroll
             for (int ch = 0; ch < CH; ++ch) {
                 const int tl = 8 * (ltid + ch * NT), t0 = seg0 + tl;
                 float gA[8], gB[8];
-                cvt8<T>(gr[ch][0], gA);
-                cvt8<T>(gr[ch][1], gB);
+                cvt8<T>(gcur[ch][0], gA);
+                cvt8<T>(gcur[ch][1], gB);
                 if constexpr (LO) {
-                    add_lo8(grl[ch][0], gA);
-                    add_lo8(grl[ch][1], gB);
+                    add_lo8(glcur[ch][0], gA);
+                    add_lo8(glcur[ch][1], gB);
                 }
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
@@ -1523,8 +1531,9 @@ __global__ __launch_bounds__(Plan<14>::NT) void hyena_conv_seg_kernel(
             int Ns = LAST;
 #pragma unroll
             for (int p = 1; p <= P::NPASS - 1; ++p) {
-                if (p == P::NPASS - 1) {   // x0 rows of this segment: the last pass to land
+                if (p == P::NPASS - 1) {   // x0 rows of this segment (and the g rows of the next): the last pass to land
                     if constexpr (GATED) {
+                        request_g(m + 1 < S ? m + 1 : m, gcur, glcur, ltid);
 #pragma unroll
                         for (int rd = 0; rd < 2; ++rd) {
                             const T* row = (rd == 0 ? zA : zB) + (size_t)c * Lp;
@@ -1831,7 +1840,7 @@ static void launch_conv_t(const void* z, void* y, const float2* kf, const float2
         }
     }
     if constexpr (LOGN == 14 && std::is_same<T, f16_t>::value && !LO) {
-        static const bool stamp = std::getenv("CLM_STAMP") && std::getenv("CLM_STAMP")[0] == '1';
+        static const bool stamp = debug_flag("stamp");
         if (stamp) {
             const size_t wgs = (size_t)grid.x * grid.y;
             if (wgs > s_conv_stamp_wgs) {
@@ -1869,7 +1878,7 @@ void launch_hyena_conv(int prec, const void* z, void* y, const float2* kf, const
                        unsigned char* ylo) {
     // 16384-point class, 16-bit activations: persistent workgroups with next-unit requests (CONV_ONESHOT: one workgroup per
     // unit -- A/B runs; the developer stamps live in that kernel only)
-    static const bool stamp = std::getenv("CLM_STAMP") && std::getenv("CLM_STAMP")[0] == '1';
+    static const bool stamp = debug_flag("stamp");
     const bool ids = ids8 != nullptr && ztab != nullptr;
     const bool gated = (flags & CONV_GATED) != 0 && !ids;
     const bool lo = prec == PREC_F16C && ylo != nullptr;

@@ -616,7 +616,7 @@ int tf_forward_t(clm_tf_handle* h, const void* ids, int ids_dtype, int64_t strid
         tf::LinArgs a{};
         a.M = M; a.eps = 1e-5f;
         // (the unfused A/B forms read the attention output as ONE 16-bit plane: not for fp16c, whose out_proj takes two)
-        static const bool unfused_ffn_env = std::getenv("CLM_TF_UNFUSED_FFN") && std::getenv("CLM_TF_UNFUSED_FFN")[0] == '1';
+        static const bool unfused_ffn_env = debug_flag("tf_unfused_ffn");
         const bool unfused_ffn = unfused_ffn_env && PREC != PREC_F16C;
         if (i == 0 || unfused_ffn) {   // later layers: computed at the end of the previous layer's feed-forward kernel
             TfTimer t(h, st, 2);
@@ -628,7 +628,7 @@ int tf_forward_t(clm_tf_handle* h, const void* ids, int ids_dtype, int64_t strid
             launch_attention_fwd(PREC, h->qkv, h->att, B, L3, st, PREC == PREC_F16C);   // fp16c: hi and lo planes (attention.hip)
         }
         TfTimer tl(h, st, 2);
-        static const bool unfused_layer_env = std::getenv("CLM_TF_UNFUSED_LAYER") && std::getenv("CLM_TF_UNFUSED_LAYER")[0] == '1';
+        static const bool unfused_layer_env = debug_flag("tf_unfused_layer");
         const bool unfused_layer = unfused_layer_env && PREC != PREC_F16C;
         const bool whole_layer = !unfused_layer && !unfused_ffn;   // out_proj + LN1 at the head of the feed-forward kernel
         if (!whole_layer) {

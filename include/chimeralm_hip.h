@@ -222,7 +222,7 @@ int clm_debug_stop_after(clm_handle* h, int layer, int stage);
 #define CLM_STAGE_HEADMLP 8
 #define CLM_STAGE_FILTER 9
 #define CLM_STAGE_TAIL 10   /* profile only: fused out_proj + LN2 + fc1 + GELU + fc2 (16-bit modes) */
-#define CLM_STAGE_MLP 11    /* profile only: fused LN2 + fc1 + GELU + fc2 (16-bit modes, CLM_SPLIT_TAIL=1) */
+#define CLM_STAGE_MLP 11    /* profile only: fused LN2 + fc1 + GELU + fc2 (16-bit modes, CLM_DEBUG=split_tail) */
 #define CLM_N_STAGES 12
 int clm_profile_enable(clm_handle* h, int on);
 /* Synchronises, then returns accumulated milliseconds and launch counts per stage since the last reset. */

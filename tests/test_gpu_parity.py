@@ -314,9 +314,9 @@ def test_block0_id_table_long_reads(sd, built_lib, monkeypatch, L):
     ids[0, 8190:8196] = [11, 0, 1, 2, 3, 15]                # specials across the first segment boundary
     t = torch.from_numpy(ids).cuda()
     e1 = Engine("cuda:0", precision="fp16", chunk_reads=4)
-    monkeypatch.setenv("CLM_NO_IDCONV", "1")
+    monkeypatch.setenv("CLM_DEBUG", "no_idconv")
     e2 = Engine("cuda:0", precision="fp16", chunk_reads=4)
-    monkeypatch.delenv("CLM_NO_IDCONV")
+    monkeypatch.delenv("CLM_DEBUG")
     e1.load_state_dict(sd), e2.load_state_dict(sd)
     a, b = e1.forward(t).cpu(), e2.forward(t).cpu()
     assert (a - b).abs().max() < TOL["fp16"]
@@ -326,7 +326,7 @@ def test_block0_id_table_long_reads(sd, built_lib, monkeypatch, L):
 @pytest.mark.parametrize("prec", ["fp16", "bf16"])
 def test_block0_id_table_convolution_matches_in_proj_path(sd, built_lib, monkeypatch, prec):
     """16-bit modes skip block 0's in_proj: the convolution looks x0|x1|v up by token id (ztab).  Same logits as the
-    explicit in_proj path (CLM_NO_IDCONV=1) up to the 16-bit rounding of z that the table path does not have; covers every
+    explicit in_proj path (CLM_DEBUG=no_idconv) up to the 16-bit rounding of z that the table path does not have; covers every
     row of the 16-row embedding table (specials, N, the padding rows 12-15) and both read parities of a pair."""
     from chimeralm_amd.engine import Engine
 
@@ -335,9 +335,9 @@ def test_block0_id_table_convolution_matches_in_proj_path(sd, built_lib, monkeyp
     ids[1, -3:] = [12, 13, 15]                  # rows of the 16-row table beyond the 12-token vocabulary
     t = torch.from_numpy(ids).cuda()
     e1 = Engine("cuda:0", precision=prec, chunk_reads=8)
-    monkeypatch.setenv("CLM_NO_IDCONV", "1")
+    monkeypatch.setenv("CLM_DEBUG", "no_idconv")
     e2 = Engine("cuda:0", precision=prec, chunk_reads=8)
-    monkeypatch.delenv("CLM_NO_IDCONV")
+    monkeypatch.delenv("CLM_DEBUG")
     e1.load_state_dict(sd), e2.load_state_dict(sd)
     a, b = e1.forward(t).cpu(), e2.forward(t).cpu()
     assert (a - b).abs().max() < TOL[prec]
@@ -358,7 +358,7 @@ def test_full_size_8k_reads(engines, sd, prec):
 def test_lone_last_token_is_peeled_off_the_tile_kernels(sd, built_lib, monkeypatch, prec, B, L):
     """Reads of 128 k + 1 tokens: the last token (the [SEP] of every 8k-bp read) is causally isolated in the backbone and runs
     through fp32 matrix-vector kernels instead of a 128-token tile of its own (csrc/lone_token.hip).  Same logits as with the
-    token kept in the tile kernels (CLM_NO_LONE_PEEL=1) up to that one token's 16-bit roundings, both within the mode's bound
+    token kept in the tile kernels (CLM_DEBUG=no_lone_peel) up to that one token's 16-bit roundings, both within the mode's bound
     of the oracle; read 0 of the batch is all [PAD] but for its [SEP] (left padding to the extreme)."""
     from chimeralm_amd.engine import Engine
 
@@ -366,9 +366,9 @@ def test_lone_last_token_is_peeled_off_the_tile_kernels(sd, built_lib, monkeypat
     ids[0, : L - 1] = 4                                         # read 0: pads only, then [SEP]
     t = torch.from_numpy(ids).cuda()
     e0 = Engine("cuda:0", precision=prec, chunk_reads=4)
-    monkeypatch.setenv("CLM_NO_LONE_PEEL", "1")
+    monkeypatch.setenv("CLM_DEBUG", "no_lone_peel")
     e1 = Engine("cuda:0", precision=prec, chunk_reads=4)
-    monkeypatch.delenv("CLM_NO_LONE_PEEL")
+    monkeypatch.delenv("CLM_DEBUG")
     e0.load_state_dict(sd), e1.load_state_dict(sd)
     a, b = e0.forward(t).cpu(), e1.forward(t).cpu()
     assert torch.equal(a, e0.forward(t).cpu())                  # deterministic
@@ -377,27 +377,27 @@ def test_lone_last_token_is_peeled_off_the_tile_kernels(sd, built_lib, monkeypat
     e0.close(), e1.close()
 
 
-@pytest.mark.parametrize("prec,B,L,env", [("fp16c", 5, 8193, "CLM_CONV_ONESHOT"), ("fp16c", 3, 6000, "CLM_CONV_ONESHOT"),
-                                          ("bf16", 4, 4098, "CLM_CONV_ONESHOT"), ("fp16c", 5, 8193, "CLM_CONV_NO_XCD"),
-                                          ("fp16c", 3, 20000, "CLM_CONV_NO_XCD")])
+@pytest.mark.parametrize("prec,B,L,env", [("fp16c", 5, 8193, "conv_oneshot"), ("fp16c", 3, 6000, "conv_oneshot"),
+                                          ("bf16", 4, 4098, "conv_oneshot"), ("fp16c", 5, 8193, "conv_no_xcd"),
+                                          ("fp16c", 3, 20000, "conv_no_xcd")])
 def test_persistent_convolution_equals_one_workgroup_per_unit(sd, built_lib, monkeypatch, prec, B, L, env):
     """Reads of 4,098..8,193 tokens in the 16-bit modes run through hyena_conv_pers_kernel (persistent workgroups, next unit's rows
     requested behind the last inverse pass, XCD-aware unit order; block 0: its id-table variant).  Against hyena_conv_kernel
-    (CLM_CONV_ONESHOT=1) the same transform but x0's short filter evaluated in phase C: fp32-rounding-level differences in y that
+    (CLM_DEBUG=conv_oneshot) the same transform but x0's short filter evaluated in phase C: fp32-rounding-level differences in y that
     flip a few 16-bit roundings -- logits agree to a fraction of the mode's error, and both kernels stand against the oracle.
-    The plain unit order (CLM_CONV_NO_XCD=1) only permutes which workgroup does which unit: bit-identical, for the segmented
+    The plain unit order (CLM_DEBUG=conv_no_xcd) only permutes which workgroup does which unit: bit-identical, for the segmented
     long-read kernel too (20,000 tokens).  Odd batches: a unit with one read."""
     from chimeralm_amd.engine import Engine
 
     ids = _ids(B, L, seed=97, pads=3)
     t = torch.from_numpy(ids).cuda()
     e0 = Engine("cuda:0", precision=prec, chunk_reads=4)
-    monkeypatch.setenv(env, "1")                         # read by clm_create
+    monkeypatch.setenv("CLM_DEBUG", env)                 # read by clm_create
     e1 = Engine("cuda:0", precision=prec, chunk_reads=4)
-    monkeypatch.delenv(env)
+    monkeypatch.delenv("CLM_DEBUG")
     e0.load_state_dict(sd), e1.load_state_dict(sd)
     a, b = e0.forward(t).cpu(), e1.forward(t).cpu()
-    if env == "CLM_CONV_NO_XCD":
+    if env == "conv_no_xcd":
         assert torch.equal(a, b), (a - b).abs().max().item()
     else:
         assert (a - b).abs().max() < 0.3 * TOL[prec]          # a fraction of the mode's own error bound
@@ -412,7 +412,7 @@ def test_gated_hand_over_equals_raw_rows(sd, built_lib, monkeypatch, prec, B, L)
     the convolution x0f and g (two rows per channel instead of x0 | x1 | v); tiles go to the workgroups in contiguous ranges, the
     filter's two-token history travels from tile to tile in LDS, the first two tokens of a range that starts inside a read are
     recomputed by a patch kernel, the peeled last token takes its history from the read's last tile.  Against the previous
-    hand-over (CLM_RAW_Z=1: three rows, filtered and gated by the convolution): the same arithmetic up to WHERE the 16-bit
+    hand-over (CLM_DEBUG=raw_z: three rows, filtered and gated by the convolution): the same arithmetic up to WHERE the 16-bit
     rounding of z sits (before the filter then, after it now) -- logits agree to a fraction of the mode's bound, and both stand
     against the oracle.  Shapes: persistent 8k kernel (full and ragged units, odd batch, a lone read), one-shot kernels of three
     transform sizes, the segmented kernel with and without its dot-product tail; 5 x 64 tiles on 256 workgroups = ranges of 2
@@ -422,9 +422,9 @@ def test_gated_hand_over_equals_raw_rows(sd, built_lib, monkeypatch, prec, B, L)
     ids = _ids(B, L, seed=131, pads=3)
     t = torch.from_numpy(ids).cuda()
     e0 = Engine("cuda:0", precision=prec, chunk_reads=8)
-    monkeypatch.setenv("CLM_RAW_Z", "1")
+    monkeypatch.setenv("CLM_DEBUG", "raw_z")
     e1 = Engine("cuda:0", precision=prec, chunk_reads=8)
-    monkeypatch.delenv("CLM_RAW_Z")
+    monkeypatch.delenv("CLM_DEBUG")
     e0.load_state_dict(sd), e1.load_state_dict(sd)
     a, b = e0.forward(t).cpu(), e1.forward(t).cpu()
     assert torch.equal(a, e0.forward(t).cpu())                  # deterministic

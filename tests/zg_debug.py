@@ -16,9 +16,9 @@ dt = np.float16
 out = {}
 for mode in ("gated", "raw"):
     if mode == "raw":
-        os.environ["CLM_RAW_Z"] = "1"
+        os.environ["CLM_DEBUG"] = "raw_z"
     e = Engine("cuda:0", precision=prec, chunk_reads=8)
-    os.environ.pop("CLM_RAW_Z", None)
+    os.environ.pop("CLM_DEBUG", None)
     e.load_state_dict(sd)
     lg = e.forward(t).cpu().numpy()
     torch.cuda.synchronize()
