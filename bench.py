@@ -230,6 +230,7 @@ def main():
     ap.add_argument("--head-scale", type=float, default=3.0, help="factor on every head layer of the default-init weights")
     ap.add_argument("--logit-gap", type=float, default=3.6, help="mean |logit0 - logit1| the output layer is rescaled to (0: off)")
     ap.add_argument("--selfcheck-tol", type=float, default=5e-4, help="the guard's threshold (half the reference's tolerance)")
+    ap.add_argument("--no-guard", action="store_true", help="developer A/B runs (timing-only library builds give wrong logits): selfcheck off")
     ap.add_argument("--mlp-lo", action="store_true", help="fp16c: start at the guard's second level (fc1 / fc2 on hi + lo weights) -- "
                     "what the product runs on weights whose MLP rounding shows; to price that level")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -262,7 +263,7 @@ def main():
     # layer x `--head-scale` (3, as the parity tests' weight draws), then the output layer rescaled so that the mean gap over 16
     # seeded reads -- measured with the exact-fp32 engine -- is 3.6.
     torch.manual_seed(0)
-    model = lm.ChimeraLM.new(precision=a.precision, selfcheck_tol=a.selfcheck_tol)
+    model = lm.ChimeraLM.new(precision=a.precision, selfcheck_tol=a.selfcheck_tol, selfcheck=False if a.no_guard else None)
     net = model.net
     n_data = max(1, min(4, a.steps))                 # a few distinct resident batches, cycled
     batches = [torch.from_numpy(synthetic_ids(i, a.batch, a.bases)[lo:hi]).to(device) for i in range(n_data)]

@@ -126,6 +126,10 @@ constexpr int LO2_E8M0 = 127 - 10;
 //  an operand of v_fma_mix_f32, not converted back first: (x - h) S = fma(h, -S, x S); 12 instructions per four values where
 //  the plain form took 20, and every LayerNorm tile, z row and y row of fp16c pays them per element)
 __device__ __forceinline__ unsigned lo8_pack4(float x0, float x1, float x2, float x3, u16x4& h) {
+    if constexpr (lab::NOLOPACK) {      // timing-only: the halfs alone
+        h = u16x4{from_float<f16_t>(x0).bits, from_float<f16_t>(x1).bits, from_float<f16_t>(x2).bits, from_float<f16_t>(x3).bits};
+        return 0u;
+    }
     typedef _Float16 h2 __attribute__((ext_vector_type(2)));
     typedef float f2 __attribute__((ext_vector_type(2)));
     const h2 a = __builtin_convertvector(f2{x0, x1}, h2), b = __builtin_convertvector(f2{x2, x3}, h2);

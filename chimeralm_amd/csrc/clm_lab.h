@@ -49,5 +49,31 @@ constexpr bool NOFIR = true;       // no short filter, no lane exchange in the g
 #else
 constexpr bool NOFIR = false;
 #endif
+// round 4: what the activations' lo bytes cost, piece by piece
+#if defined(CLM_LAB) && defined(CLM_EXP_NOLO2)
+constexpr bool NOLO2 = true;       // no activations' lo term in the compensated products (no lo-tile reads, no weight-byte gather, no MFMA)
+#else
+constexpr bool NOLO2 = false;
+#endif
+#if defined(CLM_LAB) && defined(CLM_EXP_NOLOPACK)
+constexpr bool NOLOPACK = true;    // producers write zero lo bytes instead of packing them (LayerNorm tiles, z rows)
+#else
+constexpr bool NOLOPACK = false;
+#endif
+#if defined(CLM_LAB) && defined(CLM_EXP_NOZLO)
+constexpr bool NOZLO = true;       // the gated in_proj stage stages and stores no lo planes (halfs only)
+#else
+constexpr bool NOZLO = false;
+#endif
+#if defined(CLM_LAB) && defined(CLM_EXP_NOYLO)
+constexpr bool NOYLO = true;       // the tail kernel neither loads nor stages y's lo bytes
+#else
+constexpr bool NOYLO = false;
+#endif
+#if defined(CLM_LAB) && defined(CLM_EXP_YLO_COAL)
+constexpr bool YLO_COAL = true;    // y lo staging with the coalesced lane assignment (8 lanes per 128-byte line; 4-way conflicted LDS writes)
+#else
+constexpr bool YLO_COAL = false;
+#endif
 }  // namespace lab
 }  // namespace clm

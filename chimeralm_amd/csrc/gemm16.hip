@@ -368,6 +368,7 @@ __device__ __forceinline__ void zg_store_half(const f32x16 (&a)[4], f16_t* zs, v
         }
     }
     __builtin_amdgcn_sched_barrier(0);
+    if constexpr (lab::NOZLO) return;
     unsigned char* z8 = reinterpret_cast<unsigned char*>(zs);
 #pragma unroll
     for (int m2 = 0; m2 < 2; ++m2)
@@ -810,7 +811,8 @@ __device__ __forceinline__ void tail_load_y_piece(const TailArgs& m, uint4 (&yx)
 // assignment -- eight lanes per 128-byte line of a row -- made those writes 4-way conflicted; the loads here touch 64 lines per
 // instruction, 16 bytes each, which the other seven waves complete: 4 instructions per thread and tile, a tile ahead of their use.)
 __device__ __forceinline__ void tail_load_ylo(const TailArgs& m, uint4 (&yl)[4], int b, int t0, int tid) {
-    const int cg = tid & 63, tk = (tid >> 6) * 16, tkc = t0 + tk < m.Lp ? tk : 0;   // clamped, masked at the LDS store
+    const int cg = lab::YLO_COAL ? (tid >> 6) * 8 + (tid & 7) : tid & 63, tk = (lab::YLO_COAL ? (tid >> 3) & 7 : tid >> 6) * 16;
+    const int tkc = t0 + tk < m.Lp ? tk : 0;               // clamped, masked at the LDS store
     const unsigned char* src = m.ylo + ((size_t)b * D + 4 * cg) * m.Lp + t0 + tkc;
 #pragma unroll
     for (int r = 0; r < 4; ++r) yl[r] = *reinterpret_cast<const uint4*>(src + (size_t)r * m.Lp);
@@ -818,7 +820,7 @@ __device__ __forceinline__ void tail_load_ylo(const TailArgs& m, uint4 (&yl)[4],
 // ... and turns them into the token-major lo tile the MFMA reads (RSL, lo_pos): per token quad a 4 x 4 byte transpose in
 // registers (8 v_perm_b32), then one dword (4 consecutive channels) per token.
 __device__ __forceinline__ void tail_stage_ylo(unsigned char* Aly, const uint4 (&yl)[4], int t0, int Lp, int tid) {
-    const int cg = tid & 63, tk = (tid >> 6) * 16;
+    const int cg = lab::YLO_COAL ? (tid >> 6) * 8 + (tid & 7) : tid & 63, tk = (lab::YLO_COAL ? (tid >> 3) & 7 : tid >> 6) * 16;
     const bool in_row = t0 + tk < Lp;
     unsigned char* dst = Aly + tk * RSL + lo_pos(4 * cg);
 #pragma unroll
@@ -915,7 +917,7 @@ __global__ __launch_bounds__(512) void tail16_kernel(TailArgs m, unsigned long l
     uint4 yx[8];                                           // y tile pieces of this thread
     // fp16c, round 4: y comes as hi + lo bytes; the lo plane is staged into a token-major tile behind the y tile (under As / Hs,
     // dead during out_proj) and adds the activations' lo term to out_proj (compute_km LO2)
-    constexpr bool LOY = PREC == PREC_F16C;
+    constexpr bool LOY = PREC == PREC_F16C && !lab::NOYLO;
     uint4 yl[LOY ? 4 : 1];
     unsigned char* Aly = smem + (size_t)D * RSKM * 2;
     static_assert((size_t)D * RSKM * 2 % 16 == 0 && (size_t)D * RSKM * 2 + 128 * RSL <= (size_t)2 * BM * RS16 * 2, "y lo tile fits behind the y tile");

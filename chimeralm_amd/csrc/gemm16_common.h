@@ -37,11 +37,12 @@ __device__ __forceinline__ unsigned short to_bits(float v) {
 // LO2 (fp16c only): the activations' lo tile `Al` (RSL, lo_pos) adds a third term per row tile and 64-deep group.
 // MT0, NMT (fp16c only): the row tiles [MT0, MT0 + NMT) of the 128-token tile instead of all four (the gated in_proj stage runs its
 // v block in two 64-token halves: half the accumulator registers at a time).
-template <int PREC, bool ROWS_N, int AHEAD = 4, bool LO2 = false, int MT0 = 0, int NMT = 4>
+template <int PREC, bool ROWS_N, int AHEAD = 4, bool LO2_ = false, int MT0 = 0, int NMT = 4>
 __device__ __forceinline__ void compute_tm(const typename CT<PREC>::elem* As, int part, int lrow, int lhalf,
                                            const u16x8 (&src)[1][SETK], f32x16 (&acc)[4], const unsigned char* Al = nullptr) {
-    static_assert(!LO2 || PREC == PREC_F16C, "activation lo tiles exist in the compensated mode only");
+    static_assert(!LO2_ || PREC == PREC_F16C, "activation lo tiles exist in the compensated mode only");
     static_assert((MT0 == 0 && NMT == 4) || PREC == PREC_F16C, "row-tile ranges are implemented for the compensated mode");
+    constexpr bool LO2 = LO2_ && !lab::NOLO2;
     // Explicitly software-pipelined over the 4*KPS (k-step, row tile) items: the A fragment of item i + AHEAD is requested
     // before the MFMA(s) of item i (ring of AHEAD + 1 fragments), and that order is pinned with sched_group_barrier.  Left to
     // itself hipcc serialises `ds_read -> s_waitcnt lgkmcnt(0) -> mfma` wherever registers are tight (fc1: both accumulators
@@ -143,10 +144,11 @@ __device__ __forceinline__ void compute_tm(const typename CT<PREC>::elem* As, in
 
 // Same, A operand taken from the k-major tile Ys[k][token] with the transposing read: a 16-lane group reads a
 // 4(k) x 16(token) block and lane i receives token i's four k values (cdna_hip_programming.md T10).
-template <int PREC, bool LO2 = false>
+template <int PREC, bool LO2_ = false>
 __device__ __forceinline__ void compute_km(const typename CT<PREC>::elem* Ys, int part, int lane,
                                            const u16x8 (&src)[1][SETK], f32x16 (&acc)[4], const unsigned char* Al = nullptr) {
-    static_assert(!LO2 || PREC == PREC_F16C, "activation lo tiles exist in the compensated mode only");
+    static_assert(!LO2_ || PREC == PREC_F16C, "activation lo tiles exist in the compensated mode only");
+    constexpr bool LO2 = LO2_ && !lab::NOLO2;
     constexpr int FR = WFR<PREC>, KP = KPS<PREC>;
     const int li = lane & 15, g1 = (lane >> 4) & 1, h = lane >> 5, q = li >> 2, p = li & 3;
     const typename CT<PREC>::elem* base = Ys + (8 * h + q) * RSKM + 16 * g1 + 4 * p;
