@@ -70,10 +70,5 @@ constexpr bool NOYLO = true;       // the tail kernel neither loads nor stages y
 #else
 constexpr bool NOYLO = false;
 #endif
-#if defined(CLM_LAB) && defined(CLM_EXP_YLO_COAL)
-constexpr bool YLO_COAL = true;    // y lo staging with the coalesced lane assignment (8 lanes per 128-byte line; 4-way conflicted LDS writes)
-#else
-constexpr bool YLO_COAL = false;
-#endif
 }  // namespace lab
 }  // namespace clm

@@ -809,10 +809,10 @@ __device__ __forceinline__ void tail_load_y_piece(const TailArgs& m, uint4 (&yx)
 // channels 4 cg .., cg = its LANE, tokens 16 tp .., tp = its wave -- so that the 32 lanes of a ds_write_b32 group write 32
 // different 4-channel columns of one token row, i.e. 32 different banks (lo_pos is a bit permutation of cg).  (The coalesced
 // assignment -- eight lanes per 128-byte line of a row -- made those writes 4-way conflicted; the loads here touch 64 lines per
-// instruction, 16 bytes each, which the other seven waves complete: 4 instructions per thread and tile, a tile ahead of their use.)
+// instruction, 16 bytes each, which the other seven waves complete: 4 instructions per thread and tile, a tile ahead of their use.
+// Same-box A/B of the two assignments: 21.25 vs 21.09 ms of tail kernel per step over three alternations -- no difference.)
 __device__ __forceinline__ void tail_load_ylo(const TailArgs& m, uint4 (&yl)[4], int b, int t0, int tid) {
-    const int cg = lab::YLO_COAL ? (tid >> 6) * 8 + (tid & 7) : tid & 63, tk = (lab::YLO_COAL ? (tid >> 3) & 7 : tid >> 6) * 16;
-    const int tkc = t0 + tk < m.Lp ? tk : 0;               // clamped, masked at the LDS store
+    const int cg = tid & 63, tk = (tid >> 6) * 16, tkc = t0 + tk < m.Lp ? tk : 0;   // clamped, masked at the LDS store
     const unsigned char* src = m.ylo + ((size_t)b * D + 4 * cg) * m.Lp + t0 + tkc;
 #pragma unroll
     for (int r = 0; r < 4; ++r) yl[r] = *reinterpret_cast<const uint4*>(src + (size_t)r * m.Lp);
@@ -820,7 +820,7 @@ __device__ __forceinline__ void tail_load_ylo(const TailArgs& m, uint4 (&yl)[4],
 // ... and turns them into the token-major lo tile the MFMA reads (RSL, lo_pos): per token quad a 4 x 4 byte transpose in
 // registers (8 v_perm_b32), then one dword (4 consecutive channels) per token.
 __device__ __forceinline__ void tail_stage_ylo(unsigned char* Aly, const uint4 (&yl)[4], int t0, int Lp, int tid) {
-    const int cg = lab::YLO_COAL ? (tid >> 6) * 8 + (tid & 7) : tid & 63, tk = (lab::YLO_COAL ? (tid >> 3) & 7 : tid >> 6) * 16;
+    const int cg = tid & 63, tk = (tid >> 6) * 16;
     const bool in_row = t0 + tk < Lp;
     unsigned char* dst = Aly + tk * RSL + lo_pos(4 * cg);
 #pragma unroll
