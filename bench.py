@@ -31,6 +31,7 @@ sys.path.insert(0, str(Path(__file__).resolve().parent))
 D, DI, NLAYER = 256, 1024, 4
 PEAK_TFLOPS = {"fp32": 157.3, "bf16": 2500.0, "fp16": 2500.0, "fp16c": 2500.0}      # dense MFMA peaks, MI355X_MICROARCH.md
 SUSTAINED_MFMA16_TFLOPS = 1630.0   # measured, see roofline["peak_sustained_measured"]
+SCLK_UNDER_TAIL_HZ = 2.15e9        # shader clock during the forward loop (profiles/r03_power.txt: 2.15 GHz at 1.26 kW)
 # MFMA instructions issued per algorithmic product: fp16c multiplies every activation fragment with the hi AND the lo half of
 # the weight pair (include/chimeralm_hip.h CLM_PREC_F16C)
 # fp16c: in_proj + out_proj (a third of a block's products) run hi on fp16 MFMAs + lo on fp8 MFMAs at half their cycles; the MLP is plain
@@ -87,7 +88,9 @@ def measured_traffic(stage: str, config: dict, dtype: str):
         if d.get("config") == config and d.get("dtype") == dtype and stage in d.get("stages", {}):
             if d.get("kernel_sources_sha") != kernel_sources_sha():
                 return {"stale": f"profiles/{f.name} was collected on other kernel sources"}
-            return {"hbm_bytes_per_launch": d["stages"][stage]["hbm_bytes_per_dispatch"], "source": f"profiles/{f.name}"}
+            e = d["stages"][stage]
+            return {"hbm_bytes_per_launch": e["hbm_bytes_per_dispatch"], "source": f"profiles/{f.name}",
+                    "mfma_busy": (e.get("mfma_busy_cycles_per_dispatch"), e.get("pmc_pass_avg_us"))}
     return None
 
 
@@ -429,6 +432,12 @@ def main():
             roof["traffic_stale"] = tr["stale"]
         elif tr:
             roof["traffic"], roof["traffic_unit"], roof["traffic_source"] = tr["hbm_bytes_per_launch"], "bytes/launch", tr["source"]
+            if tr.get("mfma_busy") and tr["mfma_busy"][0]:
+                # MFMA pipe occupancy from the same committed counter digest: SQ_VALU_MFMA_BUSY_CYCLES (summed over 1,024 SIMDs) over
+                # SIMDs x the kernel's duration in that counter pass x the shader clock the power log shows under this kernel
+                cyc, us = tr["mfma_busy"]
+                roof["mfma_busy_frac"] = cyc / (1024 * us * 1e-6 * SCLK_UNDER_TAIL_HZ)
+                roof["mfma_busy_note"] = f"SQ_VALU_MFMA_BUSY_CYCLES {cyc:.3g} per dispatch / (1,024 SIMDs x {us:.0f} us x {SCLK_UNDER_TAIL_HZ / 1e9:.2f} GHz), {tr['source']}"
             alg = stage_bytes_per_token(dom, es) or TAIL_BYTES_PER_TOKEN.get(dom, {}).get(es, 0.0)
             if fused_next:   # + z of the next block (3 of 4 launches); block 0 reads ids instead of its residual rows
                 alg += Z_ROWS * D * es * (NLAYER - 1) / NLAYER - D * 4 / NLAYER

@@ -54,6 +54,7 @@ def main(tag):
     if stats:
         shutil.copy(stats[0], dst / f"{tag}_kernel_stats.csv")
     lines, traffic = [], defaultdict(lambda: {"fetch_kb": None, "write_kb": None})
+    busy = {}          # kernel -> (mean SQ_VALU_MFMA_BUSY_CYCLES per dispatch, mean dispatch duration in us of the SAME counter pass)
     for sub in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_inst", "pmc_icache"):
         acc, dur = counters(str(src / sub / "**" / "*counter_collection.csv"))
         if not acc:
@@ -70,6 +71,8 @@ def main(tag):
                     traffic[n]["fetch_kb"] = sum(v) / len(v)
                 if c == "WRITE_SIZE":
                     traffic[n]["write_kb"] = sum(v) / len(v)
+                if c == "SQ_VALU_MFMA_BUSY_CYCLES" and sum(v) > 0:
+                    busy[n] = (sum(v) / len(v), sum(d) / len(d))
     (dst / f"{tag}_pmc_summary.txt").write_text("\n".join(lines) + "\n")
     out = {}
     for n, t in traffic.items():
@@ -78,6 +81,10 @@ def main(tag):
         stage = next((s for k, s in sorted(STAGE_OF.items(), key=lambda kv: -len(kv[0])) if k in n), None)   # longest name first
         e = {"kernel": n, "fetch_size_kb": t["fetch_kb"], "write_size_kb": t["write_kb"],
              "hbm_bytes_per_dispatch": (2.0 * t["fetch_kb"] + t["write_kb"]) * 1024.0}
+        if n in busy:
+            # MFMA pipe occupancy: busy cycles are summed over the chip's 1,024 SIMDs; both figures are means over the
+            # dispatches of ONE counter pass (the guard's small launches included in both), so their ratio is the kernel's
+            e["mfma_busy_cycles_per_dispatch"], e["pmc_pass_avg_us"] = busy[n]
         if stage and (stage not in out or e["hbm_bytes_per_dispatch"] > out[stage]["hbm_bytes_per_dispatch"]):
             out[stage] = e
     cfg = json.loads(bench[-1])["config"] if bench else {}
