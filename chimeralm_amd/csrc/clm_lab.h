@@ -70,5 +70,15 @@ constexpr bool NOYLO = true;       // the tail kernel neither loads nor stages y
 #else
 constexpr bool NOYLO = false;
 #endif
+#if defined(CLM_LAB) && defined(CLM_EXP_YLO_NOMFMA)
+constexpr bool YLO_NOMFMA = true;  // y's lo plane loaded and staged, but out_proj without its lo term
+#else
+constexpr bool YLO_NOMFMA = false;
+#endif
+#if defined(CLM_LAB) && defined(CLM_EXP_YLO_NOLOAD)
+constexpr bool YLO_NOLOAD = true;  // out_proj with its lo term (reading whatever the tile holds), y's lo plane neither loaded nor staged
+#else
+constexpr bool YLO_NOLOAD = false;
+#endif
 }  // namespace lab
 }  // namespace clm

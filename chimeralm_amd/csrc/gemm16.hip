@@ -812,6 +812,7 @@ __device__ __forceinline__ void tail_load_y_piece(const TailArgs& m, uint4 (&yx)
 // instruction, 16 bytes each, which the other seven waves complete: 4 instructions per thread and tile, a tile ahead of their use.
 // Same-box A/B of the two assignments: 21.25 vs 21.09 ms of tail kernel per step over three alternations -- no difference.)
 __device__ __forceinline__ void tail_load_ylo(const TailArgs& m, uint4 (&yl)[4], int b, int t0, int tid) {
+    if constexpr (lab::YLO_NOLOAD) return;
     const int cg = tid & 63, tk = (tid >> 6) * 16, tkc = t0 + tk < m.Lp ? tk : 0;   // clamped, masked at the LDS store
     const unsigned char* src = m.ylo + ((size_t)b * D + 4 * cg) * m.Lp + t0 + tkc;
 #pragma unroll
@@ -820,6 +821,7 @@ __device__ __forceinline__ void tail_load_ylo(const TailArgs& m, uint4 (&yl)[4],
 // ... and turns them into the token-major lo tile the MFMA reads (RSL, lo_pos): per token quad a 4 x 4 byte transpose in
 // registers (8 v_perm_b32), then one dword (4 consecutive channels) per token.
 __device__ __forceinline__ void tail_stage_ylo(unsigned char* Aly, const uint4 (&yl)[4], int t0, int Lp, int tid) {
+    if constexpr (lab::YLO_NOLOAD) return;
     const int cg = tid & 63, tk = (tid >> 6) * 16;
     const bool in_row = t0 + tk < Lp;
     unsigned char* dst = Aly + tk * RSL + lo_pos(4 * cg);
@@ -972,7 +974,7 @@ __global__ __launch_bounds__(512) void tail16_kernel(TailArgs m, unsigned long l
             }
         }
     }
-    phase_km<PREC, D, D, PF, LOY>(Ys, wo, 0, 0, w1, 0, 0, wave, lane, bs, acc2, Aly);   // (first fc1 set requested under the last set)
+    phase_km<PREC, D, D, PF, LOY && !lab::YLO_NOMFMA>(Ys, wo, 0, 0, w1, 0, 0, wave, lane, bs, acc2, Aly);   // (first fc1 set requested under the last set)
     CLM_STAMP_AT(2);
     // ---- 2./3. LayerNorm-2 of r straight from the accumulators -> As (16-bit)
     ln_acc_to_tile<PREC>(acc2, P1, P2, m.ln_g, m.ln_b, m.eps, As, t0, L, wave, lrow, lhalf);

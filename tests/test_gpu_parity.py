@@ -86,6 +86,34 @@ def test_fp16c_parity_shapes(engines, sd, B, L):
     _check(engines["fp16c"], "fp16c", _ids(B, L, pads=min(3, L - 1)), sd)
 
 
+@pytest.mark.parametrize("B,L", [(3, 130), (2, 257), (5, 300), (4, 513), (3, 1000), (2, 1500), (3, 2047)])
+def test_fp16c_kernels_below_the_default_length_switch(sd, built_lib, B, L):
+    """The guard may move the short-read switch down to 256 tokens when the loaded weights allow it, so the 16-bit kernels of fp16c --
+    round 4: with the lo planes of y / z and the lo tiles of both LayerNorms -- must be RIGHT at those lengths too (one-shot
+    convolution kernels of 256 .. 4096 points with lo bytes, partial last tiles whose rows beyond the read are masked, the peeled
+    lone token at 257 / 513): forced with clm_set_short_read_len(1).  Their error grows like 1 / sqrt(L) (which is why the switch
+    exists); round 3's mode measured 5.6e-4 at
+    1,000 tokens and 1.5e-3 at 100."""
+    from chimeralm_amd.engine import Engine
+
+    ids = _ids(B, L, seed=411, pads=2)
+    ref = ho.forward(torch.from_numpy(ids.astype(np.int64)), sd).numpy()
+    e = Engine("cuda:0", precision="fp16c", chunk_reads=4)
+    e.load_state_dict(sd)
+    e.set_f16c_min_len(1)
+    assert e.effective_precision(L) == "fp16c"
+    t = torch.from_numpy(ids).cuda()
+    got = e.forward(t).cpu().numpy()
+    assert np.isfinite(got).all()
+    err = float(np.abs(got - ref).max())
+    print(f"fp16c kernels at {B} x {L}: |logits - oracle| {err:.2e}")
+    assert err <= GATE, err                                                      # measured 1.1e-4 (2,047 tokens) .. 5.3e-4 (257)
+    assert np.array_equal(got, e.forward(t).cpu().numpy())                      # deterministic
+    decided = np.abs(ref[:, 0] - ref[:, 1]) > 4e-3
+    assert (got.argmax(1)[decided] == ref.argmax(1)[decided]).all()
+    e.close()
+
+
 # The UNGUARDED mode over the 32 batches of the study.  Round 3 (weights hi + lo only): worst 1.04e-3, 13 of 32 above the guard's
 # 5e-4 -- the bound had to sit ABOVE the gate.  Round 4 (+ e5m2 lo bytes for y, the gated z rows and both LayerNorm tiles):
 # median 1.3e-4, worst 5.4e-4 (draw 7 at 3,000 tokens, 2.3e-4 with the MLP weights compensated too), everything else <= 2.9e-4.
@@ -145,6 +173,34 @@ def test_fp16c_gate_over_weight_draws_and_lengths(built_lib, wseed):
     if wseed in (1, 2, 3):
         _check(e, "fp16c", _ids(6, 100, seed=60 + wseed), sdw)        # 100 tokens: the fp32 kernels inside the mode
     e.close()
+
+
+def test_second_level_of_fp16c_is_closer_where_the_mlp_weights_show(built_lib):
+    """clm_set_mlp_compensation: fc1 / fc2 on hi + lo weights.  On the study's MLP-sensitive weight draw (7) the first level's worst
+    batch (3,000 tokens: 5.4e-4) drops to 2-3e-4; switching back restores the first level's logits bit for bit."""
+    from chimeralm_amd.engine import Engine
+
+    sdw = ho.make_state_dict(7, head_scale=3.0)
+    rng = np.random.default_rng(1000 * 7 + 3000)
+    ids = rng.integers(7, 11, size=(4, 3000)).astype(np.uint8)
+    ids[:, -1] = 1
+    ids[0, :1000] = 4
+    ref = ho.forward(torch.from_numpy(ids.astype(np.int64)), sdw).numpy()
+    e = Engine("cuda:0", precision="fp16c", chunk_reads=4)
+    e.load_state_dict(sdw)
+    t = torch.from_numpy(ids).cuda()
+    l1 = e.forward(t).cpu().numpy()
+    e.set_mlp_compensation(True)
+    l2 = e.forward(t).cpu().numpy()
+    e.set_mlp_compensation(False)
+    assert np.array_equal(e.forward(t).cpu().numpy(), l1)
+    e1, e2 = float(np.abs(l1 - ref).max()), float(np.abs(l2 - ref).max())
+    print(f"weights 7, 4 x 3000: level 1 {e1:.2e}, level 2 {e2:.2e}")
+    assert e2 < 0.7 * e1 and e2 <= 3.5e-4 and e1 <= RAW_FP16C_BOUND
+    e32 = Engine("cuda:0", precision="fp32", chunk_reads=4)
+    with pytest.raises(Exception, match="not a CLM_PREC_F16C handle"):
+        e32.set_mlp_compensation(True)
+    e.close(), e32.close()
 
 
 def test_selfcheck_and_fallback_through_the_c_abi(engines, sd):
