@@ -76,9 +76,19 @@ constexpr bool YLO_NOMFMA = true;  // y's lo plane loaded and staged, but out_pr
 constexpr bool YLO_NOMFMA = false;
 #endif
 #if defined(CLM_LAB) && defined(CLM_EXP_YLO_NOLOAD)
-constexpr bool YLO_NOLOAD = true;  // out_proj with its lo term (reading whatever the tile holds), y's lo plane neither loaded nor staged
+constexpr bool YLO_NOLOAD = true;  // y's lo plane not loaded: zeros staged instead (transposes, LDS writes and the lo term as in the product)
 #else
 constexpr bool YLO_NOLOAD = false;
+#endif
+#if defined(CLM_LAB) && defined(CLM_EXP_YLO_NOPERM)
+constexpr bool YLO_NOPERM = true;  // y's lo plane loaded and written to the tile without the 4 x 4 byte transposes
+#else
+constexpr bool YLO_NOPERM = false;
+#endif
+#if defined(CLM_LAB) && defined(CLM_EXP_NORESID)
+constexpr bool NORESID = true;     // the tail kernel loads no residual rows (zeros): what the loads at the tile boundary cost
+#else
+constexpr bool NORESID = false;
 #endif
 }  // namespace lab
 }  // namespace clm

@@ -784,6 +784,11 @@ constexpr int TAIL_NSTAMP = 28;      // 0..20 phase boundaries, 21..26 the six h
 // the 32 token rows of one accumulator tile
 __device__ __forceinline__ void tail_load_resid_piece(const TailArgs& m, float4 (&hv)[4], int mt, int b, int t0, int wave,
                                                       int lrow, int lhalf) {
+    if constexpr (lab::NORESID) {      // timing-only: no residual rows (what the loads at the tile boundary cost)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) hv[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+        return;
+    }
     const int t = t0 + mt * 32 + lrow, tc = t < m.L ? t : 0;
     const float* row = m.ids8 ? m.emb + (size_t)m.ids8[(size_t)b * m.Lp + tc] * D + wave * 32 + 4 * lhalf
                               : m.h + ((size_t)b * m.L + tc) * D + wave * 32 + 4 * lhalf;
@@ -812,7 +817,11 @@ __device__ __forceinline__ void tail_load_y_piece(const TailArgs& m, uint4 (&yx)
 // instruction, 16 bytes each, which the other seven waves complete: 4 instructions per thread and tile, a tile ahead of their use.
 // Same-box A/B of the two assignments: 21.25 vs 21.09 ms of tail kernel per step over three alternations -- no difference.)
 __device__ __forceinline__ void tail_load_ylo(const TailArgs& m, uint4 (&yl)[4], int b, int t0, int tid) {
-    if constexpr (lab::YLO_NOLOAD) return;
+    if constexpr (lab::YLO_NOLOAD) {     // timing-only: zeros instead of the four loads (garbage would be NaN bytes: another clock)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) yl[r] = make_uint4(0, 0, 0, 0);
+        return;
+    }
     const int cg = tid & 63, tk = (tid >> 6) * 16, tkc = t0 + tk < m.Lp ? tk : 0;   // clamped, masked at the LDS store
     const unsigned char* src = m.ylo + ((size_t)b * D + 4 * cg) * m.Lp + t0 + tkc;
 #pragma unroll
@@ -821,7 +830,6 @@ __device__ __forceinline__ void tail_load_ylo(const TailArgs& m, uint4 (&yl)[4],
 // ... and turns them into the token-major lo tile the MFMA reads (RSL, lo_pos): per token quad a 4 x 4 byte transpose in
 // registers (8 v_perm_b32), then one dword (4 consecutive channels) per token.
 __device__ __forceinline__ void tail_stage_ylo(unsigned char* Aly, const uint4 (&yl)[4], int t0, int Lp, int tid) {
-    if constexpr (lab::YLO_NOLOAD) return;
     const int cg = tid & 63, tk = (tid >> 6) * 16;
     const bool in_row = t0 + tk < Lp;
     unsigned char* dst = Aly + tk * RSL + lo_pos(4 * cg);
@@ -833,8 +841,8 @@ __device__ __forceinline__ void tail_stage_ylo(unsigned char* Aly, const uint4 (
         const unsigned d3 = a == 0 ? yl[3].x : a == 1 ? yl[3].y : a == 2 ? yl[3].z : yl[3].w;
         const unsigned x0 = __builtin_amdgcn_perm(d1, d0, 0x05010400u), x1 = __builtin_amdgcn_perm(d1, d0, 0x07030602u);
         const unsigned y0 = __builtin_amdgcn_perm(d3, d2, 0x05010400u), y1 = __builtin_amdgcn_perm(d3, d2, 0x07030602u);
-        const unsigned o[4] = {__builtin_amdgcn_perm(y0, x0, 0x05040100u), __builtin_amdgcn_perm(y0, x0, 0x07060302u),
-                               __builtin_amdgcn_perm(y1, x1, 0x05040100u), __builtin_amdgcn_perm(y1, x1, 0x07060302u)};
+        const unsigned o[4] = {lab::YLO_NOPERM ? d0 : __builtin_amdgcn_perm(y0, x0, 0x05040100u), lab::YLO_NOPERM ? d1 : __builtin_amdgcn_perm(y0, x0, 0x07060302u),
+                               lab::YLO_NOPERM ? d2 : __builtin_amdgcn_perm(y1, x1, 0x05040100u), lab::YLO_NOPERM ? d3 : __builtin_amdgcn_perm(y1, x1, 0x07060302u)};
 #pragma unroll
         for (int e = 0; e < 4; ++e) *reinterpret_cast<unsigned*>(dst + (4 * a + e) * RSL) = in_row ? o[e] : 0u;
     }
@@ -845,17 +853,23 @@ __device__ __forceinline__ void tail_stage_ylo(unsigned char* Aly, const uint4 (
 // tile, and a scratch reload with its own vmcnt(0) in the next tile's out_proj epilogue).  All four are requested when the
 // stage's accumulators are dead (tail16_kernel, after inproj_blocks); same-box timings of the in_proj variant with 2 / 1 / 0
 // pieces in the hooks: 1.437 / 1.428 / 1.407 ms per launch.
-template <typename E, int PIECES>
+template <typename E, int PIECES, int NYL = 1>
 struct ResidHook {
     const TailArgs& m;
     float4 (&hv)[4][4];
     uint4 (&yx)[8];
+    uint4 (&yl)[NYL];                                      // fp16c: y's lo bytes ride with the second y piece (NYL = 4)
     int b, t0, wave, lrow, lhalf, tid;
     unsigned long long* stamp;                             // developer build only (nullptr otherwise)
     __device__ __forceinline__ void operator()(int step) const {
         if (stamp && tid == 0) stamp[21 + step] = __builtin_amdgcn_s_memtime();
         if (step < PIECES) tail_load_resid_piece(m, hv[step], step, b, t0, wave, lrow, lhalf);
-        else if (step >= 4) tail_load_y_piece<E>(m, yx, step - 4, b, t0, tid);
+        else if (step >= 4) {
+            tail_load_y_piece<E>(m, yx, step - 4, b, t0, tid);
+            if constexpr (NYL == 4) {
+                if (step == 5) tail_load_ylo(m, yl, b, t0, tid);
+            }
+        }
     }
 };
 
@@ -1102,19 +1116,18 @@ __global__ __launch_bounds__(512) void tail16_kernel(TailArgs m, unsigned long l
                 const GatedTile gt{tile == tile_begin || tx == 0, tile == tile_begin && tx != 0,
                                    tile + 1 == tile_end && tile + 1 < total && (tile + 1) % tiles_x != 0,
                                    tx == tiles_x - 1 && m.edge_read != nullptr, (int)blockIdx.x};
-                const ResidHook<elem, PIECES> rhook{m, hv, yx, nb_, nt0, wave, lrow, lhalf, tid,
-                                                    STAMP ? stamps + (size_t)tile * TAIL_NSTAMP : nullptr};
+                const ResidHook<elem, PIECES, LOY ? 4 : 1> rhook{m, hv, yx, yl, nb_, nt0, wave, lrow, lhalf, tid,
+                                                                 STAMP ? stamps + (size_t)tile * TAIL_NSTAMP : nullptr};
                 if constexpr (PREC == PREC_F16C)
                     inproj_blocks_gated_lo(As, Alf, Alf + 128 * RSL, Bt + BT_NB, wn, m, gt, b, t0, wave, lane, bs, acc1, acc2, rhook);
                 else
                     inproj_blocks_gated<PREC>(As, Hs, Bt + BT_NB, wn, m, gt, b, t0, wave, lane, bs, acc1, acc2, rhook);
             } else
             inproj_blocks<PREC>(As, Hs, wn, Bt + BT_NB, m.n_z, b, t0, Lp, wave, lane, bs, acc1,
-                                ResidHook<elem, PIECES>{m, hv, yx, nb_, nt0, wave, lrow, lhalf, tid,
-                                                        STAMP ? stamps + (size_t)tile * TAIL_NSTAMP : nullptr});
+                                ResidHook<elem, PIECES, LOY ? 4 : 1>{m, hv, yx, yl, nb_, nt0, wave, lrow, lhalf, tid,
+                                                                     STAMP ? stamps + (size_t)tile * TAIL_NSTAMP : nullptr});
 #pragma unroll
             for (int mt = PIECES; mt < 4; ++mt) tail_load_resid_piece(m, hv[mt], mt, nb_, nt0, wave, lrow, lhalf);
-            if constexpr (LOY) tail_load_ylo(m, yl, nb_, nt0, tid);
         } else {
             score_pool_tile<PREC, LOF>(m.sp, As, reinterpret_cast<float*>(Hs), b, tile % tiles_x, tid, bs, acc1, Alf);
             // (requested before the score stage these 96 registers spill through its erf epilogue: one launch in four)
