@@ -546,6 +546,35 @@ def test_baseline_batch_size_independent_properties(sd, built_lib, prec, B, chun
     e.close()
 
 
+@pytest.mark.parametrize("prec,B,L,cut", [("fp32", 3, 8193, 5000), ("fp16c", 6, 8193, 4097), ("fp16c", 2, 32769, 20000), ("fp16", 5, 3000, 1500)])
+def test_the_residual_stream_is_causal(sd, built_lib, prec, B, L, cut):
+    """A property of the operator that does not need the oracle, at the bench's read lengths: the backbone is causal (the long
+    filter is applied as a causal convolution -- zero-padded to twice the length, hyena.py:244-256 through the backbone's fftconv --
+    and everything else is token-wise), so bases after position `cut` cannot move the residual stream at or before it.  The FFT
+    mixes every position of a read (and of its pair partner in the packed transform), so the claim holds to rounding, not
+    bitwise: the stream before the cut must agree to a few parts in 1e5 of its scale, while the stream after it must move."""
+    from chimeralm_amd.engine import Engine
+
+    ids = _ids(B, L, seed=53)
+    ids2 = ids.copy()
+    ids2[:, cut:L - 1] = _ids(B, L, seed=54)[:, cut:L - 1]                       # (the closing [SEP] stays)
+    assert (ids2[:, cut:] != ids[:, cut:]).mean() > 0.5
+    e = Engine("cuda:0", precision=prec)
+    e.load_state_dict(sd)
+    e.forward(torch.from_numpy(ids).cuda())
+    h1 = e.debug_fetch("h", (B, L, 256)).copy()
+    e.forward(torch.from_numpy(ids2).cuda())
+    h2 = e.debug_fetch("h", (B, L, 256)).copy()
+    e.close()
+    scale = float(np.abs(h1).max())
+    before = float(np.abs(h1[:, :cut] - h2[:, :cut]).max())
+    after = float(np.abs(h1[:, cut:L - 1] - h2[:, cut:L - 1]).max())
+    print(f"{prec} {B} x {L}, cut {cut}: stream scale {scale:.3g}, moved before the cut {before:.2e}, after {after:.2e}")
+    assert np.isfinite(h1).all() and np.isfinite(h2).all()
+    assert before <= (2e-6 if prec == "fp32" else 1e-4) * scale
+    assert after > 1e-2 * scale
+
+
 def test_shape_churn_filter_cache_and_workspace_regrowth(sd, built_lib):
     """A stream of batches of changing shape through ONE engine: the filter sets (one per transform size, one for long reads) are built on
     first use, the workspace grows on demand, short and long-read kernels alternate.  Every result must equal the one the

@@ -103,6 +103,12 @@ def main(tag):
             b["roofline"]["traffic_unit"] = "bytes/launch"
             b["roofline"]["traffic_source"] = f"profiles/{tag}_traffic.json"
             b["roofline"].pop("traffic_stale", None)      # the line was printed before this round's digest existed
+            if st.get("mfma_busy_cycles_per_dispatch"):   # as bench.py computes it from the digest at run time
+                from bench import SCLK_UNDER_TAIL_HZ
+                cyc, us = st["mfma_busy_cycles_per_dispatch"], st["pmc_pass_avg_us"]
+                b["roofline"]["mfma_busy_frac"] = cyc / (1024 * us * 1e-6 * SCLK_UNDER_TAIL_HZ)
+                b["roofline"]["mfma_busy_note"] = (f"SQ_VALU_MFMA_BUSY_CYCLES {cyc:.3g} per dispatch / (1,024 SIMDs x {us:.0f} us x "
+                                                   f"{SCLK_UNDER_TAIL_HZ / 1e9:.2f} GHz), profiles/{tag}_traffic.json")
             (dst / f"{tag}_bench.json").write_text(json.dumps(b) + "\n")
     print("\n".join(lines[:60]))
 
