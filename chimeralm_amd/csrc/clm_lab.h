@@ -85,6 +85,11 @@ constexpr bool YLO_NOPERM = true;  // y's lo plane loaded and written to the til
 #else
 constexpr bool YLO_NOPERM = false;
 #endif
+#if defined(CLM_LAB) && defined(CLM_EXP_YLO_MAP64)
+constexpr bool YLO_MAP64 = true;   // y's lo tile: a lane = a 4-channel column, a wave = 16 tokens (64 lines per load instruction; round 4's first form)
+#else
+constexpr bool YLO_MAP64 = false;
+#endif
 #if defined(CLM_LAB) && defined(CLM_EXP_NORESID)
 constexpr bool NORESID = true;     // the tail kernel loads no residual rows (zeros): what the loads at the tile boundary cost
 #else

@@ -810,19 +810,24 @@ __device__ __forceinline__ void tail_load_y_piece(const TailArgs& m, uint4 (&yx)
     for (int i = 4 * half; i < 4 * half + 4; ++i)
         yx[i] = *reinterpret_cast<const uint4*>(src + (size_t)((tid >> 4) + 32 * i) * m.Lp + tkc);
 }
-// Round 4 (fp16c): the y tile's lo bytes, [256 channels][128 tokens] in HBM as y itself.  A thread takes 4 channels x 16 tokens:
-// channels 4 cg .., cg = its LANE, tokens 16 tp .., tp = its wave -- so that the 32 lanes of a ds_write_b32 group write 32
-// different 4-channel columns of one token row, i.e. 32 different banks (lo_pos is a bit permutation of cg).  (The coalesced
-// assignment -- eight lanes per 128-byte line of a row -- made those writes 4-way conflicted; the loads here touch 64 lines per
-// instruction, 16 bytes each, which the other seven waves complete: 4 instructions per thread and tile, a tile ahead of their use.
-// Same-box A/B of the two assignments: 21.25 vs 21.09 ms of tail kernel per step over three alternations -- no difference.)
+// Round 4 (fp16c): the y tile's lo bytes, [256 channels][128 tokens] in HBM as y itself.  A thread takes 4 channels x 16 tokens
+// (four 16-byte loads, then 4 x 4 byte transposes into the token-major lo tile).  Thread -> (4-channel column cg, 16-token run):
+// 16 columns x 4 runs per wave -- a load instruction reads 64 contiguous bytes of 16 rows, and the 32 lanes of a ds_write_b32
+// group write 16 different columns (lo_pos maps cg = 0..15 onto 16 different dwords) of two token rows 16 apart: 2-way
+// conflicted.  Same-box alternations, tail kernel per step: a lane = a column, a wave = one run (64 lines per load instruction,
+// conflict-free writes) 21.30 / 21.34 / 21.34 against 21.16 / 21.16 / 21.18 ms for this form; eight lanes per 128-byte line
+// (8 lines per instruction, 4-way conflicted writes) was no faster than the first either.  The loads themselves are what the
+// plane costs (0.85 of 1.2 ms per step, profiles/r04_timing_only.txt), whatever their shape.
+// thread -> (4-channel column, 16-token run) of the y lo tile
+__device__ __forceinline__ int ylo_cg(int tid) { return lab::YLO_MAP64 ? (tid & 63) : (tid & 15) + 16 * ((tid >> 6) & 3); }
+__device__ __forceinline__ int ylo_tk(int tid) { return lab::YLO_MAP64 ? (tid >> 6) * 16 : 16 * (((tid >> 4) & 3) + 4 * (tid >> 8)); }
 __device__ __forceinline__ void tail_load_ylo(const TailArgs& m, uint4 (&yl)[4], int b, int t0, int tid) {
     if constexpr (lab::YLO_NOLOAD) {     // timing-only: zeros instead of the four loads (garbage would be NaN bytes: another clock)
 #pragma unroll
         for (int r = 0; r < 4; ++r) yl[r] = make_uint4(0, 0, 0, 0);
         return;
     }
-    const int cg = tid & 63, tk = (tid >> 6) * 16, tkc = t0 + tk < m.Lp ? tk : 0;   // clamped, masked at the LDS store
+    const int cg = ylo_cg(tid), tk = ylo_tk(tid), tkc = t0 + tk < m.Lp ? tk : 0;   // clamped, masked at the LDS store
     const unsigned char* src = m.ylo + ((size_t)b * D + 4 * cg) * m.Lp + t0 + tkc;
 #pragma unroll
     for (int r = 0; r < 4; ++r) yl[r] = *reinterpret_cast<const uint4*>(src + (size_t)r * m.Lp);
@@ -830,7 +835,7 @@ __device__ __forceinline__ void tail_load_ylo(const TailArgs& m, uint4 (&yl)[4],
 // ... and turns them into the token-major lo tile the MFMA reads (RSL, lo_pos): per token quad a 4 x 4 byte transpose in
 // registers (8 v_perm_b32), then one dword (4 consecutive channels) per token.
 __device__ __forceinline__ void tail_stage_ylo(unsigned char* Aly, const uint4 (&yl)[4], int t0, int Lp, int tid) {
-    const int cg = tid & 63, tk = (tid >> 6) * 16;
+    const int cg = ylo_cg(tid), tk = ylo_tk(tid);
     const bool in_row = t0 + tk < Lp;
     unsigned char* dst = Aly + tk * RSL + lo_pos(4 * cg);
 #pragma unroll
