@@ -35,8 +35,9 @@ SCLK_UNDER_TAIL_HZ = 2.15e9        # shader clock during the forward loop (profi
 # MFMA instructions issued per algorithmic product: fp16c multiplies every activation fragment with the hi AND the lo half of
 # the weight pair (include/chimeralm_hip.h CLM_PREC_F16C)
 # fp16c: in_proj + out_proj (a third of a block's products) run hi on fp16 MFMAs + lo on fp8 MFMAs at half their cycles; the MLP is plain
-# round 4: + the activations' lo term (a second fp8 MFMA) in out_proj and the score layer (1/12 of the products)
-MFMA_ISSUE_FACTOR = {"fp32": 1.0, "bf16": 1.0, "fp16": 1.0, "fp16c": 1.0 + 0.5 / 3 + 0.5 / 12}
+# round 4: + the activations' lo term (a second fp8 MFMA per row tile and 64-deep group) in the same products: out_proj (y's lo
+# plane) and in_proj (the LayerNorm-1 lo tile), or out_proj and the score layer in the last block's kernel
+MFMA_ISSUE_FACTOR = {"fp32": 1.0, "bf16": 1.0, "fp16": 1.0, "fp16c": 1.0 + 0.5 / 3 + 0.5 / 3}
 MLP_LO_ISSUE = 0.5 * 2 / 3          # fc1 / fc2 (2/3 of the products) with their lo half on the fp8 MFMA too (the guard's second level)
 # arithmetic behind each --precision, as the JSON line's "dtype" words it
 DTYPE_NOTE = {"fp32": "fp32 (v_mfma_f32_32x32x2_f32, exact)", "fp16": "fp16 MFMA inputs, fp32 accumulate (reduced precision: outside the 1e-3 gate)",
