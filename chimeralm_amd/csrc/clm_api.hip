@@ -82,6 +82,7 @@ struct clm_handle {
     void* packed_score = nullptr;
     // 16-bit handles: exact-fp32 packing of the same weights (fp16c's reads shorter than f16c_min_len, clm_selfcheck, clm_set_fallback)
     void* packed32[NLAYER][4] = {};
+    void* packed32t[NLAYER][4] = {};   // exact fp32, the fused tail's packing (tail32.hip): in_proj, out_proj, fc1, fc2
     void* packed_score32 = nullptr;
     LayerW lw32[NLAYER]{};
     // PREC_F16C: fc1 / fc2 packed as hi + lo as well (the mode's second level, clm_set_mlp_compensation; lw.w_fc1 / w_fc2 are plain fp16)
@@ -135,6 +136,7 @@ struct clm_handle {
     bool no_idconv = false;       // CLM_DEBUG=no_idconv: run block 0's in_proj instead of the id-table convolution (A/B runs)
     int conv_flags = 0;           // CLM_DEBUG=conv_oneshot / conv_no_xcd: CONV_* switches of the convolution launchers (A/B runs, tests)
     bool no_lone_peel = false;    // CLM_DEBUG=no_lone_peel: keep the lone last token of 128 k + 1-token reads in a tile of its own (A/B runs)
+    bool unfused_fp32 = false;    // CLM_DEBUG=unfused_fp32: exact fp32 through the separate GEMM kernels of rounds 1-3 (tests cross-check the fused tail)
     bool force_generic = false;   // CLM_DEBUG=generic_gemm: route 16-bit modes through the generic kernels (A/B runs)
     bool prof = false;
     std::vector<ProfRec> recs;
@@ -319,6 +321,7 @@ void free_packed(clm_handle* h) {
         {
             if (h->packed[i][j]) { (void)hipFree(h->packed[i][j]); h->packed[i][j] = nullptr; }
             if (h->packed32[i][j]) { (void)hipFree(h->packed32[i][j]); h->packed32[i][j] = nullptr; }
+            if (h->packed32t[i][j]) { (void)hipFree(h->packed32t[i][j]); h->packed32t[i][j] = nullptr; }
             if (j < 2 && h->packed_mlpc[i][j]) { (void)hipFree(h->packed_mlpc[i][j]); h->packed_mlpc[i][j] = nullptr; }
         }
     if (h->packed_score) { (void)hipFree(h->packed_score); h->packed_score = nullptr; }
@@ -332,6 +335,9 @@ void free_packed(clm_handle* h) {
 
 const float* W(clm_handle* h, const std::string& key) { return h->w[key].d; }
 
+// exact fp32 runs its block tails fused (tail32.hip) unless a debug stop wants an intermediate or CLM_DEBUG=unfused_fp32 asks
+bool fused_fp32(const clm_handle* h) { return !h->unfused_fp32 && h->stop_stage < 0; }
+
 int ensure_workspace(clm_handle* h, int Bc, int L, hipStream_t st) {
     const int prec = effective_prec(h, L);                   // (honours the self-check's referee pass and the fallback)
     const size_t es = elem_size(prec), Lp = (size_t)round_up(L, LP_ALIGN), nb = (size_t)Bc, nl = (size_t)L;
@@ -339,7 +345,7 @@ int ensure_workspace(clm_handle* h, int Bc, int L, hipStream_t st) {
     need[WS_H] = nb * nl * D * 4;
     need[WS_Z] = nb * D3 * Lp * es;
     need[WS_Y] = nb * D * Lp * es;
-    need[WS_U] = (prec == PREC_F32 || h->force_generic) ? nb * DI * nl * es : 0;   // the 1024-wide fc1 output: unfused paths only
+    need[WS_U] = ((prec == PREC_F32 && !fused_fp32(h)) || (prec != PREC_F32 && h->force_generic)) ? nb * DI * nl * es : 0;   // the 1024-wide fc1 output: unfused paths only
     need[WS_SCORES] = nb * nl * 4;
     need[WS_STATS] = nb * 2 * 4;
     // pooling partials: [POOL_SPLIT][4][256] per read (fp32 path) or one POOL_PSTRIDE row per 128-token tile
@@ -495,7 +501,8 @@ bool stop_here(clm_handle* h, int layer, int stage) { return h->stop_layer == la
 // per chunk, and 288 GB of HBM have room), a quarter of that in exact fp32 (its 1024-wide fc1 output is 4 KiB per token, and the
 // proven size).  Even, so that a chunk boundary never splits a read pair of the packed transform.
 int chunk_for(const clm_handle* h, int L) {
-    const long long cap_tokens = effective_prec(h, L) == PREC_F32 ? 64LL * 8256 : 256LL * 8256;
+    // (exact fp32 with the fused tail has no fc1 output in HBM either: the same cap as the 16-bit modes)
+    const long long cap_tokens = (effective_prec(h, L) == PREC_F32 && !fused_fp32(h)) ? 64LL * 8256 : 256LL * 8256;
     long long c = cap_tokens / round_up(L, LP_ALIGN);
     if (c > h->cfg.chunk_reads) c = h->cfg.chunk_reads;
     if (c > 1) c &= ~1LL;
@@ -535,6 +542,8 @@ int forward_chunk(clm_handle* h, const void* ids, int ids_dtype, int64_t row_str
     // ... and hands z over in the form the convolution reads: x0f and g = x1f * vf, filtered and gated by the in_proj stage itself
     // (two rows per channel instead of three; gemm16.hip inproj_blocks_gated)
     const bool zgated = fuse_next && !h->raw_z;
+    // exact fp32: one fused kernel per block tail, the next block's in_proj included (tail32.hip)
+    const bool fused32 = prec == PREC_F32 && fused_fp32(h);
     // fp16c, round 4: y (every block) and the gated rows of z carry one lo byte per element next to the halfs
     unsigned char* const ylo = (prec == PREC_F16C && tuned16) ? h->ylo : nullptr;
     if (zgated && tail16_grid(((peel ? L - 1 : L) + 127) / 128 * Bc) > 1024)
@@ -553,8 +562,10 @@ int forward_chunk(clm_handle* h, const void* ids, int ids_dtype, int64_t row_str
         const LayerW& lw = alt32 ? h->lw32[i] : h->lw[i];
         // block 0 in the 16-bit modes: its in_proj output is a function of the token id alone, the convolution looks it
         // up (ztab), single-shot and segmented kernel alike -- unless a debug stop asks for z itself or CLM_DEBUG=no_idconv
-        const bool idconv = i == 0 && (idpath || (tuned16 && !h->no_idconv && !stop_here(h, 0, CLM_STAGE_INPROJ)));
-        if (!idconv && !(fuse_next && i > 0)) {
+        // (exact fp32 with the fused tail, single-shot convolution: the same table -- it is fp32 -- so block 0 needs no in_proj launch)
+        const bool idconv = i == 0 && (idpath || (tuned16 && !h->no_idconv && !stop_here(h, 0, CLM_STAGE_INPROJ)) ||
+                                       (fused32 && S == 1 && !h->no_idconv));
+        if (!idconv && !(fuse_next && i > 0) && !(fused32 && i > 0)) {
             StageTimer t(h, st, CLM_STAGE_INPROJ);
             if (tuned16) launch_inproj16(prec, h->h, lw.ln1_g, lw.ln1_b, lw.w_in, lw.b_in, h->z, Bc, L, Lp, eps, st);
             else launch_inproj(prec, h->h, lw.ln1_g, lw.ln1_b, lw.w_in, lw.b_in, h->z, Bc, L, Lp, eps, st);
@@ -620,6 +631,12 @@ int forward_chunk(clm_handle* h, const void* ids, int ids_dtype, int64_t row_str
                 la.ylo = ylo; la.zlo = ta.zlo;
                 launch_lone_token(prec, la, st);
             }
+        } else if (fused32) {
+            StageTimer t(h, st, CLM_STAGE_TAIL);
+            const LayerW* nx = i + 1 < NLAYER ? &(alt32 ? h->lw32[i + 1] : h->lw[i + 1]) : nullptr;
+            launch_tail32(reinterpret_cast<const float*>(h->y), h->h, lw.t_out, lw.t_fc1, lw.t_fc2, nx ? nx->t_in : nullptr, lw.b_out,
+                          lw.b_fc1, lw.b_fc2, nx ? nx->b_in : nullptr, lw.ln2_g, lw.ln2_b, nx ? nx->ln1_g : nullptr,
+                          nx ? nx->ln1_b : nullptr, reinterpret_cast<float*>(h->z), Bc, L, Lp, eps, st);
         } else {
             {
                 StageTimer t(h, st, CLM_STAGE_OUTPROJ);
@@ -712,6 +729,7 @@ int clm_create(const clm_config* cfg, int device, clm_handle** out) {
     // developer switches (A/B runs, tests): ONE variable, CLM_DEBUG, a comma-separated list read when a handle is created
     // (clm_common.h debug_flag) -- no product behaviour hangs on the environment
     h->force_generic = debug_flag("generic_gemm");     // 16-bit modes through the generic kernels
+    h->unfused_fp32 = debug_flag("unfused_fp32");      // exact fp32 through the separate GEMM kernels instead of tail32_kernel
     h->no_fuse_next = debug_flag("no_fuse_next");      // separate in_proj / score kernels instead of fusing them into the tail
     h->no_idconv = debug_flag("no_idconv");            // block 0's in_proj instead of the id-table convolution
     h->split_tail = debug_flag("split_tail");          // separate out_proj16 + mlp16 kernels instead of the fused tail
@@ -811,6 +829,15 @@ int clm_finalize(clm_handle* h) {
         lw.b_fc1 = W(h, p + "mlp.fc1.bias"); lw.b_fc2 = W(h, p + "mlp.fc2.bias");
         lw.short_w = W(h, p + "mixer.short_filter.weight"); lw.short_b = W(h, p + "mixer.short_filter.bias");
         lw.filt_bias = W(h, p + "mixer.filter_fn.bias");
+        {   // exact fp32 (the engine's own mode, or the referee / short-read / fall-back path of a 16-bit engine): the fused tail's packing
+            struct { const char* key; int n, k; } tw[4] = {{"mixer.in_proj.weight", D3, D}, {"mixer.out_proj.weight", D, D},
+                                                           {"mlp.fc1.weight", DI, D}, {"mlp.fc2.weight", D, DI}};
+            for (int j = 0; j < 4; ++j) {
+                HIPCHK(h, hipMalloc(&h->packed32t[i][j], (size_t)tw[j].n * tw[j].k * 4));
+                launch_pack_f32t(W(h, p + tw[j].key), h->packed32t[i][j], tw[j].n, tw[j].k, st);
+            }
+            lw.t_in = h->packed32t[i][0]; lw.t_out = h->packed32t[i][1]; lw.t_fc1 = h->packed32t[i][2]; lw.t_fc2 = h->packed32t[i][3];
+        }
         if (prec != PREC_F32) {   // the exact-fp32 packing next to the 16-bit one: fp16c's short reads, clm_selfcheck, clm_set_fallback
             if ((rc = pack_as(PREC_F32, p + "mixer.in_proj.weight", D3, D, &h->packed32[i][0]))) return rc;
             if ((rc = pack_as(PREC_F32, p + "mixer.out_proj.weight", D, D, &h->packed32[i][1]))) return rc;

@@ -169,12 +169,20 @@ struct LayerW {            // device pointers, fp32 unless noted
     const float *b_in, *b_out, *b_fc1, *b_fc2;
     const float *short_w, *short_b;             // [768][3], [768]
     const float *filt_bias;                     // [256]  (D skip term)
+    const void *t_in = nullptr, *t_out = nullptr, *t_fc1 = nullptr, *t_fc2 = nullptr;   // exact fp32: the fused tail's packing (tail32.hip)
 };
 
 // embedding gather: ids [B, L] (dtype code CLM_DT_*) -> h fp32 [B, L, 256]
 void launch_embed(const void* ids, int ids_dtype, int64_t row_stride, const float* table, float* h,
                   unsigned char* ids8 /*[B][Lp] clamped ids, may be null*/, int B, int L, int Lp, hipStream_t st,
                   int* bad_ids = nullptr /*device-visible flag set when an id is outside [0, 16)*/);
+
+// exact fp32, fused (tail32.hip): out_proj + LN2 + MLP + both residuals on h in place, then -- w_in_next != null -- the next
+// block's LayerNorm-1 + in_proj into z (rows x0 | x1 | v, fp32).  Weights in launch_pack_f32t's order.
+void launch_tail32(const float* y, float* h, const void* w_out, const void* w_fc1, const void* w_fc2, const void* w_in_next,
+                   const float* b_out, const float* b_fc1, const float* b_fc2, const float* b_in_next, const float* ln2_g,
+                   const float* ln2_b, const float* n_g, const float* n_b, float* z, int B, int L, int Lp, float eps, hipStream_t st);
+void launch_pack_f32t(const float* w /*[n][k]*/, void* out /*n * k floats*/, int n, int k, hipStream_t st);
 
 // GEMM family (gemm.hip).  `prec` selects compute dtype; T16 activations are bf16/f16 (or fp32 for PREC_F32).
 // z  = in_proj(LN1(h))      -> channel-major [B, 768, Lp]

@@ -1833,11 +1833,11 @@ static void launch_conv_t(const void* z, void* y, const float2* kf, const float2
                             no_stamps, no_ids, no_tab, ylo);
             return;
         }
-        if (ids8) {
-            CLM_CONV_LAUNCH((hyena_conv_kernel<LOGN, T, false, true, false, LO>), (const T*)nullptr, yt, kf, tw, ktime, short_w, short_b,
-                            B, L, Lp, no_stamps, ids8, ztab, ylo);
-            return;
-        }
+    }
+    if (ids8) {     // block 0: z looked up by token id (exact fp32 too, round 4: its block 0 then needs no in_proj launch)
+        CLM_CONV_LAUNCH((hyena_conv_kernel<LOGN, T, false, true, false, LO>), (const T*)nullptr, yt, kf, tw, ktime, short_w, short_b,
+                        B, L, Lp, no_stamps, ids8, ztab, ylo);
+        return;
     }
     if constexpr (LOGN == 14 && std::is_same<T, f16_t>::value && !LO) {
         static const bool stamp = debug_flag("stamp");
@@ -1865,7 +1865,7 @@ static void launch_conv_p(int prec, const void* z, void* y, const float2* kf, co
     if (prec == PREC_F16C && ylo)
         launch_conv_t<LOGN, f16_t, true>(z, y, kf, tw, ktime, short_w, short_b, B, L, Lp, ids8, ztab, st, gated, ylo);
     else if (prec == PREC_F32)
-        launch_conv_t<LOGN, float>(z, y, kf, tw, ktime, short_w, short_b, B, L, Lp, nullptr, nullptr, st, false);
+        launch_conv_t<LOGN, float>(z, y, kf, tw, ktime, short_w, short_b, B, L, Lp, ids8, ztab, st, false);
     else if (prec == PREC_BF16)
         launch_conv_t<LOGN, bf16_t>(z, y, kf, tw, ktime, short_w, short_b, B, L, Lp, ids8, ztab, st, gated);
     else

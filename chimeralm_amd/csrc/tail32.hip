@@ -1,0 +1,317 @@
+// tail32.hip -- the exact-fp32 engine's fused block tail (round 4).
+//
+// One kernel per Hyena block, on v_mfma_f32_32x32x2_f32 throughout, for the part of the block that is token-wise
+//   /root/reference/chimeralm/models/components/hyena.py:244-256 -> the backbone's block: x = x + mixer(norm1(x)); x = x + mlp(norm2(x))
+//       r  = h + b_out + W_out y                    (y = the convolution's output, channel-major in HBM)
+//       h' = r + b_2 + W_2 gelu_tanh(W_1 LN2(r) + b_1)
+//       z  = W_in' LN1'(h') + b_in'                 (the NEXT block's in_proj, rows x0 | x1 | v as the fp32 convolution reads them)
+// where round 1-3's fp32 path ran five separate GEMM kernels per block with the 1024-wide fc1 output, the normalised tiles and
+// the intermediate residual all crossing HBM in fp32 (gemm.hip; kept: block 0's in_proj, the score layer, and the whole path
+// under CLM_DEBUG=unfused_fp32, which tests/ uses to cross-check this kernel).
+//
+// Tile = 64 tokens x 256 features per workgroup (8 waves; a wave owns 32 output features of every product, both 32-token row
+// tiles): an fp32 tile of 64 tokens fills the LDS a 16-bit tile of 128 does (As + Hs = 2 x 65 KiB).  Weights are the MFMA's A
+// operand (accumulator rows = output features, lane = token), packed per (256-wide block, wave, 8-deep k-step, lane) as one
+// float4 -- the four k values a lane feeds to four consecutive MFMAs: the reduction index may be permuted freely, so MFMA j of a
+// k-step pairs k = 8 s + j (lanes 0-31) with k = 8 s + 4 + j (lanes 32-63) and both operands are 16-byte loads.  A 64-deep weight
+// set (8 float4 = 32 registers) is requested one set ahead of its use; a set is 64 MFMAs of 64 cycles per wave, so neither the
+// L2 latency nor the 16 ds_read_b128 of a set are anywhere near the matrix pipe's time: the kernel is MFMA-bound by construction
+// (12 blocks x 256 MFMAs x 64 cycles x 2 waves per SIMD = 393k cycles per tile against ~25k of LayerNorm / GELU / epilogue VALU).
+#include "chimeralm_hip.h"
+#include "clm_common.h"
+
+namespace clm {
+
+namespace {
+
+constexpr int BM32 = 64;          // tokens per tile
+constexpr int RS32 = 260;         // row stride (floats) of the token-major tiles: 1040 B -- the 16 rows of a ds_read_b128 lane group
+                                  // fall on 16 different 16-byte bank groups (260 = 4 mod 64)
+constexpr int RSY = 72;           // row stride (floats) of the k-major y tile: the two half-waves of an MFMA read rows k and k + 4, i.e. 288 floats = banks + 32
+constexpr int KS_SET = 8;         // k-steps (of 8) per weight set: 64 deep
+
+using f32x4 = float __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ const f32x4* wset_ptr(const f32x4* wp, int nb, int ksteps_all, int ks0, int wave, int lane) {
+    return wp + ((size_t)(nb * 8 + wave) * ksteps_all + ks0) * 64 + lane;
+}
+__device__ __forceinline__ void load_wset(const f32x4* p, f32x4 (&ws)[KS_SET]) {
+#pragma unroll
+    for (int s = 0; s < KS_SET; ++s) ws[s] = p[(size_t)s * 64];
+}
+__device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0); }
+
+// acc[mt] += W-set x T[tokens mt*32.., k = 64 part ..): token-major tile
+__device__ __forceinline__ void compute_set_tm(const float* T, int part, int lrow, int lhalf, const f32x4 (&ws)[KS_SET], f32x16 (&acc)[2]) {
+    const float* a0 = T + lrow * RS32 + part * 64 + lhalf * 4;
+    f32x4 af[2][2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) af[0][mt] = *reinterpret_cast<const f32x4*>(a0 + mt * 32 * RS32);
+#pragma unroll
+    for (int s = 0; s < KS_SET; ++s) {
+        if (s + 1 < KS_SET) {
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) af[(s + 1) & 1][mt] = *reinterpret_cast<const f32x4*>(a0 + mt * 32 * RS32 + (s + 1) * 8);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) acc[mt] = mfma32(ws[s][j], af[s & 1][mt][j], acc[mt]);
+    }
+}
+// same from the k-major tile Ys[k][token] (out_proj: y is channel-major)
+__device__ __forceinline__ void compute_set_km(const float* Ys, int part, int lrow, int lhalf, const f32x4 (&ws)[KS_SET], f32x16 (&acc)[2]) {
+    const float* a0 = Ys + (part * 64 + lhalf * 4) * RSY + lrow;
+#pragma unroll
+    for (int s = 0; s < KS_SET; ++s)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) acc[mt] = mfma32(ws[s][j], a0[(s * 8 + j) * RSY + mt * 32], acc[mt]);
+}
+
+// one 256-deep product: sets 0..3 starting at k-step ks0 of (wp, nb); ws[0] holds set 0 on entry, and on exit the first set of
+// what follows (`nxt`, requested under the last set: unconditional)
+template <bool KM>
+__device__ __forceinline__ void product256(const float* T, const f32x4* wp, int nb, int ksteps_all, int ks0, const f32x4* nxt,
+                                           int wave, int lane, f32x4 (&ws)[2][KS_SET], f32x16 (&acc)[2]) {
+    const int lrow = lane & 31, lhalf = lane >> 5;
+    static_for<0, 4>([&](auto pc) {
+        constexpr int p = decltype(pc)::value;
+        if constexpr (p < 3) load_wset(wset_ptr(wp, nb, ksteps_all, ks0 + (p + 1) * KS_SET, wave, lane), ws[(p + 1) & 1]);
+        else load_wset(nxt, ws[0]);
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (KM) compute_set_km(T, p, lrow, lhalf, ws[p & 1], acc);
+        else compute_set_tm(T, p, lrow, lhalf, ws[p & 1], acc);
+        __builtin_amdgcn_sched_barrier(0);
+    });
+}
+
+// LayerNorm over the 256 features of the 64 tokens in accumulator layout (rows = this wave's 32 features, lane = token) -> T
+// (fp32, token-major); two-pass statistics like every fp32 LayerNorm of the engine (gemm_common.h stage_a_tile).  Ends with a
+// barrier (T complete); its first barrier also orders every earlier LDS read of the workgroup before the writes.
+__device__ __forceinline__ void ln_to_tile(const f32x16 (&acc)[2], float* P1, float* P2, const float* __restrict__ g,
+                                           const float* __restrict__ bta, float eps, float* T, int valid, int wave, int lrow, int lhalf) {
+    float mean[2], rstd[2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+        float s = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s += acc[mt][r];
+        s += __shfl_xor(s, 32, 64);
+        if (lhalf == 0) P1[wave * BM32 + mt * 32 + lrow] = s;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+        float s = 0.f;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) s += P1[w * BM32 + mt * 32 + lrow];
+        mean[mt] = s * (1.0f / D);
+        float v = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float d = acc[mt][r] - mean[mt];
+            v += d * d;
+        }
+        v += __shfl_xor(v, 32, 64);
+        if (lhalf == 0) P2[wave * BM32 + mt * 32 + lrow] = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+        float v = 0.f;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) v += P2[w * BM32 + mt * 32 + lrow];
+        rstd[mt] = 1.0f / sqrtf(v * (1.0f / D) + eps);
+    }
+    const float* gp = g + wave * 32 + 4 * lhalf;
+    const float* bp = bta + wave * 32 + 4 * lhalf;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const float4 g4 = *reinterpret_cast<const float4*>(gp + 8 * q);
+        const float4 b4 = *reinterpret_cast<const float4*>(bp + 8 * q);
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            const bool ok = mt * 32 + lrow < valid;          // rows beyond the read leave as zeros
+            f32x4 y;
+            y[0] = ok ? (acc[mt][4 * q + 0] - mean[mt]) * rstd[mt] * g4.x + b4.x : 0.f;
+            y[1] = ok ? (acc[mt][4 * q + 1] - mean[mt]) * rstd[mt] * g4.y + b4.y : 0.f;
+            y[2] = ok ? (acc[mt][4 * q + 2] - mean[mt]) * rstd[mt] * g4.z + b4.z : 0.f;
+            y[3] = ok ? (acc[mt][4 * q + 3] - mean[mt]) * rstd[mt] * g4.w + b4.w : 0.f;
+            *reinterpret_cast<f32x4*>(T + (mt * 32 + lrow) * RS32 + wave * 32 + 8 * q + 4 * lhalf) = y;
+        }
+    }
+    __syncthreads();
+}
+
+}  // namespace
+
+struct Tail32Args {
+    const float* y;           // [B, 256, Lp] fp32
+    float* h;                 // [B, L, 256] residual stream, updated in place
+    const f32x4 *w_out, *w_fc1, *w_fc2, *w_in;   // packed (pack_f32t_kernel); w_in: the NEXT block's in_proj, or null
+    const float *b_out, *b_fc1, *b_fc2, *b_in, *ln2_g, *ln2_b, *n_g, *n_b;
+    float* z;                 // [B, 768, Lp] fp32 (NEXT)
+    int B, L, Lp, tiles_x;
+    float eps;
+};
+
+template <bool NEXT>
+__global__ __launch_bounds__(512) void tail32_kernel(Tail32Args m) {
+    extern __shared__ __attribute__((aligned(16))) float smem32[];
+    float* As = smem32;                                     // LN2(r) / LN1'(h') tile [64][RS32]      (the y tile aliases As + Hs)
+    float* Hs = As + BM32 * RS32;                           // gelu(fc1) chunk [64][RS32]
+    float* Ys = smem32;                                     // y tile [256 channels][RSY], k-major
+    float* P1 = smem32 + 2 * BM32 * RS32;                   // LayerNorm partials [8][64]
+    float* P2 = P1 + 8 * BM32;
+    static_assert(D * RSY <= 2 * BM32 * RS32, "the y tile fits As + Hs");
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lrow = lane & 31, lhalf = lane >> 5;
+    const int b = (int)blockIdx.x / m.tiles_x, t0 = ((int)blockIdx.x % m.tiles_x) * BM32, L = m.L, Lp = m.Lp;
+    const int valid = L - t0 < BM32 ? L - t0 : BM32;
+    f32x4 ws[2][KS_SET];
+    f32x16 acc1[2], acc2[2];
+    load_wset(wset_ptr(m.w_out, 0, D / 8, 0, wave, lane), ws[0]);
+    // ---- 0. y tile -> LDS (k-major, as it lies in HBM): 16 lanes x 16 bytes per channel row, 32 channels per pass
+    {
+        const int tk = (tid & 15) * 4;
+        const float* src = m.y + (size_t)b * D * Lp + t0 + tk;
+        const bool in_row = t0 + tk < Lp;                   // (Lp is a multiple of 64: a 16-byte piece is inside the row or beyond it)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int c = (tid >> 4) + 32 * i;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (in_row) v = *reinterpret_cast<const f32x4*>(src + (size_t)c * Lp);
+            *reinterpret_cast<f32x4*>(Ys + c * RSY + tk) = v;
+        }
+    }
+    // ---- 1. r = h + b_out + W_out y: the accumulators start from the residual rows
+    {
+        const float* bo = m.b_out + wave * 32 + 4 * lhalf;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            const int t = t0 + mt * 32 + lrow, tc = t < L ? t : L - 1;
+            const float* row = m.h + ((size_t)b * L + tc) * D + wave * 32 + 4 * lhalf;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 hv = *reinterpret_cast<const float4*>(row + 8 * q);
+                const float4 bb = *reinterpret_cast<const float4*>(bo + 8 * q);
+                acc2[mt][4 * q + 0] = hv.x + bb.x;
+                acc2[mt][4 * q + 1] = hv.y + bb.y;
+                acc2[mt][4 * q + 2] = hv.z + bb.z;
+                acc2[mt][4 * q + 3] = hv.w + bb.w;
+            }
+        }
+    }
+    __syncthreads();
+    product256<true>(Ys, m.w_out, 0, D / 8, 0, wset_ptr(m.w_fc1, 0, D / 8, 0, wave, lane), wave, lane, ws, acc2);
+    // ---- 2. LayerNorm-2 -> As
+    ln_to_tile(acc2, P1, P2, m.ln2_g, m.ln2_b, m.eps, As, valid, wave, lrow, lhalf);
+    // ---- 3. MLP in four 256-wide chunks of the hidden layer (acc2 holds r)
+#pragma unroll 1
+    for (int j = 0; j < DI / 256; ++j) {
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc1[mt][r] = 0.f;
+        product256<false>(As, m.w_fc1, j, D / 8, 0, wset_ptr(m.w_fc2, 0, DI / 8, j * 32, wave, lane), wave, lane, ws, acc1);
+        {
+            const float* b1 = m.b_fc1 + j * 256 + wave * 32 + 4 * lhalf;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 bb = *reinterpret_cast<const float4*>(b1 + 8 * q);
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) {
+                    f32x4 g = {gelu_tanh(acc1[mt][4 * q + 0] + bb.x), gelu_tanh(acc1[mt][4 * q + 1] + bb.y),
+                               gelu_tanh(acc1[mt][4 * q + 2] + bb.z), gelu_tanh(acc1[mt][4 * q + 3] + bb.w)};
+                    *reinterpret_cast<f32x4*>(Hs + (mt * 32 + lrow) * RS32 + wave * 32 + 8 * q + 4 * lhalf) = g;
+                }
+            }
+        }
+        __syncthreads();
+        const f32x4* nxt = j + 1 < DI / 256 ? wset_ptr(m.w_fc1, j + 1, D / 8, 0, wave, lane)
+                                            : wset_ptr(NEXT ? m.w_in : m.w_fc1, 0, D / 8, 0, wave, lane);
+        product256<false>(Hs, m.w_fc2, 0, DI / 8, j * 32, nxt, wave, lane, ws, acc2);
+        __syncthreads();                                    // every wave is done reading Hs before the next chunk lands in it
+    }
+    // ---- 4. h' = acc2 + b_2: 16 bytes per lane and feature quad (a lane = a token row of h)
+    {
+        const float* b2p = m.b_fc2 + wave * 32 + 4 * lhalf;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4 bb = *reinterpret_cast<const float4*>(b2p + 8 * q);
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                acc2[mt][4 * q + 0] += bb.x;
+                acc2[mt][4 * q + 1] += bb.y;
+                acc2[mt][4 * q + 2] += bb.z;
+                acc2[mt][4 * q + 3] += bb.w;
+                if (mt * 32 + lrow < valid)
+                    *reinterpret_cast<float4*>(m.h + ((size_t)b * L + t0 + mt * 32 + lrow) * D + wave * 32 + 4 * lhalf + 8 * q) =
+                        make_float4(acc2[mt][4 * q + 0], acc2[mt][4 * q + 1], acc2[mt][4 * q + 2], acc2[mt][4 * q + 3]);
+            }
+        }
+    }
+    // ---- 5. the next block's LayerNorm-1 + in_proj on the tile still in registers: z rows x0 | x1 | v
+    if constexpr (NEXT) {
+        ln_to_tile(acc2, P1, P2, m.n_g, m.n_b, m.eps, As, valid, wave, lrow, lhalf);
+#pragma unroll 1
+        for (int nb = 0; nb < D3 / 256; ++nb) {
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc1[mt][r] = 0.f;
+            product256<false>(As, m.w_in, nb, D / 8, 0, wset_ptr(m.w_in, nb + 1 < D3 / 256 ? nb + 1 : 0, D / 8, 0, wave, lane), wave,
+                              lane, ws, acc1);
+            // rows = features: 32 lanes = 32 consecutive tokens of one channel row (128 bytes)
+            const float* bi = m.b_in + nb * 256 + wave * 32 + 4 * lhalf;
+            float* zb = m.z + ((size_t)b * D3 + nb * 256 + wave * 32 + 4 * lhalf) * Lp + t0 + lrow;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int f = (r & 3) + 8 * (r >> 2);
+                const float bias = bi[f];
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+                    if (mt * 32 + lrow < valid) zb[(size_t)f * Lp + mt * 32] = acc1[mt][r] + bias;
+            }
+        }
+    }
+}
+
+// W [N][K] row-major fp32 -> [N / 256][8 waves][K / 8 k-steps][64 lanes] float4: lane (lrow, lhalf) of wave w holds
+// W[nb * 256 + w * 32 + lrow][8 s + 4 lhalf + 0..3]
+__global__ __launch_bounds__(256) void pack_f32t_kernel(const float* __restrict__ w, f32x4* __restrict__ out, int N, int K) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x, total = (size_t)N * K / 4;
+    if (i >= total) return;
+    const int lane = (int)(i & 63), lrow = lane & 31, lhalf = lane >> 5;
+    const size_t rest = i >> 6;
+    const int ksteps = K / 8, s = (int)(rest % ksteps), nw = (int)(rest / ksteps);       // nw = nb * 8 + wave
+    const float* src = w + (size_t)(nw * 32 + lrow) * K + 8 * s + 4 * lhalf;
+    out[i] = f32x4{src[0], src[1], src[2], src[3]};
+}
+
+void launch_pack_f32t(const float* w, void* out, int n, int k, hipStream_t st) {
+    const size_t total = (size_t)n * k / 4;
+    hipLaunchKernelGGL(pack_f32t_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, w, reinterpret_cast<f32x4*>(out), n, k);
+}
+
+void launch_tail32(const float* y, float* h, const void* w_out, const void* w_fc1, const void* w_fc2, const void* w_in_next,
+                   const float* b_out, const float* b_fc1, const float* b_fc2, const float* b_in_next, const float* ln2_g,
+                   const float* ln2_b, const float* n_g, const float* n_b, float* z, int B, int L, int Lp, float eps, hipStream_t st) {
+    Tail32Args m{y, h, reinterpret_cast<const f32x4*>(w_out), reinterpret_cast<const f32x4*>(w_fc1), reinterpret_cast<const f32x4*>(w_fc2),
+                 reinterpret_cast<const f32x4*>(w_in_next), b_out, b_fc1, b_fc2, b_in_next, ln2_g, ln2_b, n_g, n_b, z, B, L, Lp,
+                 (L + BM32 - 1) / BM32, eps};
+    const size_t lds = (size_t)(2 * BM32 * RS32 + 2 * 8 * BM32) * sizeof(float);
+    const dim3 grid((unsigned)(m.tiles_x * B)), block(512);
+    if (w_in_next) {
+        static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(tail32_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), true);
+        (void)once;
+        hipLaunchKernelGGL(tail32_kernel<true>, grid, block, lds, st, m);
+    } else {
+        static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(tail32_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), true);
+        (void)once;
+        hipLaunchKernelGGL(tail32_kernel<false>, grid, block, lds, st, m);
+    }
+}
+
+}  // namespace clm

@@ -461,6 +461,32 @@ def test_persistent_convolution_equals_one_workgroup_per_unit(sd, built_lib, mon
     e0.close(), e1.close()
 
 
+@pytest.mark.parametrize("B,L", [(3, 257), (5, 64), (2, 65), (1, 1), (4, 1000), (3, 8193), (2, 20000), (7, 130)])
+def test_fused_fp32_tail_equals_the_separate_gemm_kernels(sd, built_lib, monkeypatch, B, L):
+    """Exact fp32 runs one fused kernel per block tail since round 4 (tail32.hip: out_proj + LN2 + MLP + both residuals + the next
+    block's LN1 / in_proj on 64-token tiles).  Against the five separate GEMM kernels of rounds 1-3 (CLM_DEBUG=unfused_fp32) the same
+    fp32 products in another summation order: logits agree to fp32 rounding, and both stand against the oracle at the exact mode's
+    bound.  Tiles that end inside a read, reads shorter than a tile, one token, pads, the segmented long-read path."""
+    from chimeralm_amd.engine import Engine
+
+    ids = _ids(B, L, seed=61, pads=2 if L > 8 else 0)
+    t = torch.from_numpy(ids).cuda()
+    e0 = Engine("cuda:0", precision="fp32")
+    monkeypatch.setenv("CLM_DEBUG", "unfused_fp32")      # read by clm_create
+    e1 = Engine("cuda:0", precision="fp32")
+    monkeypatch.delenv("CLM_DEBUG")
+    e0.load_state_dict(sd), e1.load_state_dict(sd)
+    a, b = e0.forward(t).cpu(), e1.forward(t).cpu()
+    h0 = e0.debug_fetch("h", (B, L, 256)).copy()
+    h1 = e1.debug_fetch("h", (B, L, 256)).copy()
+    scale = float(np.abs(h1).max())
+    print(f"fp32 fused vs separate kernels, {B} x {L}: |dlogit| {(a - b).abs().max().item():.2e}, stream {np.abs(h0 - h1).max():.2e} of {scale:.3g}")
+    assert (a - b).abs().max() <= 2e-5
+    assert np.abs(h0 - h1).max() <= 1e-5 * scale
+    _check(e0, "fp32", ids, sd)
+    e0.close(), e1.close()
+
+
 @pytest.mark.parametrize("prec,B,L", [("fp16c", 5, 8193), ("fp16c", 3, 6000), ("fp16c", 4, 4097), ("fp16", 3, 1000), ("bf16", 2, 300),
                                       ("fp16c", 3, 20000), ("fp16c", 2, 16385), ("fp16", 7, 2049), ("fp16c", 1, 8193)])
 def test_gated_hand_over_equals_raw_rows(sd, built_lib, monkeypatch, prec, B, L):
@@ -571,7 +597,8 @@ def test_the_residual_stream_is_causal(sd, built_lib, prec, B, L, cut):
     after = float(np.abs(h1[:, cut:L - 1] - h2[:, cut:L - 1]).max())
     print(f"{prec} {B} x {L}, cut {cut}: stream scale {scale:.3g}, moved before the cut {before:.2e}, after {after:.2e}")
     assert np.isfinite(h1).all() and np.isfinite(h2).all()
-    assert before <= (2e-6 if prec == "fp32" else 1e-4) * scale
+    # (fp16c: z / y travel at ~15 bits; plain fp16: at 11 -- an FFT-rounding-level change flips a half's last bit: 2^-11 of the element)
+    assert before <= {"fp32": 2e-6, "fp16c": 1e-4, "fp16": 1e-3}[prec] * scale
     assert after > 1e-2 * scale
 
 
