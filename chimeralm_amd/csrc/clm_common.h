@@ -183,6 +183,11 @@ void launch_tail32(const float* y, float* h, const void* w_out, const void* w_fc
                    const float* b_out, const float* b_fc1, const float* b_fc2, const float* b_in_next, const float* ln2_g,
                    const float* ln2_b, const float* n_g, const float* n_b, float* z, int B, int L, int Lp, float eps, hipStream_t st);
 void launch_pack_f32t(const float* w /*[n][k]*/, void* out /*n * k floats*/, int n, int k, hipStream_t st);
+// SequenceCNNTransformer, exact fp32 (tail32.hip enc32_kernel): att == null: qkv of the rows of h as they are; otherwise one encoder
+// layer after its attention (out_proj + LN1 + FFN + LN2 on h in place) and, w_qkv != null, the next layer's in_proj into qkv
+void launch_enc32(const float* att, float* h, const void* w_o, const void* w1, const void* w2, const void* w_qkv, const float* b_o,
+                  const float* b1, const float* b2, const float* b_qkv, const float* ln1_g, const float* ln1_b, const float* ln2_g,
+                  const float* ln2_b, float* qkv, size_t M, float eps, hipStream_t st);
 
 // GEMM family (gemm.hip).  `prec` selects compute dtype; T16 activations are bf16/f16 (or fp32 for PREC_F32).
 // z  = in_proj(LN1(h))      -> channel-major [B, 768, Lp]

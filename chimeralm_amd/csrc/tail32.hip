@@ -90,7 +90,9 @@ __device__ __forceinline__ void product256(const float* T, const f32x4* wp, int 
 // LayerNorm over the 256 features of the 64 tokens in accumulator layout (rows = this wave's 32 features, lane = token) -> T
 // (fp32, token-major); two-pass statistics like every fp32 LayerNorm of the engine (gemm_common.h stage_a_tile).  Ends with a
 // barrier (T complete); its first barrier also orders every earlier LDS read of the workgroup before the writes.
-__device__ __forceinline__ void ln_to_tile(const f32x16 (&acc)[2], float* P1, float* P2, const float* __restrict__ g,
+// KEEP: the normalised values also replace the accumulator contents (post-norm blocks: they are the next residual).
+template <bool KEEP = false>
+__device__ __forceinline__ void ln_to_tile(f32x16 (&acc)[2], float* P1, float* P2, const float* __restrict__ g,
                                            const float* __restrict__ bta, float eps, float* T, int valid, int wave, int lrow, int lhalf) {
     float mean[2], rstd[2];
 #pragma unroll
@@ -139,6 +141,10 @@ __device__ __forceinline__ void ln_to_tile(const f32x16 (&acc)[2], float* P1, fl
             y[1] = ok ? (acc[mt][4 * q + 1] - mean[mt]) * rstd[mt] * g4.y + b4.y : 0.f;
             y[2] = ok ? (acc[mt][4 * q + 2] - mean[mt]) * rstd[mt] * g4.z + b4.z : 0.f;
             y[3] = ok ? (acc[mt][4 * q + 3] - mean[mt]) * rstd[mt] * g4.w + b4.w : 0.f;
+            if constexpr (KEEP) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[mt][4 * q + e] = y[e];
+            }
             *reinterpret_cast<f32x4*>(T + (mt * 32 + lrow) * RS32 + wave * 32 + 8 * q + 4 * lhalf) = y;
         }
     }
@@ -278,6 +284,146 @@ __global__ __launch_bounds__(512) void tail32_kernel(Tail32Args m) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// SequenceCNNTransformer, exact fp32: one kernel per encoder layer for everything but the attention itself
+//   /root/reference/chimeralm/models/components/transformer.py:64-68 (nn.TransformerEncoderLayer, post-norm, ReLU, no masks)
+//       x1  = LN1(h + W_o att + b_o)
+//       h'  = LN2(x1 + W_2 relu(W_1 x1 + b_1) + b_2)
+//       qkv = W_qkv' h' + b_qkv'                       (the NEXT layer's in_proj; FIRST: only this, on the tile of h as it is)
+// Same 64-token tile, weight packing and MFMA loop as tail32_kernel; activations are token-major in HBM ([M, 256] rows).
+struct Enc32Args {
+    const float* att;         // [M, 256]
+    float* h;                 // [M, 256] residual stream (post-norm: normalised), updated in place
+    const f32x4 *w_o, *w1, *w2, *w_qkv;
+    const float *b_o, *b1, *b2, *b_qkv, *ln1_g, *ln1_b, *ln2_g, *ln2_b;
+    float* qkv;               // [M, 768]
+    size_t M;
+    float eps;
+};
+
+__device__ __forceinline__ void stage_rows32(const float* __restrict__ src, size_t row0, size_t M, float* T, int tid) {
+    const int lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int r = wave + 8 * i;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (row0 + r < M) v = *reinterpret_cast<const f32x4*>(src + (row0 + r) * D + lane * 4);
+        *reinterpret_cast<f32x4*>(T + r * RS32 + lane * 4) = v;
+    }
+}
+
+template <bool FIRST>
+__global__ __launch_bounds__(512) void enc32_kernel(Enc32Args m) {
+    extern __shared__ __attribute__((aligned(16))) float smem32[];
+    float* As = smem32;
+    float* Hs = As + BM32 * RS32;
+    float* P1 = smem32 + 2 * BM32 * RS32;
+    float* P2 = P1 + 8 * BM32;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lrow = lane & 31, lhalf = lane >> 5;
+    const size_t row0 = (size_t)blockIdx.x * BM32;
+    const int valid = m.M - row0 < (size_t)BM32 ? (int)(m.M - row0) : BM32;
+    f32x4 ws[2][KS_SET];
+    f32x16 acc1[2], acc2[2];
+    if constexpr (FIRST) {
+        load_wset(wset_ptr(m.w_qkv, 0, D / 8, 0, wave, lane), ws[0]);
+        stage_rows32(m.h, row0, m.M, As, tid);
+        __syncthreads();
+    } else {
+        load_wset(wset_ptr(m.w_o, 0, D / 8, 0, wave, lane), ws[0]);
+        stage_rows32(m.att, row0, m.M, As, tid);
+        {   // acc2 = h + b_o
+            const float* bo = m.b_o + wave * 32 + 4 * lhalf;
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                const size_t r = row0 + mt * 32 + lrow, rc = r < m.M ? r : m.M - 1;
+                const float* row = m.h + rc * D + wave * 32 + 4 * lhalf;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float4 hv = *reinterpret_cast<const float4*>(row + 8 * q);
+                    const float4 bb = *reinterpret_cast<const float4*>(bo + 8 * q);
+                    acc2[mt][4 * q + 0] = hv.x + bb.x;
+                    acc2[mt][4 * q + 1] = hv.y + bb.y;
+                    acc2[mt][4 * q + 2] = hv.z + bb.z;
+                    acc2[mt][4 * q + 3] = hv.w + bb.w;
+                }
+            }
+        }
+        __syncthreads();
+        product256<false>(As, m.w_o, 0, D / 8, 0, wset_ptr(m.w1, 0, D / 8, 0, wave, lane), wave, lane, ws, acc2);
+        ln_to_tile<true>(acc2, P1, P2, m.ln1_g, m.ln1_b, m.eps, As, valid, wave, lrow, lhalf);       // As = x1, acc2 = x1
+#pragma unroll 1
+        for (int j = 0; j < DI / 256; ++j) {
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc1[mt][r] = 0.f;
+            product256<false>(As, m.w1, j, D / 8, 0, wset_ptr(m.w2, 0, DI / 8, j * 32, wave, lane), wave, lane, ws, acc1);
+            {
+                const float* b1 = m.b1 + j * 256 + wave * 32 + 4 * lhalf;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float4 bb = *reinterpret_cast<const float4*>(b1 + 8 * q);
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt) {
+                        f32x4 g = {fmaxf(acc1[mt][4 * q + 0] + bb.x, 0.f), fmaxf(acc1[mt][4 * q + 1] + bb.y, 0.f),
+                                   fmaxf(acc1[mt][4 * q + 2] + bb.z, 0.f), fmaxf(acc1[mt][4 * q + 3] + bb.w, 0.f)};
+                        *reinterpret_cast<f32x4*>(Hs + (mt * 32 + lrow) * RS32 + wave * 32 + 8 * q + 4 * lhalf) = g;
+                    }
+                }
+            }
+            __syncthreads();
+            const f32x4* nxt = j + 1 < DI / 256 ? wset_ptr(m.w1, j + 1, D / 8, 0, wave, lane)
+                                                : wset_ptr(m.w_qkv ? m.w_qkv : m.w1, 0, D / 8, 0, wave, lane);
+            product256<false>(Hs, m.w2, 0, DI / 8, j * 32, nxt, wave, lane, ws, acc2);
+            __syncthreads();
+        }
+        {   // + b_2, LayerNorm-2 -> As and the accumulators; h' leaves as 16 bytes per lane and feature quad
+            const float* b2p = m.b2 + wave * 32 + 4 * lhalf;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 bb = *reinterpret_cast<const float4*>(b2p + 8 * q);
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) {
+                    acc2[mt][4 * q + 0] += bb.x;
+                    acc2[mt][4 * q + 1] += bb.y;
+                    acc2[mt][4 * q + 2] += bb.z;
+                    acc2[mt][4 * q + 3] += bb.w;
+                }
+            }
+        }
+        ln_to_tile<true>(acc2, P1, P2, m.ln2_g, m.ln2_b, m.eps, As, valid, wave, lrow, lhalf);
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+                if (mt * 32 + lrow < valid)
+                    *reinterpret_cast<float4*>(m.h + (row0 + mt * 32 + lrow) * D + wave * 32 + 4 * lhalf + 8 * q) =
+                        make_float4(acc2[mt][4 * q + 0], acc2[mt][4 * q + 1], acc2[mt][4 * q + 2], acc2[mt][4 * q + 3]);
+        if (!m.w_qkv) return;                                  // (uniform: after the last layer)
+    }
+    // qkv = W_qkv As + b_qkv, rows = features: a lane writes 4 consecutive features of its token row
+#pragma unroll 1
+    for (int nb = 0; nb < D3 / 256; ++nb) {
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc1[mt][r] = 0.f;
+        product256<false>(As, m.w_qkv, nb, D / 8, 0, wset_ptr(m.w_qkv, nb + 1 < D3 / 256 ? nb + 1 : 0, D / 8, 0, wave, lane), wave, lane,
+                          ws, acc1);
+        const float* bq = m.b_qkv + nb * 256 + wave * 32 + 4 * lhalf;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4 bb = *reinterpret_cast<const float4*>(bq + 8 * q);
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+                if (mt * 32 + lrow < valid)
+                    *reinterpret_cast<float4*>(m.qkv + (row0 + mt * 32 + lrow) * D3 + nb * 256 + wave * 32 + 4 * lhalf + 8 * q) =
+                        make_float4(acc1[mt][4 * q + 0] + bb.x, acc1[mt][4 * q + 1] + bb.y, acc1[mt][4 * q + 2] + bb.z,
+                                    acc1[mt][4 * q + 3] + bb.w);
+        }
+    }
+}
+
 // W [N][K] row-major fp32 -> [N / 256][8 waves][K / 8 k-steps][64 lanes] float4: lane (lrow, lhalf) of wave w holds
 // W[nb * 256 + w * 32 + lrow][8 s + 4 lhalf + 0..3]
 __global__ __launch_bounds__(256) void pack_f32t_kernel(const float* __restrict__ w, f32x4* __restrict__ out, int N, int K) {
@@ -311,6 +457,26 @@ void launch_tail32(const float* y, float* h, const void* w_out, const void* w_fc
         static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(tail32_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), true);
         (void)once;
         hipLaunchKernelGGL(tail32_kernel<false>, grid, block, lds, st, m);
+    }
+}
+
+// FIRST (att == null): qkv of the tile of h as it is (the first layer's in_proj); otherwise the whole layer after its attention,
+// and -- w_qkv != null -- the next layer's in_proj.  Weights in launch_pack_f32t's order.
+void launch_enc32(const float* att, float* h, const void* w_o, const void* w1, const void* w2, const void* w_qkv, const float* b_o,
+                  const float* b1, const float* b2, const float* b_qkv, const float* ln1_g, const float* ln1_b, const float* ln2_g,
+                  const float* ln2_b, float* qkv, size_t M, float eps, hipStream_t st) {
+    Enc32Args m{att, h, reinterpret_cast<const f32x4*>(w_o), reinterpret_cast<const f32x4*>(w1), reinterpret_cast<const f32x4*>(w2),
+                reinterpret_cast<const f32x4*>(w_qkv), b_o, b1, b2, b_qkv, ln1_g, ln1_b, ln2_g, ln2_b, qkv, M, eps};
+    const size_t lds = (size_t)(2 * BM32 * RS32 + 2 * 8 * BM32) * sizeof(float);
+    const dim3 grid((unsigned)((M + BM32 - 1) / BM32)), block(512);
+    if (!att) {
+        static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(enc32_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), true);
+        (void)once;
+        hipLaunchKernelGGL(enc32_kernel<true>, grid, block, lds, st, m);
+    } else {
+        static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(enc32_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), true);
+        (void)once;
+        hipLaunchKernelGGL(enc32_kernel<false>, grid, block, lds, st, m);
     }
 }
 

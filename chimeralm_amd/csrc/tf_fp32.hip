@@ -191,7 +191,7 @@ size_t tf32_workspace_floats(int B, int L) {
 // `get(key)`: fp32 device pointer of a reference state-dict tensor.  h [M][256] receives the encoder output (the residual stream
 // the pooling head reads), exactly where the 16-bit path leaves it.
 int tf32_forward(const unsigned char* ids8, int ids_stride, int B, int L, int n_layers, float* ws, float* h,
-                 const float* (*get)(void*, const std::string&), void* ctx, hipStream_t st) {
+                 const float* (*get)(void*, const std::string&), void* ctx, hipStream_t st, bool unfused) {
     using namespace tf32;
     const int L1 = L / 2, L2 = L1 / 2, L3 = L2 / 2;
     const size_t M = (size_t)B * L3;
@@ -216,8 +216,25 @@ int tf32_forward(const unsigned char* ids8, int ids_stride, int B, int L, int n_
     // + positional encoding, LayerNorm -> residual stream
     hipLaunchKernelGGL(ln_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, st, x, Wt("pos_encoder.pe"), Wt("norm.weight"),
                        Wt("norm.bias"), h, M, L3, 1e-5f);
+    // Round 4: the dense layers of an encoder layer run fused on the fp32 MFMA (tail32.hip enc32_kernel: out_proj + LN1 + FFN + LN2 +
+    // the next layer's in_proj on 64-token tiles; weights in its packing under "t32.<layer>.<in|out|ff1|ff2>").  CLM_DEBUG=unfused_fp32:
+    // the seven separate launches per layer of round 2 (the tests cross-check the two).
+    auto T32 = [&](int i, const char* what) { return get(ctx, "t32." + std::to_string(i) + "." + what); };
+    auto LP = [&](int i) { return "transformer_encoder.layers." + std::to_string(i) + "."; };
+    if (!unfused && n_layers > 0)
+        launch_enc32(nullptr, h, nullptr, nullptr, nullptr, T32(0, "in"), nullptr, nullptr, nullptr, Wt(LP(0) + "self_attn.in_proj_bias"),
+                     nullptr, nullptr, nullptr, nullptr, qkv, M, 1e-5f, st);
     for (int i = 0; i < n_layers; ++i) {
-        const std::string p = "transformer_encoder.layers." + std::to_string(i) + ".";
+        const std::string p = LP(i);
+        if (!unfused) {
+            hipLaunchKernelGGL(attention_kernel, dim3((unsigned)((L3 + 255) / 256), 8, (unsigned)B), dim3(256), 0, st, qkv, att, L3);
+            const bool more = i + 1 < n_layers;
+            launch_enc32(att, h, T32(i, "out"), T32(i, "ff1"), T32(i, "ff2"), more ? T32(i + 1, "in") : nullptr,
+                         Wt(p + "self_attn.out_proj.bias"), Wt(p + "linear1.bias"), Wt(p + "linear2.bias"),
+                         more ? Wt(LP(i + 1) + "self_attn.in_proj_bias") : nullptr, Wt(p + "norm1.weight"), Wt(p + "norm1.bias"),
+                         Wt(p + "norm2.weight"), Wt(p + "norm2.bias"), qkv, M, 1e-5f, st);
+            continue;
+        }
         gemm<false, false>(h, D, Wt(p + "self_attn.in_proj_weight"), Wt(p + "self_attn.in_proj_bias"), nullptr, qkv, 768, M, 768, D, 0, st);
         hipLaunchKernelGGL(attention_kernel, dim3((unsigned)((L3 + 255) / 256), 8, (unsigned)B), dim3(256), 0, st, qkv, att, L3);
         gemm<false, false>(att, D, Wt(p + "self_attn.out_proj.weight"), Wt(p + "self_attn.out_proj.bias"), h, t, D, M, D, D, 0, st);

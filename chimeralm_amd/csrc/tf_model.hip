@@ -472,7 +472,7 @@ void launch_attention_fwd(int prec, const void* qkv, void* out, int B, int L, hi
 // tf_fp32.hip: the same forward with exact-fp32 products (the reference's precision), up to the encoder output h
 size_t tf32_workspace_floats(int B, int L);
 int tf32_forward(const unsigned char* ids8, int ids_stride, int B, int L, int n_layers, float* ws, float* h,
-                 const float* (*get)(void*, const std::string&), void* ctx, hipStream_t st);
+                 const float* (*get)(void*, const std::string&), void* ctx, hipStream_t st, bool unfused);
 
 }  // namespace clm
 
@@ -492,6 +492,7 @@ struct clm_tf_handle {
     unsigned char* ids8 = nullptr;
     void *x1 = nullptr, *x2 = nullptr, *x3 = nullptr, *hx = nullptr, *qkv = nullptr, *att = nullptr, *u = nullptr;
     float *h = nullptr, *scores = nullptr, *pooled = nullptr;
+    bool unfused_fp32 = false;                    // CLM_DEBUG=unfused_fp32 at creation: the separate fp32 launches of round 2 (tests cross-check the fused kernels)
     float* ws32 = nullptr;                        // fp32 mode: activations of tf_fp32.hip
     size_t cap_ws32 = 0;
     int last_B = 0, last_L3 = 0;
@@ -681,6 +682,7 @@ int clm_tf_create(int device, int precision, int n_layers, clm_tf_handle** out) 
     if (hipGetDeviceProperties(&prop, device) != hipSuccess || std::string(prop.gcnArchName).rfind("gfx950", 0) != 0)
         return tf_fail(nullptr, CLM_E_UNSUPPORTED, "clm_tf_create: this engine is built for gfx950 (MI355X) only");
     clm_tf_handle* h = new clm_tf_handle();
+    h->unfused_fp32 = debug_flag("unfused_fp32");
     h->device = device;
     h->prec = precision == CLM_PREC_BF16 ? PREC_BF16 : precision == CLM_PREC_F32 ? PREC_F32 : precision == CLM_PREC_F16C ? PREC_F16C
                                                                                                                        : PREC_F16;
@@ -723,7 +725,21 @@ int clm_tf_finalize(clm_tf_handle* h) {
     if (!h->w.count("pos_encoder.pe")) return tf_fail(h, CLM_E_MISSING, "clm_tf_finalize: missing buffer pos_encoder.pe");
     for (auto& kv : h->packed) (void)hipFree(kv.second);
     h->packed.clear();
-    if (h->prec == PREC_F32) {                                 // tf_fp32.hip reads the fp32 tensors as they are
+    // exact fp32 (the handle's own mode, or the referee / fall-back of a 16-bit handle): the dense layers of the encoder in the fused
+    // kernel's packing (tail32.hip enc32_kernel); everything else of tf_fp32.hip reads the fp32 tensors as they are
+    for (int i = 0; i < h->n_layers; ++i) {
+        const std::string p = "transformer_encoder.layers." + std::to_string(i) + ".", t = "t32." + std::to_string(i) + ".";
+        struct { const char* name; const char* key; int n, k; } tw[4] = {{"in", "self_attn.in_proj_weight", tf::TQKV, D}, {"out", "self_attn.out_proj.weight", D, D},
+                                                                         {"ff1", "linear1.weight", tf::TFF, D}, {"ff2", "linear2.weight", D, tf::TFF}};
+        for (auto& e : tw) {
+            void* q = nullptr;
+            TFCHK(h, hipMalloc(&q, (size_t)e.n * e.k * 4));
+            launch_pack_f32t(h->w.at(p + e.key), q, e.n, e.k, 0);
+            h->packed[t + e.name] = q;
+        }
+    }
+    if (h->prec == PREC_F32) {
+        TFCHK(h, hipDeviceSynchronize());
         h->finalized = true;
         return CLM_OK;
     }
@@ -792,8 +808,11 @@ static int tf_run(clm_tf_handle* h, bool prec32, const void* ids, int ids_dtype,
         }
         const int Lp = (L + 63) / 64 * 64;
         launch_embed(ids, ids_dtype, ids_row_stride, nullptr, nullptr, h->ids8, B, L, Lp, st);
-        auto get = [](void* ctx, const std::string& k) -> const float* { return static_cast<clm_tf_handle*>(ctx)->w.at(k); };
-        if (tf32_forward(h->ids8, Lp, B, L, h->n_layers, h->ws32, h->h, get, h, st))
+        auto get = [](void* ctx, const std::string& k) -> const float* {     // "t32.*": the fused kernel's packed weights
+            auto* hh = static_cast<clm_tf_handle*>(ctx);
+            return k.rfind("t32.", 0) == 0 ? static_cast<const float*>(hh->packed.at(k)) : hh->w.at(k);
+        };
+        if (tf32_forward(h->ids8, Lp, B, L, h->n_layers, h->ws32, h->h, get, h, st, h->unfused_fp32))
             return tf_fail(h, CLM_E_HIP, std::string("clm_tf_forward (fp32): ") + hipGetErrorString(hipGetLastError()));
         auto W = [&](const std::string& k) { return h->w.at(k); };
         hipLaunchKernelGGL(tf::pool_head_kernel, dim3(B), dim3(256), 0, st, h->h, W("attn_pool.weight"), W("attn_pool.bias"),

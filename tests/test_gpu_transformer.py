@@ -64,6 +64,27 @@ def test_forward_matches_oracle(built_lib, golden_dir, prec, seed, B, L, pads):
     net.close()
 
 
+@pytest.mark.parametrize("seed,B,L,pads", [(0, 2, 1000, 0), (1, 3, 777, 40), (2, 1, 8, 0), (5, 5, 520, 3), (6, 2, 4101, 0)])
+def test_fused_fp32_encoder_equals_the_separate_kernels(built_lib, monkeypatch, seed, B, L, pads):
+    """Exact fp32 runs the dense layers of an encoder layer and the attention on the fp32 MFMA in fused kernels since round 4
+    (tail32.hip enc32_kernel; tf_fp32.hip).  Against the separate launches of round 2 (CLM_DEBUG=unfused_fp32): the same fp32
+    products in another summation order -- logits and the encoder output agree to fp32 rounding; one-tile, ragged-tile and padded cases."""
+    sd = to.make_state_dict(seed, to.PRODUCTION, scale=3.0)
+    ids = torch.from_numpy(to.synthetic_ids(300 + seed, B, L, pads)).cuda()
+    a_net = _model(sd, "fp32")
+    a = a_net(ids).cpu().numpy()
+    ha = a_net.debug_fetch("hidden", (B, L // 8, 256)).copy()
+    a_net.close()
+    monkeypatch.setenv("CLM_DEBUG", "unfused_fp32")      # read by clm_tf_create
+    b_net = _model(sd, "fp32")
+    b = b_net(ids).cpu().numpy()
+    hb = b_net.debug_fetch("hidden", (B, L // 8, 256)).copy()
+    b_net.close()
+    monkeypatch.delenv("CLM_DEBUG")
+    print(f"tf fp32 fused vs separate, {B} x {L}: |dlogit| {np.abs(a - b).max():.2e}, |dhidden| {np.abs(ha - hb).max():.2e} of {np.abs(hb).max():.3g}")
+    assert np.abs(a - b).max() <= 5e-5 and np.abs(ha - hb).max() <= 2e-5 * max(1.0, float(np.abs(hb).max()))
+
+
 @pytest.mark.parametrize("prec", ["fp16c", "fp32"])
 def test_more_shorter_reads_after_a_long_batch_regrow_the_pooled_buffer(built_lib, prec):
     """`pooled` is [B][256] and scales with B alone; 4 x 4096 then 16 x 512 on ONE handle fits every token / row
