@@ -183,6 +183,9 @@ void launch_tail32(const float* y, float* h, const void* w_out, const void* w_fc
                    const float* b_out, const float* b_fc1, const float* b_fc2, const float* b_in_next, const float* ln2_g,
                    const float* ln2_b, const float* n_g, const float* n_b, float* z, int B, int L, int Lp, float eps, hipStream_t st);
 void launch_pack_f32t(const float* w /*[n][k]*/, void* out /*n * k floats*/, int n, int k, hipStream_t st);
+// SequenceCNNTransformer, exact fp32 (tail32.hip conv32_kernel): Conv1d(k = 3, padding = 1) + ReLU + MaxPool1d(2); w = three taps
+// [dk][co][ci], each packed by launch_pack_f32t
+void launch_conv32(const float* x, const void* w, const float* bias, float* out, int B, int Lin, hipStream_t st);
 // SequenceCNNTransformer, exact fp32 (tail32.hip enc32_kernel): att == null: qkv of the rows of h as they are; otherwise one encoder
 // layer after its attention (out_proj + LN1 + FFN + LN2 on h in place) and, w_qkv != null, the next layer's in_proj into qkv
 void launch_enc32(const float* att, float* h, const void* w_o, const void* w1, const void* w2, const void* w_qkv, const float* b_o,

@@ -424,6 +424,68 @@ __global__ __launch_bounds__(512) void enc32_kernel(Enc32Args m) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// SequenceCNNTransformer, exact fp32: Conv1d(256 -> 256, k = 3, padding = 1) + ReLU + MaxPool1d(2) of the CNN stem
+//   /root/reference/chimeralm/models/components/transformer.py:47-58
+// as three 256-deep products over ONE staged tile: rows t0 - 1 .. t0 + 64 of the read (zero outside it) lie in LDS once, and tap dk
+// reads them shifted by dk rows; weights [3][256][256] (tap-major, each tap in launch_pack_f32t's order).  The pooling pairs are
+// adjacent lanes of the accumulator layout (lane = position): one lane exchange, then the even lanes store 16 bytes per feature quad.
+struct Conv32Args {
+    const float* x;           // [B, Lin, 256]
+    const f32x4* w;           // [3] x packed [256, 256]
+    const float* bias;
+    float* out;               // [B, Lin / 2, 256]
+    int B, Lin, tiles_x;
+};
+
+__global__ __launch_bounds__(512) void conv32_kernel(Conv32Args m) {
+    extern __shared__ __attribute__((aligned(16))) float smem32[];
+    float* Xs = smem32;                                     // [66][RS32]: row r = position t0 - 1 + r
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lrow = lane & 31, lhalf = lane >> 5;
+    const int b = (int)blockIdx.x / m.tiles_x, t0 = ((int)blockIdx.x % m.tiles_x) * BM32, Lin = m.Lin, Lout = Lin / 2;
+    f32x4 ws[2][KS_SET];
+    f32x16 acc[2];
+    load_wset(wset_ptr(m.w, 0, D / 8, 0, wave, lane), ws[0]);
+    {
+        const float* src = m.x + (size_t)b * Lin * D + lane * 4;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) {
+            const int r = wave + 8 * i, t = t0 - 1 + r;
+            if (r < BM32 + 2) {
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (t >= 0 && t < Lin) v = *reinterpret_cast<const f32x4*>(src + (size_t)t * D);
+                *reinterpret_cast<f32x4*>(Xs + r * RS32 + lane * 4) = v;
+            }
+        }
+    }
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[mt][r] = 0.f;
+    __syncthreads();
+    static_for<0, 3>([&](auto dkc) {
+        constexpr int dk = decltype(dkc)::value;
+        const f32x4* wdk = m.w + (size_t)dk * (D * D / 4);
+        const f32x4* nxt = wset_ptr(dk < 2 ? m.w + (size_t)(dk + 1) * (D * D / 4) : m.w, 0, D / 8, 0, wave, lane);
+        product256<false>(Xs + dk * RS32, wdk, 0, D / 8, 0, nxt, wave, lane, ws, acc);
+    });
+    const float* bp = m.bias + wave * 32 + 4 * lhalf;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const float4 bb = *reinterpret_cast<const float4*>(bp + 8 * q);
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            float v[4] = {fmaxf(acc[mt][4 * q + 0] + bb.x, 0.f), fmaxf(acc[mt][4 * q + 1] + bb.y, 0.f),
+                          fmaxf(acc[mt][4 * q + 2] + bb.z, 0.f), fmaxf(acc[mt][4 * q + 3] + bb.w, 0.f)};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], __shfl_xor(v[e], 1, 64));       // positions 2 p, 2 p + 1: adjacent lanes
+            const int pos = (t0 + mt * 32 + lrow) >> 1;
+            if (!(lrow & 1) && pos < Lout)
+                *reinterpret_cast<float4*>(m.out + ((size_t)b * Lout + pos) * D + wave * 32 + 4 * lhalf + 8 * q) = make_float4(v[0], v[1], v[2], v[3]);
+        }
+    }
+}
+
 // W [N][K] row-major fp32 -> [N / 256][8 waves][K / 8 k-steps][64 lanes] float4: lane (lrow, lhalf) of wave w holds
 // W[nb * 256 + w * 32 + lrow][8 s + 4 lhalf + 0..3]
 __global__ __launch_bounds__(256) void pack_f32t_kernel(const float* __restrict__ w, f32x4* __restrict__ out, int N, int K) {
@@ -478,6 +540,15 @@ void launch_enc32(const float* att, float* h, const void* w_o, const void* w1, c
         (void)once;
         hipLaunchKernelGGL(enc32_kernel<false>, grid, block, lds, st, m);
     }
+}
+
+// x [B, Lin, 256] -> relu(conv1d_k3(x) + bias) pooled by 2 -> out [B, Lin / 2, 256]; w: three taps, each packed by launch_pack_f32t
+void launch_conv32(const float* x, const void* w, const float* bias, float* out, int B, int Lin, hipStream_t st) {
+    Conv32Args m{x, reinterpret_cast<const f32x4*>(w), bias, out, B, Lin, (Lin + BM32 - 1) / BM32};
+    const size_t lds = (size_t)(BM32 + 2) * RS32 * sizeof(float);
+    static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv32_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), true);
+    (void)once;
+    hipLaunchKernelGGL(conv32_kernel, dim3((unsigned)(m.tiles_x * B)), dim3(512), lds, st, m);
 }
 
 }  // namespace clm

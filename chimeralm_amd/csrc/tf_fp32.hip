@@ -10,6 +10,7 @@
 //   * LayerNorm (post-norm: LN(x + sublayer(x))), positional encoding, ReLU / MaxPool1d(2) as plain fp32 kernels.
 // It is a correctness reference on the GPU, not tuned: stages are separate kernels and activations live in HBM as fp32.
 #include <string>
+#include <utility>
 
 #include "clm_common.h"
 
@@ -173,6 +174,126 @@ __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict_
     }
 }
 
+// Round 4: the same attention on the fp32 MFMA (v_mfma_f32_32x32x2_f32), built like the 16-bit kernel (attention.hip): scores
+// TRANSPOSED, S^T = K Q^T (rows = keys, column = the lane's query), so the softmax statistics are register reductions plus one
+// exchange between the half-waves; P^T never leaves the registers -- accumulator register t of a 32-key block IS the B operand of
+// MFMA step t of O^T = V^T P^T, with the A operand read from the V row of the key that register holds (the reduction index may be
+// paired freely: lanes 0-31 feed key (t & 3) + 8 (t >> 2), lanes 32-63 that key + 4).  Per 64-key tile a wave issues 64 MFMAs of 64
+// cycles next to ~900 cycles of softmax VALU: MFMA-bound, where the scalar kernel above spends 2 x 32 FMAs per (query, key).
+// 128 queries per workgroup (4 waves), K / V tiles of 64 keys double-buffered: 38 KiB of LDS, four workgroups per CU.
+constexpr int A32_QT = 128, A32_KT = 64, A32_KRS = 36, A32_VRS = 40;   // row strides (floats): 16 rows of a ds_read_b128 group on 16 bank
+                                                                      // groups (K); rows 4 apart on banks + 32 (V, ds_read_b32)
+__global__ __launch_bounds__(256, 4) void attention32_kernel(const float* __restrict__ qkv, float* __restrict__ out, int L) {
+    using f32x4 = float __attribute__((ext_vector_type(4)));
+    __shared__ __attribute__((aligned(16))) float Ks[2][A32_KT * A32_KRS];
+    __shared__ __attribute__((aligned(16))) float Vs[2][A32_KT * A32_VRS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = lane & 31, hf = lane >> 5;
+    // workgroup -> (query tile, head, read): the query tiles of one (read, head) share an XCD's L2 (as attention.hip)
+    const int ntq = (L + A32_QT - 1) / A32_QT;
+    const int g = blockIdx.x, xcd = g & 7, slot = g >> 3;
+    const int bh = (slot / ntq) * 8 + xcd, q0 = (slot % ntq) * A32_QT, h = bh & 7, b = bh >> 3;
+    const float* base = qkv + (size_t)b * L * 768 + h * 32;            // row t: q at +0, k at +256, v at +512
+    const float c = 1.4426950408889634f * 0.17677669529663687f;        // log2(e) / sqrt(32)
+    f32x4 qf[4];                                                       // Q^T as B operand: d = 8 s + 4 hf + 0..3
+    {
+        const int q = q0 + wave * 32 + n;
+        const float* qp = base + (size_t)(q < L ? q : L - 1) * 768 + 4 * hf;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) qf[s] = *reinterpret_cast<const f32x4*>(qp + 8 * s);
+    }
+    f32x4 kreg[2], vreg[2];
+    auto load_tile = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int e = tid + i * 256, j = e >> 3, d4 = e & 7;
+            const int key = k0 + j < L ? k0 + j : L - 1;                // clamped; the score mask removes the clones
+            const float* p = base + (size_t)key * 768 + 4 * d4;
+            kreg[i] = *reinterpret_cast<const f32x4*>(p + 256);
+            vreg[i] = *reinterpret_cast<const f32x4*>(p + 512);
+        }
+    };
+    auto store_tile = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int e = tid + i * 256, j = e >> 3, d4 = e & 7;
+            *reinterpret_cast<f32x4*>(&Ks[buf][j * A32_KRS + 4 * d4]) = kreg[i];
+            *reinterpret_cast<f32x4*>(&Vs[buf][j * A32_VRS + 4 * d4]) = vreg[i];
+        }
+    };
+    f32x16 o;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[r] = 0.f;
+    float m = -INFINITY, l = 0.f;
+    const int ntiles = (L + A32_KT - 1) / A32_KT;
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+#pragma unroll 1
+    for (int t = 0; t < ntiles; ++t) {
+        const int buf = t & 1, k0 = t * A32_KT;
+        if (t + 1 < ntiles) load_tile(k0 + A32_KT);
+        f32x16 s[2];
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[blk][r] = 0.f;
+            const float* kp = &Ks[buf][(blk * 32 + n) * A32_KRS + 4 * hf];
+#pragma unroll
+            for (int st = 0; st < 4; ++st) {
+                const f32x4 kf = *reinterpret_cast<const f32x4*>(kp + 8 * st);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) s[blk] = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[j], qf[st][j], s[blk], 0, 0, 0);
+            }
+        }
+        if (k0 + A32_KT > L) {
+#pragma unroll
+            for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (k0 + blk * 32 + (r & 3) + 8 * (r >> 2) + 4 * hf >= L) s[blk][r] = -INFINITY;
+        }
+        float mx = s[0][0];
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[blk][r]);
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m, mx);                              // finite: key k0 is always valid
+        const float alpha = __builtin_amdgcn_exp2f((m - m_new) * c);   // 0 on the first tile
+        const float mc = m_new * c;
+        float psum = 0.f;
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                s[blk][r] = __builtin_amdgcn_exp2f(fmaf(s[blk][r], c, -mc));
+                psum += s[blk][r];
+            }
+        l = l * alpha + psum;
+        m = m_new;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[r] *= alpha;
+        // O^T += V^T P^T: step t2 of a block pairs register t2 of P^T with the V row of the key it holds
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk) {
+            const float* vp = &Vs[buf][(blk * 32 + 4 * hf) * A32_VRS + n];
+#pragma unroll
+            for (int t2 = 0; t2 < 16; ++t2)
+                o = __builtin_amdgcn_mfma_f32_32x32x2f32(vp[((t2 & 3) + 8 * (t2 >> 2)) * A32_VRS], s[blk][t2], o, 0, 0, 0);
+        }
+        if (t + 1 < ntiles) store_tile(buf ^ 1);                       // the other buffer was last read in trip t - 1
+        __syncthreads();
+    }
+    const float inv = 1.0f / (l + __shfl_xor(l, 32, 64));
+    const int q = q0 + wave * 32 + n;
+    if (q < L) {
+        float* op = out + ((size_t)b * L + q) * D + h * 32 + 4 * hf;    // lane (query n, half hf) holds d = (r & 3) + 8 (r >> 2) + 4 hf
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq)
+            *reinterpret_cast<float4*>(op + 8 * gq) = make_float4(o[4 * gq + 0] * inv, o[4 * gq + 1] * inv, o[4 * gq + 2] * inv, o[4 * gq + 3] * inv);
+    }
+}
+
 template <bool RELU, bool CONV3>
 static void gemm(const float* A, int lda, const float* W, const float* bias, const float* R, float* C, int ldc, size_t M, int N,
                  int K, int Lrow, hipStream_t st) {
@@ -208,9 +329,14 @@ int tf32_forward(const unsigned char* ids8, int ids_stride, int B, int L, int n_
     int Lin = L;
     for (int i : {0, 3, 6}) {
         const std::string n = "cnn." + std::to_string(i);
-        gemm<true, true>(x, D, Wt(n + ".weight"), Wt(n + ".bias"), nullptr, y, D, (size_t)B * Lin, D, 3 * D, Lin, st);
         const int Lout = Lin / 2;
-        hipLaunchKernelGGL(maxpool2_kernel, dim3((unsigned)(((size_t)B * Lout * (D / 4) + 255) / 256)), dim3(256), 0, st, y, x, B, Lin, Lout);
+        if (!unfused) {      // round 4: convolution + ReLU + pooling in one kernel on the fp32 MFMA (tail32.hip conv32_kernel)
+            launch_conv32(x, get(ctx, "t32." + n), Wt(n + ".bias"), y, B, Lin, st);
+            std::swap(x, y);
+        } else {
+            gemm<true, true>(x, D, Wt(n + ".weight"), Wt(n + ".bias"), nullptr, y, D, (size_t)B * Lin, D, 3 * D, Lin, st);
+            hipLaunchKernelGGL(maxpool2_kernel, dim3((unsigned)(((size_t)B * Lout * (D / 4) + 255) / 256)), dim3(256), 0, st, y, x, B, Lin, Lout);
+        }
         Lin = Lout;
     }
     // + positional encoding, LayerNorm -> residual stream
@@ -227,7 +353,7 @@ int tf32_forward(const unsigned char* ids8, int ids_stride, int B, int L, int n_
     for (int i = 0; i < n_layers; ++i) {
         const std::string p = LP(i);
         if (!unfused) {
-            hipLaunchKernelGGL(attention_kernel, dim3((unsigned)((L3 + 255) / 256), 8, (unsigned)B), dim3(256), 0, st, qkv, att, L3);
+            hipLaunchKernelGGL(attention32_kernel, dim3((unsigned)(((L3 + A32_QT - 1) / A32_QT) * 8 * B)), dim3(256), 0, st, qkv, att, L3);
             const bool more = i + 1 < n_layers;
             launch_enc32(att, h, T32(i, "out"), T32(i, "ff1"), T32(i, "ff2"), more ? T32(i + 1, "in") : nullptr,
                          Wt(p + "self_attn.out_proj.bias"), Wt(p + "linear1.bias"), Wt(p + "linear2.bias"),

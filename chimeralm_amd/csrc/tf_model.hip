@@ -738,6 +738,20 @@ int clm_tf_finalize(clm_tf_handle* h) {
             h->packed[t + e.name] = q;
         }
     }
+    {   // ... and the three taps of each CNN-stem convolution ([co][ci][3] -> [3][co][ci], each tap packed)
+        float* split32 = nullptr;
+        TFCHK(h, hipMalloc((void**)&split32, (size_t)3 * D * D * 4));
+        for (int i : {0, 3, 6}) {
+            const std::string name = "cnn." + std::to_string(i);
+            hipLaunchKernelGGL(tf::conv_w_split_kernel, dim3((3 * D * D + 255) / 256), dim3(256), 0, 0, h->w.at(name + ".weight"), split32);
+            float* q = nullptr;
+            TFCHK(h, hipMalloc((void**)&q, (size_t)3 * D * D * 4));
+            for (int dk = 0; dk < 3; ++dk) launch_pack_f32t(split32 + (size_t)dk * D * D, q + (size_t)dk * D * D, D, D, 0);
+            TFCHK(h, hipDeviceSynchronize());                 // `split32` is reused by the next layer
+            h->packed["t32." + name] = q;
+        }
+        (void)hipFree(split32);
+    }
     if (h->prec == PREC_F32) {
         TFCHK(h, hipDeviceSynchronize());
         h->finalized = true;

@@ -82,7 +82,7 @@ def test_fused_fp32_encoder_equals_the_separate_kernels(built_lib, monkeypatch, 
     b_net.close()
     monkeypatch.delenv("CLM_DEBUG")
     print(f"tf fp32 fused vs separate, {B} x {L}: |dlogit| {np.abs(a - b).max():.2e}, |dhidden| {np.abs(ha - hb).max():.2e} of {np.abs(hb).max():.3g}")
-    assert np.abs(a - b).max() <= 5e-5 and np.abs(ha - hb).max() <= 2e-5 * max(1.0, float(np.abs(hb).max()))
+    assert np.abs(a - b).max() <= 1e-4 and np.abs(ha - hb).max() <= 2e-5 * max(1.0, float(np.abs(hb).max()))
 
 
 @pytest.mark.parametrize("prec", ["fp16c", "fp32"])
