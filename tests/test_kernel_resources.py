@@ -34,13 +34,15 @@ def test_hot_kernels_have_no_scratch_in_their_loops():
     # spilled outside the loops)
     budget = [
         # fp16c tail (round 4: + the lo planes of y / z / both LayerNorm tiles).  The gated in_proj variant -- 3 of 4 launches -- keeps
-        # ONE value in scratch, the thread index: stored in the prologue, reloaded once at the top of every tile trip, before anything
-        # is requested (nothing to wait behind); its compensated-MLP form is at zero.  The score variant spills one dword per tile
+        # the thread index in scratch (stored in the prologue, reloaded at the top of every tile trip, before anything is requested:
+        # nothing to wait behind) and, since y's lo loads moved into the in_proj hooks, two more dwords per tile -- the lane index,
+        # reloaded once behind out_proj, and a staging address, reloaded once in the in_proj stage (the same-box timing of that change
+        # includes them: -1.2 %); its compensated-MLP form is at zero.  The score variant spills one dword per tile
         # (stored before the y tile's barrier, reloaded behind the pooling barrier, where no weight set is awaited).
-        (r"tail16_kernelILi3ELb0ELi1ELb1ELb0E", 8),
+        (r"tail16_kernelILi3ELb0ELi1ELb1ELb0E", 16),
         (r"tail16_kernelILi3ELb0ELi1ELb1ELb1E", 0),
         (r"tail16_kernelILi3ELb0ELi1ELb0ELb[01]E", 0),           # (raw-rows form of the in_proj variant: A/B runs, tests)
-        (r"tail16_kernelILi3ELb0ELi2E", 12),                     # fp16c tail, score variant
+        (r"tail16_kernelILi3ELb0ELi2E", 16),                     # fp16c tail, score variant (one more dword with the 16-column y-lo staging)
         (r"tail16_kernelILi2ELb0ELi1E", 0),                      # plain fp16
         (r"hyena_conv_pers_kernelINS_5f16_tELb0E", 0),           # 8k convolution, blocks 1-3
         (r"hyena_conv_pers_kernelINS_5f16_tELb1E", 16),          # block 0 (token ids)
@@ -50,6 +52,10 @@ def test_hot_kernels_have_no_scratch_in_their_loops():
         (r"enc_ffn16_kernelILi[123]E", 0),                        # transformer layer kernel, all three 16-bit modes
         (r"conv3_relu_pool_kernelILi[123]E", 0),
         (r"attention_fwd_kernelILi2ELb[01]E", 0),                 # fp16 attention, one plane and hi + lo planes
+        (r"tail32_kernelILb[01]E", 0),                            # exact fp32, round 4: the fused block tail ...
+        (r"enc32_kernelILb[01]E", 0),                             # ... and the transformer's encoder layer, CNN stem and attention
+        (r"conv32_kernel", 0),
+        (r"attention32_kernel", 0),
     ]
     for pattern, allowed in budget:
         for name, got in _scratch(res, pattern).items():
@@ -59,5 +65,5 @@ def test_hot_kernels_have_no_scratch_in_their_loops():
 def test_tile_kernels_keep_two_waves_per_simd():
     res = _resources()
     for name, r in res.items():
-        if re.search(r"tail16_kernelILi[123]ELb0", name) or "hyena_conv_pers_kernel" in name:
+        if re.search(r"tail16_kernelILi[123]ELb0", name) or "hyena_conv_pers_kernel" in name or re.search(r"(tail|enc)32_kernel", name):
             assert int(r["Occupancy [waves/SIMD]"]) >= 2, name
