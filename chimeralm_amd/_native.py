@@ -15,13 +15,13 @@ LIB_PATH = Path(os.environ.get("CLM_LIB") or Path(__file__).resolve().parent / "
 # error codes / enums (mirror include/chimeralm_hip.h)
 OK, E_INVALID, E_HIP, E_MISSING, E_UNSUPPORTED, E_STATE = 0, -1, -2, -3, -4, -5
 DT_F32, DT_F64, DT_BF16, DT_F16, DT_U8, DT_I32, DT_I64 = range(7)
-PREC_F32, PREC_BF16, PREC_F16, PREC_F16C = 0, 1, 2, 3
+PREC_F32, PREC_BF16, PREC_F16, PREC_F16C, PREC_F16X3 = 0, 1, 2, 3, 4
 BAM_INPUT_SAM, BAM_KEEP_UNPLACED = 1, 2
-PRECISIONS = {"fp32": PREC_F32, "f32": PREC_F32, "bf16": PREC_BF16, "fp16": PREC_F16, "f16": PREC_F16, "fp16c": PREC_F16C}
+PRECISIONS = {"fp32": PREC_F32, "f32": PREC_F32, "bf16": PREC_BF16, "fp16": PREC_F16, "f16": PREC_F16, "fp16c": PREC_F16C, "fp16x3": PREC_F16X3}
 STAGES = ["embed", "ln1_in_proj", "short_long_conv", "out_proj", "ln2_fc1_gelu", "fc2", "lnf_pool_score",
           "softmax_pool", "head_mlp", "filter", "out_proj_ln2_mlp", "ln2_mlp"]
 N_STAGES = len(STAGES)
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 class ClmConfig(C.Structure):

@@ -136,6 +136,7 @@ struct clm_handle {
     bool no_idconv = false;       // CLM_DEBUG=no_idconv: run block 0's in_proj instead of the id-table convolution (A/B runs)
     int conv_flags = 0;           // CLM_DEBUG=conv_oneshot / conv_no_xcd: CONV_* switches of the convolution launchers (A/B runs, tests)
     bool no_lone_peel = false;    // CLM_DEBUG=no_lone_peel: keep the lone last token of 128 k + 1-token reads in a tile of its own (A/B runs)
+    bool x3 = false;              // CLM_PREC_F16X3: cfg.precision is PREC_F32 inside the engine, the fused tails run on hi + lo halfs (tail32.hip AR_X3)
     bool unfused_fp32 = false;    // CLM_DEBUG=unfused_fp32: exact fp32 through the separate GEMM kernels of rounds 1-3 (tests cross-check the fused tail)
     bool force_generic = false;   // CLM_DEBUG=generic_gemm: route 16-bit modes through the generic kernels (A/B runs)
     bool prof = false;
@@ -636,7 +637,7 @@ int forward_chunk(clm_handle* h, const void* ids, int ids_dtype, int64_t row_str
             const LayerW* nx = i + 1 < NLAYER ? &(alt32 ? h->lw32[i + 1] : h->lw[i + 1]) : nullptr;
             launch_tail32(reinterpret_cast<const float*>(h->y), h->h, lw.t_out, lw.t_fc1, lw.t_fc2, nx ? nx->t_in : nullptr, lw.b_out,
                           lw.b_fc1, lw.b_fc2, nx ? nx->b_in : nullptr, lw.ln2_g, lw.ln2_b, nx ? nx->ln1_g : nullptr,
-                          nx ? nx->ln1_b : nullptr, reinterpret_cast<float*>(h->z), Bc, L, Lp, eps, st);
+                          nx ? nx->ln1_b : nullptr, reinterpret_cast<float*>(h->z), Bc, L, Lp, eps, st, h->x3);
         } else {
             {
                 StageTimer t(h, st, CLM_STAGE_OUTPROJ);
@@ -714,7 +715,7 @@ int clm_create(const clm_config* cfg, int device, clm_handle** out) {
         cfg->filter_order != FORDER || cfg->emb_dim != EMB || cfg->head_hidden != HH || cfg->n_classes != NCLS)
         return fail(nullptr, CLM_E_UNSUPPORTED,
                     "only the HyenaDNA-small-32k + 512-wide attention-pooling head of chimeralm/models/lm.py is built");
-    if (cfg->precision < CLM_PREC_F32 || cfg->precision > CLM_PREC_F16C || cfg->chunk_reads < 1 ||
+    if (cfg->precision < CLM_PREC_F32 || cfg->precision > CLM_PREC_F16X3 || cfg->chunk_reads < 1 ||
         cfg->max_seq_len < 2)
         return fail(nullptr, CLM_E_INVALID, "clm_create: bad precision / chunk_reads / max_seq_len");
     int ndev = 0;
@@ -738,6 +739,11 @@ int clm_create(const clm_config* cfg, int device, clm_handle** out) {
     if (debug_flag("conv_no_xcd")) h->conv_flags |= CONV_NO_XCD;
     h->raw_z = debug_flag("raw_z");                    // the fused in_proj stage writes x0 | x1 | v as before round 3
     h->cfg = *cfg;
+    if (cfg->precision == CLM_PREC_F16X3) {             // an exact-fp32 engine whose fused tails multiply hi + lo halfs
+        h->x3 = true;
+        h->cfg.precision = CLM_PREC_F32;
+        if (h->unfused_fp32) { delete h; return fail(nullptr, CLM_E_UNSUPPORTED, "CLM_PREC_F16X3 exists in the fused tail kernels only (CLM_DEBUG=unfused_fp32 is set)"); }
+    }
     h->device = device;
     if (hipHostMalloc((void**)&h->bad_ids, sizeof(int), hipHostMallocMapped) == hipSuccess) *h->bad_ids = 0;
     else h->bad_ids = nullptr;
@@ -834,7 +840,8 @@ int clm_finalize(clm_handle* h) {
                                                            {"mlp.fc1.weight", DI, D}, {"mlp.fc2.weight", D, DI}};
             for (int j = 0; j < 4; ++j) {
                 HIPCHK(h, hipMalloc(&h->packed32t[i][j], (size_t)tw[j].n * tw[j].k * 4));
-                launch_pack_f32t(W(h, p + tw[j].key), h->packed32t[i][j], tw[j].n, tw[j].k, st);
+                if (h->x3) launch_pack_x3(W(h, p + tw[j].key), h->packed32t[i][j], tw[j].n, tw[j].k, st);
+                else launch_pack_f32t(W(h, p + tw[j].key), h->packed32t[i][j], tw[j].n, tw[j].k, st);
             }
             lw.t_in = h->packed32t[i][0]; lw.t_out = h->packed32t[i][1]; lw.t_fc1 = h->packed32t[i][2]; lw.t_fc2 = h->packed32t[i][3];
         }
@@ -1075,7 +1082,8 @@ int clm_set_short_read_len(clm_handle* h, int min_len) {
 
 int clm_effective_precision(const clm_handle* h, int L) {
     if (!h || L < 1) return CLM_E_INVALID;
-    return effective_prec(h, L);
+    const int p = effective_prec(h, L);
+    return (h->x3 && p == PREC_F32) ? CLM_PREC_F16X3 : p;
 }
 
 int clm_debug_stop_after(clm_handle* h, int layer, int stage) {

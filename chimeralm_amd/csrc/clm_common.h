@@ -181,7 +181,9 @@ void launch_embed(const void* ids, int ids_dtype, int64_t row_stride, const floa
 // block's LayerNorm-1 + in_proj into z (rows x0 | x1 | v, fp32).  Weights in launch_pack_f32t's order.
 void launch_tail32(const float* y, float* h, const void* w_out, const void* w_fc1, const void* w_fc2, const void* w_in_next,
                    const float* b_out, const float* b_fc1, const float* b_fc2, const float* b_in_next, const float* ln2_g,
-                   const float* ln2_b, const float* n_g, const float* n_b, float* z, int B, int L, int Lp, float eps, hipStream_t st);
+                   const float* ln2_b, const float* n_g, const float* n_b, float* z, int B, int L, int Lp, float eps, hipStream_t st,
+                   bool x3 = false /*three fp16 MFMAs on hi + lo halfs per product, weights from launch_pack_x3*/);
+void launch_pack_x3(const float* w /*[n][k]*/, void* out /*n * k * 4 bytes*/, int n, int k, hipStream_t st);
 void launch_pack_f32t(const float* w /*[n][k]*/, void* out /*n * k floats*/, int n, int k, hipStream_t st);
 // SequenceCNNTransformer, exact fp32 (tail32.hip conv32_kernel): Conv1d(k = 3, padding = 1) + ReLU + MaxPool1d(2); w = three taps
 // [dk][co][ci], each packed by launch_pack_f32t

@@ -41,8 +41,59 @@ __device__ __forceinline__ void load_wset(const f32x4* p, f32x4 (&ws)[KS_SET]) {
 }
 __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0); }
 
+// ---- ARITH: the arithmetic of the products.  AR_F32: exact fp32 on v_mfma_f32_32x32x2_f32.  AR_X3 ("fp16x3"): every operand split
+// into two halfs, x = hi + lo with hi = fp16(x), lo = fp16(x - hi) (~21 bits), and a product as THREE fp16 MFMAs into the fp32
+// accumulator -- w_hi a_hi + w_lo a_hi + w_hi a_lo (the dropped w_lo a_lo is 2^-22 of the product) -- at 96 cycles per 16-deep step
+// and row tile where the fp32 MFMA takes 512.  A tile row then holds 256 hi halfs | 256 lo halfs in the 1024 bytes of its 256
+// floats (same stride, same bank behaviour); a weight "fragment" is 8 halfs, (hi, lo) pairs alternating, so a 64-deep set is again
+// 8 fragments of 16 bytes and the set machinery is shared.  Weights are packed x 2^10 (X3_WS), which keeps their lo halfs out of
+// fp16's subnormal range down to |w| ~ 2.5e-4; accumulators that also hold unscaled terms (the residual) are scaled before and
+// unscaled after their products (powers of two: exact).
+enum { AR_F32 = 0, AR_X3 = 1 };
+constexpr float X3_WS = 1024.f, X3_WSI = 1.0f / 1024.f;
+template <int AR> constexpr float WSCALE = AR == AR_X3 ? X3_WS : 1.0f;
+template <int AR> constexpr float WUNSCALE = AR == AR_X3 ? X3_WSI : 1.0f;
+using v4i16 = short __attribute__((ext_vector_type(4)));
+typedef v4i16 __attribute__((address_space(3))) * lds_v4i16_ptr32;
+constexpr int RSKM64 = 96;        // AR_X3: row stride (halfs) of a k-major y plane [256 channels][64 tokens]: 192 B -- the four rows of a
+                                  // transposing read fall on four different 64-byte bank groups (0, 192, 128, 64 mod 256)
+
+__device__ __forceinline__ f32x16 mfma16(f32x4 a, f32x4 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+// four consecutive features of one token row into a tile (fp32: 16 bytes; x3: 8 bytes of hi halfs + 8 bytes of lo halfs)
+template <int AR>
+__device__ __forceinline__ void tile_store4(float* T, int row, int col, f32x4 v) {
+    if constexpr (AR == AR_F32) {
+        *reinterpret_cast<f32x4*>(T + row * RS32 + col) = v;
+    } else {
+        typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+        const h4 hi = __builtin_convertvector(v, h4);
+        const f32x4 back = __builtin_convertvector(hi, f32x4);
+        const h4 lo = __builtin_convertvector(v - back, h4);
+        char* base = reinterpret_cast<char*>(T + row * RS32) + col * 2;
+        *reinterpret_cast<h4*>(base) = hi;
+        *reinterpret_cast<h4*>(base + 512) = lo;
+    }
+}
+
 // acc[mt] += W-set x T[tokens mt*32.., k = 64 part ..): token-major tile
+template <int AR>
 __device__ __forceinline__ void compute_set_tm(const float* T, int part, int lrow, int lhalf, const f32x4 (&ws)[KS_SET], f32x16 (&acc)[2]) {
+    if constexpr (AR == AR_X3) {
+        const char* a0 = reinterpret_cast<const char*>(T + lrow * RS32) + (part * 64 + lhalf * 8) * 2;
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                const f32x4 ah = *reinterpret_cast<const f32x4*>(a0 + mt * 32 * RS32 * 4 + s * 32);
+                const f32x4 al = *reinterpret_cast<const f32x4*>(a0 + 512 + mt * 32 * RS32 * 4 + s * 32);
+                acc[mt] = mfma16(ws[2 * s], ah, acc[mt]);
+                acc[mt] = mfma16(ws[2 * s + 1], ah, acc[mt]);
+                acc[mt] = mfma16(ws[2 * s], al, acc[mt]);
+            }
+        return;
+    }
     const float* a0 = T + lrow * RS32 + part * 64 + lhalf * 4;
     f32x4 af[2][2];
 #pragma unroll
@@ -59,8 +110,36 @@ __device__ __forceinline__ void compute_set_tm(const float* T, int part, int lro
             for (int mt = 0; mt < 2; ++mt) acc[mt] = mfma32(ws[s][j], af[s & 1][mt][j], acc[mt]);
     }
 }
-// same from the k-major tile Ys[k][token] (out_proj: y is channel-major)
-__device__ __forceinline__ void compute_set_km(const float* Ys, int part, int lrow, int lhalf, const f32x4 (&ws)[KS_SET], f32x16 (&acc)[2]) {
+// same from the k-major tile (out_proj: y is channel-major).  fp32: Ys[k][token] floats; x3: two planes of halfs [k][RSKM64] read with
+// the transposing LDS read (a 16-lane group reads a 4(k) x 16(token) block, lane i receives token i's four k values)
+template <int AR>
+__device__ __forceinline__ void compute_set_km(const float* Ys, int part, int lane, const f32x4 (&ws)[KS_SET], f32x16 (&acc)[2]) {
+    const int lrow = lane & 31, lhalf = lane >> 5;
+    if constexpr (AR == AR_X3) {
+        const unsigned short* Yh = reinterpret_cast<const unsigned short*>(Ys);
+        const int li = lane & 15, g1 = (lane >> 4) & 1, q = li >> 2, p = li & 3;
+        const unsigned short* base = Yh + (8 * lhalf + q) * RSKM64 + 16 * g1 + 4 * p;
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                const unsigned short* p0 = base + ((part * 4 + s) * 16) * RSKM64 + mt * 32;
+                f32x4 a2[2];
+#pragma unroll
+                for (int pl = 0; pl < 2; ++pl) {
+                    const unsigned short* pp = p0 + pl * (D * RSKM64);
+                    const v4i16 l4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4i16_ptr32)(pp));
+                    const v4i16 h4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4i16_ptr32)(pp + 4 * RSKM64));
+                    typedef short s8 __attribute__((ext_vector_type(8)));
+                    const s8 both = {l4[0], l4[1], l4[2], l4[3], h4[0], h4[1], h4[2], h4[3]};
+                    a2[pl] = __builtin_bit_cast(f32x4, both);
+                }
+                acc[mt] = mfma16(ws[2 * s], a2[0], acc[mt]);
+                acc[mt] = mfma16(ws[2 * s + 1], a2[0], acc[mt]);
+                acc[mt] = mfma16(ws[2 * s], a2[1], acc[mt]);
+            }
+        return;
+    }
     const float* a0 = Ys + (part * 64 + lhalf * 4) * RSY + lrow;
 #pragma unroll
     for (int s = 0; s < KS_SET; ++s)
@@ -70,9 +149,9 @@ __device__ __forceinline__ void compute_set_km(const float* Ys, int part, int lr
             for (int mt = 0; mt < 2; ++mt) acc[mt] = mfma32(ws[s][j], a0[(s * 8 + j) * RSY + mt * 32], acc[mt]);
 }
 
-// one 256-deep product: sets 0..3 starting at k-step ks0 of (wp, nb); ws[0] holds set 0 on entry, and on exit the first set of
+// one 256-deep product: sets 0..3 starting at fragment ks0 of (wp, nb); ws[0] holds set 0 on entry, and on exit the first set of
 // what follows (`nxt`, requested under the last set: unconditional)
-template <bool KM>
+template <bool KM, int AR = AR_F32>
 __device__ __forceinline__ void product256(const float* T, const f32x4* wp, int nb, int ksteps_all, int ks0, const f32x4* nxt,
                                            int wave, int lane, f32x4 (&ws)[2][KS_SET], f32x16 (&acc)[2]) {
     const int lrow = lane & 31, lhalf = lane >> 5;
@@ -81,8 +160,8 @@ __device__ __forceinline__ void product256(const float* T, const f32x4* wp, int 
         if constexpr (p < 3) load_wset(wset_ptr(wp, nb, ksteps_all, ks0 + (p + 1) * KS_SET, wave, lane), ws[(p + 1) & 1]);
         else load_wset(nxt, ws[0]);
         __builtin_amdgcn_sched_barrier(0);
-        if constexpr (KM) compute_set_km(T, p, lrow, lhalf, ws[p & 1], acc);
-        else compute_set_tm(T, p, lrow, lhalf, ws[p & 1], acc);
+        if constexpr (KM) compute_set_km<AR>(T, p, lane, ws[p & 1], acc);
+        else compute_set_tm<AR>(T, p, lrow, lhalf, ws[p & 1], acc);
         __builtin_amdgcn_sched_barrier(0);
     });
 }
@@ -91,7 +170,7 @@ __device__ __forceinline__ void product256(const float* T, const f32x4* wp, int 
 // (fp32, token-major); two-pass statistics like every fp32 LayerNorm of the engine (gemm_common.h stage_a_tile).  Ends with a
 // barrier (T complete); its first barrier also orders every earlier LDS read of the workgroup before the writes.
 // KEEP: the normalised values also replace the accumulator contents (post-norm blocks: they are the next residual).
-template <bool KEEP = false>
+template <bool KEEP = false, int AR = AR_F32>
 __device__ __forceinline__ void ln_to_tile(f32x16 (&acc)[2], float* P1, float* P2, const float* __restrict__ g,
                                            const float* __restrict__ bta, float eps, float* T, int valid, int wave, int lrow, int lhalf) {
     float mean[2], rstd[2];
@@ -145,7 +224,7 @@ __device__ __forceinline__ void ln_to_tile(f32x16 (&acc)[2], float* P1, float* P
 #pragma unroll
                 for (int e = 0; e < 4; ++e) acc[mt][4 * q + e] = y[e];
             }
-            *reinterpret_cast<f32x4*>(T + (mt * 32 + lrow) * RS32 + wave * 32 + 8 * q + 4 * lhalf) = y;
+            tile_store4<AR>(T, mt * 32 + lrow, wave * 32 + 8 * q + 4 * lhalf, y);
         }
     }
     __syncthreads();
@@ -163,15 +242,16 @@ struct Tail32Args {
     float eps;
 };
 
-template <bool NEXT>
+template <bool NEXT, int AR = AR_F32>
 __global__ __launch_bounds__(512) void tail32_kernel(Tail32Args m) {
+    constexpr float WS = WSCALE<AR>, WSI = WUNSCALE<AR>;
     extern __shared__ __attribute__((aligned(16))) float smem32[];
     float* As = smem32;                                     // LN2(r) / LN1'(h') tile [64][RS32]      (the y tile aliases As + Hs)
     float* Hs = As + BM32 * RS32;                           // gelu(fc1) chunk [64][RS32]
     float* Ys = smem32;                                     // y tile [256 channels][RSY], k-major
     float* P1 = smem32 + 2 * BM32 * RS32;                   // LayerNorm partials [8][64]
     float* P2 = P1 + 8 * BM32;
-    static_assert(D * RSY <= 2 * BM32 * RS32, "the y tile fits As + Hs");
+    static_assert(D * RSY <= 2 * BM32 * RS32 && 2 * D * RSKM64 * 2 <= 2 * BM32 * RS32 * 4, "the y tile fits As + Hs");
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lrow = lane & 31, lhalf = lane >> 5;
     const int b = (int)blockIdx.x / m.tiles_x, t0 = ((int)blockIdx.x % m.tiles_x) * BM32, L = m.L, Lp = m.Lp;
     const int valid = L - t0 < BM32 ? L - t0 : BM32;
@@ -188,7 +268,16 @@ __global__ __launch_bounds__(512) void tail32_kernel(Tail32Args m) {
             const int c = (tid >> 4) + 32 * i;
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
             if (in_row) v = *reinterpret_cast<const f32x4*>(src + (size_t)c * Lp);
-            *reinterpret_cast<f32x4*>(Ys + c * RSY + tk) = v;
+            if constexpr (AR == AR_X3) {                    // two planes of halfs [channel][RSKM64]
+                typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+                const h4 hi = __builtin_convertvector(v, h4);
+                const h4 lo = __builtin_convertvector(v - __builtin_convertvector(hi, f32x4), h4);
+                _Float16* yh = reinterpret_cast<_Float16*>(Ys) + c * RSKM64 + tk;
+                *reinterpret_cast<h4*>(yh) = hi;
+                *reinterpret_cast<h4*>(yh + D * RSKM64) = lo;
+            } else {
+                *reinterpret_cast<f32x4*>(Ys + c * RSY + tk) = v;
+            }
         }
     }
     // ---- 1. r = h + b_out + W_out y: the accumulators start from the residual rows
@@ -202,17 +291,29 @@ __global__ __launch_bounds__(512) void tail32_kernel(Tail32Args m) {
             for (int q = 0; q < 4; ++q) {
                 const float4 hv = *reinterpret_cast<const float4*>(row + 8 * q);
                 const float4 bb = *reinterpret_cast<const float4*>(bo + 8 * q);
-                acc2[mt][4 * q + 0] = hv.x + bb.x;
-                acc2[mt][4 * q + 1] = hv.y + bb.y;
-                acc2[mt][4 * q + 2] = hv.z + bb.z;
-                acc2[mt][4 * q + 3] = hv.w + bb.w;
+                acc2[mt][4 * q + 0] = (hv.x + bb.x) * WS;
+                acc2[mt][4 * q + 1] = (hv.y + bb.y) * WS;
+                acc2[mt][4 * q + 2] = (hv.z + bb.z) * WS;
+                acc2[mt][4 * q + 3] = (hv.w + bb.w) * WS;
             }
         }
     }
     __syncthreads();
-    product256<true>(Ys, m.w_out, 0, D / 8, 0, wset_ptr(m.w_fc1, 0, D / 8, 0, wave, lane), wave, lane, ws, acc2);
+    product256<true, AR>(Ys, m.w_out, 0, D / 8, 0, wset_ptr(m.w_fc1, 0, D / 8, 0, wave, lane), wave, lane, ws, acc2);
+    if constexpr (AR == AR_X3) {
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc2[mt][r] *= WSI;
+    }
     // ---- 2. LayerNorm-2 -> As
-    ln_to_tile(acc2, P1, P2, m.ln2_g, m.ln2_b, m.eps, As, valid, wave, lrow, lhalf);
+    ln_to_tile<false, AR>(acc2, P1, P2, m.ln2_g, m.ln2_b, m.eps, As, valid, wave, lrow, lhalf);
+    if constexpr (AR == AR_X3) {                             // (the fc2 products land on r in the weights' scale)
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc2[mt][r] *= WS;
+    }
     // ---- 3. MLP in four 256-wide chunks of the hidden layer (acc2 holds r)
 #pragma unroll 1
     for (int j = 0; j < DI / 256; ++j) {
@@ -220,7 +321,7 @@ __global__ __launch_bounds__(512) void tail32_kernel(Tail32Args m) {
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc1[mt][r] = 0.f;
-        product256<false>(As, m.w_fc1, j, D / 8, 0, wset_ptr(m.w_fc2, 0, DI / 8, j * 32, wave, lane), wave, lane, ws, acc1);
+        product256<false, AR>(As, m.w_fc1, j, D / 8, 0, wset_ptr(m.w_fc2, 0, DI / 8, j * 32, wave, lane), wave, lane, ws, acc1);
         {
             const float* b1 = m.b_fc1 + j * 256 + wave * 32 + 4 * lhalf;
 #pragma unroll
@@ -228,16 +329,16 @@ __global__ __launch_bounds__(512) void tail32_kernel(Tail32Args m) {
                 const float4 bb = *reinterpret_cast<const float4*>(b1 + 8 * q);
 #pragma unroll
                 for (int mt = 0; mt < 2; ++mt) {
-                    f32x4 g = {gelu_tanh(acc1[mt][4 * q + 0] + bb.x), gelu_tanh(acc1[mt][4 * q + 1] + bb.y),
-                               gelu_tanh(acc1[mt][4 * q + 2] + bb.z), gelu_tanh(acc1[mt][4 * q + 3] + bb.w)};
-                    *reinterpret_cast<f32x4*>(Hs + (mt * 32 + lrow) * RS32 + wave * 32 + 8 * q + 4 * lhalf) = g;
+                    f32x4 g = {gelu_tanh(acc1[mt][4 * q + 0] * WSI + bb.x), gelu_tanh(acc1[mt][4 * q + 1] * WSI + bb.y),
+                               gelu_tanh(acc1[mt][4 * q + 2] * WSI + bb.z), gelu_tanh(acc1[mt][4 * q + 3] * WSI + bb.w)};
+                    tile_store4<AR>(Hs, mt * 32 + lrow, wave * 32 + 8 * q + 4 * lhalf, g);
                 }
             }
         }
         __syncthreads();
         const f32x4* nxt = j + 1 < DI / 256 ? wset_ptr(m.w_fc1, j + 1, D / 8, 0, wave, lane)
                                             : wset_ptr(NEXT ? m.w_in : m.w_fc1, 0, D / 8, 0, wave, lane);
-        product256<false>(Hs, m.w_fc2, 0, DI / 8, j * 32, nxt, wave, lane, ws, acc2);
+        product256<false, AR>(Hs, m.w_fc2, 0, DI / 8, j * 32, nxt, wave, lane, ws, acc2);
         __syncthreads();                                    // every wave is done reading Hs before the next chunk lands in it
     }
     // ---- 4. h' = acc2 + b_2: 16 bytes per lane and feature quad (a lane = a token row of h)
@@ -248,10 +349,10 @@ __global__ __launch_bounds__(512) void tail32_kernel(Tail32Args m) {
             const float4 bb = *reinterpret_cast<const float4*>(b2p + 8 * q);
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt) {
-                acc2[mt][4 * q + 0] += bb.x;
-                acc2[mt][4 * q + 1] += bb.y;
-                acc2[mt][4 * q + 2] += bb.z;
-                acc2[mt][4 * q + 3] += bb.w;
+                acc2[mt][4 * q + 0] = acc2[mt][4 * q + 0] * WSI + bb.x;
+                acc2[mt][4 * q + 1] = acc2[mt][4 * q + 1] * WSI + bb.y;
+                acc2[mt][4 * q + 2] = acc2[mt][4 * q + 2] * WSI + bb.z;
+                acc2[mt][4 * q + 3] = acc2[mt][4 * q + 3] * WSI + bb.w;
                 if (mt * 32 + lrow < valid)
                     *reinterpret_cast<float4*>(m.h + ((size_t)b * L + t0 + mt * 32 + lrow) * D + wave * 32 + 4 * lhalf + 8 * q) =
                         make_float4(acc2[mt][4 * q + 0], acc2[mt][4 * q + 1], acc2[mt][4 * q + 2], acc2[mt][4 * q + 3]);
@@ -260,15 +361,15 @@ __global__ __launch_bounds__(512) void tail32_kernel(Tail32Args m) {
     }
     // ---- 5. the next block's LayerNorm-1 + in_proj on the tile still in registers: z rows x0 | x1 | v
     if constexpr (NEXT) {
-        ln_to_tile(acc2, P1, P2, m.n_g, m.n_b, m.eps, As, valid, wave, lrow, lhalf);
+        ln_to_tile<false, AR>(acc2, P1, P2, m.n_g, m.n_b, m.eps, As, valid, wave, lrow, lhalf);
 #pragma unroll 1
         for (int nb = 0; nb < D3 / 256; ++nb) {
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc1[mt][r] = 0.f;
-            product256<false>(As, m.w_in, nb, D / 8, 0, wset_ptr(m.w_in, nb + 1 < D3 / 256 ? nb + 1 : 0, D / 8, 0, wave, lane), wave,
-                              lane, ws, acc1);
+            product256<false, AR>(As, m.w_in, nb, D / 8, 0, wset_ptr(m.w_in, nb + 1 < D3 / 256 ? nb + 1 : 0, D / 8, 0, wave, lane), wave,
+                                  lane, ws, acc1);
             // rows = features: 32 lanes = 32 consecutive tokens of one channel row (128 bytes)
             const float* bi = m.b_in + nb * 256 + wave * 32 + 4 * lhalf;
             float* zb = m.z + ((size_t)b * D3 + nb * 256 + wave * 32 + 4 * lhalf) * Lp + t0 + lrow;
@@ -278,7 +379,7 @@ __global__ __launch_bounds__(512) void tail32_kernel(Tail32Args m) {
                 const float bias = bi[f];
 #pragma unroll
                 for (int mt = 0; mt < 2; ++mt)
-                    if (mt * 32 + lrow < valid) zb[(size_t)f * Lp + mt * 32] = acc1[mt][r] + bias;
+                    if (mt * 32 + lrow < valid) zb[(size_t)f * Lp + mt * 32] = acc1[mt][r] * WSI + bias;
             }
         }
     }
@@ -498,27 +599,57 @@ __global__ __launch_bounds__(256) void pack_f32t_kernel(const float* __restrict_
     out[i] = f32x4{src[0], src[1], src[2], src[3]};
 }
 
+// AR_X3: W [N][K] -> [N / 256][8 waves][K / 16 k-steps][hi | lo][64 lanes] x 8 halfs: lane (lrow, lhalf) of wave w holds
+// fp16(1024 W[nb * 256 + w * 32 + lrow][16 s + 8 lhalf + 0..7]) and, in the next fragment, the fp16 of what that rounding left
+__global__ __launch_bounds__(256) void pack_x3_kernel(const float* __restrict__ w, f32x4* __restrict__ out, int N, int K) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x, total = (size_t)N * K / 4;     // fragments: N K / 8 hi + N K / 8 lo
+    if (i >= total) return;
+    const int lane = (int)(i & 63), lrow = lane & 31, lhalf = lane >> 5;
+    const size_t rest = i >> 6;
+    const int frags = K / 8, f = (int)(rest % frags), nw = (int)(rest / frags), s = f >> 1, plane = f & 1;
+    const float* src = w + (size_t)(nw * 32 + lrow) * K + 16 * s + 8 * lhalf;
+    typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+    h8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float x = src[j] * X3_WS;
+        const _Float16 hi = (_Float16)x;
+        o[j] = plane ? (_Float16)(x - (float)hi) : hi;
+    }
+    out[i] = __builtin_bit_cast(f32x4, o);
+}
+
+void launch_pack_x3(const float* w, void* out, int n, int k, hipStream_t st) {
+    const size_t total = (size_t)n * k / 4;
+    hipLaunchKernelGGL(pack_x3_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, w, reinterpret_cast<f32x4*>(out), n, k);
+}
+
 void launch_pack_f32t(const float* w, void* out, int n, int k, hipStream_t st) {
     const size_t total = (size_t)n * k / 4;
     hipLaunchKernelGGL(pack_f32t_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, w, reinterpret_cast<f32x4*>(out), n, k);
 }
 
+template <typename Kern>
+static void launch32(Kern kern, dim3 grid, size_t lds, hipStream_t st, const Tail32Args& m) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(kern, grid, dim3(512), lds, st, m);
+}
+// x3: the products as three fp16 MFMAs on hi + lo halfs (weights from launch_pack_x3) instead of the fp32 MFMA
 void launch_tail32(const float* y, float* h, const void* w_out, const void* w_fc1, const void* w_fc2, const void* w_in_next,
                    const float* b_out, const float* b_fc1, const float* b_fc2, const float* b_in_next, const float* ln2_g,
-                   const float* ln2_b, const float* n_g, const float* n_b, float* z, int B, int L, int Lp, float eps, hipStream_t st) {
+                   const float* ln2_b, const float* n_g, const float* n_b, float* z, int B, int L, int Lp, float eps, hipStream_t st,
+                   bool x3) {
     Tail32Args m{y, h, reinterpret_cast<const f32x4*>(w_out), reinterpret_cast<const f32x4*>(w_fc1), reinterpret_cast<const f32x4*>(w_fc2),
                  reinterpret_cast<const f32x4*>(w_in_next), b_out, b_fc1, b_fc2, b_in_next, ln2_g, ln2_b, n_g, n_b, z, B, L, Lp,
                  (L + BM32 - 1) / BM32, eps};
     const size_t lds = (size_t)(2 * BM32 * RS32 + 2 * 8 * BM32) * sizeof(float);
-    const dim3 grid((unsigned)(m.tiles_x * B)), block(512);
-    if (w_in_next) {
-        static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(tail32_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), true);
-        (void)once;
-        hipLaunchKernelGGL(tail32_kernel<true>, grid, block, lds, st, m);
+    const dim3 grid((unsigned)(m.tiles_x * B));
+    if (x3) {
+        if (w_in_next) launch32(tail32_kernel<true, AR_X3>, grid, lds, st, m);
+        else launch32(tail32_kernel<false, AR_X3>, grid, lds, st, m);
     } else {
-        static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(tail32_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), true);
-        (void)once;
-        hipLaunchKernelGGL(tail32_kernel<false>, grid, block, lds, st, m);
+        if (w_in_next) launch32(tail32_kernel<true, AR_F32>, grid, lds, st, m);
+        else launch32(tail32_kernel<false, AR_F32>, grid, lds, st, m);
     }
 }
 

@@ -161,7 +161,7 @@ class Engine:
         code = self._lib.clm_effective_precision(self._h, int(length))
         if code < 0:
             raise EngineError(code, "clm_effective_precision")
-        return {N.PREC_F32: "fp32", N.PREC_BF16: "bf16", N.PREC_F16: "fp16", N.PREC_F16C: "fp16c"}[code]
+        return {N.PREC_F32: "fp32", N.PREC_BF16: "bf16", N.PREC_F16: "fp16", N.PREC_F16C: "fp16c", N.PREC_F16X3: "fp16x3"}[code]
 
     def stage_wait(self, staged: int):
         self._check(self._lib.clm_stage_wait(self._h, int(staged)))

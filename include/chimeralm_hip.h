@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define CLM_ABI_VERSION 3
+#define CLM_ABI_VERSION 4
 
 /* error codes */
 #define CLM_OK 0
@@ -57,6 +57,12 @@ extern "C" {
  * that runs at 16-bit MFMA rate AND stays within the reference's 1e-3 logit tolerance (weight rounding is the error
  * that attention pooling cannot average out, tests/error_model.py); z / y are stored as fp16 like CLM_PREC_F16. */
 #define CLM_PREC_F16C 3
+/* F16X3 (ABI 4): near-exact at fp16 MFMA rate / 3.  Every operand of a dense projection is split into two halfs, x = hi + lo with
+ * hi = fp16(x) and lo = fp16(x - hi) (~21 bits; weights pre-scaled by 2^10 so that their lo halfs stay normal), and a product is
+ * three fp16 MFMAs into the fp32 accumulator: w_hi a_hi + w_lo a_hi + w_hi a_lo.  Everything else is the exact-fp32 engine (fp32
+ * z / y / residual stream in HBM, fp32 convolution, score layer on the fp32 MFMA).  Logits within ~1e-5 of exact fp32 -- three
+ * orders of magnitude inside the reference's 1e-3 -- at 2.5x its rate; no self-check, no fall-back (csrc/tail32.hip, AR_X3). */
+#define CLM_PREC_F16X3 4
 
 typedef struct clm_handle clm_handle;
 

@@ -4,6 +4,7 @@ The parity gate (north_star: identical labels, logits within 1e-3 of the fp32 re
 two modes that claim reference parity:
   fp32   exact-fp32 MFMA                                   observed ~1e-5
   fp16c  fp16 activations x (hi + lo) fp16 weight pairs    observed 2-6e-4   <- the throughput mode (bench.py default)
+  fp16x3 every operand as two halfs, three fp16 MFMAs      observed ~1e-5    (round 4: held to 1e-4, a tenth of the gate)
 Labels must be identical on every row whose oracle margin exceeds 2 x GATE.
 The plain 16-bit modes are REDUCED-PRECISION modes outside the gate; their bounds below only pin their rounding behaviour:
   fp16   |logit - oracle| <= 5e-3  (observed 0.5-1.5e-3), labels identical wherever the oracle margin > 2e-2
@@ -24,8 +25,8 @@ pytestmark = pytest.mark.gpu
 REPO = Path(__file__).resolve().parent.parent
 
 GATE = 1e-3
-TOL = {"fp32": GATE, "fp16c": GATE, "fp16": 5e-3, "bf16": 6e-2}
-MARGIN = {"fp32": 2 * GATE, "fp16c": 2 * GATE, "fp16": 2e-2, "bf16": 2e-1}
+TOL = {"fp32": GATE, "fp16c": GATE, "fp16x3": 1e-4, "fp16": 5e-3, "bf16": 6e-2}
+MARGIN = {"fp32": 2 * GATE, "fp16c": 2 * GATE, "fp16x3": 2e-4, "fp16": 2e-2, "bf16": 2e-1}
 
 
 @pytest.fixture(scope="module")
@@ -570,6 +571,33 @@ def test_baseline_batch_size_independent_properties(sd, built_lib, prec, B, chun
         diff, _ = e.selfcheck(t[max(B - 8, 0):].contiguous())
         assert 0 < diff <= GATE
     e.close()
+
+
+@pytest.mark.parametrize("wseed,B,L,pads", [(0, 3, 257, 0), (0, 2, 64, 0), (0, 1, 1, 0), (4, 5, 130, 3), (4, 4, 1000, 0), (7, 3, 2049, 5),
+                                            (7, 2, 8193, 0), (0, 2, 20000, 0)])
+def test_fp16x3_is_fp32_class(built_lib, wseed, B, L, pads):
+    """`fp16x3` (round 4, csrc/tail32.hip AR_X3): the exact engine's fused block tails with every operand of a product split into
+    two halfs (hi = fp16(x), lo = fp16(x - hi)) and three fp16 MFMAs per product.  Held to a TENTH of the gate against the oracle
+    and against the exact-fp32 engine on the same ids -- measured: as far from the fp64-checked oracle as exact fp32 itself is
+    (~1e-5) -- over three weight draws, one-token to long reads, ragged tiles and pads."""
+    from chimeralm_amd.engine import Engine
+
+    sdw = ho.make_state_dict(wseed, head_scale=3.0)
+    ids = _ids(B, L, seed=71 + L, pads=pads if L > 8 else 0)
+    t = torch.from_numpy(ids).cuda()
+    e32, ex = Engine("cuda:0", precision="fp32"), Engine("cuda:0", precision="fp16x3")
+    e32.load_state_dict(sdw), ex.load_state_dict(sdw)
+    assert ex.effective_precision(L) == "fp16x3"
+    a, b = e32.forward(t).cpu(), ex.forward(t).cpu()
+    assert torch.equal(b, ex.forward(t).cpu())                                   # deterministic
+    d32 = (a - b).abs().max().item()
+    msg = f"weights {wseed}, {B} x {L}: |fp16x3 - exact fp32| {d32:.2e}"
+    assert d32 <= TOL["fp16x3"]
+    if L <= 2049:
+        err = _check(ex, "fp16x3", ids, sdw)
+        msg += f", |fp16x3 - oracle| {err:.2e}"
+    print(msg)
+    e32.close(), ex.close()
 
 
 @pytest.mark.parametrize("prec,B,L,cut", [("fp32", 3, 8193, 5000), ("fp16c", 6, 8193, 4097), ("fp16c", 2, 32769, 20000), ("fp16", 5, 3000, 1500)])
