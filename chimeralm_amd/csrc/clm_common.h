@@ -187,12 +187,12 @@ void launch_pack_x3(const float* w /*[n][k]*/, void* out /*n * k * 4 bytes*/, in
 void launch_pack_f32t(const float* w /*[n][k]*/, void* out /*n * k floats*/, int n, int k, hipStream_t st);
 // SequenceCNNTransformer, exact fp32 (tail32.hip conv32_kernel): Conv1d(k = 3, padding = 1) + ReLU + MaxPool1d(2); w = three taps
 // [dk][co][ci], each packed by launch_pack_f32t
-void launch_conv32(const float* x, const void* w, const float* bias, float* out, int B, int Lin, hipStream_t st);
+void launch_conv32(const float* x, const void* w, const float* bias, float* out, int B, int Lin, hipStream_t st, bool x3 = false);
 // SequenceCNNTransformer, exact fp32 (tail32.hip enc32_kernel): att == null: qkv of the rows of h as they are; otherwise one encoder
 // layer after its attention (out_proj + LN1 + FFN + LN2 on h in place) and, w_qkv != null, the next layer's in_proj into qkv
 void launch_enc32(const float* att, float* h, const void* w_o, const void* w1, const void* w2, const void* w_qkv, const float* b_o,
                   const float* b1, const float* b2, const float* b_qkv, const float* ln1_g, const float* ln1_b, const float* ln2_g,
-                  const float* ln2_b, float* qkv, size_t M, float eps, hipStream_t st);
+                  const float* ln2_b, float* qkv, size_t M, float eps, hipStream_t st, bool x3 = false);
 
 // GEMM family (gemm.hip).  `prec` selects compute dtype; T16 activations are bf16/f16 (or fp32 for PREC_F32).
 // z  = in_proj(LN1(h))      -> channel-major [B, 768, Lp]

@@ -402,6 +402,7 @@ struct Enc32Args {
     float eps;
 };
 
+template <int AR = AR_F32>
 __device__ __forceinline__ void stage_rows32(const float* __restrict__ src, size_t row0, size_t M, float* T, int tid) {
     const int lane = tid & 63, wave = tid >> 6;
 #pragma unroll
@@ -409,12 +410,13 @@ __device__ __forceinline__ void stage_rows32(const float* __restrict__ src, size
         const int r = wave + 8 * i;
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
         if (row0 + r < M) v = *reinterpret_cast<const f32x4*>(src + (row0 + r) * D + lane * 4);
-        *reinterpret_cast<f32x4*>(T + r * RS32 + lane * 4) = v;
+        tile_store4<AR>(T, r, lane * 4, v);
     }
 }
 
-template <bool FIRST>
+template <bool FIRST, int AR = AR_F32>
 __global__ __launch_bounds__(512) void enc32_kernel(Enc32Args m) {
+    constexpr float WS = WSCALE<AR>, WSI = WUNSCALE<AR>;
     extern __shared__ __attribute__((aligned(16))) float smem32[];
     float* As = smem32;
     float* Hs = As + BM32 * RS32;
@@ -427,11 +429,11 @@ __global__ __launch_bounds__(512) void enc32_kernel(Enc32Args m) {
     f32x16 acc1[2], acc2[2];
     if constexpr (FIRST) {
         load_wset(wset_ptr(m.w_qkv, 0, D / 8, 0, wave, lane), ws[0]);
-        stage_rows32(m.h, row0, m.M, As, tid);
+        stage_rows32<AR>(m.h, row0, m.M, As, tid);
         __syncthreads();
     } else {
         load_wset(wset_ptr(m.w_o, 0, D / 8, 0, wave, lane), ws[0]);
-        stage_rows32(m.att, row0, m.M, As, tid);
+        stage_rows32<AR>(m.att, row0, m.M, As, tid);
         {   // acc2 = h + b_o
             const float* bo = m.b_o + wave * 32 + 4 * lhalf;
 #pragma unroll
@@ -442,23 +444,35 @@ __global__ __launch_bounds__(512) void enc32_kernel(Enc32Args m) {
                 for (int q = 0; q < 4; ++q) {
                     const float4 hv = *reinterpret_cast<const float4*>(row + 8 * q);
                     const float4 bb = *reinterpret_cast<const float4*>(bo + 8 * q);
-                    acc2[mt][4 * q + 0] = hv.x + bb.x;
-                    acc2[mt][4 * q + 1] = hv.y + bb.y;
-                    acc2[mt][4 * q + 2] = hv.z + bb.z;
-                    acc2[mt][4 * q + 3] = hv.w + bb.w;
+                    acc2[mt][4 * q + 0] = (hv.x + bb.x) * WS;
+                    acc2[mt][4 * q + 1] = (hv.y + bb.y) * WS;
+                    acc2[mt][4 * q + 2] = (hv.z + bb.z) * WS;
+                    acc2[mt][4 * q + 3] = (hv.w + bb.w) * WS;
                 }
             }
         }
         __syncthreads();
-        product256<false>(As, m.w_o, 0, D / 8, 0, wset_ptr(m.w1, 0, D / 8, 0, wave, lane), wave, lane, ws, acc2);
-        ln_to_tile<true>(acc2, P1, P2, m.ln1_g, m.ln1_b, m.eps, As, valid, wave, lrow, lhalf);       // As = x1, acc2 = x1
+        product256<false, AR>(As, m.w_o, 0, D / 8, 0, wset_ptr(m.w1, 0, D / 8, 0, wave, lane), wave, lane, ws, acc2);
+        if constexpr (AR == AR_X3) {
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc2[mt][r] *= WSI;
+        }
+        ln_to_tile<true, AR>(acc2, P1, P2, m.ln1_g, m.ln1_b, m.eps, As, valid, wave, lrow, lhalf);   // As = x1, acc2 = x1
+        if constexpr (AR == AR_X3) {                         // (the fc2 products land on x1 in the weights' scale)
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc2[mt][r] *= WS;
+        }
 #pragma unroll 1
         for (int j = 0; j < DI / 256; ++j) {
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc1[mt][r] = 0.f;
-            product256<false>(As, m.w1, j, D / 8, 0, wset_ptr(m.w2, 0, DI / 8, j * 32, wave, lane), wave, lane, ws, acc1);
+            product256<false, AR>(As, m.w1, j, D / 8, 0, wset_ptr(m.w2, 0, DI / 8, j * 32, wave, lane), wave, lane, ws, acc1);
             {
                 const float* b1 = m.b1 + j * 256 + wave * 32 + 4 * lhalf;
 #pragma unroll
@@ -466,16 +480,16 @@ __global__ __launch_bounds__(512) void enc32_kernel(Enc32Args m) {
                     const float4 bb = *reinterpret_cast<const float4*>(b1 + 8 * q);
 #pragma unroll
                     for (int mt = 0; mt < 2; ++mt) {
-                        f32x4 g = {fmaxf(acc1[mt][4 * q + 0] + bb.x, 0.f), fmaxf(acc1[mt][4 * q + 1] + bb.y, 0.f),
-                                   fmaxf(acc1[mt][4 * q + 2] + bb.z, 0.f), fmaxf(acc1[mt][4 * q + 3] + bb.w, 0.f)};
-                        *reinterpret_cast<f32x4*>(Hs + (mt * 32 + lrow) * RS32 + wave * 32 + 8 * q + 4 * lhalf) = g;
+                        f32x4 g = {fmaxf(acc1[mt][4 * q + 0] * WSI + bb.x, 0.f), fmaxf(acc1[mt][4 * q + 1] * WSI + bb.y, 0.f),
+                                   fmaxf(acc1[mt][4 * q + 2] * WSI + bb.z, 0.f), fmaxf(acc1[mt][4 * q + 3] * WSI + bb.w, 0.f)};
+                        tile_store4<AR>(Hs, mt * 32 + lrow, wave * 32 + 8 * q + 4 * lhalf, g);
                     }
                 }
             }
             __syncthreads();
             const f32x4* nxt = j + 1 < DI / 256 ? wset_ptr(m.w1, j + 1, D / 8, 0, wave, lane)
                                                 : wset_ptr(m.w_qkv ? m.w_qkv : m.w1, 0, D / 8, 0, wave, lane);
-            product256<false>(Hs, m.w2, 0, DI / 8, j * 32, nxt, wave, lane, ws, acc2);
+            product256<false, AR>(Hs, m.w2, 0, DI / 8, j * 32, nxt, wave, lane, ws, acc2);
             __syncthreads();
         }
         {   // + b_2, LayerNorm-2 -> As and the accumulators; h' leaves as 16 bytes per lane and feature quad
@@ -485,14 +499,14 @@ __global__ __launch_bounds__(512) void enc32_kernel(Enc32Args m) {
                 const float4 bb = *reinterpret_cast<const float4*>(b2p + 8 * q);
 #pragma unroll
                 for (int mt = 0; mt < 2; ++mt) {
-                    acc2[mt][4 * q + 0] += bb.x;
-                    acc2[mt][4 * q + 1] += bb.y;
-                    acc2[mt][4 * q + 2] += bb.z;
-                    acc2[mt][4 * q + 3] += bb.w;
+                    acc2[mt][4 * q + 0] = acc2[mt][4 * q + 0] * WSI + bb.x;
+                    acc2[mt][4 * q + 1] = acc2[mt][4 * q + 1] * WSI + bb.y;
+                    acc2[mt][4 * q + 2] = acc2[mt][4 * q + 2] * WSI + bb.z;
+                    acc2[mt][4 * q + 3] = acc2[mt][4 * q + 3] * WSI + bb.w;
                 }
             }
         }
-        ln_to_tile<true>(acc2, P1, P2, m.ln2_g, m.ln2_b, m.eps, As, valid, wave, lrow, lhalf);
+        ln_to_tile<true, AR>(acc2, P1, P2, m.ln2_g, m.ln2_b, m.eps, As, valid, wave, lrow, lhalf);
 #pragma unroll
         for (int q = 0; q < 4; ++q)
 #pragma unroll
@@ -509,8 +523,8 @@ __global__ __launch_bounds__(512) void enc32_kernel(Enc32Args m) {
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc1[mt][r] = 0.f;
-        product256<false>(As, m.w_qkv, nb, D / 8, 0, wset_ptr(m.w_qkv, nb + 1 < D3 / 256 ? nb + 1 : 0, D / 8, 0, wave, lane), wave, lane,
-                          ws, acc1);
+        product256<false, AR>(As, m.w_qkv, nb, D / 8, 0, wset_ptr(m.w_qkv, nb + 1 < D3 / 256 ? nb + 1 : 0, D / 8, 0, wave, lane), wave, lane,
+                              ws, acc1);
         const float* bq = m.b_qkv + nb * 256 + wave * 32 + 4 * lhalf;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -519,8 +533,8 @@ __global__ __launch_bounds__(512) void enc32_kernel(Enc32Args m) {
             for (int mt = 0; mt < 2; ++mt)
                 if (mt * 32 + lrow < valid)
                     *reinterpret_cast<float4*>(m.qkv + (row0 + mt * 32 + lrow) * D3 + nb * 256 + wave * 32 + 4 * lhalf + 8 * q) =
-                        make_float4(acc1[mt][4 * q + 0] + bb.x, acc1[mt][4 * q + 1] + bb.y, acc1[mt][4 * q + 2] + bb.z,
-                                    acc1[mt][4 * q + 3] + bb.w);
+                        make_float4(acc1[mt][4 * q + 0] * WSI + bb.x, acc1[mt][4 * q + 1] * WSI + bb.y, acc1[mt][4 * q + 2] * WSI + bb.z,
+                                    acc1[mt][4 * q + 3] * WSI + bb.w);
         }
     }
 }
@@ -539,7 +553,9 @@ struct Conv32Args {
     int B, Lin, tiles_x;
 };
 
+template <int AR = AR_F32>
 __global__ __launch_bounds__(512) void conv32_kernel(Conv32Args m) {
+    constexpr float WSI = WUNSCALE<AR>;
     extern __shared__ __attribute__((aligned(16))) float smem32[];
     float* Xs = smem32;                                     // [66][RS32]: row r = position t0 - 1 + r
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lrow = lane & 31, lhalf = lane >> 5;
@@ -555,7 +571,7 @@ __global__ __launch_bounds__(512) void conv32_kernel(Conv32Args m) {
             if (r < BM32 + 2) {
                 f32x4 v = {0.f, 0.f, 0.f, 0.f};
                 if (t >= 0 && t < Lin) v = *reinterpret_cast<const f32x4*>(src + (size_t)t * D);
-                *reinterpret_cast<f32x4*>(Xs + r * RS32 + lane * 4) = v;
+                tile_store4<AR>(Xs, r, lane * 4, v);
             }
         }
     }
@@ -568,7 +584,7 @@ __global__ __launch_bounds__(512) void conv32_kernel(Conv32Args m) {
         constexpr int dk = decltype(dkc)::value;
         const f32x4* wdk = m.w + (size_t)dk * (D * D / 4);
         const f32x4* nxt = wset_ptr(dk < 2 ? m.w + (size_t)(dk + 1) * (D * D / 4) : m.w, 0, D / 8, 0, wave, lane);
-        product256<false>(Xs + dk * RS32, wdk, 0, D / 8, 0, nxt, wave, lane, ws, acc);
+        product256<false, AR>(Xs + dk * RS32, wdk, 0, D / 8, 0, nxt, wave, lane, ws, acc);
     });
     const float* bp = m.bias + wave * 32 + 4 * lhalf;
 #pragma unroll
@@ -576,8 +592,8 @@ __global__ __launch_bounds__(512) void conv32_kernel(Conv32Args m) {
         const float4 bb = *reinterpret_cast<const float4*>(bp + 8 * q);
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) {
-            float v[4] = {fmaxf(acc[mt][4 * q + 0] + bb.x, 0.f), fmaxf(acc[mt][4 * q + 1] + bb.y, 0.f),
-                          fmaxf(acc[mt][4 * q + 2] + bb.z, 0.f), fmaxf(acc[mt][4 * q + 3] + bb.w, 0.f)};
+            float v[4] = {fmaxf(acc[mt][4 * q + 0] * WSI + bb.x, 0.f), fmaxf(acc[mt][4 * q + 1] * WSI + bb.y, 0.f),
+                          fmaxf(acc[mt][4 * q + 2] * WSI + bb.z, 0.f), fmaxf(acc[mt][4 * q + 3] * WSI + bb.w, 0.f)};
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], __shfl_xor(v[e], 1, 64));       // positions 2 p, 2 p + 1: adjacent lanes
             const int pos = (t0 + mt * 32 + lrow) >> 1;
@@ -657,29 +673,28 @@ void launch_tail32(const float* y, float* h, const void* w_out, const void* w_fc
 // and -- w_qkv != null -- the next layer's in_proj.  Weights in launch_pack_f32t's order.
 void launch_enc32(const float* att, float* h, const void* w_o, const void* w1, const void* w2, const void* w_qkv, const float* b_o,
                   const float* b1, const float* b2, const float* b_qkv, const float* ln1_g, const float* ln1_b, const float* ln2_g,
-                  const float* ln2_b, float* qkv, size_t M, float eps, hipStream_t st) {
+                  const float* ln2_b, float* qkv, size_t M, float eps, hipStream_t st, bool x3) {
     Enc32Args m{att, h, reinterpret_cast<const f32x4*>(w_o), reinterpret_cast<const f32x4*>(w1), reinterpret_cast<const f32x4*>(w2),
                 reinterpret_cast<const f32x4*>(w_qkv), b_o, b1, b2, b_qkv, ln1_g, ln1_b, ln2_g, ln2_b, qkv, M, eps};
     const size_t lds = (size_t)(2 * BM32 * RS32 + 2 * 8 * BM32) * sizeof(float);
     const dim3 grid((unsigned)((M + BM32 - 1) / BM32)), block(512);
-    if (!att) {
-        static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(enc32_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), true);
-        (void)once;
-        hipLaunchKernelGGL(enc32_kernel<true>, grid, block, lds, st, m);
-    } else {
-        static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(enc32_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), true);
-        (void)once;
-        hipLaunchKernelGGL(enc32_kernel<false>, grid, block, lds, st, m);
-    }
+    auto go = [&](auto kern) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(kern, grid, block, lds, st, m);
+    };
+    if (!att) { if (x3) go(enc32_kernel<true, AR_X3>); else go(enc32_kernel<true, AR_F32>); }
+    else { if (x3) go(enc32_kernel<false, AR_X3>); else go(enc32_kernel<false, AR_F32>); }
 }
 
 // x [B, Lin, 256] -> relu(conv1d_k3(x) + bias) pooled by 2 -> out [B, Lin / 2, 256]; w: three taps, each packed by launch_pack_f32t
-void launch_conv32(const float* x, const void* w, const float* bias, float* out, int B, int Lin, hipStream_t st) {
+void launch_conv32(const float* x, const void* w, const float* bias, float* out, int B, int Lin, hipStream_t st, bool x3) {
     Conv32Args m{x, reinterpret_cast<const f32x4*>(w), bias, out, B, Lin, (Lin + BM32 - 1) / BM32};
     const size_t lds = (size_t)(BM32 + 2) * RS32 * sizeof(float);
-    static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv32_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), true);
-    (void)once;
-    hipLaunchKernelGGL(conv32_kernel, dim3((unsigned)(m.tiles_x * B)), dim3(512), lds, st, m);
+    auto go = [&](auto kern) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(kern, dim3((unsigned)(m.tiles_x * B)), dim3(512), lds, st, m);
+    };
+    if (x3) go(conv32_kernel<AR_X3>); else go(conv32_kernel<AR_F32>);
 }
 
 }  // namespace clm

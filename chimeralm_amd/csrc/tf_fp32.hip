@@ -294,6 +294,162 @@ __global__ __launch_bounds__(256, 4) void attention32_kernel(const float* __rest
     }
 }
 
+// fp16x3: the same attention with every operand as two halfs (hi = fp16(x), lo = fp16(x - hi)) and three fp16 MFMAs per product,
+// built like the 16-bit kernel (attention.hip): S^T = K Q^T with a lane owning one query; P^T stays in registers and, split into
+// halfs, is the B operand of O^T = V^T P^T up to the fixed permutation of the key index that is applied to V's rows when the tile
+// is staged; V^T fragments by transposing LDS reads.  q / k / v arrive as fp32 and are split on their way into registers / LDS.
+constexpr int AX_QT = 128, AX_KT = 64, AX_KRS = 40, AX_VRS = 32;       // halfs: K rows 80 B, V rows 64 B (attention.hip's strides)
+__device__ __forceinline__ int ax_v_row(int k) { return (k & ~12) | ((k & 4) << 1) | ((k & 8) >> 1); }
+__global__ __launch_bounds__(256, 4) void attention_x3_kernel(const float* __restrict__ qkv, float* __restrict__ out, int L) {
+    using f32x4 = float __attribute__((ext_vector_type(4)));
+    typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+    typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+    typedef float f8 __attribute__((ext_vector_type(8)));
+    using v4i16 = short __attribute__((ext_vector_type(4)));
+    typedef v4i16 __attribute__((address_space(3))) * lds_v4;
+    __shared__ __attribute__((aligned(16))) _Float16 Ks[2][2][AX_KT * AX_KRS];       // [buffer][hi | lo]
+    __shared__ __attribute__((aligned(16))) _Float16 Vs[2][2][AX_KT * AX_VRS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = lane & 31, hf = lane >> 5;
+    const int ntq = (L + AX_QT - 1) / AX_QT;
+    const int g = blockIdx.x, xcd = g & 7, slot = g >> 3;
+    const int bh = (slot / ntq) * 8 + xcd, q0 = (slot % ntq) * AX_QT, h = bh & 7, b = bh >> 3;
+    const float* base = qkv + (size_t)b * L * 768 + h * 32;
+    const float c = 1.4426950408889634f * 0.17677669529663687f;        // log2(e) / sqrt(32)
+    auto split8 = [](f8 v, h8& hi, h8& lo) {
+        hi = __builtin_convertvector(v, h8);
+        lo = __builtin_convertvector(v - __builtin_convertvector(hi, f8), h8);
+    };
+    h8 qh[2], ql[2];                                                   // Q^T as B operand: d = 16 s + 8 hf + 0..7
+    {
+        const int q = q0 + wave * 32 + n;
+        const float* qp = base + (size_t)(q < L ? q : L - 1) * 768 + 8 * hf;
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(qp + 16 * s2), bq = *reinterpret_cast<const f32x4*>(qp + 16 * s2 + 4);
+            split8(f8{a[0], a[1], a[2], a[3], bq[0], bq[1], bq[2], bq[3]}, qh[s2], ql[s2]);
+        }
+    }
+    // staging: thread -> (key row, 4-float piece) x 2 of the K and of the V tile
+    f32x4 kreg[2], vreg[2];
+    auto load_tile = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int e = tid + i * 256, j = e >> 3, d4 = e & 7;
+            const int key = k0 + j < L ? k0 + j : L - 1;
+            const float* p = base + (size_t)key * 768 + 4 * d4;
+            kreg[i] = *reinterpret_cast<const f32x4*>(p + 256);
+            vreg[i] = *reinterpret_cast<const f32x4*>(p + 512);
+        }
+    };
+    auto store_tile = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int e = tid + i * 256, j = e >> 3, d4 = e & 7;
+            const h4 kh = __builtin_convertvector(kreg[i], h4), vh = __builtin_convertvector(vreg[i], h4);
+            const h4 kl = __builtin_convertvector(kreg[i] - __builtin_convertvector(kh, f32x4), h4);
+            const h4 vl = __builtin_convertvector(vreg[i] - __builtin_convertvector(vh, f32x4), h4);
+            *reinterpret_cast<h4*>(&Ks[buf][0][j * AX_KRS + 4 * d4]) = kh;
+            *reinterpret_cast<h4*>(&Ks[buf][1][j * AX_KRS + 4 * d4]) = kl;
+            *reinterpret_cast<h4*>(&Vs[buf][0][ax_v_row(j) * AX_VRS + 4 * d4]) = vh;
+            *reinterpret_cast<h4*>(&Vs[buf][1][ax_v_row(j) * AX_VRS + 4 * d4]) = vl;
+        }
+    };
+    auto mm = [](h8 a, h8 bq, f32x16 acc) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bq, acc, 0, 0, 0); };
+    f32x16 o;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[r] = 0.f;
+    float m = -INFINITY, l = 0.f;
+    const int ntiles = (L + AX_KT - 1) / AX_KT;
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+#pragma unroll 1
+    for (int t = 0; t < ntiles; ++t) {
+        const int buf = t & 1, k0 = t * AX_KT;
+        if (t + 1 < ntiles) load_tile(k0 + AX_KT);
+        f32x16 s[2];
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[blk][r] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const h8 kh = *reinterpret_cast<const h8*>(&Ks[buf][0][(blk * 32 + n) * AX_KRS + 16 * ks + 8 * hf]);
+                const h8 kl = *reinterpret_cast<const h8*>(&Ks[buf][1][(blk * 32 + n) * AX_KRS + 16 * ks + 8 * hf]);
+                s[blk] = mm(kh, qh[ks], s[blk]);
+                s[blk] = mm(kl, qh[ks], s[blk]);
+                s[blk] = mm(kh, ql[ks], s[blk]);
+            }
+        }
+        if (k0 + AX_KT > L) {
+#pragma unroll
+            for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (k0 + blk * 32 + (r & 3) + 8 * (r >> 2) + 4 * hf >= L) s[blk][r] = -INFINITY;
+        }
+        float mx = s[0][0];
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[blk][r]);
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m, mx);
+        const float alpha = __builtin_amdgcn_exp2f((m - m_new) * c);
+        const float mc = m_new * c;
+        float psum = 0.f;
+        h8 ph[2][2], pl[2][2];                                         // P^T as B operand: [block][k-step of 16 keys], hi and lo halfs
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                f8 p;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    p[j] = __builtin_amdgcn_exp2f(fmaf(s[blk][8 * ks + j], c, -mc));
+                    psum += p[j];
+                }
+                split8(p, ph[blk][ks], pl[blk][ks]);
+            }
+        l = l * alpha + psum;
+        m = m_new;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[r] *= alpha;
+        {
+            const int li = lane & 15, g1 = (lane >> 4) & 1, q4 = li >> 2, p4 = li & 3;
+            const int voff = (8 * hf + q4) * AX_VRS + 16 * g1 + 4 * p4;
+#pragma unroll
+            for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    h8 vf[2];
+#pragma unroll
+                    for (int pln = 0; pln < 2; ++pln) {
+                        const _Float16* p0 = &Vs[buf][pln][voff + (blk * 32 + ks * 16) * AX_VRS];
+                        const v4i16 lo4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(p0));
+                        const v4i16 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(p0 + 4 * AX_VRS));
+                        typedef short s8 __attribute__((ext_vector_type(8)));
+                        const s8 both = {lo4[0], lo4[1], lo4[2], lo4[3], hi4[0], hi4[1], hi4[2], hi4[3]};
+                        vf[pln] = __builtin_bit_cast(h8, both);
+                    }
+                    o = mm(vf[0], ph[blk][ks], o);
+                    o = mm(vf[1], ph[blk][ks], o);
+                    o = mm(vf[0], pl[blk][ks], o);
+                }
+        }
+        if (t + 1 < ntiles) store_tile(buf ^ 1);
+        __syncthreads();
+    }
+    const float inv = 1.0f / (l + __shfl_xor(l, 32, 64));
+    const int q = q0 + wave * 32 + n;
+    if (q < L) {
+        float* op = out + ((size_t)b * L + q) * D + h * 32 + 4 * hf;
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq)
+            *reinterpret_cast<float4*>(op + 8 * gq) = make_float4(o[4 * gq + 0] * inv, o[4 * gq + 1] * inv, o[4 * gq + 2] * inv, o[4 * gq + 3] * inv);
+    }
+}
+
 template <bool RELU, bool CONV3>
 static void gemm(const float* A, int lda, const float* W, const float* bias, const float* R, float* C, int ldc, size_t M, int N,
                  int K, int Lrow, hipStream_t st) {
@@ -312,7 +468,7 @@ size_t tf32_workspace_floats(int B, int L) {
 // `get(key)`: fp32 device pointer of a reference state-dict tensor.  h [M][256] receives the encoder output (the residual stream
 // the pooling head reads), exactly where the 16-bit path leaves it.
 int tf32_forward(const unsigned char* ids8, int ids_stride, int B, int L, int n_layers, float* ws, float* h,
-                 const float* (*get)(void*, const std::string&), void* ctx, hipStream_t st, bool unfused) {
+                 const float* (*get)(void*, const std::string&), void* ctx, hipStream_t st, bool unfused, bool x3) {
     using namespace tf32;
     const int L1 = L / 2, L2 = L1 / 2, L3 = L2 / 2;
     const size_t M = (size_t)B * L3;
@@ -331,7 +487,7 @@ int tf32_forward(const unsigned char* ids8, int ids_stride, int B, int L, int n_
         const std::string n = "cnn." + std::to_string(i);
         const int Lout = Lin / 2;
         if (!unfused) {      // round 4: convolution + ReLU + pooling in one kernel on the fp32 MFMA (tail32.hip conv32_kernel)
-            launch_conv32(x, get(ctx, "t32." + n), Wt(n + ".bias"), y, B, Lin, st);
+            launch_conv32(x, get(ctx, "t32." + n), Wt(n + ".bias"), y, B, Lin, st, x3);
             std::swap(x, y);
         } else {
             gemm<true, true>(x, D, Wt(n + ".weight"), Wt(n + ".bias"), nullptr, y, D, (size_t)B * Lin, D, 3 * D, Lin, st);
@@ -349,16 +505,17 @@ int tf32_forward(const unsigned char* ids8, int ids_stride, int B, int L, int n_
     auto LP = [&](int i) { return "transformer_encoder.layers." + std::to_string(i) + "."; };
     if (!unfused && n_layers > 0)
         launch_enc32(nullptr, h, nullptr, nullptr, nullptr, T32(0, "in"), nullptr, nullptr, nullptr, Wt(LP(0) + "self_attn.in_proj_bias"),
-                     nullptr, nullptr, nullptr, nullptr, qkv, M, 1e-5f, st);
+                     nullptr, nullptr, nullptr, nullptr, qkv, M, 1e-5f, st, x3);
     for (int i = 0; i < n_layers; ++i) {
         const std::string p = LP(i);
         if (!unfused) {
-            hipLaunchKernelGGL(attention32_kernel, dim3((unsigned)(((L3 + A32_QT - 1) / A32_QT) * 8 * B)), dim3(256), 0, st, qkv, att, L3);
+            if (x3) hipLaunchKernelGGL(attention_x3_kernel, dim3((unsigned)(((L3 + AX_QT - 1) / AX_QT) * 8 * B)), dim3(256), 0, st, qkv, att, L3);
+            else hipLaunchKernelGGL(attention32_kernel, dim3((unsigned)(((L3 + A32_QT - 1) / A32_QT) * 8 * B)), dim3(256), 0, st, qkv, att, L3);
             const bool more = i + 1 < n_layers;
             launch_enc32(att, h, T32(i, "out"), T32(i, "ff1"), T32(i, "ff2"), more ? T32(i + 1, "in") : nullptr,
                          Wt(p + "self_attn.out_proj.bias"), Wt(p + "linear1.bias"), Wt(p + "linear2.bias"),
                          more ? Wt(LP(i + 1) + "self_attn.in_proj_bias") : nullptr, Wt(p + "norm1.weight"), Wt(p + "norm1.bias"),
-                         Wt(p + "norm2.weight"), Wt(p + "norm2.bias"), qkv, M, 1e-5f, st);
+                         Wt(p + "norm2.weight"), Wt(p + "norm2.bias"), qkv, M, 1e-5f, st, x3);
             continue;
         }
         gemm<false, false>(h, D, Wt(p + "self_attn.in_proj_weight"), Wt(p + "self_attn.in_proj_bias"), nullptr, qkv, 768, M, 768, D, 0, st);

@@ -472,7 +472,7 @@ void launch_attention_fwd(int prec, const void* qkv, void* out, int B, int L, hi
 // tf_fp32.hip: the same forward with exact-fp32 products (the reference's precision), up to the encoder output h
 size_t tf32_workspace_floats(int B, int L);
 int tf32_forward(const unsigned char* ids8, int ids_stride, int B, int L, int n_layers, float* ws, float* h,
-                 const float* (*get)(void*, const std::string&), void* ctx, hipStream_t st, bool unfused);
+                 const float* (*get)(void*, const std::string&), void* ctx, hipStream_t st, bool unfused, bool x3);
 
 }  // namespace clm
 
@@ -492,6 +492,7 @@ struct clm_tf_handle {
     unsigned char* ids8 = nullptr;
     void *x1 = nullptr, *x2 = nullptr, *x3 = nullptr, *hx = nullptr, *qkv = nullptr, *att = nullptr, *u = nullptr;
     float *h = nullptr, *scores = nullptr, *pooled = nullptr;
+    bool arith_x3 = false;                        // CLM_PREC_F16X3: prec is PREC_F32, the fused fp32-path kernels run on hi + lo halfs
     bool unfused_fp32 = false;                    // CLM_DEBUG=unfused_fp32 at creation: the separate fp32 launches of round 2 (tests cross-check the fused kernels)
     float* ws32 = nullptr;                        // fp32 mode: activations of tf_fp32.hip
     size_t cap_ws32 = 0;
@@ -674,9 +675,10 @@ extern "C" {
 
 int clm_tf_create(int device, int precision, int n_layers, clm_tf_handle** out) {
     if (!out || n_layers < 1 || n_layers > 64) return tf_fail(nullptr, CLM_E_INVALID, "clm_tf_create: bad argument");
-    if (precision != CLM_PREC_F16 && precision != CLM_PREC_BF16 && precision != CLM_PREC_F32 && precision != CLM_PREC_F16C)
+    if (precision != CLM_PREC_F16 && precision != CLM_PREC_BF16 && precision != CLM_PREC_F32 && precision != CLM_PREC_F16C &&
+        precision != CLM_PREC_F16X3)
         return tf_fail(nullptr, CLM_E_UNSUPPORTED,
-                       "clm_tf_create: precision must be fp32 (exact, the reference's arithmetic), fp16c, fp16 or bf16");
+                       "clm_tf_create: precision must be fp32 (exact, the reference's arithmetic), fp16x3, fp16c, fp16 or bf16");
     if (hipSetDevice(device) != hipSuccess) return tf_fail(nullptr, CLM_E_HIP, "clm_tf_create: hipSetDevice failed");
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) != hipSuccess || std::string(prop.gcnArchName).rfind("gfx950", 0) != 0)
@@ -684,8 +686,14 @@ int clm_tf_create(int device, int precision, int n_layers, clm_tf_handle** out) 
     clm_tf_handle* h = new clm_tf_handle();
     h->unfused_fp32 = debug_flag("unfused_fp32");
     h->device = device;
-    h->prec = precision == CLM_PREC_BF16 ? PREC_BF16 : precision == CLM_PREC_F32 ? PREC_F32 : precision == CLM_PREC_F16C ? PREC_F16C
-                                                                                                                       : PREC_F16;
+    // fp16x3: the exact-fp32 path with its fused kernels multiplying hi + lo halfs (three fp16 MFMAs per product; tail32.hip AR_X3)
+    h->arith_x3 = precision == CLM_PREC_F16X3;
+    if (h->arith_x3 && h->unfused_fp32) {
+        delete h;
+        return tf_fail(nullptr, CLM_E_UNSUPPORTED, "clm_tf_create: fp16x3 exists in the fused kernels only (CLM_DEBUG=unfused_fp32 is set)");
+    }
+    h->prec = precision == CLM_PREC_BF16 ? PREC_BF16 : (precision == CLM_PREC_F32 || h->arith_x3) ? PREC_F32 : precision == CLM_PREC_F16C ? PREC_F16C
+                                                                                                                                   : PREC_F16;
     h->n_layers = n_layers;
     *out = h;
     return CLM_OK;
@@ -734,7 +742,8 @@ int clm_tf_finalize(clm_tf_handle* h) {
         for (auto& e : tw) {
             void* q = nullptr;
             TFCHK(h, hipMalloc(&q, (size_t)e.n * e.k * 4));
-            launch_pack_f32t(h->w.at(p + e.key), q, e.n, e.k, 0);
+            if (h->arith_x3) launch_pack_x3(h->w.at(p + e.key), q, e.n, e.k, 0);
+            else launch_pack_f32t(h->w.at(p + e.key), q, e.n, e.k, 0);
             h->packed[t + e.name] = q;
         }
     }
@@ -746,7 +755,10 @@ int clm_tf_finalize(clm_tf_handle* h) {
             hipLaunchKernelGGL(tf::conv_w_split_kernel, dim3((3 * D * D + 255) / 256), dim3(256), 0, 0, h->w.at(name + ".weight"), split32);
             float* q = nullptr;
             TFCHK(h, hipMalloc((void**)&q, (size_t)3 * D * D * 4));
-            for (int dk = 0; dk < 3; ++dk) launch_pack_f32t(split32 + (size_t)dk * D * D, q + (size_t)dk * D * D, D, D, 0);
+            for (int dk = 0; dk < 3; ++dk) {
+                if (h->arith_x3) launch_pack_x3(split32 + (size_t)dk * D * D, q + (size_t)dk * D * D, D, D, 0);
+                else launch_pack_f32t(split32 + (size_t)dk * D * D, q + (size_t)dk * D * D, D, D, 0);
+            }
             TFCHK(h, hipDeviceSynchronize());                 // `split32` is reused by the next layer
             h->packed["t32." + name] = q;
         }
@@ -826,7 +838,7 @@ static int tf_run(clm_tf_handle* h, bool prec32, const void* ids, int ids_dtype,
             auto* hh = static_cast<clm_tf_handle*>(ctx);
             return k.rfind("t32.", 0) == 0 ? static_cast<const float*>(hh->packed.at(k)) : hh->w.at(k);
         };
-        if (tf32_forward(h->ids8, Lp, B, L, h->n_layers, h->ws32, h->h, get, h, st, h->unfused_fp32))
+        if (tf32_forward(h->ids8, Lp, B, L, h->n_layers, h->ws32, h->h, get, h, st, h->unfused_fp32, h->arith_x3))
             return tf_fail(h, CLM_E_HIP, std::string("clm_tf_forward (fp32): ") + hipGetErrorString(hipGetLastError()));
         auto W = [&](const std::string& k) { return h->w.at(k); };
         hipLaunchKernelGGL(tf::pool_head_kernel, dim3(B), dim3(256), 0, st, h->h, W("attn_pool.weight"), W("attn_pool.bias"),

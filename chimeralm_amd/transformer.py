@@ -5,7 +5,7 @@ Same constructor arguments, same `state_dict()` keys (torch's own modules are us
 `transformer_encoder.layers.{i}.self_attn.in_proj_weight` etc. come out exactly as in the reference, and `pos_encoder.pe` is a
 buffer of the same shape), same `forward(input_ids, input_quals=None) -> logits [B, 2]`, same `number_of_classes` attribute that
 `ClassificationLit` reads.  The arithmetic runs in csrc/tf_model.hip + csrc/attention.hip behind the `clm_tf_*` C ABI; there is no
-CPU path.  Engine knobs absent in the reference: `precision` in {"fp32", "fp16c", "fp16", "bf16"} (fp32 = the reference's arithmetic;
+CPU path.  Engine knobs absent in the reference: `precision` in {"fp32", "fp16x3", "fp16c", "fp16", "bf16"} (fp32 = the reference's arithmetic;
 fp16c = fp16 activations x weights as fp16 hi + fp8 lo, the Hyena path's compensated mode) and `selfcheck` /
 `selfcheck_tol`: before the first batch after a weight load (and again every `selfcheck_every`-th batch and for a batch more than 1.5x shorter or longer than any checked so far) the
 16-bit mode is measured against the exact-fp32 kernels of the same engine on seeded reads and on the batch's first reads
@@ -47,8 +47,9 @@ class SequenceCNNTransformer(nn.Module):
         if (vocab_size, d_model, cnn_kernel_size, nhead, dim_feedforward, number_of_classes) != (12, 256, 3, 8, 1024, 2):
             raise NotImplementedError("the MI355X encoder implements the production shape: vocab 12, d_model 256, kernel 3, "
                                       "8 heads, feed-forward 1024, 2 classes (configs/model/transformer.yaml)")
-        if precision not in ("fp32", "fp16c", "fp16", "bf16"):
-            raise ValueError("precision must be fp32 (exact fp32 products: the reference's arithmetic, the parity mode), fp16c "
+        if precision not in ("fp32", "fp16x3", "fp16c", "fp16", "bf16"):
+            raise ValueError("precision must be fp32 (exact fp32 products: the reference's arithmetic, the parity mode), fp16x3 "
+                             "(every operand as two halfs, three fp16 MFMAs per product: fp32-class accuracy at 2.5x the rate), fp16c "
                              "(fp16 activations x hi + lo weights, self-checked) or fp16 / bf16 (plain 16-bit MFMA inputs, fp32 "
                              "accumulation and statistics: reduced precision)")
         self.number_of_classes, self.precision, self.num_encoder_layers = number_of_classes, precision, num_encoder_layers
