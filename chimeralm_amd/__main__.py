@@ -36,7 +36,7 @@ def predict(
     num_workers: int = typer.Option(0, "--workers", "-w", help="Number of workers"),
     ckpt_path: Path | None = typer.Option(None, "--ckpt", "-c", hidden=True, help="Path to the checkpoint file"),
     weights: str = typer.Option("yangliz5/chimeralm", "--weights", help="Directory/file with model.safetensors"),
-    precision: str = typer.Option("fp16c", "--precision", help="arithmetic of the dense projections: fp16c (default: fp16 activations x fp16 hi + fp8 lo weights -- MLP weights plain fp16 -- at 16-bit MFMA rate, checked against the exact-fp32 kernels on the loaded weights before the first batch, replaced by them if more than --selfcheck-tol off) | fp32 (exact, the reference's) | fp16 | bf16 (reduced precision)"),
+    precision: str = typer.Option("fp16c", "--precision", help="arithmetic of the dense projections: fp16c (default: fp16 activations x fp16 hi + fp8 lo weights -- MLP weights plain fp16 -- at 16-bit MFMA rate, checked against the exact-fp32 kernels on the loaded weights before the first batch, replaced by them if more than --selfcheck-tol off) | fp32 (exact, the reference's) | fp16x3 (every operand as two halfs, three fp16 MFMAs per product: fp32-class accuracy at twice the exact rate, no check needed) | fp16 | bf16 (reduced precision)"),
     selfcheck_tol: float = typer.Option(5e-4, "--selfcheck-tol", help="largest |logit difference| from exact fp32 the fp16c mode may show in its self-check (0 disables the check)"),
     feeder: str = typer.Option("native", "--feeder", help="BAM input: native (C++ decoder thread, pinned ring) | python"),
     random: bool = typer.Option(False, "--random", "-r", help="Make the prediction not deterministic"),

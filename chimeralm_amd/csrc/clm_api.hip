@@ -83,6 +83,9 @@ struct clm_handle {
     // 16-bit handles: exact-fp32 packing of the same weights (fp16c's reads shorter than f16c_min_len, clm_selfcheck, clm_set_fallback)
     void* packed32[NLAYER][4] = {};
     void* packed32t[NLAYER][4] = {};   // exact fp32, the fused tail's packing (tail32.hip): in_proj, out_proj, fc1, fc2
+    void* packed32x[NLAYER][4] = {};   // CLM_PREC_F16X3: the same weights as hi + lo halfs (launch_pack_x3); lwx = lw with these
+    LayerW lwx[NLAYER] = {};
+    bool referee = false;              // inside clm_selfcheck's second pass: an fp16x3 handle runs its exact-fp32 tails
     void* packed_score32 = nullptr;
     LayerW lw32[NLAYER]{};
     // PREC_F16C: fc1 / fc2 packed as hi + lo as well (the mode's second level, clm_set_mlp_compensation; lw.w_fc1 / w_fc2 are plain fp16)
@@ -323,6 +326,7 @@ void free_packed(clm_handle* h) {
             if (h->packed[i][j]) { (void)hipFree(h->packed[i][j]); h->packed[i][j] = nullptr; }
             if (h->packed32[i][j]) { (void)hipFree(h->packed32[i][j]); h->packed32[i][j] = nullptr; }
             if (h->packed32t[i][j]) { (void)hipFree(h->packed32t[i][j]); h->packed32t[i][j] = nullptr; }
+            if (h->packed32x[i][j]) { (void)hipFree(h->packed32x[i][j]); h->packed32x[i][j] = nullptr; }
             if (j < 2 && h->packed_mlpc[i][j]) { (void)hipFree(h->packed_mlpc[i][j]); h->packed_mlpc[i][j] = nullptr; }
         }
     if (h->packed_score) { (void)hipFree(h->packed_score); h->packed_score = nullptr; }
@@ -545,6 +549,7 @@ int forward_chunk(clm_handle* h, const void* ids, int ids_dtype, int64_t row_str
     const bool zgated = fuse_next && !h->raw_z;
     // exact fp32: one fused kernel per block tail, the next block's in_proj included (tail32.hip)
     const bool fused32 = prec == PREC_F32 && fused_fp32(h);
+    const bool x3 = h->x3 && fused32 && !h->referee;            // fp16x3: hi + lo halfs in the fused tails (the referee pass: exact)
     // fp16c, round 4: y (every block) and the gated rows of z carry one lo byte per element next to the halfs
     unsigned char* const ylo = (prec == PREC_F16C && tuned16) ? h->ylo : nullptr;
     if (zgated && tail16_grid(((peel ? L - 1 : L) + 127) / 128 * Bc) > 1024)
@@ -560,7 +565,7 @@ int forward_chunk(clm_handle* h, const void* ids, int ids_dtype, int64_t row_str
     }
     if (stop_here(h, -1, CLM_STAGE_EMBED)) return CLM_OK;
     for (int i = 0; i < NLAYER; ++i) {
-        const LayerW& lw = alt32 ? h->lw32[i] : h->lw[i];
+        const LayerW& lw = alt32 ? h->lw32[i] : (x3 ? h->lwx[i] : h->lw[i]);
         // block 0 in the 16-bit modes: its in_proj output is a function of the token id alone, the convolution looks it
         // up (ztab), single-shot and segmented kernel alike -- unless a debug stop asks for z itself or CLM_DEBUG=no_idconv
         // (exact fp32 with the fused tail, single-shot convolution: the same table -- it is fp32 -- so block 0 needs no in_proj launch)
@@ -634,10 +639,10 @@ int forward_chunk(clm_handle* h, const void* ids, int ids_dtype, int64_t row_str
             }
         } else if (fused32) {
             StageTimer t(h, st, CLM_STAGE_TAIL);
-            const LayerW* nx = i + 1 < NLAYER ? &(alt32 ? h->lw32[i + 1] : h->lw[i + 1]) : nullptr;
+            const LayerW* nx = i + 1 < NLAYER ? &(alt32 ? h->lw32[i + 1] : (x3 ? h->lwx[i + 1] : h->lw[i + 1])) : nullptr;
             launch_tail32(reinterpret_cast<const float*>(h->y), h->h, lw.t_out, lw.t_fc1, lw.t_fc2, nx ? nx->t_in : nullptr, lw.b_out,
                           lw.b_fc1, lw.b_fc2, nx ? nx->b_in : nullptr, lw.ln2_g, lw.ln2_b, nx ? nx->ln1_g : nullptr,
-                          nx ? nx->ln1_b : nullptr, reinterpret_cast<float*>(h->z), Bc, L, Lp, eps, st, h->x3);
+                          nx ? nx->ln1_b : nullptr, reinterpret_cast<float*>(h->z), Bc, L, Lp, eps, st, x3);
         } else {
             {
                 StageTimer t(h, st, CLM_STAGE_OUTPROJ);
@@ -840,10 +845,18 @@ int clm_finalize(clm_handle* h) {
                                                            {"mlp.fc1.weight", DI, D}, {"mlp.fc2.weight", D, DI}};
             for (int j = 0; j < 4; ++j) {
                 HIPCHK(h, hipMalloc(&h->packed32t[i][j], (size_t)tw[j].n * tw[j].k * 4));
-                if (h->x3) launch_pack_x3(W(h, p + tw[j].key), h->packed32t[i][j], tw[j].n, tw[j].k, st);
-                else launch_pack_f32t(W(h, p + tw[j].key), h->packed32t[i][j], tw[j].n, tw[j].k, st);
+                launch_pack_f32t(W(h, p + tw[j].key), h->packed32t[i][j], tw[j].n, tw[j].k, st);
+                if (h->x3) {
+                    HIPCHK(h, hipMalloc(&h->packed32x[i][j], (size_t)tw[j].n * tw[j].k * 4));
+                    launch_pack_x3(W(h, p + tw[j].key), h->packed32x[i][j], tw[j].n, tw[j].k, st);
+                }
             }
             lw.t_in = h->packed32t[i][0]; lw.t_out = h->packed32t[i][1]; lw.t_fc1 = h->packed32t[i][2]; lw.t_fc2 = h->packed32t[i][3];
+            if (h->x3) {
+                h->lwx[i] = lw;
+                h->lwx[i].t_in = h->packed32x[i][0]; h->lwx[i].t_out = h->packed32x[i][1];
+                h->lwx[i].t_fc1 = h->packed32x[i][2]; h->lwx[i].t_fc2 = h->packed32x[i][3];
+            }
         }
         if (prec != PREC_F32) {   // the exact-fp32 packing next to the 16-bit one: fp16c's short reads, clm_selfcheck, clm_set_fallback
             if ((rc = pack_as(PREC_F32, p + "mixer.in_proj.weight", D3, D, &h->packed32[i][0]))) return rc;
@@ -1001,7 +1014,7 @@ int clm_selfcheck(clm_handle* h, const void* ids, int ids_dtype, int64_t ids_row
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     *max_abs_diff = 0.f;
     if (labels_differ) *labels_differ = 0;
-    if (h->cfg.precision == PREC_F32) return CLM_OK;             // the handle IS the referee
+    if (h->cfg.precision == PREC_F32 && !h->x3) return CLM_OK;   // the handle IS the referee
     if (B > h->sc_cap) {
         HIPCHK(h, hipStreamSynchronize(st));
         if (h->sc_logits) HIPCHK(h, hipFree(h->sc_logits));
@@ -1017,6 +1030,7 @@ int clm_selfcheck(clm_handle* h, const void* ids, int ids_dtype, int64_t ids_row
     int rc = CLM_OK;
     for (int pass = 0; pass < 2 && !rc; ++pass) {
         h->force_prec = pass == 0 ? mode_prec : (int)PREC_F32;
+        h->referee = pass == 1;
         const int chunk = chunk_for(h, L);
         for (int b0 = 0; b0 < B && !rc; b0 += chunk) {
             const int Bc = B - b0 < chunk ? B - b0 : chunk;
@@ -1025,6 +1039,7 @@ int clm_selfcheck(clm_handle* h, const void* ids, int ids_dtype, int64_t ids_row
         }
     }
     h->force_prec = -1;
+    h->referee = false;
     h->prof = prof;
     if (rc) return rc;
     std::vector<float> host((size_t)2 * h->sc_cap * NCLS);

@@ -1,6 +1,6 @@
 /* abi_client.c -- a plain-C client of the engine's C ABI (no Python, no torch in the process).
  *
- *   abi_client <weights.bin> <ids.bin> <B> <L> <precision: 0 fp32 | 1 bf16 | 2 fp16 | 3 fp16c>
+ *   abi_client <weights.bin> <ids.bin> <B> <L> <precision: 0 fp32 | 1 bf16 | 2 fp16 | 3 fp16c | 4 fp16x3>
  *
  * weights.bin: repeated records  { u32 key_len, key bytes, u32 ndim, i64 shape[ndim], f32 data[prod(shape)] }  (written by
  * tests/test_gpu_c_abi.py from a state_dict with the reference's checkpoint keys); ids.bin: B*L token ids as uint8.

@@ -33,7 +33,8 @@ def write_weights(path: Path, sd: dict) -> None:
             f.write(a.tobytes())
 
 
-@pytest.mark.parametrize("prec,code,tol,bases", [("fp32", 0, 1e-3, 700), ("fp16", 2, 5e-3, 700), ("fp16c", 3, 1e-3, 2600)])
+@pytest.mark.parametrize("prec,code,tol,bases", [("fp32", 0, 1e-3, 700), ("fp16", 2, 5e-3, 700), ("fp16c", 3, 1e-3, 2600),
+                                                 ("fp16x3", 4, 1e-4, 700)])
 def test_c_client_matches_oracle(tmp_path, built_lib, prec, code, tol, bases):
     """fp16c (code 3, the CLI / bench default) at a length its fp16 kernels run (>= 2,048 tokens); the client also calls
     clm_selfcheck and prints what it measured."""

@@ -591,6 +591,8 @@ def test_fp16x3_is_fp32_class(built_lib, wseed, B, L, pads):
     a, b = e32.forward(t).cpu(), ex.forward(t).cpu()
     assert torch.equal(b, ex.forward(t).cpu())                                   # deterministic
     d32 = (a - b).abs().max().item()
+    diff, flips = ex.selfcheck(t)                                                # the handle's own referee pass: its exact-fp32 tails
+    assert abs(diff - d32) <= 1e-6 and flips == 0
     msg = f"weights {wseed}, {B} x {L}: |fp16x3 - exact fp32| {d32:.2e}"
     assert d32 <= TOL["fp16x3"]
     if L <= 2049:
