@@ -61,19 +61,30 @@ constexpr int RSKM64 = 96;        // AR_X3: row stride (halfs) of a k-major y pl
 __device__ __forceinline__ f32x16 mfma16(f32x4 a, f32x4 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
 }
+// x -> (hi, lo) halfs.  Values beyond fp16's range do not become inf: hi saturates at +-65504 and lo carries the rest (up to twice
+// the range; beyond that the pair saturates) -- the mode has no guard, so an outlier must not turn into a NaN logit.
+typedef _Float16 h4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x4 clamp_h(f32x4 v) {
+    f32x4 r;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) r[e] = __builtin_amdgcn_fmed3f(v[e], -65504.f, 65504.f);
+    return r;
+}
+__device__ __forceinline__ void split4(f32x4 v, h4_t& hi, h4_t& lo) {
+    hi = __builtin_convertvector(clamp_h(v), h4_t);
+    lo = __builtin_convertvector(clamp_h(v - __builtin_convertvector(hi, f32x4)), h4_t);
+}
 // four consecutive features of one token row into a tile (fp32: 16 bytes; x3: 8 bytes of hi halfs + 8 bytes of lo halfs)
 template <int AR>
 __device__ __forceinline__ void tile_store4(float* T, int row, int col, f32x4 v) {
     if constexpr (AR == AR_F32) {
         *reinterpret_cast<f32x4*>(T + row * RS32 + col) = v;
     } else {
-        typedef _Float16 h4 __attribute__((ext_vector_type(4)));
-        const h4 hi = __builtin_convertvector(v, h4);
-        const f32x4 back = __builtin_convertvector(hi, f32x4);
-        const h4 lo = __builtin_convertvector(v - back, h4);
+        h4_t hi, lo;
+        split4(v, hi, lo);
         char* base = reinterpret_cast<char*>(T + row * RS32) + col * 2;
-        *reinterpret_cast<h4*>(base) = hi;
-        *reinterpret_cast<h4*>(base + 512) = lo;
+        *reinterpret_cast<h4_t*>(base) = hi;
+        *reinterpret_cast<h4_t*>(base + 512) = lo;
     }
 }
 
@@ -269,12 +280,11 @@ __global__ __launch_bounds__(512) void tail32_kernel(Tail32Args m) {
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
             if (in_row) v = *reinterpret_cast<const f32x4*>(src + (size_t)c * Lp);
             if constexpr (AR == AR_X3) {                    // two planes of halfs [channel][RSKM64]
-                typedef _Float16 h4 __attribute__((ext_vector_type(4)));
-                const h4 hi = __builtin_convertvector(v, h4);
-                const h4 lo = __builtin_convertvector(v - __builtin_convertvector(hi, f32x4), h4);
+                h4_t hi, lo;
+                split4(v, hi, lo);
                 _Float16* yh = reinterpret_cast<_Float16*>(Ys) + c * RSKM64 + tk;
-                *reinterpret_cast<h4*>(yh) = hi;
-                *reinterpret_cast<h4*>(yh + D * RSKM64) = lo;
+                *reinterpret_cast<h4_t*>(yh) = hi;
+                *reinterpret_cast<h4_t*>(yh + D * RSKM64) = lo;
             } else {
                 *reinterpret_cast<f32x4*>(Ys + c * RSY + tk) = v;
             }
@@ -629,8 +639,8 @@ __global__ __launch_bounds__(256) void pack_x3_kernel(const float* __restrict__ 
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         const float x = src[j] * X3_WS;
-        const _Float16 hi = (_Float16)x;
-        o[j] = plane ? (_Float16)(x - (float)hi) : hi;
+        const _Float16 hi = (_Float16)__builtin_amdgcn_fmed3f(x, -65504.f, 65504.f);       // (|w| > 64: saturating, like split4)
+        o[j] = plane ? (_Float16)__builtin_amdgcn_fmed3f(x - (float)hi, -65504.f, 65504.f) : hi;
     }
     out[i] = __builtin_bit_cast(f32x4, o);
 }

@@ -315,9 +315,15 @@ __global__ __launch_bounds__(256, 4) void attention_x3_kernel(const float* __res
     const int bh = (slot / ntq) * 8 + xcd, q0 = (slot % ntq) * AX_QT, h = bh & 7, b = bh >> 3;
     const float* base = qkv + (size_t)b * L * 768 + h * 32;
     const float c = 1.4426950408889634f * 0.17677669529663687f;        // log2(e) / sqrt(32)
-    auto split8 = [](f8 v, h8& hi, h8& lo) {
-        hi = __builtin_convertvector(v, h8);
-        lo = __builtin_convertvector(v - __builtin_convertvector(hi, f8), h8);
+    auto clamp8 = [](f8 v) {                                           // (beyond fp16's range: saturate, never inf -- tail32.hip split4)
+        f8 r;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) r[e] = __builtin_amdgcn_fmed3f(v[e], -65504.f, 65504.f);
+        return r;
+    };
+    auto split8 = [&](f8 v, h8& hi, h8& lo) {
+        hi = __builtin_convertvector(clamp8(v), h8);
+        lo = __builtin_convertvector(clamp8(v - __builtin_convertvector(hi, f8)), h8);
     };
     h8 qh[2], ql[2];                                                   // Q^T as B operand: d = 16 s + 8 hf + 0..7
     {
@@ -345,9 +351,15 @@ __global__ __launch_bounds__(256, 4) void attention_x3_kernel(const float* __res
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int e = tid + i * 256, j = e >> 3, d4 = e & 7;
-            const h4 kh = __builtin_convertvector(kreg[i], h4), vh = __builtin_convertvector(vreg[i], h4);
-            const h4 kl = __builtin_convertvector(kreg[i] - __builtin_convertvector(kh, f32x4), h4);
-            const h4 vl = __builtin_convertvector(vreg[i] - __builtin_convertvector(vh, f32x4), h4);
+            auto clamp4 = [](f32x4 v) {
+                f32x4 r;
+#pragma unroll
+                for (int e2 = 0; e2 < 4; ++e2) r[e2] = __builtin_amdgcn_fmed3f(v[e2], -65504.f, 65504.f);
+                return r;
+            };
+            const h4 kh = __builtin_convertvector(clamp4(kreg[i]), h4), vh = __builtin_convertvector(clamp4(vreg[i]), h4);
+            const h4 kl = __builtin_convertvector(clamp4(kreg[i] - __builtin_convertvector(kh, f32x4)), h4);
+            const h4 vl = __builtin_convertvector(clamp4(vreg[i] - __builtin_convertvector(vh, f32x4)), h4);
             *reinterpret_cast<h4*>(&Ks[buf][0][j * AX_KRS + 4 * d4]) = kh;
             *reinterpret_cast<h4*>(&Ks[buf][1][j * AX_KRS + 4 * d4]) = kl;
             *reinterpret_cast<h4*>(&Vs[buf][0][ax_v_row(j) * AX_VRS + 4 * d4]) = vh;
