@@ -405,6 +405,7 @@ def main():
         ms, launches = prof[dom]
         tokens_per_launch = (hi - lo) * L * a.steps * (NLAYER if dom not in ("embed", "lnf_pool_score", "softmax_pool", "head_mlp") else 1) / max(1, launches)
         flops_per_token = STAGE_FLOPS_PER_TOKEN.get(dom, 0)
+        fused_next = False
         if dom == "out_proj_ln2_mlp":
             # the tail kernel of block i also runs LN1 + in_proj of block i + 1 (every in_proj that has no launch of its own: 3 of a
             # forward's 4 in the 16-bit modes and in fused exact fp32, whose block 0 keeps its separate kernel) and, in the 16-bit
@@ -413,6 +414,7 @@ def main():
             fused_in = max(launches - n_in - (launches // NLAYER if n_in == 0 else 0), 0)
             fused_score = launches // NLAYER if prof.get("lnf_pool_score", (0.0, 0))[1] == 0 else 0
             flops_per_token += (fused_in * STAGE_FLOPS_PER_TOKEN["ln1_in_proj"] + fused_score * STAGE_FLOPS_PER_TOKEN["lnf_pool_score"]) / max(1, launches)
+            fused_next = fused_in > 0
         if dom in STAGE_FLOPS_PER_TOKEN:
             achieved = flops_per_token * tokens_per_launch / (ms / launches * 1e-3) / 1e12
             roof = {"bound": "mfma", "kernel": dom, "achieved": achieved, "peak": PEAK_TFLOPS[peak_key],
