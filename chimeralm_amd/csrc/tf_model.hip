@@ -492,6 +492,7 @@ struct clm_tf_handle {
     unsigned char* ids8 = nullptr;
     void *x1 = nullptr, *x2 = nullptr, *x3 = nullptr, *hx = nullptr, *qkv = nullptr, *att = nullptr, *u = nullptr;
     float *h = nullptr, *scores = nullptr, *pooled = nullptr;
+    bool referee = false;                         // inside clm_tf_selfcheck's second pass: an fp16x3 handle runs its exact-fp32 kernels
     bool arith_x3 = false;                        // CLM_PREC_F16X3: prec is PREC_F32, the fused fp32-path kernels run on hi + lo halfs
     bool unfused_fp32 = false;                    // CLM_DEBUG=unfused_fp32 at creation: the separate fp32 launches of round 2 (tests cross-check the fused kernels)
     float* ws32 = nullptr;                        // fp32 mode: activations of tf_fp32.hip
@@ -742,9 +743,14 @@ int clm_tf_finalize(clm_tf_handle* h) {
         for (auto& e : tw) {
             void* q = nullptr;
             TFCHK(h, hipMalloc(&q, (size_t)e.n * e.k * 4));
-            if (h->arith_x3) launch_pack_x3(h->w.at(p + e.key), q, e.n, e.k, 0);
-            else launch_pack_f32t(h->w.at(p + e.key), q, e.n, e.k, 0);
+            launch_pack_f32t(h->w.at(p + e.key), q, e.n, e.k, 0);
             h->packed[t + e.name] = q;
+            if (h->arith_x3) {                                // fp16x3: the same weights as hi + lo halfs ("x3." keys); "t32." = its referee
+                void* qx = nullptr;
+                TFCHK(h, hipMalloc(&qx, (size_t)e.n * e.k * 4));
+                launch_pack_x3(h->w.at(p + e.key), qx, e.n, e.k, 0);
+                h->packed["x3." + std::to_string(i) + "." + e.name] = qx;
+            }
         }
     }
     {   // ... and the three taps of each CNN-stem convolution ([co][ci][3] -> [3][co][ci], each tap packed)
@@ -755,12 +761,15 @@ int clm_tf_finalize(clm_tf_handle* h) {
             hipLaunchKernelGGL(tf::conv_w_split_kernel, dim3((3 * D * D + 255) / 256), dim3(256), 0, 0, h->w.at(name + ".weight"), split32);
             float* q = nullptr;
             TFCHK(h, hipMalloc((void**)&q, (size_t)3 * D * D * 4));
-            for (int dk = 0; dk < 3; ++dk) {
-                if (h->arith_x3) launch_pack_x3(split32 + (size_t)dk * D * D, q + (size_t)dk * D * D, D, D, 0);
-                else launch_pack_f32t(split32 + (size_t)dk * D * D, q + (size_t)dk * D * D, D, D, 0);
+            for (int dk = 0; dk < 3; ++dk) launch_pack_f32t(split32 + (size_t)dk * D * D, q + (size_t)dk * D * D, D, D, 0);
+            h->packed["t32." + name] = q;
+            if (h->arith_x3) {
+                float* qx = nullptr;
+                TFCHK(h, hipMalloc((void**)&qx, (size_t)3 * D * D * 4));
+                for (int dk = 0; dk < 3; ++dk) launch_pack_x3(split32 + (size_t)dk * D * D, qx + (size_t)dk * D * D, D, D, 0);
+                h->packed["x3." + name] = qx;
             }
             TFCHK(h, hipDeviceSynchronize());                 // `split32` is reused by the next layer
-            h->packed["t32." + name] = q;
         }
         (void)hipFree(split32);
     }
@@ -834,11 +843,13 @@ static int tf_run(clm_tf_handle* h, bool prec32, const void* ids, int ids_dtype,
         }
         const int Lp = (L + 63) / 64 * 64;
         launch_embed(ids, ids_dtype, ids_row_stride, nullptr, nullptr, h->ids8, B, L, Lp, st);
-        auto get = [](void* ctx, const std::string& k) -> const float* {     // "t32.*": the fused kernel's packed weights
+        const bool use_x3 = h->arith_x3 && !h->referee;
+        auto get = [](void* ctx, const std::string& k) -> const float* {     // "t32.*": the fused kernels' packed weights ("x3.*" in fp16x3)
             auto* hh = static_cast<clm_tf_handle*>(ctx);
-            return k.rfind("t32.", 0) == 0 ? static_cast<const float*>(hh->packed.at(k)) : hh->w.at(k);
+            if (k.rfind("t32.", 0) != 0) return hh->w.at(k);
+            return static_cast<const float*>(hh->packed.at((hh->arith_x3 && !hh->referee) ? "x3." + k.substr(4) : k));
         };
-        if (tf32_forward(h->ids8, Lp, B, L, h->n_layers, h->ws32, h->h, get, h, st, h->unfused_fp32, h->arith_x3))
+        if (tf32_forward(h->ids8, Lp, B, L, h->n_layers, h->ws32, h->h, get, h, st, h->unfused_fp32, use_x3))
             return tf_fail(h, CLM_E_HIP, std::string("clm_tf_forward (fp32): ") + hipGetErrorString(hipGetLastError()));
         auto W = [&](const std::string& k) { return h->w.at(k); };
         hipLaunchKernelGGL(tf::pool_head_kernel, dim3(B), dim3(256), 0, st, h->h, W("attn_pool.weight"), W("attn_pool.bias"),
@@ -902,7 +913,7 @@ int clm_tf_selfcheck(clm_tf_handle* h, const void* ids, int ids_dtype, int64_t i
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     float diff = 0.f;
     int differ = 0;
-    if (h->prec != PREC_F32) {
+    if (h->prec != PREC_F32 || h->arith_x3) {                  // (an fp16x3 handle: its own exact-fp32 kernels are the referee)
         if (B > h->sc_cap) {
             TFCHK(h, hipDeviceSynchronize());
             if (h->sc_logits) (void)hipFree(h->sc_logits);
@@ -912,8 +923,11 @@ int clm_tf_selfcheck(clm_tf_handle* h, const void* ids, int ids_dtype, int64_t i
         }
         float* lm = h->sc_logits;
         float* lx = h->sc_logits + (size_t)h->sc_cap * NCLS;
-        if (int rc = tf_run(h, false, ids, ids_dtype, ids_row_stride, B, L, lm, st)) return rc;
-        if (int rc = tf_run(h, true, ids, ids_dtype, ids_row_stride, B, L, lx, st)) return rc;
+        if (int rc = tf_run(h, h->arith_x3, ids, ids_dtype, ids_row_stride, B, L, lm, st)) return rc;
+        h->referee = true;
+        const int rc2 = tf_run(h, true, ids, ids_dtype, ids_row_stride, B, L, lx, st);
+        h->referee = false;
+        if (rc2) return rc2;
         std::vector<float> a((size_t)B * NCLS), b((size_t)B * NCLS);
         TFCHK(h, hipMemcpyAsync(a.data(), lm, a.size() * 4, hipMemcpyDeviceToHost, st));
         TFCHK(h, hipMemcpyAsync(b.data(), lx, b.size() * 4, hipMemcpyDeviceToHost, st));

@@ -59,6 +59,11 @@ def test_forward_matches_oracle(built_lib, golden_dir, prec, seed, B, L, pads):
     assert (got.argmax(1)[decided] == ref.argmax(1)[decided]).all()
     pooled = net.debug_fetch("pooled", (B, 256))
     assert np.abs(pooled - trace["pooled"].numpy()).max() < TOL_HIDDEN[prec]
+    if prec == "fp16x3":        # the handle's own referee pass (its exact-fp32 kernels): what the mode is off by on these ids
+        from chimeralm_amd import _native as N
+        d = net._measure(N.load(), "test", torch.from_numpy(ids).cuda())
+        print(f"fp16x3 B={B} L={L}: clm_tf_selfcheck |fp16x3 - exact fp32| = {d:.2e}")
+        assert 0 < d <= TOL[prec]
     # ids as uint8 with a row stride give the same bits
     wide = torch.zeros((B, L + 5), dtype=torch.uint8).cuda()
     wide[:, :L] = torch.from_numpy(ids.astype(np.uint8)).cuda()
