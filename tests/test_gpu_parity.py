@@ -137,6 +137,8 @@ def test_fp16c_gate_over_weight_draws_and_lengths(built_lib, wseed):
     sdw = ho.make_state_dict(wseed, head_scale=3.0)
     e = Engine("cuda:0", precision="fp16c", chunk_reads=4)
     e.load_state_dict(sdw)
+    ex = Engine("cuda:0", precision="fp16x3", chunk_reads=4)           # round 4: the same 32 batches through fp16x3 (bound: a tenth of the gate)
+    ex.load_state_dict(sdw)
     worst = 0.0
     for L in (2048, 3000, 4097, 8193):
         rng = np.random.default_rng(1000 * wseed + L)
@@ -160,6 +162,9 @@ def test_fp16c_gate_over_weight_draws_and_lengths(built_lib, wseed):
         print(f"weights {wseed}  L {L:5d}: raw |fp16c - oracle| {err:.2e}  (clm_selfcheck {sc:.2e})   guarded module: "
               f"{'FELL BACK to fp32' if rep['fallback'] else 'kept, MLP hi + lo' if rep.get('mlp_compensation') else 'kept'}"
               f" -> |logits - oracle| {perr:.2e}")
+        errx = float(np.abs(ex.forward(t).cpu().numpy() - ref).max())
+        print(f"      fp16x3 on the same batch: |fp16x3 - oracle| {errx:.2e}")
+        assert errx <= TOL["fp16x3"]
         assert np.isfinite(got).all() and err <= RAW_FP16C_BOUND
         assert (got.argmax(1) == ref.argmax(1))[np.abs(ref[:, 0] - ref[:, 1]) > 2 * RAW_FP16C_BOUND].all()
         # the self-check referee (exact-fp32 kernels) is itself within ~2e-5 of the oracle: what it measures IS the mode's error
@@ -173,7 +178,7 @@ def test_fp16c_gate_over_weight_draws_and_lengths(built_lib, wseed):
         del m
     if wseed in (1, 2, 3):
         _check(e, "fp16c", _ids(6, 100, seed=60 + wseed), sdw)        # 100 tokens: the fp32 kernels inside the mode
-    e.close()
+    e.close(), ex.close()
 
 
 def test_second_level_of_fp16c_is_closer_where_the_mlp_weights_show(built_lib):
