@@ -185,7 +185,7 @@ class HyenaDna(nn.Module):
     seeded synthetic samples of 4,097, 2,048, 1,024, 512 and 256 tokens -- the shortest one that still stays within
     `selfcheck_tol` (5e-4, half the tolerance; with every longer one) becomes the length below which reads take the fp32 kernels
     inside the mode (`clm_set_short_read_len`; 4,098 if not even the longest sample passes) -- and four reads spread over that
-    batch.  Later: four reads of every `selfcheck_every`-th batch (64) and of any batch more than 1.5x shorter or longer than every
+    batch.  Later: four reads of every `selfcheck_every`-th batch (16) and of any batch more than 1.5x shorter or longer than every
     batch checked so far.  A sample, not a bound: batches in between are not measured.  A BATCH above the threshold moves fp16c to
     its second level -- its MLP products run on plain fp16 weights (fast; enough on most weights) and then on hi + lo weights like
     the other projections (`clm_set_mlp_compensation`, ~10 % slower), heard again from the start -- and only if that form fails on
@@ -195,7 +195,7 @@ class HyenaDna(nn.Module):
 
     def __init__(self, number_of_classes: int, head: nn.Module, backbone_name: str = "hyenadna-small-32k-seqlen", *,
                  freeze_backbone: bool = False, precision: str = "fp16c", chunk_reads: int = 256,
-                 selfcheck: bool | None = None, selfcheck_tol: float = 5e-4, selfcheck_every: int = 64):
+                 selfcheck: bool | None = None, selfcheck_tol: float = 5e-4, selfcheck_every: int = 16):
         super().__init__()
         if number_of_classes != 2:
             raise NotImplementedError("the engine implements the binary (2-class) head only")

@@ -14,7 +14,7 @@ from .hyena import BinarySequenceClassifier, HyenaDna
 class ChimeraLM:
     @classmethod
     def new(cls, *, save_attention: bool = False, precision: str = "fp16c", chunk_reads: int = 256,
-            selfcheck: bool | None = None, selfcheck_tol: float = 5e-4, selfcheck_every: int = 64) -> ClassificationLit:
+            selfcheck: bool | None = None, selfcheck_tol: float = 5e-4, selfcheck_every: int = 16) -> ClassificationLit:
         """Randomly initialised model of the production architecture (lm.py:39-61).  `precision` / `selfcheck`: see
         `chimeralm_amd.hyena.HyenaDna` -- the default "fp16c" is measured against the exact-fp32 kernels on the loaded weights
         before the first batch and replaced by them if it is more than `selfcheck_tol` off."""
@@ -37,7 +37,7 @@ class ChimeraLM:
     @classmethod
     def from_pretrained(cls, model_name: str = "yangliz5/chimeralm", *, save_attention: bool = False,
                         precision: str = "fp16c", chunk_reads: int = 256, selfcheck: bool | None = None,
-                        selfcheck_tol: float = 5e-4, selfcheck_every: int = 64) -> ClassificationLit:
+                        selfcheck_tol: float = 5e-4, selfcheck_every: int = 16) -> ClassificationLit:
         """Released weights (lm.py:12-37).  `model_name` is a local directory / file holding `model.safetensors`
         or a Lightning `.ckpt`; a Hub repo id is resolved through the local HF cache only (no network here)."""
         model = cls.new(save_attention=save_attention, precision=precision, chunk_reads=chunk_reads, selfcheck=selfcheck,

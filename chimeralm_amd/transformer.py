@@ -42,7 +42,7 @@ class SequenceCNNTransformer(nn.Module):
     def __init__(self, vocab_size: int, max_len: int, d_model: int = 256, cnn_kernel_size: int = 3, dropout: float = 0.1,
                  num_encoder_layers: int = 2, nhead: int = 8, dim_feedforward: int = 1024, number_of_classes: int = 2,
                  padding_idx: int = 4, *, precision: str = "fp16", selfcheck: bool | None = None, selfcheck_tol: float = 5e-4,
-                 selfcheck_every: int = 64):
+                 selfcheck_every: int = 16):
         super().__init__()
         if (vocab_size, d_model, cnn_kernel_size, nhead, dim_feedforward, number_of_classes) != (12, 256, 3, 8, 1024, 2):
             raise NotImplementedError("the MI355X encoder implements the production shape: vocab 12, d_model 256, kernel 3, "
