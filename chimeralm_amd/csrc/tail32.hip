@@ -1,4 +1,8 @@
-// tail32.hip -- the exact-fp32 engine's fused block tail (round 4).
+// tail32.hip -- the fused kernels of the exact-fp32 engine and of its fp16x3 form (round 4):
+//   tail32_kernel   Hyena block tail (this comment)                          enc32_kernel   SequenceCNNTransformer encoder layer
+//   conv32_kernel   the transformer's CNN stem (conv k = 3 + ReLU + pool)     pack_f32t / pack_x3 kernels: the weight packings
+// all on one 64-token tile, one weight-set pipeline and one MFMA loop, instantiated for two arithmetics (AR_F32: the fp32 MFMA;
+// AR_X3: every operand as two halfs, three fp16 MFMAs per product -- see ARITH below).  The fp32 / x3 attention lives in tf_fp32.hip.
 //
 // One kernel per Hyena block, on v_mfma_f32_32x32x2_f32 throughout, for the part of the block that is token-wise
 //   /root/reference/chimeralm/models/components/hyena.py:244-256 -> the backbone's block: x = x + mixer(norm1(x)); x = x + mlp(norm2(x))
@@ -657,10 +661,12 @@ void launch_pack_f32t(const float* w, void* out, int n, int k, hipStream_t st) {
     hipLaunchKernelGGL(pack_f32t_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, w, reinterpret_cast<f32x4*>(out), n, k);
 }
 
-template <typename Kern>
-static void launch32(Kern kern, dim3 grid, size_t lds, hipStream_t st, const Tail32Args& m) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(kern, grid, dim3(512), lds, st, m);
+// one instantiation per kernel: the dynamic-LDS attribute is set once per process and kernel
+template <auto Kern, typename Args>
+static void launch_lds(dim3 grid, dim3 block, size_t lds, hipStream_t st, const Args& m) {
+    static const bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(Kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), true);
+    (void)once;
+    hipLaunchKernelGGL(Kern, grid, block, lds, st, m);
 }
 // x3: the products as three fp16 MFMAs on hi + lo halfs (weights from launch_pack_x3) instead of the fp32 MFMA
 void launch_tail32(const float* y, float* h, const void* w_out, const void* w_fc1, const void* w_fc2, const void* w_in_next,
@@ -672,12 +678,13 @@ void launch_tail32(const float* y, float* h, const void* w_out, const void* w_fc
                  (L + BM32 - 1) / BM32, eps};
     const size_t lds = (size_t)(2 * BM32 * RS32 + 2 * 8 * BM32) * sizeof(float);
     const dim3 grid((unsigned)(m.tiles_x * B));
+    const dim3 block(512);
     if (x3) {
-        if (w_in_next) launch32(tail32_kernel<true, AR_X3>, grid, lds, st, m);
-        else launch32(tail32_kernel<false, AR_X3>, grid, lds, st, m);
+        if (w_in_next) launch_lds<tail32_kernel<true, AR_X3>>(grid, block, lds, st, m);
+        else launch_lds<tail32_kernel<false, AR_X3>>(grid, block, lds, st, m);
     } else {
-        if (w_in_next) launch32(tail32_kernel<true, AR_F32>, grid, lds, st, m);
-        else launch32(tail32_kernel<false, AR_F32>, grid, lds, st, m);
+        if (w_in_next) launch_lds<tail32_kernel<true, AR_F32>>(grid, block, lds, st, m);
+        else launch_lds<tail32_kernel<false, AR_F32>>(grid, block, lds, st, m);
     }
 }
 
@@ -690,23 +697,22 @@ void launch_enc32(const float* att, float* h, const void* w_o, const void* w1, c
                 reinterpret_cast<const f32x4*>(w_qkv), b_o, b1, b2, b_qkv, ln1_g, ln1_b, ln2_g, ln2_b, qkv, M, eps};
     const size_t lds = (size_t)(2 * BM32 * RS32 + 2 * 8 * BM32) * sizeof(float);
     const dim3 grid((unsigned)((M + BM32 - 1) / BM32)), block(512);
-    auto go = [&](auto kern) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(kern, grid, block, lds, st, m);
-    };
-    if (!att) { if (x3) go(enc32_kernel<true, AR_X3>); else go(enc32_kernel<true, AR_F32>); }
-    else { if (x3) go(enc32_kernel<false, AR_X3>); else go(enc32_kernel<false, AR_F32>); }
+    if (!att) {
+        if (x3) launch_lds<enc32_kernel<true, AR_X3>>(grid, block, lds, st, m);
+        else launch_lds<enc32_kernel<true, AR_F32>>(grid, block, lds, st, m);
+    } else {
+        if (x3) launch_lds<enc32_kernel<false, AR_X3>>(grid, block, lds, st, m);
+        else launch_lds<enc32_kernel<false, AR_F32>>(grid, block, lds, st, m);
+    }
 }
 
 // x [B, Lin, 256] -> relu(conv1d_k3(x) + bias) pooled by 2 -> out [B, Lin / 2, 256]; w: three taps, each packed by launch_pack_f32t
 void launch_conv32(const float* x, const void* w, const float* bias, float* out, int B, int Lin, hipStream_t st, bool x3) {
     Conv32Args m{x, reinterpret_cast<const f32x4*>(w), bias, out, B, Lin, (Lin + BM32 - 1) / BM32};
     const size_t lds = (size_t)(BM32 + 2) * RS32 * sizeof(float);
-    auto go = [&](auto kern) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(kern, dim3((unsigned)(m.tiles_x * B)), dim3(512), lds, st, m);
-    };
-    if (x3) go(conv32_kernel<AR_X3>); else go(conv32_kernel<AR_F32>);
+    const dim3 grid((unsigned)(m.tiles_x * B)), block(512);
+    if (x3) launch_lds<conv32_kernel<AR_X3>>(grid, block, lds, st, m);
+    else launch_lds<conv32_kernel<AR_F32>>(grid, block, lds, st, m);
 }
 
 }  // namespace clm
