@@ -398,84 +398,93 @@ def main():
     host_lat.sort()
 
     if rank == 0:
-        es = 4 if eff in ("fp32", "fp16x3") else 2
-        peak_key = eff                               # a guard that fell back runs -- and is priced against -- the fp32 MFMA
         total_ms = sum(ms for ms, _ in prof.values()) or 1.0
-        dom = max(prof, key=lambda k: prof[k][0])
-        ms, launches = prof[dom]
-        tokens_per_launch = (hi - lo) * L * a.steps * (NLAYER if dom not in ("embed", "lnf_pool_score", "softmax_pool", "head_mlp") else 1) / max(1, launches)
-        flops_per_token = STAGE_FLOPS_PER_TOKEN.get(dom, 0)
-        fused_next = False
-        if dom == "out_proj_ln2_mlp":
-            # the tail kernel of block i also runs LN1 + in_proj of block i + 1 (every in_proj that has no launch of its own: 3 of a
-            # forward's 4 in the 16-bit modes and in fused exact fp32, whose block 0 keeps its separate kernel) and, in the 16-bit
-            # modes, ln_f + the pooling-score GEMM in the last block's launch: average over the launches
-            n_in = prof.get("ln1_in_proj", (0.0, 0))[1]
-            fused_in = max(launches - n_in - (launches // NLAYER if n_in == 0 else 0), 0)
-            fused_score = launches // NLAYER if prof.get("lnf_pool_score", (0.0, 0))[1] == 0 else 0
-            flops_per_token += (fused_in * STAGE_FLOPS_PER_TOKEN["ln1_in_proj"] + fused_score * STAGE_FLOPS_PER_TOKEN["lnf_pool_score"]) / max(1, launches)
-            fused_next = fused_in > 0
-        if dom in STAGE_FLOPS_PER_TOKEN:
-            achieved = flops_per_token * tokens_per_launch / (ms / launches * 1e-3) / 1e12
-            roof = {"bound": "mfma", "kernel": dom, "achieved": achieved, "peak": PEAK_TFLOPS[peak_key],
-                    "unit": "TFLOP/s", "frac": achieved / PEAK_TFLOPS[peak_key], "traffic": None}
-        else:
-            achieved = stage_bytes_per_token(dom, es) * tokens_per_launch / (ms / launches * 1e-3) / 1e9
-            roof = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                    "frac": achieved / PEAK_HBM_GBS, "traffic": None}
-        if roof["bound"] == "mfma" and eff != "fp32":
-            # what the pool's MI355X sustains with every MFMA pipe busy (tools/micro/mfma_probe.cpp, profiles/r01_mfma_probe.txt:
-            # 32 cycles per 32x32x16 MFMA per SIMD at the 1.55 GHz the chip holds under that load, against 2.4 GHz nominal)
-            roof["peak_sustained_measured"] = SUSTAINED_MFMA16_TFLOPS
-            roof["frac_of_sustained"] = achieved / SUSTAINED_MFMA16_TFLOPS
-        roof["flops_per_token_per_launch"] = flops_per_token if dom in STAGE_FLOPS_PER_TOKEN else None
-        roof["avg_launch_ms"] = ms / max(1, launches)
-        roof["launches"] = launches
         config = {"workload": f"synthetic {a.bases}-bp reads, global batch {a.batch}, 1 forward per step",
                   "global_batch": a.batch, "tokens_per_read": L, "reads_per_gpu": hi - lo, "chunk_reads": a.chunk_reads,
                   "parallelism": f"read-sharded x{world}, logits all-gather" if world > 1 else "single GPU"}
-        tr = measured_traffic(dom, config, a.precision)
-        if tr and "stale" in tr:
-            roof["traffic_stale"] = tr["stale"]
-        elif tr:
-            roof["traffic"], roof["traffic_unit"], roof["traffic_source"] = tr["hbm_bytes_per_launch"], "bytes/launch", tr["source"]
-            if tr.get("mfma_busy") and tr["mfma_busy"][0]:
-                # MFMA pipe occupancy from the same committed counter digest: SQ_VALU_MFMA_BUSY_CYCLES (summed over 1,024 SIMDs) over
-                # SIMDs x the kernel's duration in that counter pass x the shader clock the power log shows under this kernel
-                cyc, us = tr["mfma_busy"]
-                roof["mfma_busy_frac"] = cyc / (1024 * us * 1e-6 * SCLK_UNDER_TAIL_HZ)
-                roof["mfma_busy_note"] = f"SQ_VALU_MFMA_BUSY_CYCLES {cyc:.3g} per dispatch / (1,024 SIMDs x {us:.0f} us x {SCLK_UNDER_TAIL_HZ / 1e9:.2f} GHz), {tr['source']}"
-            alg = stage_bytes_per_token(dom, es) or TAIL_BYTES_PER_TOKEN.get(dom, {}).get(es, 0.0)
-            if fused_next:   # + z of the next block (3 of 4 launches); block 0 reads ids instead of its residual rows
-                alg += Z_ROWS * D * es * (NLAYER - 1) / NLAYER - D * 4 / NLAYER
-            roof["algorithmic_hbm_bytes_per_launch"] = alg * tokens_per_launch
-        if roof["bound"] == "mfma":
-            # MFMA work actually issued (fp16c: two instructions per product) against the same peaks: pipe occupancy
-            factor = MFMA_ISSUE_FACTOR[eff] + (MLP_LO_ISSUE if (eff == "fp16c" and rep.get("mlp_compensation")) else 0.0)
-            roof["mfma_issue_factor"] = factor
-            roof["issued_tflops"] = achieved * factor
-            roof["issued_frac"] = roof["issued_tflops"] / PEAK_TFLOPS[peak_key]
+        # (everything below `value` is reporting: an exception in it must not cost the line -- a NameError here once would have)
+        try:
+            es = 4 if eff in ("fp32", "fp16x3") else 2
+            peak_key = eff                               # a guard that fell back runs -- and is priced against -- the fp32 MFMA
+            dom = max(prof, key=lambda k: prof[k][0])
+            ms, launches = prof[dom]
+            tokens_per_launch = (hi - lo) * L * a.steps * (NLAYER if dom not in ("embed", "lnf_pool_score", "softmax_pool", "head_mlp") else 1) / max(1, launches)
+            flops_per_token = STAGE_FLOPS_PER_TOKEN.get(dom, 0)
+            fused_next = False
+            if dom == "out_proj_ln2_mlp":
+                # the tail kernel of block i also runs LN1 + in_proj of block i + 1 (every in_proj that has no launch of its own: 3 of a
+                # forward's 4 in the 16-bit modes and in fused exact fp32, whose block 0 keeps its separate kernel) and, in the 16-bit
+                # modes, ln_f + the pooling-score GEMM in the last block's launch: average over the launches
+                n_in = prof.get("ln1_in_proj", (0.0, 0))[1]
+                fused_in = max(launches - n_in - (launches // NLAYER if n_in == 0 else 0), 0)
+                fused_score = launches // NLAYER if prof.get("lnf_pool_score", (0.0, 0))[1] == 0 else 0
+                flops_per_token += (fused_in * STAGE_FLOPS_PER_TOKEN["ln1_in_proj"] + fused_score * STAGE_FLOPS_PER_TOKEN["lnf_pool_score"]) / max(1, launches)
+                fused_next = fused_in > 0
+            if dom in STAGE_FLOPS_PER_TOKEN:
+                achieved = flops_per_token * tokens_per_launch / (ms / launches * 1e-3) / 1e12
+                roof = {"bound": "mfma", "kernel": dom, "achieved": achieved, "peak": PEAK_TFLOPS[peak_key],
+                        "unit": "TFLOP/s", "frac": achieved / PEAK_TFLOPS[peak_key], "traffic": None}
+            else:
+                achieved = stage_bytes_per_token(dom, es) * tokens_per_launch / (ms / launches * 1e-3) / 1e9
+                roof = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                        "frac": achieved / PEAK_HBM_GBS, "traffic": None}
+            if roof["bound"] == "mfma" and eff != "fp32":
+                # what the pool's MI355X sustains with every MFMA pipe busy (tools/micro/mfma_probe.cpp, profiles/r01_mfma_probe.txt:
+                # 32 cycles per 32x32x16 MFMA per SIMD at the 1.55 GHz the chip holds under that load, against 2.4 GHz nominal)
+                roof["peak_sustained_measured"] = SUSTAINED_MFMA16_TFLOPS
+                roof["frac_of_sustained"] = achieved / SUSTAINED_MFMA16_TFLOPS
+            roof["flops_per_token_per_launch"] = flops_per_token if dom in STAGE_FLOPS_PER_TOKEN else None
+            roof["avg_launch_ms"] = ms / max(1, launches)
+            roof["launches"] = launches
+            tr = measured_traffic(dom, config, a.precision)
+            if tr and "stale" in tr:
+                roof["traffic_stale"] = tr["stale"]
+            elif tr:
+                roof["traffic"], roof["traffic_unit"], roof["traffic_source"] = tr["hbm_bytes_per_launch"], "bytes/launch", tr["source"]
+                if tr.get("mfma_busy") and tr["mfma_busy"][0]:
+                    # MFMA pipe occupancy from the same committed counter digest: SQ_VALU_MFMA_BUSY_CYCLES (summed over 1,024 SIMDs) over
+                    # SIMDs x the kernel's duration in that counter pass x the shader clock the power log shows under this kernel
+                    cyc, us = tr["mfma_busy"]
+                    roof["mfma_busy_frac"] = cyc / (1024 * us * 1e-6 * SCLK_UNDER_TAIL_HZ)
+                    roof["mfma_busy_note"] = f"SQ_VALU_MFMA_BUSY_CYCLES {cyc:.3g} per dispatch / (1,024 SIMDs x {us:.0f} us x {SCLK_UNDER_TAIL_HZ / 1e9:.2f} GHz), {tr['source']}"
+                alg = stage_bytes_per_token(dom, es) or TAIL_BYTES_PER_TOKEN.get(dom, {}).get(es, 0.0)
+                if fused_next:   # + z of the next block (3 of 4 launches); block 0 reads ids instead of its residual rows
+                    alg += Z_ROWS * D * es * (NLAYER - 1) / NLAYER - D * 4 / NLAYER
+                roof["algorithmic_hbm_bytes_per_launch"] = alg * tokens_per_launch
+            if roof["bound"] == "mfma":
+                # MFMA work actually issued (fp16c: two instructions per product) against the same peaks: pipe occupancy
+                factor = MFMA_ISSUE_FACTOR[eff] + (MLP_LO_ISSUE if (eff == "fp16c" and rep.get("mlp_compensation")) else 0.0)
+                roof["mfma_issue_factor"] = factor
+                roof["issued_tflops"] = achieved * factor
+                roof["issued_frac"] = roof["issued_tflops"] / PEAK_TFLOPS[peak_key]
+        except Exception as exc:  # noqa: BLE001
+            roof = {"bound": "mfma", "kernel": None, "achieved": None, "peak": None, "unit": "TFLOP/s", "frac": None,
+                    "traffic": None, "error": f"roofline accounting failed: {exc!r}"}
         fp32_rate = None
-        if world == 1 and eff != "fp32" and not a.no_fp32_leg:
-            # the exact-fp32 engine on the same batches, so that the driver's run also times the mode that is bit-for-bit the
-            # reference's arithmetic (a few steps: it is ~5x slower)
-            e32 = Engine(device, precision="fp32", chunk_reads=a.chunk_reads)
-            e32.load_state_dict(model.state_dict())
-            e32.forward(batches[0], out=logits)
-            torch.cuda.synchronize(device)
-            k32 = max(2, min(3, a.steps))
-            t3 = time.perf_counter()
-            for i in range(k32):
-                e32.forward(batches[i % n_data], out=logits)
-            torch.cuda.synchronize(device)
-            fp32_rate = a.batch * k32 / (time.perf_counter() - t3)
-            if guard is not None and guard.get("max_abs_dlogit_vs_exact_fp32") is None:
-                # a mode without a self-check of its own (fp16x3, fp16, bf16): the whole last batch against the exact engine, here
-                ref32 = e32.forward(batches[(k32 - 1) % n_data]).float().cpu()
-                mine = eng.forward(batches[(k32 - 1) % n_data]).float().cpu()
-                guard["max_abs_dlogit_vs_exact_fp32"] = float((ref32 - mine).abs().max())
-                guard["samples"] = [[f"the whole batch x {L} (outside the timed region)", guard["max_abs_dlogit_vs_exact_fp32"]]]
-            e32.close()
+        fp32_leg_error = None
+        try:
+            if world == 1 and eff != "fp32" and not a.no_fp32_leg:
+                # the exact-fp32 engine on the same batches, so that the driver's run also times the mode that is bit-for-bit the
+                # reference's arithmetic (a few steps: it is ~5x slower)
+                e32 = Engine(device, precision="fp32", chunk_reads=a.chunk_reads)
+                e32.load_state_dict(model.state_dict())
+                e32.forward(batches[0], out=logits)
+                torch.cuda.synchronize(device)
+                k32 = max(2, min(3, a.steps))
+                t3 = time.perf_counter()
+                for i in range(k32):
+                    e32.forward(batches[i % n_data], out=logits)
+                torch.cuda.synchronize(device)
+                fp32_rate = a.batch * k32 / (time.perf_counter() - t3)
+                if guard is not None and guard.get("max_abs_dlogit_vs_exact_fp32") is None:
+                    # a mode without a self-check of its own (fp16x3, fp16, bf16): the whole last batch against the exact engine, here
+                    ref32 = e32.forward(batches[(k32 - 1) % n_data]).float().cpu()
+                    mine = eng.forward(batches[(k32 - 1) % n_data]).float().cpu()
+                    guard["max_abs_dlogit_vs_exact_fp32"] = float((ref32 - mine).abs().max())
+                    guard["samples"] = [[f"the whole batch x {L} (outside the timed region)", guard["max_abs_dlogit_vs_exact_fp32"]]]
+                e32.close()
+        except Exception as exc:  # noqa: BLE001
+            fp32_rate, fp32_leg_error = None, repr(exc)
         res = {
             "metric": f"reads/sec (whole node), {a.bases}-bp reads batch={a.batch}", "value": a.batch * a.steps / elapsed,
             "unit": "reads/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -497,13 +506,17 @@ def main():
                             "gather_ms_max": gather_ms[-1] if gather_ms else None},
             "guard": guard,
             "fp32_exact_reads_per_s": fp32_rate,
+            **({"fp32_leg_error": fp32_leg_error} if fp32_leg_error else {}),
             "pcie_inclusive_reads_per_s": host_rate,
             "dense_tflops_per_gpu": 6_423_040 * L * (hi - lo) * a.steps / elapsed / 1e12,
             "stage_ms_share": {k: round(v[0] / total_ms, 4) for k, v in prof.items() if v[1]},
             "roofline": roof,
         }
         if world == 1 and not a.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(a.bases)
+            try:
+                res["cpu_baseline"] = cpu_baseline(a.bases)
+            except Exception as exc:  # noqa: BLE001
+                res["cpu_baseline"] = {"value": None, "unit": "reads/s", "cores": None, "kind": "port", "sample": None, "error": repr(exc)}
         print(json.dumps(res), flush=True)
     cdist.barrier()
     if world > 1:
