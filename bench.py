@@ -348,7 +348,7 @@ def main():
     eff = eng.effective_precision(L)                 # what reads of this length ran in, after the guard's verdict(s)
     guard = None
     if a.precision != "fp32":
-        guard = {"verdict": ("fell back to exact fp32" if rep.get("fallback") else
+        guard = {"verdict": (f"fell back to {rep.get('fallback_precision', 'fp16x3')}" if rep.get("fallback") else
                              "kept, MLP weights switched to hi + lo" if rep.get("mlp_compensation") else
                              "kept" if net.selfcheck else "not guarded (selfcheck off for this mode)"),
                  "effective_precision": eff, "max_abs_dlogit_vs_exact_fp32": rep.get("max_abs_dlogit"), "tol": rep.get("tol"),

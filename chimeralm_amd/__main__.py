@@ -102,7 +102,7 @@ def predict(
     rep = getattr(model.net, "selfcheck_report", None)
     if rep:
         log.info(f"[rank {rank}] precision {precision}: self-check against exact fp32 max |dlogit| {rep.get('max_abs_dlogit', 0.0):.2e} "
-                 f"(threshold {rep.get('tol')}) -> {'FELL BACK to exact fp32' if rep.get('fallback') else 'kept'}")
+                 f"(threshold {rep.get('tol')}) -> {('FELL BACK to ' + rep.get('fallback_precision', 'fp16x3')) if rep.get('fallback') else 'kept'}")
     log.info(f"[rank {rank}] {n} reads; predictions saved to {output_path}")
 
 

@@ -21,7 +21,7 @@ PRECISIONS = {"fp32": PREC_F32, "f32": PREC_F32, "bf16": PREC_BF16, "fp16": PREC
 STAGES = ["embed", "ln1_in_proj", "short_long_conv", "out_proj", "ln2_fc1_gelu", "fc2", "lnf_pool_score",
           "softmax_pool", "head_mlp", "filter", "out_proj_ln2_mlp", "ln2_mlp"]
 N_STAGES = len(STAGES)
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 
 class ClmConfig(C.Structure):

@@ -83,9 +83,11 @@ struct clm_handle {
     // 16-bit handles: exact-fp32 packing of the same weights (fp16c's reads shorter than f16c_min_len, clm_selfcheck, clm_set_fallback)
     void* packed32[NLAYER][4] = {};
     void* packed32t[NLAYER][4] = {};   // exact fp32, the fused tail's packing (tail32.hip): in_proj, out_proj, fc1, fc2
-    void* packed32x[NLAYER][4] = {};   // CLM_PREC_F16X3: the same weights as hi + lo halfs (launch_pack_x3); lwx = lw with these
+    // the same weights as hi + lo halfs (launch_pack_x3; tail32.hip AR_X3): the arithmetic of a CLM_PREC_F16X3 handle AND, round 5,
+    // of every 16-bit handle's short reads and first fall-back level -- lwx = the handle's fp32-path LayerW with these
+    void* packed32x[NLAYER][4] = {};
     LayerW lwx[NLAYER] = {};
-    bool referee = false;              // inside clm_selfcheck's second pass: an fp16x3 handle runs its exact-fp32 tails
+    bool referee = false;              // inside clm_selfcheck's second pass: exact fp32, whatever the handle's mode or fall-back level
     void* packed_score32 = nullptr;
     LayerW lw32[NLAYER]{};
     // PREC_F16C: fc1 / fc2 packed as hi + lo as well (the mode's second level, clm_set_mlp_compensation; lw.w_fc1 / w_fc2 are plain fp16)
@@ -94,7 +96,9 @@ struct clm_handle {
     int f16c_min_len = 2048;
     // clm_selfcheck / clm_set_fallback: the exact-fp32 kernels of the same handle as referee of, and replacement for, the 16-bit path
     int force_prec = -1;          // >= 0 inside clm_selfcheck: the arithmetic forward_chunk runs in, whatever the length
-    bool fallback32 = false;      // every read through the exact-fp32 kernels (a 16-bit handle whose self-check failed)
+    // clm_set_fallback: 0 = the handle's own mode; 1 = the next arithmetic INSIDE the gate (a 16-bit handle: fp16x3 -- fp32-class
+    // results at about twice the exact rate; an fp16x3 handle: exact fp32); 2 = exact fp32 on every handle
+    int fallback = 0;
     float* sc_logits = nullptr;   // [2][sc_cap][2] device: logits of the two passes of a self-check
     int sc_cap = 0;
     // host batches: two device staging buffers fed by the handle's own copy stream
@@ -483,8 +487,16 @@ struct StageTimer {
 
 int effective_prec(const clm_handle* h, int L) {
     if (h->force_prec >= 0) return h->force_prec;
-    if (h->fallback32) return (int)PREC_F32;
+    if (h->fallback > 0) return (int)PREC_F32;
     return (h->cfg.precision == PREC_F16C && L < h->f16c_min_len) ? (int)PREC_F32 : h->cfg.precision;
+}
+// Does the fp32 path of this handle multiply hi + lo halfs (three fp16 MFMAs per product, tail32.hip AR_X3) right now?  An fp16x3
+// handle: unless told to fall back; a 16-bit handle (short reads of fp16c, fall-back level 1): unless told to fall back all the
+// way (level 2).  Never inside the referee pass of a self-check, never on an fp32 handle.
+bool fp32_path_is_x3(const clm_handle* h) {
+    if (h->referee) return false;
+    if (h->x3) return h->fallback == 0;
+    return h->cfg.precision != PREC_F32 && h->fallback < 2;
 }
 
 // Asynchronous error of an EARLIER forward (the call itself returned before its kernels ran): reported once, by the next
@@ -549,7 +561,7 @@ int forward_chunk(clm_handle* h, const void* ids, int ids_dtype, int64_t row_str
     const bool zgated = fuse_next && !h->raw_z;
     // exact fp32: one fused kernel per block tail, the next block's in_proj included (tail32.hip)
     const bool fused32 = prec == PREC_F32 && fused_fp32(h);
-    const bool x3 = h->x3 && fused32 && !h->referee;            // fp16x3: hi + lo halfs in the fused tails (the referee pass: exact)
+    const bool x3 = fused32 && fp32_path_is_x3(h);              // fp16x3: hi + lo halfs in the fused tails (the referee pass: exact)
     // fp16c, round 4: y (every block) and the gated rows of z carry one lo byte per element next to the halfs
     unsigned char* const ylo = (prec == PREC_F16C && tuned16) ? h->ylo : nullptr;
     if (zgated && tail16_grid(((peel ? L - 1 : L) + 127) / 128 * Bc) > 1024)
@@ -565,7 +577,7 @@ int forward_chunk(clm_handle* h, const void* ids, int ids_dtype, int64_t row_str
     }
     if (stop_here(h, -1, CLM_STAGE_EMBED)) return CLM_OK;
     for (int i = 0; i < NLAYER; ++i) {
-        const LayerW& lw = alt32 ? h->lw32[i] : (x3 ? h->lwx[i] : h->lw[i]);
+        const LayerW& lw = x3 ? h->lwx[i] : (alt32 ? h->lw32[i] : h->lw[i]);
         // block 0 in the 16-bit modes: its in_proj output is a function of the token id alone, the convolution looks it
         // up (ztab), single-shot and segmented kernel alike -- unless a debug stop asks for z itself or CLM_DEBUG=no_idconv
         // (exact fp32 with the fused tail, single-shot convolution: the same table -- it is fp32 -- so block 0 needs no in_proj launch)
@@ -639,7 +651,7 @@ int forward_chunk(clm_handle* h, const void* ids, int ids_dtype, int64_t row_str
             }
         } else if (fused32) {
             StageTimer t(h, st, CLM_STAGE_TAIL);
-            const LayerW* nx = i + 1 < NLAYER ? &(alt32 ? h->lw32[i + 1] : (x3 ? h->lwx[i + 1] : h->lw[i + 1])) : nullptr;
+            const LayerW* nx = i + 1 < NLAYER ? &(x3 ? h->lwx[i + 1] : (alt32 ? h->lw32[i + 1] : h->lw[i + 1])) : nullptr;
             launch_tail32(reinterpret_cast<const float*>(h->y), h->h, lw.t_out, lw.t_fc1, lw.t_fc2, nx ? nx->t_in : nullptr, lw.b_out,
                           lw.b_fc1, lw.b_fc2, nx ? nx->b_in : nullptr, lw.ln2_g, lw.ln2_b, nx ? nx->ln1_g : nullptr,
                           nx ? nx->ln1_b : nullptr, reinterpret_cast<float*>(h->z), Bc, L, Lp, eps, st, x3);
@@ -811,6 +823,8 @@ int clm_finalize(clm_handle* h) {
     free_packed(h);
     free_filters(h);
     const int prec = h->cfg.precision;
+    // hi + lo halfs of the tail weights: an fp16x3 handle's own arithmetic; a 16-bit handle's short reads and first fall-back level
+    const bool pack_x3 = (h->x3 || prec != PREC_F32) && !h->unfused_fp32;
     hipStream_t st = 0;
     auto pack_as = [&](int pr, const std::string& key, int n, int k, void** out) -> int {
         HIPCHK(h, hipMalloc(out, packed_weight_bytes(pr, n, k)));
@@ -846,17 +860,12 @@ int clm_finalize(clm_handle* h) {
             for (int j = 0; j < 4; ++j) {
                 HIPCHK(h, hipMalloc(&h->packed32t[i][j], (size_t)tw[j].n * tw[j].k * 4));
                 launch_pack_f32t(W(h, p + tw[j].key), h->packed32t[i][j], tw[j].n, tw[j].k, st);
-                if (h->x3) {
+                if (pack_x3) {
                     HIPCHK(h, hipMalloc(&h->packed32x[i][j], (size_t)tw[j].n * tw[j].k * 4));
                     launch_pack_x3(W(h, p + tw[j].key), h->packed32x[i][j], tw[j].n, tw[j].k, st);
                 }
             }
             lw.t_in = h->packed32t[i][0]; lw.t_out = h->packed32t[i][1]; lw.t_fc1 = h->packed32t[i][2]; lw.t_fc2 = h->packed32t[i][3];
-            if (h->x3) {
-                h->lwx[i] = lw;
-                h->lwx[i].t_in = h->packed32x[i][0]; h->lwx[i].t_out = h->packed32x[i][1];
-                h->lwx[i].t_fc1 = h->packed32x[i][2]; h->lwx[i].t_fc2 = h->packed32x[i][3];
-            }
         }
         if (prec != PREC_F32) {   // the exact-fp32 packing next to the 16-bit one: fp16c's short reads, clm_selfcheck, clm_set_fallback
             if ((rc = pack_as(PREC_F32, p + "mixer.in_proj.weight", D3, D, &h->packed32[i][0]))) return rc;
@@ -866,6 +875,11 @@ int clm_finalize(clm_handle* h) {
             h->lw32[i] = lw;
             h->lw32[i].w_in = h->packed32[i][0]; h->lw32[i].w_out = h->packed32[i][1];
             h->lw32[i].w_fc1 = h->packed32[i][2]; h->lw32[i].w_fc2 = h->packed32[i][3];
+        }
+        if (pack_x3) {            // the fp32 path's LayerW with the fused tail's weights as hi + lo halfs
+            h->lwx[i] = prec != PREC_F32 ? h->lw32[i] : lw;
+            h->lwx[i].t_in = h->packed32x[i][0]; h->lwx[i].t_out = h->packed32x[i][1];
+            h->lwx[i].t_fc1 = h->packed32x[i][2]; h->lwx[i].t_fc2 = h->packed32x[i][3];
         }
     }
     {
@@ -1025,7 +1039,9 @@ int clm_selfcheck(clm_handle* h, const void* ids, int ids_dtype, int64_t ids_row
     // pass 0: the arithmetic the handle's mode runs reads of this length in (whatever clm_set_fallback says); pass 1: exact fp32
     const int mode_prec = (h->cfg.precision == PREC_F16C && L < h->f16c_min_len) ? (int)PREC_F32 : h->cfg.precision;
     const bool prof = h->prof;
+    const int fallback = h->fallback;
     h->prof = false;                                            // not part of anybody's timed region
+    h->fallback = 0;                                            // the MODE is on trial (short reads of fp16c: its fp16x3 kernels)
     const size_t ies = ids_dtype == CLM_DT_I64 ? 8 : (ids_dtype == CLM_DT_I32 ? 4 : 1);
     int rc = CLM_OK;
     for (int pass = 0; pass < 2 && !rc; ++pass) {
@@ -1041,6 +1057,7 @@ int clm_selfcheck(clm_handle* h, const void* ids, int ids_dtype, int64_t ids_row
     h->force_prec = -1;
     h->referee = false;
     h->prof = prof;
+    h->fallback = fallback;
     if (rc) return rc;
     std::vector<float> host((size_t)2 * h->sc_cap * NCLS);
     HIPCHK(h, hipMemcpyAsync(host.data(), h->sc_logits, host.size() * 4, hipMemcpyDeviceToHost, st));
@@ -1077,7 +1094,8 @@ int clm_logit_deviation(const float* a, const float* b, int B, int n_classes, fl
 int clm_set_fallback(clm_handle* h, int on) {
     if (!h) return CLM_E_INVALID;
     if (!h->finalized) return fail(h, CLM_E_STATE, "clm_set_fallback before clm_finalize");
-    h->fallback32 = on != 0 && h->cfg.precision != PREC_F32;
+    if (on < 0 || on > 2) return fail(h, CLM_E_INVALID, "clm_set_fallback: level must be 0, 1 or 2");
+    h->fallback = (h->cfg.precision == PREC_F32 && !h->x3) ? 0 : on;   // (an exact-fp32 handle has nothing to fall back to)
     return CLM_OK;
 }
 
@@ -1098,7 +1116,7 @@ int clm_set_short_read_len(clm_handle* h, int min_len) {
 int clm_effective_precision(const clm_handle* h, int L) {
     if (!h || L < 1) return CLM_E_INVALID;
     const int p = effective_prec(h, L);
-    return (h->x3 && p == PREC_F32) ? CLM_PREC_F16X3 : p;
+    return (p == PREC_F32 && fused_fp32(h) && fp32_path_is_x3(h)) ? CLM_PREC_F16X3 : p;
 }
 
 int clm_debug_stop_after(clm_handle* h, int layer, int stage) {

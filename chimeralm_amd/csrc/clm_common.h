@@ -4,6 +4,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
+#include <cstdio>
 #include <type_traits>
 
 #include "clm_lab.h"
@@ -152,6 +154,24 @@ __device__ __forceinline__ void lo8_unpack4(unsigned w, float (&d)[4]) {
 
 // developer switches: is `name` in the comma-separated environment variable CLM_DEBUG?  (clm_api.hip; A/B runs and tests only)
 bool debug_flag(const char* name);
+
+// hipFuncAttributeMaxDynamicSharedMemorySize is a property of (kernel, DEVICE): a C-ABI client may hold handles on several GPUs in
+// one process, so every launch site keeps one bit per device instead of a once-per-process flag (a handle on a second
+// device launched its > 64-KiB-LDS kernels without the attribute).  CLM_SET_LDS(kernel pointer, bytes) before the launch.
+inline void ensure_lds_attr(const void* kern, size_t lds, std::atomic<unsigned long long>& done) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (done.load(std::memory_order_relaxed) & bit) return;
+    const hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e == hipSuccess) done.fetch_or(bit, std::memory_order_relaxed);
+    else std::fprintf(stderr, "chimeralm_hip: hipFuncSetAttribute(MaxDynamicSharedMemorySize = %zu) failed on device %d: %s\n", lds, dev, hipGetErrorString(e));
+}
+#define CLM_SET_LDS(kern, lds)                                                             \
+    do {                                                                                   \
+        static std::atomic<unsigned long long> clm_lds_done_{0};                           \
+        ::clm::ensure_lds_attr(reinterpret_cast<const void*>(kern), (lds), clm_lds_done_); \
+    } while (0)
 
 // ---- kernel launchers (definitions in the .hip files); all are asynchronous on `st` --------------------
 // PREC_F16C ("fp16c"): fp16 activations x weights held as hi + lo (in_proj, out_proj, score layer; the MLP weights are plain fp16

@@ -206,12 +206,7 @@ static void launch_gemm(const GemmArgs& a, hipStream_t st) {
     using C = CT<PREC>;
     constexpr size_t lds = (size_t)C::BM * C::RS * sizeof(typename C::elem);
     auto kern = gemm_kernel<PREC, ASRC, EPI, K, N>;
-    static bool attr_done = false;
-    if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)lds);
-        attr_done = true;
-    }
+    CLM_SET_LDS(kern, lds);
     dim3 grid((a.L + C::BM - 1) / C::BM, a.B), block(256);
     hipLaunchKernelGGL(kern, grid, block, lds, st, a);
 }

@@ -1149,13 +1149,9 @@ __global__ __launch_bounds__(512) void tail16_kernel(TailArgs m, unsigned long l
 }
 
 // ================================================================================================ launchers
-template <typename Kern>
-static void set_lds(Kern kern, size_t lds) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-}
 template <typename Kern, typename Args>
 static void launch16_inst(Kern kern, dim3 grid, dim3 block, size_t lds, hipStream_t st, const Args& args) {
-    set_lds(kern, lds);
+    CLM_SET_LDS(kern, lds);                                  // (one static per instantiation of this launcher = per kernel)
     hipLaunchKernelGGL(kern, grid, block, lds, st, args);
 }
 // one instantiation per 16-bit arithmetic mode (bf16, fp16, fp16 with hi + lo weights)
@@ -1246,8 +1242,7 @@ void tail16_dump_stamps() {
 template <int PREC, int NEXT, bool ZG = false, bool MLPC = false>
 static void launch_tail_inst(const TailArgs& m, dim3 grid, size_t lds, hipStream_t st) {
     if (ZG) lds += (size_t)(ZG_HALO_FLOATS - D3) * 4;        // the stash takes the in_proj bias table's place and 3 KiB more
-    static bool once = (set_lds(tail16_kernel<PREC, false, NEXT, ZG, MLPC>, lds), true);
-    (void)once;
+    CLM_SET_LDS((tail16_kernel<PREC, false, NEXT, ZG, MLPC>), lds);
     hipLaunchKernelGGL((tail16_kernel<PREC, false, NEXT, ZG, MLPC>), grid, dim3(512), lds, st, m, (unsigned long long*)nullptr);
 }
 
@@ -1289,12 +1284,10 @@ void launch_tail16(int prec, const TailArgs& m, int next, hipStream_t st) {
         (void)hipMemsetAsync(s_stamp_buf, 0, wgs * TAIL_NSTAMP * 8, st);
         if (zg) {
             constexpr size_t ldz = lds + (size_t)(ZG_HALO_FLOATS - D3) * 4;
-            static bool once = (set_lds(tail16_kernel<PREC_F16C, true, NEXT_INPROJ, true>, ldz), true);
-            (void)once;
+            CLM_SET_LDS((tail16_kernel<PREC_F16C, true, NEXT_INPROJ, true>), ldz);
             hipLaunchKernelGGL((tail16_kernel<PREC_F16C, true, NEXT_INPROJ, true>), grid, block, ldz, st, m, s_stamp_buf);
         } else {
-            static bool once = (set_lds(tail16_kernel<PREC_F16C, true, NEXT_INPROJ>, lds), true);
-            (void)once;
+            CLM_SET_LDS((tail16_kernel<PREC_F16C, true, NEXT_INPROJ>), lds);
             hipLaunchKernelGGL((tail16_kernel<PREC_F16C, true, NEXT_INPROJ>), grid, block, lds, st, m, s_stamp_buf);
         }
         return;

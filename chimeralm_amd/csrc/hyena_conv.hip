@@ -1131,11 +1131,7 @@ static void launch_conv_pers_inst(const void* z, void* y, const float2* kf, cons
     using P = Plan<14>;
     constexpr size_t lds = (size_t)2 * padded_size(P::N) * sizeof(float) + 256;
     auto kern = hyena_conv_pers_kernel<T, IDS, GATED, LO>;
-    static bool attr_done = false;
-    if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_done = true;
-    }
+    CLM_SET_LDS(kern, lds);
     static const int cus = [] {
         int dev = 0, n = 256;
         if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
@@ -1673,12 +1669,7 @@ static void launch_conv_seg_inst(const void* z, void* y, const float2* kf, int K
     using P = Plan<14>;
     constexpr size_t lds = (size_t)2 * padded_size(P::N) * sizeof(float) + 256;   // + the 3x16 id table
     auto kern = hyena_conv_seg_kernel<T, LONE, IDS, GATED, LO>;
-    static bool attr_done = false;
-    if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)lds);
-        attr_done = true;
-    }
+    CLM_SET_LDS(kern, lds);
     static_assert(D % XCDS == 0, "channels split evenly over the XCDs");
     dim3 grid(((B + 1) / 2) * D), block(P::NT);
     hipLaunchKernelGGL(kern, grid, block, lds, st, reinterpret_cast<const T*>(z), reinterpret_cast<T*>(y), kf, KS, tw,
@@ -1802,16 +1793,12 @@ void conv_dump_stamps() {
         if (k != 6) std::fprintf(stderr, "  %-14s %9.0f  %5.1f %%\n", names[k], sum[k] / (n ? n : 1), 100.0 * sum[k] / (n ? n : 1) / tot);
 }
 
-// one launch site = one static: the dynamic-LDS attribute is set once per kernel instantiation
-#define CLM_CONV_LAUNCH(KERN, ...)                                                                                                 \
-    do {                                                                                                                           \
-        auto kern_ = KERN;                                                                                                         \
-        static bool done_ = false;                                                                                                 \
-        if (!done_) {                                                                                                              \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern_), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-            done_ = true;                                                                                                          \
-        }                                                                                                                          \
-        hipLaunchKernelGGL(kern_, grid, block, lds, st, __VA_ARGS__);                                                              \
+// one launch site = one static: the dynamic-LDS attribute is set once per kernel instantiation and device
+#define CLM_CONV_LAUNCH(KERN, ...)                                    \
+    do {                                                              \
+        auto kern_ = KERN;                                            \
+        CLM_SET_LDS(kern_, lds);                                      \
+        hipLaunchKernelGGL(kern_, grid, block, lds, st, __VA_ARGS__); \
     } while (0)
 
 // LO: fp16c (T = f16_t) with a lo plane for y -- the gated rows then carry lo bytes too

@@ -661,11 +661,10 @@ void launch_pack_f32t(const float* w, void* out, int n, int k, hipStream_t st) {
     hipLaunchKernelGGL(pack_f32t_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, w, reinterpret_cast<f32x4*>(out), n, k);
 }
 
-// one instantiation per kernel: the dynamic-LDS attribute is set once per process and kernel
+// one instantiation per kernel: the dynamic-LDS attribute is set once per kernel and device
 template <auto Kern, typename Args>
 static void launch_lds(dim3 grid, dim3 block, size_t lds, hipStream_t st, const Args& m) {
-    static const bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(Kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), true);
-    (void)once;
+    CLM_SET_LDS(Kern, lds);
     hipLaunchKernelGGL(Kern, grid, block, lds, st, m);
 }
 // x3: the products as three fp16 MFMAs on hi + lo halfs (weights from launch_pack_x3) instead of the fp32 MFMA

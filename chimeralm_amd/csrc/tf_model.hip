@@ -498,7 +498,10 @@ struct clm_tf_handle {
     float* ws32 = nullptr;                        // fp32 mode: activations of tf_fp32.hip
     size_t cap_ws32 = 0;
     int last_B = 0, last_L3 = 0;
-    bool fallback32 = false;                      // clm_tf_set_fallback: a 16-bit handle runs tf_fp32.hip (the raw fp32 tensors stay loaded)
+    // clm_tf_set_fallback (as clm_set_fallback): 0 = the handle's mode; 1 = the next arithmetic inside the gate (16-bit handle: the
+    // fp32-path kernels on hi + lo halfs = fp16x3; fp16x3 handle: exact fp32); 2 = exact fp32 (the raw fp32 tensors stay loaded)
+    int fallback = 0;
+    bool have_x3 = false;                         // the "x3.*" packings exist (fp16x3 and 16-bit handles, fused kernels only)
     float* sc_logits = nullptr;                   // clm_tf_selfcheck: [2][cap] device logits of the two forwards
     int sc_cap = 0;
     // profiling taps (clm_tf_profile_*): HIP events on the launch stream around each stage, stages: 0 conv stack + pe/LN,
@@ -584,8 +587,7 @@ void tf_launch_linear(const tf::LinArgs& a, hipStream_t st) {
     constexpr size_t lds = EPI == tf::E_ACT ? (size_t)(128 * RS16 + 8 * 128 * tf::ZRS) * 2
                                             : (size_t)2 * 128 * RS16 * 2 + (size_t)2 * 16 * 128 * 4;
     auto kern = tf::linear16_kernel<PREC, EPI, K, N>;
-    static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), true);
-    (void)once;
+    CLM_SET_LDS(kern, lds);
     hipLaunchKernelGGL(kern, dim3((unsigned)((a.M + 127) / 128)), dim3(512), lds, st, a);
 }
 
@@ -601,9 +603,8 @@ int tf_forward_t(clm_tf_handle* h, const void* ids, int ids_dtype, int64_t strid
     {
         auto k1 = tf::conv3_relu_pool_kernel<PREC, true>;
         auto k2 = tf::conv3_relu_pool_kernel<PREC, false>;
-        static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(k1), hipFuncAttributeMaxDynamicSharedMemorySize, (int)conv_lds),
-                            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k2), hipFuncAttributeMaxDynamicSharedMemorySize, (int)conv_lds), true);
-        (void)once;
+        CLM_SET_LDS(k1, conv_lds);
+        CLM_SET_LDS(k2, conv_lds);
         hipLaunchKernelGGL(k1, dim3((2 * L1 + 127) / 128, B), dim3(512), conv_lds, st, h->ids8, Lp, W("embedding.weight"),
                            (const elem*)nullptr, h->packed.at("cnn.0"), W("cnn.0.bias"), (elem*)h->x1, L, L1);
         hipLaunchKernelGGL(k2, dim3((2 * L2 + 127) / 128, B), dim3(512), conv_lds, st, (const unsigned char*)nullptr, 0,
@@ -649,8 +650,7 @@ int tf_forward_t(clm_tf_handle* h, const void* ids, int ids_dtype, int64_t strid
                           W(p + "norm1.weight"), W(p + "norm1.bias")};
             constexpr size_t lds = (size_t)2 * 128 * RS16 * 2 + (size_t)2 * 16 * 128 * 4;
             auto kern = tf::enc_ffn16_kernel<PREC>;
-            static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), true);
-            (void)once;
+            CLM_SET_LDS(kern, lds);
             hipLaunchKernelGGL(kern, dim3((unsigned)((M + 127) / 128)), dim3(512), lds, st, f);
         } else {
             a.a = h->hx; a.w = h->packed.at(p + "ff1"); a.bias = W(p + "linear1.bias"); a.out16 = h->u; a.relu = 1;
@@ -734,6 +734,7 @@ int clm_tf_finalize(clm_tf_handle* h) {
     if (!h->w.count("pos_encoder.pe")) return tf_fail(h, CLM_E_MISSING, "clm_tf_finalize: missing buffer pos_encoder.pe");
     for (auto& kv : h->packed) (void)hipFree(kv.second);
     h->packed.clear();
+    h->have_x3 = (h->arith_x3 || h->prec != PREC_F32) && !h->unfused_fp32;
     // exact fp32 (the handle's own mode, or the referee / fall-back of a 16-bit handle): the dense layers of the encoder in the fused
     // kernel's packing (tail32.hip enc32_kernel); everything else of tf_fp32.hip reads the fp32 tensors as they are
     for (int i = 0; i < h->n_layers; ++i) {
@@ -745,7 +746,7 @@ int clm_tf_finalize(clm_tf_handle* h) {
             TFCHK(h, hipMalloc(&q, (size_t)e.n * e.k * 4));
             launch_pack_f32t(h->w.at(p + e.key), q, e.n, e.k, 0);
             h->packed[t + e.name] = q;
-            if (h->arith_x3) {                                // fp16x3: the same weights as hi + lo halfs ("x3." keys); "t32." = its referee
+            if (h->have_x3) {                                 // fp16x3 (a handle's mode, or a 16-bit handle's first fall-back level): the same weights as hi + lo halfs ("x3." keys); "t32." = the referee
                 void* qx = nullptr;
                 TFCHK(h, hipMalloc(&qx, (size_t)e.n * e.k * 4));
                 launch_pack_x3(h->w.at(p + e.key), qx, e.n, e.k, 0);
@@ -763,7 +764,7 @@ int clm_tf_finalize(clm_tf_handle* h) {
             TFCHK(h, hipMalloc((void**)&q, (size_t)3 * D * D * 4));
             for (int dk = 0; dk < 3; ++dk) launch_pack_f32t(split32 + (size_t)dk * D * D, q + (size_t)dk * D * D, D, D, 0);
             h->packed["t32." + name] = q;
-            if (h->arith_x3) {
+            if (h->have_x3) {
                 float* qx = nullptr;
                 TFCHK(h, hipMalloc((void**)&qx, (size_t)3 * D * D * 4));
                 for (int dk = 0; dk < 3; ++dk) launch_pack_x3(split32 + (size_t)dk * D * D, qx + (size_t)dk * D * D, D, D, 0);
@@ -811,7 +812,12 @@ int clm_tf_finalize(clm_tf_handle* h) {
     return CLM_OK;
 }
 
-// One forward in the arithmetic `prec32 ? exact fp32 : the handle's 16-bit mode` (workspaces of BOTH kinds may be live: the
+static bool tf_fp32_path_is_x3(const clm_tf_handle* h) {
+    if (h->referee || !h->have_x3) return false;
+    return h->arith_x3 ? h->fallback == 0 : h->fallback < 2;
+}
+
+// One forward in the arithmetic `prec32 ? the fp32 path (exact, or fp16x3: tf_fp32_path_is_x3) : the handle's 16-bit mode` (workspaces of BOTH kinds may be live: the
 // self-check runs one after the other on the same ids).
 static int tf_run(clm_tf_handle* h, bool prec32, const void* ids, int ids_dtype, int64_t ids_row_stride, int B, int L,
                   float* logits_out, hipStream_t st) {
@@ -843,11 +849,12 @@ static int tf_run(clm_tf_handle* h, bool prec32, const void* ids, int ids_dtype,
         }
         const int Lp = (L + 63) / 64 * 64;
         launch_embed(ids, ids_dtype, ids_row_stride, nullptr, nullptr, h->ids8, B, L, Lp, st);
-        const bool use_x3 = h->arith_x3 && !h->referee;
+        // hi + lo halfs on the fp32 path: an fp16x3 handle unless told to fall back; a 16-bit handle at fall-back level 1
+        const bool use_x3 = tf_fp32_path_is_x3(h);
         auto get = [](void* ctx, const std::string& k) -> const float* {     // "t32.*": the fused kernels' packed weights ("x3.*" in fp16x3)
             auto* hh = static_cast<clm_tf_handle*>(ctx);
             if (k.rfind("t32.", 0) != 0) return hh->w.at(k);
-            return static_cast<const float*>(hh->packed.at((hh->arith_x3 && !hh->referee) ? "x3." + k.substr(4) : k));
+            return static_cast<const float*>(hh->packed.at(tf_fp32_path_is_x3(hh) ? "x3." + k.substr(4) : k));
         };
         if (tf32_forward(h->ids8, Lp, B, L, h->n_layers, h->ws32, h->h, get, h, st, h->unfused_fp32, use_x3))
             return tf_fail(h, CLM_E_HIP, std::string("clm_tf_forward (fp32): ") + hipGetErrorString(hipGetLastError()));
@@ -898,7 +905,7 @@ int clm_tf_forward(clm_tf_handle* h, const void* ids, int ids_dtype, int64_t ids
     if (!logits_out) return tf_fail(h, CLM_E_INVALID, "clm_tf_forward: bad argument (L >= 8)");
     if (int rc = tf_check_args(h, "clm_tf_forward", ids, ids_dtype, ids_row_stride, B, L)) return rc;
     TFCHK(h, hipSetDevice(h->device));
-    return tf_run(h, h->prec == PREC_F32 || h->fallback32, ids, ids_dtype, ids_row_stride, B, L, logits_out,
+    return tf_run(h, h->prec == PREC_F32 || h->fallback > 0, ids, ids_dtype, ids_row_stride, B, L, logits_out,
                   reinterpret_cast<hipStream_t>(stream));
 }
 
@@ -923,7 +930,11 @@ int clm_tf_selfcheck(clm_tf_handle* h, const void* ids, int ids_dtype, int64_t i
         }
         float* lm = h->sc_logits;
         float* lx = h->sc_logits + (size_t)h->sc_cap * NCLS;
-        if (int rc = tf_run(h, h->arith_x3, ids, ids_dtype, ids_row_stride, B, L, lm, st)) return rc;
+        const int fallback = h->fallback;
+        h->fallback = 0;                                       // the MODE is on trial, whatever clm_tf_set_fallback says
+        const int rc1 = tf_run(h, h->arith_x3, ids, ids_dtype, ids_row_stride, B, L, lm, st);
+        h->fallback = fallback;
+        if (rc1) return rc1;
         h->referee = true;
         const int rc2 = tf_run(h, true, ids, ids_dtype, ids_row_stride, B, L, lx, st);
         h->referee = false;
@@ -941,7 +952,8 @@ int clm_tf_selfcheck(clm_tf_handle* h, const void* ids, int ids_dtype, int64_t i
 
 int clm_tf_set_fallback(clm_tf_handle* h, int on) {
     if (!h) return CLM_E_INVALID;
-    h->fallback32 = on != 0;
+    if (on < 0 || on > 2) return tf_fail(h, CLM_E_INVALID, "clm_tf_set_fallback: level must be 0, 1 or 2");
+    h->fallback = (h->prec == PREC_F32 && !h->arith_x3) ? 0 : on;
     return CLM_OK;
 }
 

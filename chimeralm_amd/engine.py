@@ -145,12 +145,13 @@ class Engine:
                                             input_ids.stride(0), B, L, C.c_void_p(stream), C.byref(diff), C.byref(differ)))
         return float(diff.value), int(differ.value)
 
-    def set_fallback(self, on: bool = True):
-        """Every later forward of this engine runs in the exact-fp32 kernels (`clm_set_fallback`)."""
-        self._check(self._lib.clm_set_fallback(self._h, int(on)))
+    def set_fallback(self, level: int | bool = 1):
+        """`clm_set_fallback`: 0 = the engine's own mode; 1 = every later forward runs in the next arithmetic inside the 1e-3 gate
+        (a 16-bit engine: fp16x3, fp32-class logits at about twice the exact rate; an fp16x3 engine: exact fp32); 2 = exact fp32."""
+        self._check(self._lib.clm_set_fallback(self._h, int(level)))
 
     def set_f16c_min_len(self, min_len: int):
-        """fp16c: reads shorter than `min_len` tokens run in the exact-fp32 kernels (`clm_set_short_read_len`)."""
+        """fp16c: reads shorter than `min_len` tokens run in the fp16x3 kernels (`clm_set_short_read_len`)."""
         self._check(self._lib.clm_set_short_read_len(self._h, int(min_len)))
 
     def set_mlp_compensation(self, on: bool = True):

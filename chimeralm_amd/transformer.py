@@ -5,11 +5,16 @@ Same constructor arguments, same `state_dict()` keys (torch's own modules are us
 `transformer_encoder.layers.{i}.self_attn.in_proj_weight` etc. come out exactly as in the reference, and `pos_encoder.pe` is a
 buffer of the same shape), same `forward(input_ids, input_quals=None) -> logits [B, 2]`, same `number_of_classes` attribute that
 `ClassificationLit` reads.  The arithmetic runs in csrc/tf_model.hip + csrc/attention.hip behind the `clm_tf_*` C ABI; there is no
-CPU path.  Engine knobs absent in the reference: `precision` in {"fp32", "fp16x3", "fp16c", "fp16", "bf16"} (fp32 = the reference's arithmetic;
-fp16c = fp16 activations x weights as fp16 hi + fp8 lo, the Hyena path's compensated mode) and `selfcheck` /
-`selfcheck_tol`: before the first batch after a weight load (and again every `selfcheck_every`-th batch and for a batch more than 1.5x shorter or longer than any checked so far) the
-16-bit mode is measured against the exact-fp32 kernels of the same engine on seeded reads and on the batch's first reads
-(`clm_tf_selfcheck`); above the threshold the module falls back to fp32 for good and says so.  On by default for fp16c.
+CPU path.  Engine knobs absent in the reference: `precision` in {"fp32", "fp16x3", "fp16c", "fp16", "bf16"} -- fp32 = the
+reference's arithmetic; **fp16x3 (the default)** = every operand as two halfs, three fp16 MFMAs per product: 7e-6 .. 2.2e-5 from the
+reference module on the cases it was run on, 2.3x the exact rate, unguarded; fp16c = fp16 activations x weights as fp16 hi + fp8
+lo, the Hyena path's compensated mode: twice fp16x3's rate, but 2e-3 from the reference on those cases -- outside its 1e-3
+tolerance there, so it is opt-in and guarded -- and `selfcheck` / `selfcheck_tol`: before the first batch
+after a weight load (and again every `selfcheck_every`-th batch, for a batch more than 1.5x shorter or longer than any checked so
+far, and for the batch after a measurement within 10 % of the threshold) the mode is measured against the exact-fp32 kernels of the
+same engine on seeded reads and on rows of the batch (`clm_tf_selfcheck`); above the threshold the module falls back for good --
+a 16-bit mode to fp16x3, the next-fastest arithmetic inside the tolerance (`clm_tf_set_fallback` level 1), fp16x3 to exact fp32 --
+and says so.  On by default for fp16c.
 """
 from __future__ import annotations
 
@@ -41,7 +46,7 @@ class TransformerEngineError(RuntimeError):
 class SequenceCNNTransformer(nn.Module):
     def __init__(self, vocab_size: int, max_len: int, d_model: int = 256, cnn_kernel_size: int = 3, dropout: float = 0.1,
                  num_encoder_layers: int = 2, nhead: int = 8, dim_feedforward: int = 1024, number_of_classes: int = 2,
-                 padding_idx: int = 4, *, precision: str = "fp16", selfcheck: bool | None = None, selfcheck_tol: float = 5e-4,
+                 padding_idx: int = 4, *, precision: str = "fp16x3", selfcheck: bool | None = None, selfcheck_tol: float = 5e-4,
                  selfcheck_every: int = 16):
         super().__init__()
         if (vocab_size, d_model, cnn_kernel_size, nhead, dim_feedforward, number_of_classes) != (12, 256, 3, 8, 1024, 2):
@@ -60,6 +65,7 @@ class SequenceCNNTransformer(nn.Module):
         self._checked_min_len: int | None = None
         self._checked_max_len: int | None = None
         self._batches_since_check = 0
+        self._recheck_next = False
         self.embedding = nn.Embedding(vocab_size, d_model, padding_idx=padding_idx)
         self.pos_encoder = _PosEnc(d_model, max_len)
         conv = lambda: nn.Conv1d(d_model, d_model, kernel_size=cnn_kernel_size, padding=1)  # noqa: E731
@@ -97,6 +103,7 @@ class SequenceCNNTransformer(nn.Module):
             self._check(lib.clm_tf_finalize(self._h))
             self._check(lib.clm_tf_set_fallback(self._h, 0))
             self._sig, self._checked_min_len, self._checked_max_len, self._batches_since_check, self.selfcheck_report = sig, None, None, 0, {}
+            self._recheck_next = False
         return lib
 
     # ------------------------------------------------------------------ the 16-bit mode on trial
@@ -112,13 +119,13 @@ class SequenceCNNTransformer(nn.Module):
 
     def guard_due(self, n_tokens: int) -> bool:
         """As `HyenaDna.guard_due`: the first batch since a weight load, a batch more than 1.5x shorter or longer than every batch
-        checked so far, and every `selfcheck_every`-th batch."""
+        checked so far, the batch after a measurement within 10 % of the threshold, and every `selfcheck_every`-th batch."""
         if not self.selfcheck or self.precision == "fp32" or self.selfcheck_report.get("fallback"):
             return False
         if self._checked_min_len is None:
             return True
         self._batches_since_check += 1
-        return (3 * n_tokens < 2 * self._checked_min_len or 2 * n_tokens > 3 * self._checked_max_len
+        return (self._recheck_next or 3 * n_tokens < 2 * self._checked_min_len or 2 * n_tokens > 3 * self._checked_max_len
                 or (self.selfcheck_every > 0 and self._batches_since_check >= self.selfcheck_every))
 
     def guard(self, lib, input_ids: torch.Tensor) -> None:
@@ -128,15 +135,19 @@ class SequenceCNNTransformer(nn.Module):
         if not self.guard_due(L):
             return
         worst = rep.get("max_abs_dlogit", 0.0)
+        now = 0.0
         if self._checked_min_len is None:                      # first batch since the weights were loaded: seeded reads
             g = torch.Generator().manual_seed(20241)
             Ls = min(4096, 8 * self.pos_encoder.pe.shape[1])   # (a model built with a short max_len cannot take 4,096 tokens)
             ids = torch.randint(7, 11, (4, Ls), generator=g, dtype=torch.uint8)
             ids[0, : Ls // 3] = 4                              # one read left-padded, as the collator pads
-            worst = max(worst, self._measure(lib, f"synthetic 4 x {Ls}", ids.to(input_ids.device)))
+            now = max(now, self._measure(lib, f"synthetic 4 x {Ls}", ids.to(input_ids.device)))
         B = input_ids.shape[0]
         rows = list(range(B)) if B <= 4 else sorted({round(i * (B - 1) / 3) for i in range(4)})   # spread over the batch
-        worst = max(worst, self._measure(lib, f"batch rows {rows} x {L}", input_ids[rows].contiguous()))
+        now = max(now, self._measure(lib, f"batch rows {rows} x {L}", input_ids[rows].contiguous()))
+        now = now if now == now else float("inf")
+        worst = max(worst, now)
+        self._recheck_next = 0.9 * self.selfcheck_tol < now <= self.selfcheck_tol
         rep.update(max_abs_dlogit=worst, tol=self.selfcheck_tol, precision=self.precision)
         self._checked_min_len = L if self._checked_min_len is None else min(L, self._checked_min_len)
         self._checked_max_len = max(L, self._checked_max_len or 0)
@@ -144,12 +155,15 @@ class SequenceCNNTransformer(nn.Module):
         if not worst <= self.selfcheck_tol:                    # (NaN fails too)
             self._check(lib.clm_tf_set_fallback(self._h, 1))
             rep["fallback"] = True
+            rep["fallback_precision"] = "fp32" if self.precision == "fp16x3" else "fp16x3"
             import logging
             import warnings
 
+            what = ("exact fp32 (the reference's arithmetic)" if self.precision == "fp16x3" else
+                    "fp16x3 (every operand as two halfs, three fp16 MFMAs per product: fp32-class logits, about half the rate)")
             msg = (f"chimeralm_amd: SequenceCNNTransformer precision={self.precision!r} differs from the exact-fp32 kernels by "
-                   f"{worst:.2e} in the logits on the loaded weights (threshold {self.selfcheck_tol:.1e}); falling back to exact "
-                   "fp32 for this model (the reference's arithmetic, about 12x slower)")
+                   f"{worst:.2e} in the logits on the loaded weights (threshold {self.selfcheck_tol:.1e}); falling back to {what} "
+                   "for this model")
             logging.getLogger("chimeralm_amd").warning(msg)
             warnings.warn(msg, RuntimeWarning, stacklevel=3)
         rep.setdefault("fallback", False)

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define CLM_ABI_VERSION 4
+#define CLM_ABI_VERSION 5
 
 /* error codes */
 #define CLM_OK 0
@@ -61,7 +61,8 @@ extern "C" {
  * hi = fp16(x) and lo = fp16(x - hi) (~21 bits; weights pre-scaled by 2^10 so that their lo halfs stay normal), and a product is
  * three fp16 MFMAs into the fp32 accumulator: w_hi a_hi + w_lo a_hi + w_hi a_lo.  Everything else is the exact-fp32 engine (fp32
  * z / y / residual stream in HBM, fp32 convolution, score layer on the fp32 MFMA).  Logits within ~1e-5 of exact fp32 -- three
- * orders of magnitude inside the reference's 1e-3 -- at 2.5x its rate; no self-check, no fall-back (csrc/tail32.hip, AR_X3). */
+ * orders of magnitude inside the reference's 1e-3 -- at 2x its rate; unguarded by default (csrc/tail32.hip, AR_X3).  ABI 5: also
+ * the arithmetic every 16-bit handle runs its short reads (clm_set_short_read_len) and its first fall-back level in. */
 #define CLM_PREC_F16X3 4
 
 typedef struct clm_handle clm_handle;
@@ -141,22 +142,30 @@ int clm_check(clm_handle* h, void* stream);
  *   clm_selfcheck   runs `ids` (device memory, as clm_forward) through the handle's mode AND through the exact-fp32 kernels
  *                   and returns the largest |logit difference| (`max_abs_diff`, host; +inf if anything is not finite) and the
  *                   number of reads whose argmax differs (`labels_differ`, may be NULL).  Synchronises `stream`.  Not affected
- *                   by clm_set_fallback; 0 for a CLM_PREC_F32 handle and for lengths the mode itself runs in fp32.
- *   clm_set_fallback(h, 1)   every later clm_forward* of this handle runs in the exact-fp32 kernels (the caller's reaction to a
- *                   self-check above its threshold: chimeralm_amd/hyena.py uses 5e-4, half the reference tolerance); 0 undoes it.
- *   clm_effective_precision  the CLM_PREC_* code reads of L tokens run in right now. */
+ *                   by clm_set_fallback; 0 for a CLM_PREC_F32 handle.  Lengths a CLM_PREC_F16C handle runs in its fp16x3 kernels
+ *                   (clm_set_short_read_len) are measured like any other: fp16x3 against exact fp32.
+ *   clm_set_fallback(h, level)   ABI 5: a LEVEL, not a switch -- the reference computes one precision always (hyena.py:244-256), so
+ *                   the answer to "the fast mode is off" is the next-fastest arithmetic that is inside its tolerance, not the
+ *                   slowest.  0 = the handle's own mode.  1 = every later clm_forward* runs in the next arithmetic inside the
+ *                   gate: CLM_PREC_F16X3 on a 16-bit handle (fp32-class logits at about twice the exact-fp32 rate), exact fp32
+ *                   on a CLM_PREC_F16X3 handle.  2 = exact fp32 on every handle.  (The caller's reaction to a self-check above its
+ *                   threshold: chimeralm_amd/hyena.py uses level 1 at 5e-4, half the reference tolerance.)  No effect on a
+ *                   CLM_PREC_F32 handle.  Other values: CLM_E_INVALID.
+ *   clm_effective_precision  the CLM_PREC_* code reads of L tokens run in right now (CLM_PREC_F16X3 for the short reads of a
+ *                   CLM_PREC_F16C handle and for a 16-bit handle at fall-back level 1). */
 int clm_selfcheck(clm_handle* h, const void* ids, int ids_dtype, int64_t ids_row_stride, int B, int L, void* stream,
                   float* max_abs_diff, int* labels_differ);
-int clm_set_fallback(clm_handle* h, int on);
+int clm_set_fallback(clm_handle* h, int level);
 int clm_effective_precision(const clm_handle* h, int L);
 /* The reduction both self-checks report (pure host arithmetic, no device needed): a, b = logits [B][n_classes] of the mode and of
  * the referee; *max_abs_diff = the largest |a - b|, +inf as soon as ANY difference is not finite (and it stays +inf: a NaN in read
  * 0 must not be overwritten by a finite difference of read 1); *labels_differ = reads whose argmax differs (may be NULL). */
 int clm_logit_deviation(const float* a, const float* b, int B, int n_classes, float* max_abs_diff, int* labels_differ);
-/* CLM_PREC_F16C only: reads shorter than `min_len` tokens run in the exact-fp32 kernels inside the mode (default 2,048: the
- * mode's error is a sum of per-token fp16 roundings that the attention pooling averages like 1 / sqrt(L); below some length it
- * no longer fits half the tolerance).  That length depends on the weights: the caller may MEASURE it with clm_selfcheck on reads
- * of decreasing length (chimeralm_amd/hyena.py does, at 1,024 / 512 / 256 tokens) and lower or raise the switch. */
+/* CLM_PREC_F16C only: reads shorter than `min_len` tokens run in the fp16x3 kernels inside the mode (ABI 5; exact fp32 before, and
+ * still at fall-back level 2) -- default 2,048: the mode's error is a sum of per-token fp16 roundings that the attention pooling
+ * averages like 1 / sqrt(L); below some length it no longer fits half the tolerance.  That length depends on the weights: the caller
+ * may MEASURE it with clm_selfcheck(mode) on reads of decreasing length after clm_set_short_read_len(h, 1) (chimeralm_amd/hyena.py
+ * does, at 1,024 / 512 / 256 tokens, and lowers the switch only with a margin of 2 under its threshold) and lower or raise it. */
 int clm_set_short_read_len(clm_handle* h, int min_len);
 /* CLM_PREC_F16C only (round 4): the two MLP products (fc1, fc2: two thirds of the dense FLOPs) run on plain fp16 weights by default
  * -- on most weights their rounding does not show in the logits -- and on hi + lo weights, like in_proj / out_proj / the score
@@ -180,7 +189,7 @@ int clm_attention_fwd(const void* qkv, void* out, int B, int L, int precision, v
  * asserts the same, transformer.py:21).  clm_tf_debug_fetch names: "hidden" fp32 [B, L/8, 256] (encoder output),
  * "scores" fp32 [B, L/8] (pooling scores before the softmax), "pooled" fp32 [B, 256]. */
 typedef struct clm_tf_handle clm_tf_handle;
-int clm_tf_create(int device, int precision /* CLM_PREC_F32 (exact, parity mode) | CLM_PREC_F16C | CLM_PREC_F16 | CLM_PREC_BF16 */,
+int clm_tf_create(int device, int precision /* CLM_PREC_F32 (exact, parity mode) | CLM_PREC_F16X3 (fp32-class, the module default) | CLM_PREC_F16C | CLM_PREC_F16 | CLM_PREC_BF16 */,
                   int n_layers, clm_tf_handle** out);
 int clm_tf_load_weight(clm_tf_handle* h, const char* key, const void* data, int dtype, const int64_t* shape, int ndim);
 int clm_tf_finalize(clm_tf_handle* h);
@@ -189,10 +198,11 @@ int clm_tf_forward(clm_tf_handle* h, const void* ids, int ids_dtype, int64_t ids
 /* Round 3: the 16-bit mode on trial, as clm_selfcheck / clm_set_fallback for the Hyena engine.  A 16-bit handle keeps the raw fp32
  * tensors, so the exact-fp32 kernels (tf_fp32.hip) can run on the same handle: clm_tf_selfcheck runs `ids` through the handle's
  * mode and through them, synchronises `stream` and reports max |logit difference| and the number of reads whose label differs
- * (0 / 0 on an fp32 handle); clm_tf_set_fallback(h, 1) makes every later clm_tf_forward of the handle use the fp32 kernels. */
+ * (0 / 0 on an fp32 handle); clm_tf_set_fallback(h, level) has clm_set_fallback's levels: 1 = every later clm_tf_forward of a
+ * 16-bit handle runs the fp32-path kernels on hi + lo halfs (fp16x3; exact fp32 on an fp16x3 handle), 2 = exact fp32. */
 int clm_tf_selfcheck(clm_tf_handle* h, const void* ids, int ids_dtype, int64_t ids_row_stride, int B, int L, void* stream,
                      float* max_abs_diff_out, int* labels_differ_out);
-int clm_tf_set_fallback(clm_tf_handle* h, int on);
+int clm_tf_set_fallback(clm_tf_handle* h, int level);
 int clm_tf_debug_fetch(clm_tf_handle* h, const char* name, void* host_out, size_t bytes);
 /* Profiling taps of the 16-bit path (bench.py --net transformer): accumulated HIP-event time on the launch stream and number of
  * spans per stage -- 0 conv stack + positional encoding / LayerNorm, 1 attention, 2 encoder layer kernel (out_proj + LayerNorm-1

@@ -82,7 +82,7 @@ def test_16bit_modes(engines, sd, prec, B, L):
 @pytest.mark.parametrize("B,L", [(1, 2), (1, 5), (2, 128), (4, 513), (3, 2047), (3, 2048), (7, 2049), (2, 4097)])
 def test_fp16c_parity_shapes(engines, sd, B, L):
     """The throughput mode at the gate over the same shape classes as the fp32 mode.  Reads below 2048 tokens run through the
-    exact-fp32 kernels inside the fp16c engine (too few tokens for the pooling to average the fp16 activation roundings,
+    fp16x3 kernels inside the fp16c engine (too few tokens for the pooling to average the fp16 activation roundings,
     clm_api.hip effective_prec); 2047 / 2048 straddle that switch and alternate the element type of the shared z / y buffers."""
     _check(engines["fp16c"], "fp16c", _ids(B, L, pads=min(3, L - 1)), sd)
 
@@ -160,7 +160,7 @@ def test_fp16c_gate_over_weight_draws_and_lengths(built_lib, wseed):
         rep = m.net.selfcheck_report
         perr = float(np.abs(out - ref).max())
         print(f"weights {wseed}  L {L:5d}: raw |fp16c - oracle| {err:.2e}  (clm_selfcheck {sc:.2e})   guarded module: "
-              f"{'FELL BACK to fp32' if rep['fallback'] else 'kept, MLP hi + lo' if rep.get('mlp_compensation') else 'kept'}"
+              f"{'FELL BACK to fp16x3' if rep['fallback'] else 'kept, MLP hi + lo' if rep.get('mlp_compensation') else 'kept'}"
               f" -> |logits - oracle| {perr:.2e}")
         errx = float(np.abs(ex.forward(t).cpu().numpy() - ref).max())
         print(f"      fp16x3 on the same batch: |fp16x3 - oracle| {errx:.2e}")
@@ -171,13 +171,13 @@ def test_fp16c_gate_over_weight_draws_and_lengths(built_lib, wseed):
         assert abs(sc - err) <= 6e-5
         assert perr <= GATE and (out.argmax(1) == ref.argmax(1))[np.abs(ref[:, 0] - ref[:, 1]) > 2 * GATE].all()
         ran16 = not rep["fallback"] and m.net.engine(t.device).effective_precision(L) == "fp16c"
-        print(f"      length switch measured on these weights: {rep.get('f16c_min_len')} tokens; this batch ran in {'fp16c' if ran16 else 'exact fp32'}")
+        print(f"      length switch measured on these weights: {rep.get('f16c_min_len')} tokens; this batch ran in {'fp16c' if ran16 else 'fp16x3'}")
         if ran16:
             assert perr <= 5e-4 + 6e-5                       # kept: this batch was measured within the threshold
         worst = max(worst, err)
         del m
     if wseed in (1, 2, 3):
-        _check(e, "fp16c", _ids(6, 100, seed=60 + wseed), sdw)        # 100 tokens: the fp32 kernels inside the mode
+        _check(e, "fp16c", _ids(6, 100, seed=60 + wseed), sdw)        # 100 tokens: the fp16x3 kernels inside the mode
     e.close(), ex.close()
 
 
@@ -211,9 +211,14 @@ def test_second_level_of_fp16c_is_closer_where_the_mlp_weights_show(built_lib):
 
 def test_selfcheck_and_fallback_through_the_c_abi(engines, sd):
     """clm_selfcheck runs a batch through the handle's 16-bit mode AND the exact-fp32 kernels of the same handle:
-    the difference it reports is exactly max |mode logits - fp32-engine logits|; clm_set_fallback(1) makes every later forward
-    of the 16-bit handle bit-identical to the fp32 engine's (same kernels, same packing), clm_set_fallback(0) undoes it."""
+    the difference it reports is exactly max |mode logits - fp32-engine logits|.  clm_set_fallback is a LEVEL (ABI 5): 1 makes every
+    later forward of the 16-bit handle bit-identical to an fp16x3 engine's (the next arithmetic inside the gate: same kernels, same
+    packing), 2 to the fp32 engine's, 0 undoes it; on an fp16x3 handle level 1 is exact fp32 (it did nothing there)."""
+    from chimeralm_amd.engine import Engine, EngineError
+
     e, e32 = engines["fp16c"], engines["fp32"]
+    ex = Engine("cuda:0", precision="fp16x3", chunk_reads=4)
+    ex.load_state_dict(sd)
     for B, L in ((4, 2500), (3, 8193), (2, 16385)):
         t = torch.from_numpy(_ids(B, L, seed=301, pads=3)).cuda()
         a, r = e.forward(t).cpu(), e32.forward(t).cpu()
@@ -221,27 +226,49 @@ def test_selfcheck_and_fallback_through_the_c_abi(engines, sd):
         assert diff == float((a - r).abs().max()) and 0 < diff <= GATE
         assert differ == int((a.argmax(1) != r.argmax(1)).sum())
         assert torch.equal(e.forward(t).cpu(), a)                          # the self-check leaves the mode as it was
-        e.set_fallback(True)
+        x = ex.forward(t).cpu()
+        assert 0 < float((x - r).abs().max()) <= TOL["fp16x3"]
+        e.set_fallback(1)
+        assert e.effective_precision(L) == "fp16x3"
+        assert torch.equal(e.forward(t).cpu(), x)
+        assert e.selfcheck(t)[0] == diff                                   # not affected by the fallback level
+        e.set_fallback(2)
         assert e.effective_precision(L) == "fp32"
         assert torch.equal(e.forward(t).cpu(), r)
-        assert e.selfcheck(t)[0] == diff                                   # not affected by the fallback switch
-        e.set_fallback(False)
+        e.set_fallback(0)
         assert e.effective_precision(L) == "fp16c"
         assert torch.equal(e.forward(t).cpu(), a)
-    short = torch.from_numpy(_ids(3, 700, seed=302)).cuda()                # the mode itself runs these in fp32: nothing to measure
-    assert e.selfcheck(short) == (0.0, 0) and e.effective_precision(700) == "fp32"
+        if L == 2500:                                                      # an fp16x3 handle: level 1 = its own exact kernels
+            ex.set_fallback(1)
+            assert ex.effective_precision(L) == "fp32" and torch.equal(ex.forward(t).cpu(), r)
+            assert ex.selfcheck(t)[0] == float((x - r).abs().max())        # (the mode on trial, whatever the level)
+            ex.set_fallback(0)
+            assert ex.effective_precision(L) == "fp16x3" and torch.equal(ex.forward(t).cpu(), x)
+    with pytest.raises(EngineError, match="level must be"):
+        e.set_fallback(3)
+    short = torch.from_numpy(_ids(3, 700, seed=302)).cuda()                # the mode itself runs these in its fp16x3 kernels
+    d_short, differ_short = e.selfcheck(short)
+    assert e.effective_precision(700) == "fp16x3" and 0 < d_short <= TOL["fp16x3"] and differ_short == 0
+    assert torch.equal(e.forward(short).cpu(), ex.forward(short).cpu())
+    e.set_fallback(2)
+    assert e.effective_precision(700) == "fp32" and torch.equal(e.forward(short).cpu(), e32.forward(short).cpu())
+    e.set_fallback(0)
     assert e32.selfcheck(short) == (0.0, 0)
+    e32.set_fallback(1)                                                    # an exact handle has nothing to fall back to
+    assert e32.effective_precision(700) == "fp32"
+    e32.set_fallback(0)
+    ex.close()
     bf = engines["bf16"]                                                   # any 16-bit handle holds the referee
     d16, _ = bf.selfcheck(torch.from_numpy(_ids(3, 1000, seed=303)).cuda())
     assert GATE < d16 < TOL["bf16"]
 
 
-def test_module_selfcheck_falls_back_to_fp32_when_the_mode_breaks(built_lib):
+def test_module_selfcheck_falls_back_to_fp16x3_when_the_mode_breaks(built_lib):
     """`HyenaDna(precision="fp16c")` measures the mode on the LOADED weights before its first batch (seeded synthetic reads at
-    2,048 / 4,097 tokens + the batch's first reads) and falls back to exact fp32 above 5e-4.  Two weight sets: the seeded
-    draw 0 with the head weights scaled x1 (the mode passes and stays) and x6 (seven head layers: logits and their errors
-    grow ~20x over the parity tests' x3: the mode breaks; the module must notice, warn, and from then on give the fp32 engine's
-    logits bit for bit)."""
+    2,048 / 4,097 tokens + rows of the batch) and falls back above 5e-4 -- round 5: to fp16x3, the next-fastest arithmetic inside
+    the gate, not to exact fp32.  Two weight sets: the seeded draw 0 with the head weights scaled x1 (the mode passes and stays)
+    and x6 (seven head layers: logits and their errors grow ~20x over the parity tests' x3: the mode breaks; the module must
+    notice, warn, and from then on give an fp16x3 engine's logits bit for bit -- which are within 1e-4 of the oracle)."""
     import warnings
 
     from chimeralm_amd import lm
@@ -262,7 +289,7 @@ def test_module_selfcheck_falls_back_to_fp32_when_the_mode_breaks(built_lib):
     ref = ho.forward(ids.cpu(), good)
     assert (out.cpu() - ref).abs().max() <= GATE
     eng = m.net.engine(ids.device)
-    assert eng.effective_precision(3000) == "fp16c" and eng.effective_precision(rep["f16c_min_len"] - 1) == "fp32"
+    assert eng.effective_precision(3000) == "fp16c" and eng.effective_precision(rep["f16c_min_len"] - 1) == "fp16x3"
     m.net(ids)
     assert len(m.net.selfcheck_report["samples"]) == n_samples              # not again for a length inside the checked range ...
     short = ids[:, : rep["f16c_min_len"] + 40].contiguous()                 # ... but for a batch more than 1.5x shorter
@@ -272,25 +299,26 @@ def test_module_selfcheck_falls_back_to_fp32_when_the_mode_breaks(built_lib):
 
     bad = ho.make_state_dict(0, head_scale=6.0)
     m.load_state_dict(bad, strict=True)                                     # same module: new weights, new hearing
-    e32 = Engine("cuda:0", precision="fp32", chunk_reads=64)
+    e32 = Engine("cuda:0", precision="fp16x3", chunk_reads=64)
     e32.load_state_dict(bad)
     raw = Engine("cuda:0", precision="fp16c", chunk_reads=64)                # what the unguarded mode would answer
     raw.load_state_dict(bad)
-    # (1) the longest sample (4,097 tokens) fails: the length switch goes above it, and this 3,000-token batch runs in the fp32
-    #     kernels INSIDE the mode -- the fp32 engine's logits bit for bit, no fallback yet
+    # (1) the longest sample (4,097 tokens) fails: the length switch goes above it, and this 3,000-token batch runs in the fp16x3
+    #     kernels INSIDE the mode -- an fp16x3 engine's logits bit for bit, no fallback yet
     with warnings.catch_warnings():
         warnings.simplefilter("error", RuntimeWarning)
         out = m.net(ids)
     rep = m.net.selfcheck_report
-    assert rep["fallback"] is False and rep["f16c_min_len"] == 4098 and m.net.engine(ids.device).effective_precision(3000) == "fp32"
+    assert rep["fallback"] is False and rep["f16c_min_len"] == 4098 and m.net.engine(ids.device).effective_precision(3000) == "fp16x3"
     assert torch.equal(out.cpu(), e32.forward(ids).cpu())
+    assert (out.cpu() - ho.forward(ids.cpu(), bad)).abs().max() <= 2 * TOL["fp16x3"]      # (logits ~20x the parity tests')
     assert (raw.forward(ids).cpu() - out.cpu()).abs().max() > 5e-4
-    # (2) a batch above the switch is judged by its own rows: both levels of the mode fail on it -> exact fp32 for good
+    # (2) a batch above the switch is judged by its own rows: both levels of the mode fail on it -> fp16x3 for good
     long_ids = torch.from_numpy(_ids(4, 6000, seed=312, pads=2).astype(np.int64)).cuda()
-    with pytest.warns(RuntimeWarning, match="falling back to exact fp32"):
+    with pytest.warns(RuntimeWarning, match="falling back to fp16x3"):
         out = m.net(long_ids)
     rep = m.net.selfcheck_report
-    assert rep["fallback"] is True and rep["mlp_compensation"] is True and rep["max_abs_dlogit"] > 5e-4
+    assert rep["fallback"] is True and rep["fallback_precision"] == "fp16x3" and rep["mlp_compensation"] is True and rep["max_abs_dlogit"] > 5e-4
     assert torch.equal(out.cpu(), e32.forward(long_ids).cpu())
     assert (raw.forward(long_ids).cpu() - out.cpu()).abs().max() > 5e-4
     e32.close(), raw.close()

@@ -157,9 +157,10 @@ def test_fp16c_is_inside_the_gate_at_unit_logits(built_lib, seed, B, L):
     guarded.close()
 
 
-def test_selfcheck_falls_back_to_fp32_and_the_abi_agrees(built_lib):
+def test_selfcheck_falls_back_to_fp16x3_and_the_abi_agrees(built_lib):
     """Weights at scale 3, 1,000-token reads (logits ~5): the mode is 2e-3 off, the module measures that through `clm_tf_selfcheck`,
-    falls back, and from then on returns the fp32 engine's bits; the C entry's figure is the difference of the two modes."""
+    falls back -- round 5: to fp16x3, the next-fastest arithmetic inside the gate, not to the slowest -- and from then on returns an
+    fp16x3 engine's bits; the C entry's figure is the difference of the two modes; level 2 of the C entry is exact fp32."""
     import ctypes as C
 
     from chimeralm_amd import _native as N
@@ -168,6 +169,9 @@ def test_selfcheck_falls_back_to_fp32_and_the_abi_agrees(built_lib):
     ids = torch.from_numpy(to.synthetic_ids(100, 3, 1000)).cuda()
     exact = _model(sd, "fp32")
     want = exact(ids).cpu()
+    x3 = _model(sd, "fp16x3")
+    want_x3 = x3(ids).cpu()
+    assert (want_x3 - want).abs().max().item() < 1e-4 and not torch.equal(want_x3, want)
     raw = _model(sd, "fp16c")
     got_raw = raw(ids).cpu()
     lib = N.load()
@@ -178,25 +182,36 @@ def test_selfcheck_falls_back_to_fp32_and_the_abi_agrees(built_lib):
     print(f"clm_tf_selfcheck: {diff.value:.3e}; |fp16c - fp32| of two handles: {mine:.3e}")
     assert abs(diff.value - mine) < 1e-6 and diff.value > 5e-4 and differ.value == 0
     assert torch.equal(raw(ids).cpu(), got_raw)                  # the check leaves the mode as it was
-    assert lib.clm_tf_set_fallback(raw._h, 1) == 0
+    assert lib.clm_tf_set_fallback(raw._h, 1) == 0                # level 1: the fp32-path kernels on hi + lo halfs
+    assert torch.equal(raw(ids).cpu(), want_x3)
+    assert lib.clm_tf_selfcheck(raw._h, C.c_void_p(ids.data_ptr()), N.DT_I64, ids.stride(0), 3, 1000, None, C.byref(diff),
+                                C.byref(differ)) == 0 and abs(diff.value - mine) < 1e-6      # the MODE is on trial, whatever the level
+    assert lib.clm_tf_set_fallback(raw._h, 2) == 0                # level 2: exact fp32
     assert torch.equal(raw(ids).cpu(), want)
+    assert lib.clm_tf_set_fallback(raw._h, 3) != 0
     assert lib.clm_tf_set_fallback(raw._h, 0) == 0
     assert torch.equal(raw(ids).cpu(), got_raw)
+    # an fp16x3 handle: level 1 = its own exact kernels (the switch did nothing on such a handle)
+    assert lib.clm_tf_set_fallback(x3._h, 1) == 0 and torch.equal(x3(ids).cpu(), want)
+    assert lib.clm_tf_set_fallback(x3._h, 0) == 0 and torch.equal(x3(ids).cpu(), want_x3)
     # an fp32 handle reports 0 / 0
     assert lib.clm_tf_selfcheck(exact._h, C.c_void_p(ids.data_ptr()), N.DT_I64, ids.stride(0), 3, 1000, None, C.byref(diff),
                                 C.byref(differ)) == 0 and diff.value == 0.0 and differ.value == 0
     raw.close()
     guarded = _model(sd, "fp16c", selfcheck=True)
-    with pytest.warns(RuntimeWarning, match="falling back to exact fp32"):
+    with pytest.warns(RuntimeWarning, match="falling back to fp16x3"):
         got = guarded(ids).cpu()
     rep = guarded.selfcheck_report
-    assert rep["fallback"] is True and rep["max_abs_dlogit"] > rep["tol"] == 5e-4
-    assert torch.equal(got, want) and torch.equal(guarded(ids[:2, :499]).cpu(), exact(ids[:2, :499]).cpu())
+    assert rep["fallback"] is True and rep["fallback_precision"] == "fp16x3" and rep["max_abs_dlogit"] > rep["tol"] == 5e-4
+    assert torch.equal(got, want_x3) and torch.equal(guarded(ids[:2, :499]).cpu(), x3(ids[:2, :499]).cpu())
     guarded.load_state_dict(to.make_state_dict(0, to.PRODUCTION, scale=0.25), strict=True)   # new weights: on trial again
     guarded(ids)
     assert guarded.selfcheck_report["fallback"] is False
     guarded.close()
     exact.close()
+    x3.close()
+    from chimeralm_amd.transformer import SequenceCNNTransformer
+    assert SequenceCNNTransformer(vocab_size=12, max_len=16).precision == "fp16x3"     # the module default is a mode inside the gate
 
 
 def test_random_shapes_fp16c_against_the_exact_kernels(built_lib):
