@@ -1,6 +1,6 @@
 """Headline benchmark of the ChimeraLM `predict` hot path on MI355X (contract: see the task description).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch 256] [--bases 8192] [--precision P]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch 256] [--bases 8192] [--precision P]     (N > 1: starts its own ranks)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
            bench.py --gpus N --steps K --warmup W
 
@@ -243,6 +243,17 @@ def main():
     ap.add_argument("--net", default="hyena", choices=["hyena", "transformer"],
                     help="hyena = the production predict path (the headline metric); transformer = SequenceCNNTransformer")
     a = ap.parse_args()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` by itself: one rank per GPU, started here -- BEFORE anything in this process touches HIP -- under
+        # torch.distributed.run on a port that is free now (as `chimeralm_amd predict -g N` does).  Rank 0's JSON line is the
+        # children's stdout, relayed as it is; this process exits with their status.  The driver's own torchrun form is unchanged.
+        import subprocess
+
+        from chimeralm_amd.distributed import free_port
+
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", os.environ.get("MASTER_PORT") or str(free_port()), str(Path(__file__).resolve()), *sys.argv[1:]]
+        raise SystemExit(subprocess.call(cmd))
     if a.net == "transformer":
         return bench_transformer(a)
 
@@ -355,6 +366,17 @@ def main():
                  "f16c_min_len": rep.get("f16c_min_len"), "selfcheck_every": net.selfcheck_every,
                  "checks_inside_timed_region": rep.get("checks", 0) - checks0,
                  "samples": [(x["sample"], x["max_abs_dlogit"]) for x in rep.get("samples", [])]}
+    if guard is not None:
+        # the guard's verdict is per RANK (each engine hears its own shard): every rank's (arithmetic, level, fall-back) travels with
+        # the line, and a disagreement -- a run priced as uniform that was not -- is flagged
+        mine = {"rank": rank, "effective_precision": eff, "fallback": bool(rep.get("fallback")), "mlp_compensation": bool(rep.get("mlp_compensation")),
+                "max_abs_dlogit": rep.get("max_abs_dlogit"), "checks_inside_timed_region": rep.get("checks", 0) - checks0}
+        by_rank = [mine]
+        if world > 1:
+            by_rank = [None] * world
+            torch.distributed.all_gather_object(by_rank, mine)
+        guard["by_rank"] = by_rank
+        guard["ranks_agree"] = len({(g["effective_precision"], g["fallback"], g["mlp_compensation"]) for g in by_rank}) == 1
     gather_ms = sorted(gather.spans_ms()) if world > 1 else []
     if world > 1:                            # the collective's result, checked once: this rank's rows of the gathered batch
         assert torch.equal(out[lo:hi], logits2[(a.steps - 1) & 1]), "all-gather returned other logits than this rank computed"

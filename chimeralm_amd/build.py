@@ -16,7 +16,7 @@ LIB = CSRC / "libchimeralm_hip.so"
 # hipcc's per-kernel resource remarks of the last build (registers, scratch, LDS): tests/test_kernel_resources.py holds the hot
 # kernels to "no scratch" -- spills there are vector-memory traffic inside loops that were tuned to hide it
 RESOURCES = CSRC / "kernel_resources.txt"
-SOURCES = ["clm_api.hip", "gemm.hip", "gemm16.hip", "tail32.hip", "hyena_conv.hip", "head.hip", "lone_token.hip", "attention.hip", "tf_model.hip", "tf_fp32.hip", "bam_feeder.cpp", "bam_filter.cpp"]
+SOURCES = ["clm_api.hip", "gemm.hip", "gemm16.hip", "tail32.hip", "hyena_conv.hip", "head.hip", "pad_prefix.hip", "lone_token.hip", "attention.hip", "tf_model.hip", "tf_fp32.hip", "bam_feeder.cpp", "bam_filter.cpp"]
 HEADERS = ["clm_common.h", "clm_lab.h", "gemm_common.h", "gemm16_common.h", "fft_core.h", "fft_passes.h", "bgzf.h"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast", "-Wall", "-Wno-unused-function",
          "-Wno-pass-failed"]

@@ -128,13 +128,32 @@ struct clm_handle {
     std::vector<FilterSet> filters;
     uint64_t clock = 0;
     // workspace (one chunk of reads)
-    size_t ws_cap[13] = {};       // bytes of each workspace buffer (ensure_workspace: WS_H .. WS_YLO)
+    size_t ws_cap[15] = {};       // bytes of each workspace buffer (ensure_workspace: WS_H .. WS_TILES)
     size_t ws_es = 0;             // element size z / y were last written with
     float* h = nullptr;
     void *z = nullptr, *y = nullptr, *u = nullptr;
     float *scores = nullptr, *stats = nullptr, *partial = nullptr, *pooled = nullptr, *lone_ws = nullptr;
     float2* gscratch = nullptr;                     // segment spectra of the long-read convolution
     unsigned char* ylo = nullptr;                   // PREC_F16C: lo bytes of y [B][256][Lp] (round 4, clm_common.h lo8_pack4)
+    // Round 5, the [PAD] prefix of left-padded batches (pad_prefix.hip): per read the 128-token tiles wholly inside its leading run
+    // of [PAD], the list of tiles the tail kernels compute, and per arithmetic one table of what an all-[PAD] read leaves behind
+    int* pad_p0 = nullptr;                          // [B]
+    int* tile_list = nullptr;                       // [1 + B * tiles_x]
+    struct PadTable {
+        int prec = -1;                              // the arithmetic it was computed in (effective precision, fp16c's level, fp32 path: x3?)
+        bool mlp_lo = false, x3 = false;
+        int L = 0, Lp = 0;                          // tokens of the all-[PAD] read, row pitch of its z blocks
+        void* z[NLAYER] = {};                       // [i], i >= 1: the z block layer i's convolution reads ([D3][Lp] elements incl. lo planes)
+        float* scores = nullptr;                    // [L] pooling scores                                   (16-bit fused path)
+        float* partial = nullptr;                   // [ceil(L / 128)][POOL_PSTRIDE] pooling partials       (16-bit fused path)
+        float* hfin = nullptr;                      // [L][256] the last block's residual rows              (fp32 path: its pooling reads them)
+    };
+    std::vector<PadTable> pad_tables;
+    PadTable* capture = nullptr;                    // inside the forward that fills a table
+    unsigned char* pad_ids = nullptr;               // device, all PAD_ID: the table read's ids
+    size_t pad_ids_cap = 0;
+    float* pad_logits = nullptr;                    // device [2]: that read's logits (unused)
+    bool no_pad_skip = false;                       // CLM_DEBUG=no_pad_skip: every tile of every read is computed (A/B runs, tests)
     int last_B = 0, last_L = 0, last_Lp = 0;
     // debug / profiling
     int stop_layer = -1, stop_stage = -1;
@@ -293,7 +312,7 @@ void free_filters(clm_handle* h) {
 // The per-chunk workspace: twelve buffers, each with its own capacity in bytes and grown on its own -- a call needs Bc x (its
 // own length) of each, and chunk_for() bounds that product whatever the read length, so a handle that has seen 256 x 8k-token and
 // 32 x 32k-token batches holds the larger of the two needs per buffer, not 256 x 32k (the round-2 shape bookkeeping did).
-enum { WS_H, WS_Z, WS_Y, WS_U, WS_SCORES, WS_STATS, WS_PARTIAL, WS_POOLED, WS_GSCRATCH, WS_IDS8, WS_LONE, WS_EDGE_READ, WS_YLO, WS_N };
+enum { WS_H, WS_Z, WS_Y, WS_U, WS_SCORES, WS_STATS, WS_PARTIAL, WS_POOLED, WS_GSCRATCH, WS_IDS8, WS_LONE, WS_EDGE_READ, WS_YLO, WS_P0, WS_TILES, WS_N };
 static_assert(WS_N == sizeof(clm_handle::ws_cap) / sizeof(size_t), "one capacity per buffer");
 void** ws_slot(clm_handle* h, int i) {
     switch (i) {
@@ -309,6 +328,8 @@ void** ws_slot(clm_handle* h, int i) {
         case WS_IDS8: return (void**)&h->ids8;
         case WS_LONE: return (void**)&h->lone_ws;
         case WS_YLO: return (void**)&h->ylo;
+        case WS_P0: return (void**)&h->pad_p0;
+        case WS_TILES: return (void**)&h->tile_list;
         default: return (void**)&h->edge_read;
     }
 }
@@ -342,6 +363,17 @@ void free_packed(clm_handle* h) {
         if (h->head_t[j]) { (void)hipFree(h->head_t[j]); h->head_t[j] = nullptr; }
 }
 
+void free_pad_tables(clm_handle* h) {
+    for (auto& t : h->pad_tables) {
+        for (int i = 0; i < NLAYER; ++i)
+            if (t.z[i]) (void)hipFree(t.z[i]);
+        if (t.scores) (void)hipFree(t.scores);
+        if (t.partial) (void)hipFree(t.partial);
+        if (t.hfin) (void)hipFree(t.hfin);
+    }
+    h->pad_tables.clear();
+}
+
 const float* W(clm_handle* h, const std::string& key) { return h->w[key].d; }
 
 // exact fp32 runs its block tails fused (tail32.hip) unless a debug stop wants an intermediate or CLM_DEBUG=unfused_fp32 asks
@@ -364,6 +396,8 @@ int ensure_workspace(clm_handle* h, int Bc, int L, hipStream_t st) {
     need[WS_IDS8] = nb * Lp;
     need[WS_EDGE_READ] = nb * D3 * sizeof(float2);
     need[WS_YLO] = h->cfg.precision == PREC_F16C ? nb * D * Lp : 0;
+    need[WS_P0] = nb * sizeof(int);
+    need[WS_TILES] = (1 + nb * ((nl + 127) / 128)) * sizeof(int);
     if (conv_segments_for(L) > 1) need[WS_GSCRATCH] = ((nb + 1) / 2) * D * (size_t)conv_segments_for(L) * 16384 * sizeof(float2);
     bool grow = false;
     for (int i = 0; i < WS_N; ++i) grow |= need[i] > h->ws_cap[i];
@@ -522,8 +556,80 @@ int chunk_for(const clm_handle* h, int L) {
     const long long cap_tokens = (effective_prec(h, L) == PREC_F32 && !fused_fp32(h)) ? 64LL * 8256 : 256LL * 8256;
     long long c = cap_tokens / round_up(L, LP_ALIGN);
     if (c > h->cfg.chunk_reads) c = h->cfg.chunk_reads;
+    if (c > TILE_LIST_MAX_READS) c = TILE_LIST_MAX_READS;     // (a tile-list entry holds its read in 12 bits)
     if (c > 1) c &= ~1LL;
     return c < 1 ? 1 : (int)c;
+}
+
+int forward_chunk(clm_handle* h, const void* ids, int ids_dtype, int64_t row_stride, int Bc, int L, float* logits,
+                  hipStream_t st);
+
+// The all-[PAD] table of the arithmetic reads of this chunk run in (pad_prefix.hip), long enough for L tokens: built on first
+// use -- ONE forward of one all-[PAD] read through this very engine, with forward_chunk's capture hooks copying out what the
+// later stages read of it -- and kept until the weights change.  Lengths come in classes (1,025 ... 32,769 tokens, then
+// max_seq_len) so that a file of ragged batches builds at most a handful.  The values at position t do not depend on the length of
+// the read they were computed in (causal backbone, taps independent of L) beyond the rounding of its transform size.
+int ensure_pad_table(clm_handle* h, int prec, bool x3, int L, hipStream_t st, clm_handle::PadTable** out) {
+    for (auto& t : h->pad_tables)
+        if (t.prec == prec && t.x3 == x3 && t.mlp_lo == (prec == PREC_F16C && h->mlp_lo) && t.L >= L) { *out = &t; return CLM_OK; }
+    int LT = 1025;
+    while (LT < L && LT < 32769) LT = 2 * (LT - 1) + 1;
+    if (LT < L) LT = h->cfg.max_seq_len;
+    if (LT > h->cfg.max_seq_len) LT = h->cfg.max_seq_len;
+    if (LT < L) return fail(h, CLM_E_INVALID, "ensure_pad_table: read longer than max_seq_len");
+    HIPCHK(h, hipStreamSynchronize(st));
+    for (size_t k = 0; k < h->pad_tables.size(); ++k) {      // a shorter table of the same arithmetic is replaced
+        auto& t = h->pad_tables[k];
+        if (t.prec == prec && t.x3 == x3 && t.mlp_lo == (prec == PREC_F16C && h->mlp_lo)) {
+            for (int i = 0; i < NLAYER; ++i)
+                if (t.z[i]) (void)hipFree(t.z[i]);
+            if (t.scores) (void)hipFree(t.scores);
+            if (t.partial) (void)hipFree(t.partial);
+            if (t.hfin) (void)hipFree(t.hfin);
+            h->pad_tables.erase(h->pad_tables.begin() + (long)k);
+            break;
+        }
+    }
+    clm_handle::PadTable t;
+    t.prec = prec; t.x3 = x3; t.mlp_lo = prec == PREC_F16C && h->mlp_lo;
+    t.L = LT; t.Lp = round_up(LT, LP_ALIGN);
+    const size_t es = elem_size(prec);
+    for (int i = 1; i < NLAYER; ++i) HIPCHK(h, hipMalloc(&t.z[i], (size_t)D3 * t.Lp * es));
+    if (prec == PREC_F32) HIPCHK(h, hipMalloc((void**)&t.hfin, (size_t)LT * D * 4));
+    else {
+        HIPCHK(h, hipMalloc((void**)&t.scores, (size_t)LT * 4));
+        HIPCHK(h, hipMalloc((void**)&t.partial, (size_t)((LT + 127) / 128) * POOL_PSTRIDE * 4));
+    }
+    if ((size_t)t.Lp > h->pad_ids_cap) {
+        if (h->pad_ids) HIPCHK(h, hipFree(h->pad_ids));
+        h->pad_ids = nullptr; h->pad_ids_cap = 0;
+        HIPCHK(h, hipMalloc((void**)&h->pad_ids, (size_t)t.Lp));
+        h->pad_ids_cap = (size_t)t.Lp;
+        HIPCHK(h, hipMemsetAsync(h->pad_ids, PAD_ID, (size_t)t.Lp, st));
+    }
+    if (!h->pad_logits) HIPCHK(h, hipMalloc((void**)&h->pad_logits, NCLS * 4));
+    h->pad_tables.push_back(t);
+    clm_handle::PadTable* tp = &h->pad_tables.back();
+    const int force = h->force_prec;
+    const bool prof = h->prof;
+    h->force_prec = prec;                                    // (fp16c: the class length may lie on the other side of the length switch)
+    h->prof = false;
+    h->capture = tp;
+    const int rc = forward_chunk(h, h->pad_ids, CLM_DT_U8, t.Lp, 1, LT, h->pad_logits, st);
+    h->capture = nullptr;
+    h->prof = prof;
+    h->force_prec = force;
+    if (rc) {
+        for (int i = 0; i < NLAYER; ++i)
+            if (tp->z[i]) (void)hipFree(tp->z[i]);
+        if (tp->scores) (void)hipFree(tp->scores);
+        if (tp->partial) (void)hipFree(tp->partial);
+        if (tp->hfin) (void)hipFree(tp->hfin);
+        h->pad_tables.pop_back();
+        return rc;
+    }
+    *out = tp;
+    return CLM_OK;
 }
 
 int forward_chunk(clm_handle* h, const void* ids, int ids_dtype, int64_t row_stride, int Bc, int L, float* logits,
@@ -562,6 +668,27 @@ int forward_chunk(clm_handle* h, const void* ids, int ids_dtype, int64_t row_str
     // exact fp32: one fused kernel per block tail, the next block's in_proj included (tail32.hip)
     const bool fused32 = prec == PREC_F32 && fused_fp32(h);
     const bool x3 = fused32 && fp32_path_is_x3(h);              // fp16x3: hi + lo halfs in the fused tails (the referee pass: exact)
+    // Round 5: tiles wholly inside a read's [PAD] prefix are not computed, their rows come from the all-[PAD] table (pad_prefix.hip).
+    // In the fused paths only (the debug / unfused paths keep computing everything), never inside the forward that fills a table,
+    // and only for reads long enough to hold a whole prefix tile next to a real token.
+    const int Lmain = (tuned16 && peel) ? L - 1 : L;
+    const bool tail16_path = tuned16 && !h->split_tail;      // the persistent tail kernel runs: it walks the tile list
+    const bool pad_skip = !h->no_pad_skip && !h->capture && L >= 256 && ((tail16_path && fuse_next) || fused32);
+    clm_handle::PadTable* ptab = nullptr;
+    if (pad_skip) {                                          // (before this chunk's ids land in the workspace: the build runs through it)
+        rc = ensure_pad_table(h, prec, x3, L, st, &ptab);
+        if (rc) return rc;
+        rc = ensure_workspace(h, Bc, L, st);                 // (the build may have regrown -- never shrunk -- the buffers; cheap when not)
+        if (rc) return rc;
+        h->last_B = Bc; h->last_L = L; h->last_Lp = Lp;
+        if (h->ws_es != elem_size(prec)) {                   // (as above: the build ran in this chunk's own arithmetic, so this is a no-op)
+            HIPCHK(h, hipMemsetAsync(h->z, 0, h->ws_cap[WS_Z], st));
+            HIPCHK(h, hipMemsetAsync(h->y, 0, h->ws_cap[WS_Y], st));
+            h->ws_es = elem_size(prec);
+        }
+        rc = ensure_filters(h, L, st, &fs, &kr);             // (the build may have added a filter class: the vector behind fs moved)
+        if (rc) return rc;
+    }
     // fp16c, round 4: y (every block) and the gated rows of z carry one lo byte per element next to the halfs
     unsigned char* const ylo = (prec == PREC_F16C && tuned16) ? h->ylo : nullptr;
     if (zgated && tail16_grid(((peel ? L - 1 : L) + 127) / 128 * Bc) > 1024)
@@ -576,6 +703,7 @@ int forward_chunk(clm_handle* h, const void* ids, int ids_dtype, int64_t row_str
                      h->ids8, Bc, L, Lp, st, h->bad_ids);
     }
     if (stop_here(h, -1, CLM_STAGE_EMBED)) return CLM_OK;
+    if (tail16_path || pad_skip) launch_pad_tiles(h->ids8, Bc, Lp, Lmain, pad_skip ? 1 : 0, h->pad_p0, h->tile_list, st);
     for (int i = 0; i < NLAYER; ++i) {
         const LayerW& lw = x3 ? h->lwx[i] : (alt32 ? h->lw32[i] : h->lw[i]);
         // block 0 in the 16-bit modes: its in_proj output is a function of the token id alone, the convolution looks it
@@ -611,6 +739,7 @@ int forward_chunk(clm_handle* h, const void* ids, int ids_dtype, int64_t row_str
                         nullptr, nullptr, nullptr, nullptr, nullptr, spa};
             ta.ylo = ylo;
             ta.mlp_lo = mlpc;
+            ta.tiles = h->tile_list;
             int next = NEXT_NONE;
             if (fuse_next && i + 1 < NLAYER) {
                 const LayerW& nx = h->lw[i + 1];
@@ -649,12 +778,33 @@ int forward_chunk(clm_handle* h, const void* ids, int ids_dtype, int64_t row_str
                 la.ylo = ylo; la.zlo = ta.zlo;
                 launch_lone_token(prec, la, st);
             }
+            // the [PAD] prefix: what this block leaves for the next stage, copied out of (capture) or in from (pad_skip) the table
+            const int nrow16 = ta.zg ? 2 * D : D3, nlo = ta.zlo ? 2 * D : 0;
+            if (h->capture && fuse_next) {
+                if (next == NEXT_INPROJ) HIPCHK(h, hipMemcpyAsync(h->capture->z[i + 1], h->z, (size_t)D3 * Lp * elem_size(prec), hipMemcpyDeviceToDevice, st));
+                else {
+                    HIPCHK(h, hipMemcpyAsync(h->capture->scores, h->scores, (size_t)L * 4, hipMemcpyDeviceToDevice, st));
+                    HIPCHK(h, hipMemcpyAsync(h->capture->partial, h->partial, (size_t)((L + 127) / 128) * POOL_PSTRIDE * 4, hipMemcpyDeviceToDevice, st));
+                }
+            } else if (pad_skip) {
+                if (next == NEXT_INPROJ)
+                    launch_prefix_fill_z(h->pad_p0, h->z, ptab->z[i + 1], Bc, Lp, ptab->Lp, Lmain, (int)elem_size(prec), nrow16, nlo, st);
+                else
+                    launch_prefix_fill_pool(h->pad_p0, h->scores, h->partial, ptab->scores, ptab->partial, Bc, L, (L + 127) / 128, Lmain, st);
+            }
         } else if (fused32) {
             StageTimer t(h, st, CLM_STAGE_TAIL);
             const LayerW* nx = i + 1 < NLAYER ? &(x3 ? h->lwx[i + 1] : (alt32 ? h->lw32[i + 1] : h->lw[i + 1])) : nullptr;
             launch_tail32(reinterpret_cast<const float*>(h->y), h->h, lw.t_out, lw.t_fc1, lw.t_fc2, nx ? nx->t_in : nullptr, lw.b_out,
                           lw.b_fc1, lw.b_fc2, nx ? nx->b_in : nullptr, lw.ln2_g, lw.ln2_b, nx ? nx->ln1_g : nullptr,
-                          nx ? nx->ln1_b : nullptr, reinterpret_cast<float*>(h->z), Bc, L, Lp, eps, st, x3);
+                          nx ? nx->ln1_b : nullptr, reinterpret_cast<float*>(h->z), Bc, L, Lp, eps, st, x3, pad_skip ? h->pad_p0 : nullptr);
+            if (h->capture) {
+                if (nx) HIPCHK(h, hipMemcpyAsync(h->capture->z[i + 1], h->z, (size_t)D3 * Lp * 4, hipMemcpyDeviceToDevice, st));
+                else HIPCHK(h, hipMemcpyAsync(h->capture->hfin, h->h, (size_t)L * D * 4, hipMemcpyDeviceToDevice, st));
+            } else if (pad_skip) {
+                if (nx) launch_prefix_fill_z(h->pad_p0, h->z, ptab->z[i + 1], Bc, Lp, ptab->Lp, L, 4, D3, 0, st);
+                else launch_prefix_fill_h(h->pad_p0, h->h, ptab->hfin, Bc, L, L, st);
+            }
         } else {
             {
                 StageTimer t(h, st, CLM_STAGE_OUTPROJ);
@@ -755,6 +905,7 @@ int clm_create(const clm_config* cfg, int device, clm_handle** out) {
     if (debug_flag("conv_oneshot")) h->conv_flags |= CONV_ONESHOT;
     if (debug_flag("conv_no_xcd")) h->conv_flags |= CONV_NO_XCD;
     h->raw_z = debug_flag("raw_z");                    // the fused in_proj stage writes x0 | x1 | v as before round 3
+    h->no_pad_skip = debug_flag("no_pad_skip");        // tiles inside a read's [PAD] prefix are computed like any other
     h->cfg = *cfg;
     if (cfg->precision == CLM_PREC_F16X3) {             // an exact-fp32 engine whose fused tails multiply hi + lo halfs
         h->x3 = true;
@@ -822,6 +973,7 @@ int clm_finalize(clm_handle* h) {
     HIPCHK(h, hipDeviceSynchronize());
     free_packed(h);
     free_filters(h);
+    free_pad_tables(h);                                      // (functions of the weights)
     const int prec = h->cfg.precision;
     // hi + lo halfs of the tail weights: an fp16x3 handle's own arithmetic; a 16-bit handle's short reads and first fall-back level
     const bool pack_x3 = (h->x3 || prec != PREC_F32) && !h->unfused_fp32;
@@ -1200,6 +1352,9 @@ int clm_destroy(clm_handle* h) {
     free_workspace(h);
     free_filters(h);
     free_packed(h);
+    free_pad_tables(h);
+    if (h->pad_ids) (void)hipFree(h->pad_ids);
+    if (h->pad_logits) (void)hipFree(h->pad_logits);
     if (h->sc_logits) (void)hipFree(h->sc_logits);
     if (h->edge_bnd) (void)hipFree(h->edge_bnd);
     for (auto& sg : h->stage) {

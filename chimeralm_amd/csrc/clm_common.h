@@ -202,7 +202,8 @@ void launch_embed(const void* ids, int ids_dtype, int64_t row_stride, const floa
 void launch_tail32(const float* y, float* h, const void* w_out, const void* w_fc1, const void* w_fc2, const void* w_in_next,
                    const float* b_out, const float* b_fc1, const float* b_fc2, const float* b_in_next, const float* ln2_g,
                    const float* ln2_b, const float* n_g, const float* n_b, float* z, int B, int L, int Lp, float eps, hipStream_t st,
-                   bool x3 = false /*three fp16 MFMAs on hi + lo halfs per product, weights from launch_pack_x3*/);
+                   bool x3 = false /*three fp16 MFMAs on hi + lo halfs per product, weights from launch_pack_x3*/,
+                   const int* p0 = nullptr /*[B]: tiles inside each read's [PAD] prefix, skipped (pad_prefix.hip)*/);
 void launch_pack_x3(const float* w /*[n][k]*/, void* out /*n * k * 4 bytes*/, int n, int k, hipStream_t st);
 void launch_pack_f32t(const float* w /*[n][k]*/, void* out /*n * k floats*/, int n, int k, hipStream_t st);
 // SequenceCNNTransformer, exact fp32 (tail32.hip conv32_kernel): Conv1d(k = 3, padding = 1) + ReLU + MaxPool1d(2); w = three taps
@@ -279,7 +280,32 @@ struct TailArgs {
     const unsigned char* ylo; // [B][256][Lp] lo bytes of y, written by the convolution (null: y is plain fp16)
     int zlo;                  // zg only: the gated in_proj stage also writes the lo bytes of x0f | g into rows 512.. of n_z ([2][256][Lp])
     int mlp_lo;               // PREC_F16C: w1 / w2 are packed as hi + lo too (tail16_kernel MLPC) instead of plain fp16
+    // Round 5 (pad_prefix.hip): the tiles this launch computes, as a device list -- tiles[0] = their number, tiles[1 + j] = entry j
+    // (tile_entry / tile_b / tile_tx / tile_cont below), reads in order, tiles of a read ascending and contiguous from its first
+    // computed tile on.  Tiles wholly inside a read's [PAD] prefix are not in it: their rows come from the all-[PAD] table.
+    const int* tiles;
 };
+// entry of the tile list: read b (< 4096), 128-token tile tx of that read (< 2^19), cont = the entry before it is tile tx - 1 of the
+// same read (then the short filter's two-token history travels from one to the other as before; a read's first computed tile
+// starts without history -- right for tile 0, and for a later tile its first two tokens lie inside the prefix the table overwrites)
+__host__ __device__ inline int tile_entry(int b, int tx, bool cont) { return b | (tx << 12) | (cont ? (int)0x80000000u : 0); }
+__host__ __device__ inline int tile_b(int e) { return e & 0xfff; }
+__host__ __device__ inline int tile_tx(int e) { return (e >> 12) & 0x7ffff; }
+__host__ __device__ inline bool tile_cont(int e) { return e < 0; }
+constexpr int TILE_LIST_MAX_READS = 4096;
+constexpr int PAD_ID = 4;         // [PAD] of the reference's tokenizer (chimeralm/data/tokenizer.py:152-159 pads on the left with it)
+// p0[b] = 128-token tiles wholly inside read b's leading run of [PAD] (0 for every read when `enabled` is 0), and the tile list of
+// the reads' remaining tiles -- each read from one tile BEFORE its first non-prefix tile on (that tile hands the gated in_proj stage
+// its history; what it writes lies inside the prefix and is overwritten from the table)
+void launch_pad_tiles(const unsigned char* ids8, int B, int Lp, int Lmain, int enabled, int* p0, int* tiles, hipStream_t st);
+// rows [0, 128 p0[b]) of every read's z block (nrow16 element rows of `es` bytes + nlo byte rows behind 2 D element rows, as the
+// gated hand-over lays them out) <- the same rows of the all-[PAD] table (one read, row pitch LpT)
+void launch_prefix_fill_z(const int* p0, void* z, const void* table, int B, int Lp, int LpT, int Lmain, int es, int nrow16, int nlo, hipStream_t st);
+// the same for the last block's products: pooling scores [B][L] and per-tile pooling partials [B][ntiles][POOL_PSTRIDE]
+void launch_prefix_fill_pool(const int* p0, float* scores, float* partial, const float* t_scores, const float* t_partial, int B, int L,
+                             int ntiles, int Lmain, hipStream_t st);
+// ... and for the exact path, whose pooling kernels read the residual stream itself: rows [0, 128 p0[b]) of h [B][L][256]
+void launch_prefix_fill_h(const int* p0, float* h, const float* t_h, int B, int L, int Lmain, hipStream_t st);
 // tiles of the tail kernel are taken in CONTIGUOUS ranges per workgroup (the short filter's two-token history then comes from the
 // workgroup's own previous tile): range length for `total` tiles on `grid` workgroups
 __host__ __device__ inline int tail_range_len(int total, int grid) { return (total + grid - 1) / grid; }

@@ -500,10 +500,11 @@ __device__ __forceinline__ void inproj_blocks_gated_lo(const f16_t* As, const un
 // Tokens 0, 1 of the first tile of every workgroup range that starts inside a read (inproj_blocks_gated computed them without
 // their history): recomputed from the raw values either side of the boundary.  One workgroup per boundary, one thread per channel.
 template <typename T>
-__global__ __launch_bounds__(256) void gated_patch_kernel(TailArgs m, int tiles_x, int total, int range) {
-    const int w = blockIdx.x + 1, c = threadIdx.x, tile = w * range;
-    if (tile >= total || tile % tiles_x == 0) return;
-    const int b = tile / tiles_x, t0 = (tile % tiles_x) * 128;
+__global__ __launch_bounds__(256) void gated_patch_kernel(TailArgs m, int grid) {
+    const int range = tail_range_len(m.tiles[0], grid);
+    const int w = blockIdx.x + 1, c = threadIdx.x, tile = w * range;      // (`tile`: an index into the tile list, as in tail16_kernel)
+    if (tile >= m.tiles[0] || !tile_cont(m.tiles[1 + tile])) return;
+    const int b = tile_b(m.tiles[1 + tile]), t0 = tile_tx(m.tiles[1 + tile]) * 128;
     float zf[3][2];
 #pragma unroll
     for (int q = 0; q < 3; ++q) {
@@ -918,7 +919,10 @@ __global__ __launch_bounds__(512) void tail16_kernel(TailArgs m, unsigned long l
                 : (NEXT == NEXT_INPROJ ? m.n_bias[i - BT_NB] : 0.f);
     // Persistent workgroup over a CONTIGUOUS range of tiles (tail_range_len): consecutive tiles of a read follow each other in
     // one workgroup, which is what lets the gated in_proj stage carry the short filter's two-token history from tile to tile.
-    const int L = m.L, Lp = m.Lp, tiles_x = (m.Lmain + BM - 1) / BM, total = tiles_x * m.B;
+    // Round 5: "tiles" are entries of the device list m.tiles (pad_prefix.hip) -- every tile of every read when no read is padded,
+    // fewer when tiles lie wholly inside [PAD] prefixes; `tile` below is an index into that list, (b, t0) come from its entry.
+    const int L = m.L, Lp = m.Lp, tiles_x = (m.Lmain + BM - 1) / BM, total = m.tiles[0];
+    const int* const tlist = m.tiles + 1;
     const int range = tail_range_len(total, (int)gridDim.x), tile_begin = (int)blockIdx.x * range,
               tile_end = tile_begin + range < total ? tile_begin + range : total;
     if (tile_begin >= total) return;                        // (whole workgroup, before any barrier)
@@ -942,11 +946,13 @@ __global__ __launch_bounds__(512) void tail16_kernel(TailArgs m, unsigned long l
     uint4 yl[LOY ? 4 : 1];
     unsigned char* Aly = smem + (size_t)D * RSKM * 2;
     static_assert((size_t)D * RSKM * 2 % 16 == 0 && (size_t)D * RSKM * 2 + 128 * RSL <= (size_t)2 * BM * RS16 * 2, "y lo tile fits behind the y tile");
-    tail_load_resid(m, hv, tile_begin / tiles_x, (tile_begin % tiles_x) * BM, (int)threadIdx.x >> 6, (int)threadIdx.x & 31,
-                    ((int)threadIdx.x >> 5) & 1);
-    tail_load_y_piece<elem>(m, yx, 0, tile_begin / tiles_x, (tile_begin % tiles_x) * BM, threadIdx.x);
-    tail_load_y_piece<elem>(m, yx, 1, tile_begin / tiles_x, (tile_begin % tiles_x) * BM, threadIdx.x);
-    if constexpr (LOY) tail_load_ylo(m, yl, tile_begin / tiles_x, (tile_begin % tiles_x) * BM, threadIdx.x);
+    {
+        const int e0 = tlist[tile_begin], fb = tile_b(e0), ft0 = tile_tx(e0) * BM;
+        tail_load_resid(m, hv, fb, ft0, (int)threadIdx.x >> 6, (int)threadIdx.x & 31, ((int)threadIdx.x >> 5) & 1);
+        tail_load_y_piece<elem>(m, yx, 0, fb, ft0, threadIdx.x);
+        tail_load_y_piece<elem>(m, yx, 1, fb, ft0, threadIdx.x);
+        if constexpr (LOY) tail_load_ylo(m, yl, fb, ft0, threadIdx.x);
+    }
 #pragma unroll 1
     for (int tile = tile_begin; tile < tile_end; ++tile) {
     // the thread index is made opaque once per trip: every address below is re-derived inside the trip instead of being
@@ -955,7 +961,7 @@ __global__ __launch_bounds__(512) void tail16_kernel(TailArgs m, unsigned long l
     asm volatile("" : "+v"(tid_l));
     // (the wave index as a scalar: every address term derived from it stays out of the vector registers)
     const int tid = tid_l, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lrow = lane & 31, lhalf = lane >> 5;
-    const int b = tile / tiles_x, t0 = (tile % tiles_x) * BM;
+    const int entry = tlist[tile], b = tile_b(entry), tx = tile_tx(entry), t0 = tx * BM;
     CLM_STAMP_AT(0);
     if (STAMP && threadIdx.x == 0) stamps[(size_t)tile * TAIL_NSTAMP + 27] = __builtin_amdgcn_s_memrealtime();   // 100 MHz
     // ---- 0. everything that only depends on addresses is requested first
@@ -1086,8 +1092,8 @@ __global__ __launch_bounds__(512) void tail16_kernel(TailArgs m, unsigned long l
     }
     CLM_STAMP_AT(18);
     // residual rows of this workgroup's next tile (clamped to the current one on the last trip: unconditional loads)
-    const int nt = tile + 1 < tile_end ? tile + 1 : tile;
-    const int nb_ = nt / tiles_x, nt0 = (nt % tiles_x) * BM;
+    const int nentry = tlist[tile + 1 < tile_end ? tile + 1 : tile];
+    const int nb_ = tile_b(nentry), nt0 = tile_tx(nentry) * BM;
     if constexpr (NEXT == NEXT_NONE) {
         tail_load_resid(m, hv, nb_, nt0, wave, lrow, lhalf);
         tail_load_y_piece<elem>(m, yx, 0, nb_, nt0, tid);
@@ -1117,9 +1123,10 @@ __global__ __launch_bounds__(512) void tail16_kernel(TailArgs m, unsigned long l
             // (ZG: none in the hooks in any mode -- x1f occupies the fc2 accumulators while v is computed)
             constexpr int PIECES = (PREC == PREC_F16C || ZG) ? 0 : 4;
             if constexpr (ZG) {
-                const int tx = tile % tiles_x;
-                const GatedTile gt{tile == tile_begin || tx == 0, tile == tile_begin && tx != 0,
-                                   tile + 1 == tile_end && tile + 1 < total && (tile + 1) % tiles_x != 0,
+                // (history: from the previous LIST entry where that is the previous tile of the same read -- tile_cont)
+                const bool cont = tile_cont(entry);
+                const GatedTile gt{tile == tile_begin || !cont, tile == tile_begin && cont,
+                                   tile + 1 == tile_end && tile + 1 < total && tile_cont(tlist[tile + 1 < total ? tile + 1 : tile]),
                                    tx == tiles_x - 1 && m.edge_read != nullptr, (int)blockIdx.x};
                 const ResidHook<elem, PIECES, LOY ? 4 : 1> rhook{m, hv, yx, yl, nb_, nt0, wave, lrow, lhalf, tid,
                                                                  STAMP ? stamps + (size_t)tile * TAIL_NSTAMP : nullptr};
@@ -1134,7 +1141,7 @@ __global__ __launch_bounds__(512) void tail16_kernel(TailArgs m, unsigned long l
 #pragma unroll
             for (int mt = PIECES; mt < 4; ++mt) tail_load_resid_piece(m, hv[mt], mt, nb_, nt0, wave, lrow, lhalf);
         } else {
-            score_pool_tile<PREC, LOF>(m.sp, As, reinterpret_cast<float*>(Hs), b, tile % tiles_x, tid, bs, acc1, Alf);
+            score_pool_tile<PREC, LOF>(m.sp, As, reinterpret_cast<float*>(Hs), b, tx, tid, bs, acc1, Alf);
             // (requested before the score stage these 96 registers spill through its erf epilogue: one launch in four)
             tail_load_resid(m, hv, nb_, nt0, wave, lrow, lhalf);
             tail_load_y_piece<elem>(m, yx, 0, nb_, nt0, tid);
@@ -1257,11 +1264,11 @@ static int tail_cus() {
 int tail16_grid(int total_tiles) { return total_tiles < tail_cus() ? total_tiles : tail_cus(); }
 
 void launch_gated_patch(int prec, const TailArgs& m, hipStream_t st) {
-    const int tiles_x = (m.Lmain + 127) / 128, total = tiles_x * m.B, grid = tail16_grid(total);
+    // (the grid of the tail launch this patches: sized for every tile of every read; the list may hold fewer -- the ranges follow it)
+    const int tiles_x = (m.Lmain + 127) / 128, grid = tail16_grid(tiles_x * m.B);
     if (grid < 2) return;
-    const int range = tail_range_len(total, grid);
-    if (prec == PREC_BF16) hipLaunchKernelGGL(gated_patch_kernel<bf16_t>, dim3(grid - 1), dim3(256), 0, st, m, tiles_x, total, range);
-    else hipLaunchKernelGGL(gated_patch_kernel<f16_t>, dim3(grid - 1), dim3(256), 0, st, m, tiles_x, total, range);
+    if (prec == PREC_BF16) hipLaunchKernelGGL(gated_patch_kernel<bf16_t>, dim3(grid - 1), dim3(256), 0, st, m, grid);
+    else hipLaunchKernelGGL(gated_patch_kernel<f16_t>, dim3(grid - 1), dim3(256), 0, st, m, grid);
 }
 
 void launch_tail16(int prec, const TailArgs& m, int next, hipStream_t st) {

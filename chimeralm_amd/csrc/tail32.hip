@@ -257,6 +257,7 @@ struct Tail32Args {
     float* z;                 // [B, 768, Lp] fp32 (NEXT)
     int B, L, Lp, tiles_x;
     float eps;
+    const int* p0;            // [B] or null: 128-token tiles wholly inside each read's [PAD] prefix (pad_prefix.hip) -- not computed
 };
 
 template <bool NEXT, int AR = AR_F32>
@@ -271,6 +272,9 @@ __global__ __launch_bounds__(512) void tail32_kernel(Tail32Args m) {
     static_assert(D * RSY <= 2 * BM32 * RS32 && 2 * D * RSKM64 * 2 <= 2 * BM32 * RS32 * 4, "the y tile fits As + Hs");
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lrow = lane & 31, lhalf = lane >> 5;
     const int b = (int)blockIdx.x / m.tiles_x, t0 = ((int)blockIdx.x % m.tiles_x) * BM32, L = m.L, Lp = m.Lp;
+    // a tile wholly inside the read's [PAD] prefix: its rows of z (and of the final h) come from the all-[PAD] table, nothing here
+    // reads its neighbours (raw in_proj rows: the short filter runs in the convolution)  -- whole workgroup, before any barrier
+    if (m.p0 && t0 + BM32 <= 128 * m.p0[b]) return;
     const int valid = L - t0 < BM32 ? L - t0 : BM32;
     f32x4 ws[2][KS_SET];
     f32x16 acc1[2], acc2[2];
@@ -671,10 +675,10 @@ static void launch_lds(dim3 grid, dim3 block, size_t lds, hipStream_t st, const 
 void launch_tail32(const float* y, float* h, const void* w_out, const void* w_fc1, const void* w_fc2, const void* w_in_next,
                    const float* b_out, const float* b_fc1, const float* b_fc2, const float* b_in_next, const float* ln2_g,
                    const float* ln2_b, const float* n_g, const float* n_b, float* z, int B, int L, int Lp, float eps, hipStream_t st,
-                   bool x3) {
+                   bool x3, const int* p0) {
     Tail32Args m{y, h, reinterpret_cast<const f32x4*>(w_out), reinterpret_cast<const f32x4*>(w_fc1), reinterpret_cast<const f32x4*>(w_fc2),
                  reinterpret_cast<const f32x4*>(w_in_next), b_out, b_fc1, b_fc2, b_in_next, ln2_g, ln2_b, n_g, n_b, z, B, L, Lp,
-                 (L + BM32 - 1) / BM32, eps};
+                 (L + BM32 - 1) / BM32, eps, p0};
     const size_t lds = (size_t)(2 * BM32 * RS32 + 2 * 8 * BM32) * sizeof(float);
     const dim3 grid((unsigned)(m.tiles_x * B));
     const dim3 block(512);

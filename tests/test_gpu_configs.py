@@ -26,7 +26,7 @@ def sd():
     return ho.make_state_dict(0, head_scale=3.0)
 
 
-def test_c1_first_batch_of_12_untruncated(sd, golden_dir, built_lib):
+def test_c1_first_batch_of_12_untruncated(sd, golden_dir, built_lib, monkeypatch):
     from chimeralm_amd import bam, tokenizer as T
     from chimeralm_amd.engine import Engine
     from chimeralm_amd.feeder import BamFeeder
@@ -54,6 +54,9 @@ def test_c1_first_batch_of_12_untruncated(sd, golden_dir, built_lib):
         assert np.array_equal(fb.names, batch["id"].numpy())
         fd.release(fb)
     ref = ho.forward(ids, sd).numpy()
+    tiles = (ids.shape[1] + 127) // 128
+    npad = int(((ids == 4).int().cumprod(1).sum(1) // 128).sum())
+    print(f"C1 batch: 12 x {ids.shape[1]} tokens, {npad} of {12 * tiles} tail tiles wholly inside a [PAD] prefix")
     for prec in ("fp32", "fp16c"):
         e = Engine("cuda:0", precision=prec, chunk_reads=64)
         e.load_state_dict(sd)
@@ -62,6 +65,17 @@ def test_c1_first_batch_of_12_untruncated(sd, golden_dir, built_lib):
         err = np.abs(got - ref).max()
         assert err <= GATE, f"C1 batch of 12, {prec}: max |logit error| {err:.2e}"
         assert do.prediction_lines(got, batch["id"].numpy()) == do.prediction_lines(ref, batch["id"].numpy())
+        # round 5: the tiles inside the [PAD] prefixes came from the all-[PAD] table (csrc/pad_prefix.hip) -- against the engine that
+        # computes every tile (2e-5 in fp32, the mode's bound in fp16c)
+        monkeypatch.setenv("CLM_DEBUG", "no_pad_skip")
+        full = Engine("cuda:0", precision=prec, chunk_reads=64)
+        monkeypatch.delenv("CLM_DEBUG")
+        full.load_state_dict(sd)
+        got_full = full.forward(ids.cuda()).cpu().numpy()
+        full.close()
+        d = np.abs(got - got_full).max()
+        print(f"C1 {prec}: |logits - oracle| {err:.2e}; [PAD]-prefix tiles skipped vs computed: {d:.2e}")
+        assert d <= (2e-5 if prec == "fp32" else 2e-4) and np.abs(got_full - ref).max() <= GATE
 
 
 @pytest.mark.parametrize("prec,tol,margin", [("bf16", 6e-2, 2e-1), ("fp16c", GATE, 2 * GATE)])

@@ -41,6 +41,27 @@ def test_bench_two_ranks_on_one_gpu(built_lib):
     assert d["distributed"]["backend"] == "gloo" and d["distributed"]["world_size"] == 2 and len(d["distributed"]["devices"]) == 2
 
 
+def test_bare_bench_gpus_2_launches_its_own_ranks(built_lib):
+    """`python bench.py --gpus 2` with no launcher around it starts its two ranks itself (torch.distributed.run
+    on a free port, before anything touches HIP), relays rank 0's ONE JSON line and exits with the children's status."""
+    env = dict(os.environ, CLM_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR"):
+        env.pop(k, None)
+    cmd = [sys.executable, str(REPO / "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "8", "--bases", "2100",
+           "--no-cpu-baseline", "--no-fp32-leg"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=REPO)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["distributed"]["world_size"] == 2 and d["value"] > 0
+    assert len(d["guard"]["by_rank"]) == 2 and d["guard"]["ranks_agree"] is True   # every rank's verdict travels with the line
+    bad = subprocess.run([sys.executable, str(REPO / "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--batch", "8",
+                          "--bases", "2100", "--precision", "no-such-mode", "--no-cpu-baseline"], capture_output=True, text=True,
+                         timeout=600, env=env, cwd=REPO)
+    assert bad.returncode != 0                                 # the children's failure is this process's exit status
+
+
 def test_predict_two_ranks_on_one_gpu_union_equals_single_rank(tmp_path, golden_dir, built_lib):
     """`python -m chimeralm_amd predict BAM -g 2` (one process per rank through torchrun, a free rendezvous port) with both
     ranks on this box's one GPU over gloo: rank r classifies reads r, r+2, ... (the non-shuffling distributed sampler of the

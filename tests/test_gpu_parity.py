@@ -311,7 +311,8 @@ def test_module_selfcheck_falls_back_to_fp16x3_when_the_mode_breaks(built_lib):
     rep = m.net.selfcheck_report
     assert rep["fallback"] is False and rep["f16c_min_len"] == 4098 and m.net.engine(ids.device).effective_precision(3000) == "fp16x3"
     assert torch.equal(out.cpu(), e32.forward(ids).cpu())
-    assert (out.cpu() - ho.forward(ids.cpu(), bad)).abs().max() <= 2 * TOL["fp16x3"]      # (logits ~20x the parity tests')
+    ref_bad = ho.forward(ids.cpu(), bad)
+    assert (out.cpu() - ref_bad).abs().max() <= 5e-5 * ref_bad.abs().max()                # (logits up to +-60: 2e-5 relative measured)
     assert (raw.forward(ids).cpu() - out.cpu()).abs().max() > 5e-4
     # (2) a batch above the switch is judged by its own rows: both levels of the mode fail on it -> fp16x3 for good
     long_ids = torch.from_numpy(_ids(4, 6000, seed=312, pads=2).astype(np.int64)).cuda()

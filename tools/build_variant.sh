@@ -5,7 +5,7 @@
 set -e
 R=$(cd "$(dirname "$0")/.." && pwd); C=$R/chimeralm_amd/csrc; name=$1; shift
 T=$(mktemp -d)
-srcs="clm_api gemm gemm16 tail32 hyena_conv head lone_token attention tf_model tf_fp32"
+srcs="clm_api gemm gemm16 tail32 hyena_conv head pad_prefix lone_token attention tf_model tf_fp32"
 for s in $srcs; do
   hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=fast -Wno-unused-function -Wno-pass-failed "$@" -I$R/include -I$C -c $C/$s.hip -o $T/$s.o &
 done
