@@ -89,6 +89,7 @@ struct clm_handle {
     LayerW lwx[NLAYER] = {};
     bool referee = false;              // inside clm_selfcheck's second pass: exact fp32, whatever the handle's mode or fall-back level
     void* packed_score32 = nullptr;
+    void *packed_score32t = nullptr, *packed_score32x = nullptr;   // attention.0.weight in the fused tail's packings (tail32.hip T32_SCORE)
     LayerW lw32[NLAYER]{};
     // PREC_F16C: fc1 / fc2 packed as hi + lo as well (the mode's second level, clm_set_mlp_compensation; lw.w_fc1 / w_fc2 are plain fp16)
     void* packed_mlpc[NLAYER][2] = {};
@@ -146,7 +147,7 @@ struct clm_handle {
         void* z[NLAYER] = {};                       // [i], i >= 1: the z block layer i's convolution reads ([D3][Lp] elements incl. lo planes)
         float* scores = nullptr;                    // [L] pooling scores                                   (16-bit fused path)
         float* partial = nullptr;                   // [ceil(L / 128)][POOL_PSTRIDE] pooling partials       (16-bit fused path)
-        float* hfin = nullptr;                      // [L][256] the last block's residual rows              (fp32 path: its pooling reads them)
+        float* hfin = nullptr;                      // [L][256] the last block's residual rows              (fp32 path; its partials: per 64 tokens)
     };
     std::vector<PadTable> pad_tables;
     PadTable* capture = nullptr;                    // inside the forward that fills a table
@@ -356,6 +357,8 @@ void free_packed(clm_handle* h) {
         }
     if (h->packed_score) { (void)hipFree(h->packed_score); h->packed_score = nullptr; }
     if (h->packed_score32) { (void)hipFree(h->packed_score32); h->packed_score32 = nullptr; }
+    if (h->packed_score32t) { (void)hipFree(h->packed_score32t); h->packed_score32t = nullptr; }
+    if (h->packed_score32x) { (void)hipFree(h->packed_score32x); h->packed_score32x = nullptr; }
     if (h->ztab) { (void)hipFree(h->ztab); h->ztab = nullptr; }
     for (int i = 0; i < NLAYER; ++i)
         if (h->fir[i]) { (void)hipFree(h->fir[i]); h->fir[i] = nullptr; }
@@ -389,8 +392,9 @@ int ensure_workspace(clm_handle* h, int Bc, int L, hipStream_t st) {
     need[WS_U] = ((prec == PREC_F32 && !fused_fp32(h)) || (prec != PREC_F32 && h->force_generic)) ? nb * DI * nl * es : 0;   // the 1024-wide fc1 output: unfused paths only
     need[WS_SCORES] = nb * nl * 4;
     need[WS_STATS] = nb * 2 * 4;
-    // pooling partials: [POOL_SPLIT][4][256] per read (fp32 path) or one POOL_PSTRIDE row per 128-token tile
-    need[WS_PARTIAL] = nb * std::max((size_t)POOL_SPLIT * 4 * D, (size_t)((nl + 127) / 128) * POOL_PSTRIDE) * 4;
+    // pooling partials: [POOL_SPLIT][4][256] per read (unfused fp32 path) or one POOL_PSTRIDE row per tile -- 128 tokens in the
+    // 16-bit tail kernel, T32_TILE = 64 in the exact / fp16x3 one
+    need[WS_PARTIAL] = nb * std::max((size_t)POOL_SPLIT * 4 * D, (size_t)((nl + T32_TILE - 1) / T32_TILE) * POOL_PSTRIDE) * 4;
     need[WS_POOLED] = nb * D * 4;
     need[WS_LONE] = lone_token_ws_floats((int)nb) * 4;
     need[WS_IDS8] = nb * Lp;
@@ -595,11 +599,10 @@ int ensure_pad_table(clm_handle* h, int prec, bool x3, int L, hipStream_t st, cl
     t.L = LT; t.Lp = round_up(LT, LP_ALIGN);
     const size_t es = elem_size(prec);
     for (int i = 1; i < NLAYER; ++i) HIPCHK(h, hipMalloc(&t.z[i], (size_t)D3 * t.Lp * es));
+    // (the exact path: partials per 64-token tile, and the final residual rows as well -- clm_debug_fetch("hidden") shows them)
     if (prec == PREC_F32) HIPCHK(h, hipMalloc((void**)&t.hfin, (size_t)LT * D * 4));
-    else {
-        HIPCHK(h, hipMalloc((void**)&t.scores, (size_t)LT * 4));
-        HIPCHK(h, hipMalloc((void**)&t.partial, (size_t)((LT + 127) / 128) * POOL_PSTRIDE * 4));
-    }
+    HIPCHK(h, hipMalloc((void**)&t.scores, (size_t)LT * 4));
+    HIPCHK(h, hipMalloc((void**)&t.partial, (size_t)((LT + T32_TILE - 1) / T32_TILE) * POOL_PSTRIDE * 4));
     if ((size_t)t.Lp > h->pad_ids_cap) {
         if (h->pad_ids) HIPCHK(h, hipFree(h->pad_ids));
         h->pad_ids = nullptr; h->pad_ids_cap = 0;
@@ -795,15 +798,27 @@ int forward_chunk(clm_handle* h, const void* ids, int ids_dtype, int64_t row_str
         } else if (fused32) {
             StageTimer t(h, st, CLM_STAGE_TAIL);
             const LayerW* nx = i + 1 < NLAYER ? &(x3 ? h->lwx[i + 1] : (alt32 ? h->lw32[i + 1] : h->lw[i + 1])) : nullptr;
+            // the last block: ln_f + pooling scores + per-tile pooling partials on the tile still on chip (tail32.hip T32_SCORE)
+            const int nt32 = (L + T32_TILE - 1) / T32_TILE;
+            const Tail32Score ts{x3 ? h->packed_score32x : h->packed_score32t, W(h, "head.attention.0.bias"), W(h, "head.attention.2.weight"),
+                                 W(h, "head.attention.2.bias"), W(h, "bb.ln_f.weight"), W(h, "bb.ln_f.bias"), h->scores, h->partial};
             launch_tail32(reinterpret_cast<const float*>(h->y), h->h, lw.t_out, lw.t_fc1, lw.t_fc2, nx ? nx->t_in : nullptr, lw.b_out,
                           lw.b_fc1, lw.b_fc2, nx ? nx->b_in : nullptr, lw.ln2_g, lw.ln2_b, nx ? nx->ln1_g : nullptr,
-                          nx ? nx->ln1_b : nullptr, reinterpret_cast<float*>(h->z), Bc, L, Lp, eps, st, x3, pad_skip ? h->pad_p0 : nullptr);
+                          nx ? nx->ln1_b : nullptr, reinterpret_cast<float*>(h->z), Bc, L, Lp, eps, st, x3, pad_skip ? h->pad_p0 : nullptr,
+                          nx ? nullptr : &ts);
             if (h->capture) {
                 if (nx) HIPCHK(h, hipMemcpyAsync(h->capture->z[i + 1], h->z, (size_t)D3 * Lp * 4, hipMemcpyDeviceToDevice, st));
-                else HIPCHK(h, hipMemcpyAsync(h->capture->hfin, h->h, (size_t)L * D * 4, hipMemcpyDeviceToDevice, st));
+                else {
+                    HIPCHK(h, hipMemcpyAsync(h->capture->hfin, h->h, (size_t)L * D * 4, hipMemcpyDeviceToDevice, st));
+                    HIPCHK(h, hipMemcpyAsync(h->capture->scores, h->scores, (size_t)L * 4, hipMemcpyDeviceToDevice, st));
+                    HIPCHK(h, hipMemcpyAsync(h->capture->partial, h->partial, (size_t)nt32 * POOL_PSTRIDE * 4, hipMemcpyDeviceToDevice, st));
+                }
             } else if (pad_skip) {
                 if (nx) launch_prefix_fill_z(h->pad_p0, h->z, ptab->z[i + 1], Bc, Lp, ptab->Lp, L, 4, D3, 0, st);
-                else launch_prefix_fill_h(h->pad_p0, h->h, ptab->hfin, Bc, L, L, st);
+                else {
+                    launch_prefix_fill_h(h->pad_p0, h->h, ptab->hfin, Bc, L, L, st);
+                    launch_prefix_fill_pool(h->pad_p0, h->scores, h->partial, ptab->scores, ptab->partial, Bc, L, nt32, L, st, 128 / T32_TILE);
+                }
             }
         } else {
             {
@@ -836,6 +851,9 @@ int forward_chunk(clm_handle* h, const void* ids, int ids_dtype, int64_t row_str
         }
         StageTimer t(h, st, CLM_STAGE_HEADMLP);
         launch_head_tiles(h->partial, (L + 127) / 128, h->hw, h->pooled, logits, Bc, st);
+    } else if (fused32) {   // scores and per-tile pooling partials came out of the last block's tail kernel
+        StageTimer t(h, st, CLM_STAGE_HEADMLP);
+        launch_head_tiles(h->partial, (L + T32_TILE - 1) / T32_TILE, h->hw, h->pooled, logits, Bc, st);
     } else {
         {
             StageTimer t(h, st, CLM_STAGE_SCORE);
@@ -1038,6 +1056,12 @@ int clm_finalize(clm_handle* h) {
         int rc;
         if ((rc = pack("head.attention.0.weight", D, D, &h->packed_score))) return rc;
         if (prec != PREC_F32 && (rc = pack_as(PREC_F32, "head.attention.0.weight", D, D, &h->packed_score32))) return rc;
+        HIPCHK(h, hipMalloc(&h->packed_score32t, (size_t)D * D * 4));
+        launch_pack_f32t(W(h, "head.attention.0.weight"), h->packed_score32t, D, D, st);
+        if (pack_x3) {
+            HIPCHK(h, hipMalloc(&h->packed_score32x, (size_t)D * D * 4));
+            launch_pack_x3(W(h, "head.attention.0.weight"), h->packed_score32x, D, D, st);
+        }
     }
     if (prec != PREC_F32)
         for (int i = 0; i < NLAYER; ++i) {

@@ -198,12 +198,21 @@ void launch_embed(const void* ids, int ids_dtype, int64_t row_stride, const floa
                   int* bad_ids = nullptr /*device-visible flag set when an id is outside [0, 16)*/);
 
 // exact fp32, fused (tail32.hip): out_proj + LN2 + MLP + both residuals on h in place, then -- w_in_next != null -- the next
-// block's LayerNorm-1 + in_proj into z (rows x0 | x1 | v, fp32).  Weights in launch_pack_f32t's order.
+// block's LayerNorm-1 + in_proj into z (rows x0 | x1 | v, fp32), or -- score != null, the last block -- ln_f + the pooling scores and
+// one online-softmax pooling partial per 64-token tile (T32_TILE; merged by launch_head_tiles).  Weights in launch_pack_f32t's order.
+constexpr int T32_TILE = 64;
+struct Tail32Score {
+    const void* w1;                       // attention.0.weight, packed like the tail's other weights (f32t, or x3 halfs)
+    const float *b1, *w2, *b2, *lnf_g, *lnf_b;
+    float* scores;                        // [B, L]
+    float* partial;                       // [B, ceil(L / T32_TILE), POOL_PSTRIDE]
+};
 void launch_tail32(const float* y, float* h, const void* w_out, const void* w_fc1, const void* w_fc2, const void* w_in_next,
                    const float* b_out, const float* b_fc1, const float* b_fc2, const float* b_in_next, const float* ln2_g,
                    const float* ln2_b, const float* n_g, const float* n_b, float* z, int B, int L, int Lp, float eps, hipStream_t st,
                    bool x3 = false /*three fp16 MFMAs on hi + lo halfs per product, weights from launch_pack_x3*/,
-                   const int* p0 = nullptr /*[B]: tiles inside each read's [PAD] prefix, skipped (pad_prefix.hip)*/);
+                   const int* p0 = nullptr /*[B]: tiles inside each read's [PAD] prefix, skipped (pad_prefix.hip)*/,
+                   const Tail32Score* score = nullptr);
 void launch_pack_x3(const float* w /*[n][k]*/, void* out /*n * k * 4 bytes*/, int n, int k, hipStream_t st);
 void launch_pack_f32t(const float* w /*[n][k]*/, void* out /*n * k floats*/, int n, int k, hipStream_t st);
 // SequenceCNNTransformer, exact fp32 (tail32.hip conv32_kernel): Conv1d(k = 3, padding = 1) + ReLU + MaxPool1d(2); w = three taps
@@ -303,8 +312,8 @@ void launch_pad_tiles(const unsigned char* ids8, int B, int Lp, int Lmain, int e
 void launch_prefix_fill_z(const int* p0, void* z, const void* table, int B, int Lp, int LpT, int Lmain, int es, int nrow16, int nlo, hipStream_t st);
 // the same for the last block's products: pooling scores [B][L] and per-tile pooling partials [B][ntiles][POOL_PSTRIDE]
 void launch_prefix_fill_pool(const int* p0, float* scores, float* partial, const float* t_scores, const float* t_partial, int B, int L,
-                             int ntiles, int Lmain, hipStream_t st);
-// ... and for the exact path, whose pooling kernels read the residual stream itself: rows [0, 128 p0[b]) of h [B][L][256]
+                             int ntiles, int Lmain, hipStream_t st, int per128 = 1 /*partials per 128 tokens: 2 for tail32's 64-token tiles*/);
+// ... and for the unfused exact path, whose pooling kernels read the residual stream itself: rows [0, 128 p0[b]) of h [B][L][256]
 void launch_prefix_fill_h(const int* p0, float* h, const float* t_h, int B, int L, int Lmain, hipStream_t st);
 // tiles of the tail kernel are taken in CONTIGUOUS ranges per workgroup (the short filter's two-token history then comes from the
 // workgroup's own previous tile): range length for `total` tiles on `grid` workgroups

@@ -179,7 +179,7 @@ void launch_head_mlp(const float* partial, const HeadW& hw, float* pooled_out, f
 // workgroup.  The classifier is a chain of four small matrix-vector products whose cost is the latency of streaming
 // the weights from L2, so: every weight element is fetched once per HR reads, each dot product is split in two halves
 // (1024 threads = 512 outputs x 2), and the weight stream runs 16 elements ahead of the FMAs in a register ping-pong.
-constexpr int HR = 4, HT = 1024, MAXTILES = (32770 + 127) / 128;
+constexpr int HR = 4, HT = 1024, MAXTILES = (32770 + 63) / 64;     // (the exact path's partials are per 64-token tile: tail32.hip)
 
 template <int IN, bool GELU>
 __device__ __forceinline__ void dense_rows(const float* __restrict__ wt, const float* __restrict__ bias,

@@ -114,10 +114,11 @@ void launch_prefix_fill_z(const int* p0, void* z, const void* table, int B, int 
 
 __global__ __launch_bounds__(256) void prefix_fill_pool_kernel(const int* __restrict__ p0, float* __restrict__ scores, float* __restrict__ partial,
                                                                const float* __restrict__ t_scores, const float* __restrict__ t_partial, int L,
-                                                               int ntiles, int Lmain) {
+                                                               int ntiles, int Lmain, int per128) {
     const int b = (int)blockIdx.y, p = p0[b];
     if (p == 0) return;
-    const int ntok = 128 * p < Lmain ? 128 * p : Lmain, nt = p < ntiles ? p : ntiles;
+    // (per128: partials per 128-token tile of p0's count -- 1 in the 16-bit path, 2 for the exact path's 64-token tiles)
+    const int ntok = 128 * p < Lmain ? 128 * p : Lmain, nt = p * per128 < ntiles ? p * per128 : ntiles;
     const int i0 = (int)blockIdx.x * 256 + (int)threadIdx.x, stride = (int)gridDim.x * 256;
     for (int i = i0; i < ntok; i += stride) scores[(size_t)b * L + i] = t_scores[i];
     // whole tiles only: a tile that ends at Lmain but is not all prefix was computed by the tail kernel (p counts WHOLE tiles)
@@ -125,9 +126,9 @@ __global__ __launch_bounds__(256) void prefix_fill_pool_kernel(const int* __rest
 }
 
 void launch_prefix_fill_pool(const int* p0, float* scores, float* partial, const float* t_scores, const float* t_partial, int B, int L,
-                             int ntiles, int Lmain, hipStream_t st) {
+                             int ntiles, int Lmain, hipStream_t st, int per128) {
     hipLaunchKernelGGL(prefix_fill_pool_kernel, dim3(16, (unsigned)B), dim3(256), 0, st, p0, scores, partial, t_scores, t_partial, L, ntiles,
-                       Lmain);
+                       Lmain, per128);
 }
 
 __global__ __launch_bounds__(256) void prefix_fill_h_kernel(const int* __restrict__ p0, float* __restrict__ h, const float* __restrict__ t_h, int L,

@@ -258,9 +258,20 @@ struct Tail32Args {
     int B, L, Lp, tiles_x;
     float eps;
     const int* p0;            // [B] or null: 128-token tiles wholly inside each read's [PAD] prefix (pad_prefix.hip) -- not computed
+    // NEXT = T32_SCORE (the last block): w_in = attention.0.weight (packed like the others), b_in = its bias, n_g / n_b = ln_f
+    const float *att_w2, *att_b2;   // attention.2 weight [256] and bias [1]
+    float* scores;            // [B, L] pooling scores
+    float* partial;           // [B, tiles_x, POOL_PSTRIDE] per-tile online-softmax pooling partials (64-token tiles here)
 };
 
-template <bool NEXT, int AR = AR_F32>
+// NEXT: what follows the block on the tile still in registers -- nothing / the next block's LayerNorm-1 + in_proj / (round 5, the
+// last block) ln_f + attention.0 + GELU(erf) + attention.2 = the pooling scores and this tile's online-softmax pooling partial, as
+// the 16-bit tail kernel has it (gemm16.hip score_pool_tile; /root/reference/chimeralm/models/components/hyena.py:117-132): the
+// separate score GEMM (3.5 ms per 256 x 8,193 launch), softmax-statistics and pooling kernels of rounds 1-4 read the fp32 residual
+// stream twice more; head_tiles_kernel (head.hip) merges the partials in a fixed order.
+enum { T32_NONE = 0, T32_INPROJ = 1, T32_SCORE = 2 };
+
+template <int NEXT, int AR = AR_F32>
 __global__ __launch_bounds__(512) void tail32_kernel(Tail32Args m) {
     constexpr float WS = WSCALE<AR>, WSI = WUNSCALE<AR>;
     extern __shared__ __attribute__((aligned(16))) float smem32[];
@@ -357,7 +368,7 @@ __global__ __launch_bounds__(512) void tail32_kernel(Tail32Args m) {
         }
         __syncthreads();
         const f32x4* nxt = j + 1 < DI / 256 ? wset_ptr(m.w_fc1, j + 1, D / 8, 0, wave, lane)
-                                            : wset_ptr(NEXT ? m.w_in : m.w_fc1, 0, D / 8, 0, wave, lane);
+                                            : wset_ptr(NEXT != T32_NONE ? m.w_in : m.w_fc1, 0, D / 8, 0, wave, lane);
         product256<false, AR>(Hs, m.w_fc2, 0, DI / 8, j * 32, nxt, wave, lane, ws, acc2);
         __syncthreads();                                    // every wave is done reading Hs before the next chunk lands in it
     }
@@ -380,7 +391,7 @@ __global__ __launch_bounds__(512) void tail32_kernel(Tail32Args m) {
         }
     }
     // ---- 5. the next block's LayerNorm-1 + in_proj on the tile still in registers: z rows x0 | x1 | v
-    if constexpr (NEXT) {
+    if constexpr (NEXT == T32_INPROJ) {
         ln_to_tile<false, AR>(acc2, P1, P2, m.n_g, m.n_b, m.eps, As, valid, wave, lrow, lhalf);
 #pragma unroll 1
         for (int nb = 0; nb < D3 / 256; ++nb) {
@@ -402,6 +413,82 @@ __global__ __launch_bounds__(512) void tail32_kernel(Tail32Args m) {
                     if (mt * 32 + lrow < valid) zb[(size_t)f * Lp + mt * 32] = acc1[mt][r] * WSI + bias;
             }
         }
+    }
+    // ---- 5'. the last block: ln_f -> As, scores, and this tile's pooling partial  m = max s_t, S = sum exp(s_t - m),
+    //          vec[c] = sum_t exp(s_t - m) ln_f(h')[t][c]   (softmax over ALL positions, pads included: hyena.py:121-132, mask None)
+    if constexpr (NEXT == T32_SCORE) {
+        ln_to_tile<false, AR>(acc2, P1, P2, m.n_g, m.n_b, m.eps, As, valid, wave, lrow, lhalf);
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc1[mt][r] = 0.f;
+        product256<false, AR>(As, m.w_in, 0, D / 8, 0, wset_ptr(m.w_in, 0, D / 8, 0, wave, lane), wave, lane, ws, acc1);   // (last slot: unused re-request)
+        float* P = Hs;                                      // [8][64] score partials of the waves (Hs is dead: every wave is past the MLP)
+        float* E = P + 8 * BM32;                            // [64] exp(s - m)
+        float* V = E + BM32;                                // [4][256] pooled-vector partials of the four 16-token groups
+        {
+            const float* b1 = m.b_in + wave * 32 + 4 * lhalf;
+            const float* w2 = m.att_w2 + wave * 32 + 4 * lhalf;
+            float sc[2] = {0.f, 0.f};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 bb = *reinterpret_cast<const float4*>(b1 + 8 * q), ww = *reinterpret_cast<const float4*>(w2 + 8 * q);
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) {
+                    sc[mt] = fmaf(gelu_erf(acc1[mt][4 * q + 0] * WSI + bb.x), ww.x, sc[mt]);
+                    sc[mt] = fmaf(gelu_erf(acc1[mt][4 * q + 1] * WSI + bb.y), ww.y, sc[mt]);
+                    sc[mt] = fmaf(gelu_erf(acc1[mt][4 * q + 2] * WSI + bb.z), ww.z, sc[mt]);
+                    sc[mt] = fmaf(gelu_erf(acc1[mt][4 * q + 3] * WSI + bb.w), ww.w, sc[mt]);
+                }
+            }
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                const float s2 = sc[mt] + __shfl_xor(sc[mt], 32, 64);
+                if (lhalf == 0) P[wave * BM32 + mt * 32 + lrow] = s2;
+            }
+        }
+        __syncthreads();
+        const int tile = (int)blockIdx.x % m.tiles_x;
+        float* pout = m.partial + ((size_t)b * m.tiles_x + tile) * POOL_PSTRIDE;
+        if (wave == 0) {                                    // 64 tokens: one per lane; the waves' partials in a fixed order
+            float s = (((P[lane] + P[BM32 + lane]) + (P[2 * BM32 + lane] + P[3 * BM32 + lane])) +
+                       ((P[4 * BM32 + lane] + P[5 * BM32 + lane]) + (P[6 * BM32 + lane] + P[7 * BM32 + lane]))) + m.att_b2[0];
+            if (lane < valid) m.scores[(size_t)b * L + t0 + lane] = s;
+            else s = -INFINITY;
+            const float mx = wave_max(s);                   // token t0 is always valid: mx is finite
+            const float e = expf(s - mx);                   // exp(-inf) = 0 for the rows past L
+            E[lane] = e;
+            const float ssum = wave_sum(e);
+            if (lane == 0) {
+                pout[D] = mx;
+                pout[D + 1] = ssum;
+            }
+        }
+        __syncthreads();
+        {   // vec: thread = (channel pair, 16-token group); the staged ln_f tile is read back (fp32 pairs, or hi + lo halfs of a pair)
+            const int c2 = tid & 127, g = tid >> 7;
+            float a0 = 0.f, a1 = 0.f;
+#pragma unroll 8
+            for (int i = 0; i < 16; ++i) {
+                const int t = g * 16 + i;
+                const float e = E[t];
+                float v0, v1;
+                if constexpr (AR == AR_X3) {
+                    typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
+                    const char* rowp = reinterpret_cast<const char*>(As + t * RS32) + c2 * 4;
+                    const h2_t hi = *reinterpret_cast<const h2_t*>(rowp), lo = *reinterpret_cast<const h2_t*>(rowp + 512);
+                    v0 = (float)hi[0] + (float)lo[0], v1 = (float)hi[1] + (float)lo[1];
+                } else {
+                    const float2 v = *reinterpret_cast<const float2*>(As + t * RS32 + 2 * c2);
+                    v0 = v.x, v1 = v.y;
+                }
+                a0 = fmaf(e, v0, a0);
+                a1 = fmaf(e, v1, a1);
+            }
+            *reinterpret_cast<float2*>(V + g * D + 2 * c2) = make_float2(a0, a1);
+        }
+        __syncthreads();
+        if (tid < D) pout[tid] = (V[tid] + V[D + tid]) + (V[2 * D + tid] + V[3 * D + tid]);
     }
 }
 
@@ -671,23 +758,29 @@ static void launch_lds(dim3 grid, dim3 block, size_t lds, hipStream_t st, const 
     CLM_SET_LDS(Kern, lds);
     hipLaunchKernelGGL(Kern, grid, block, lds, st, m);
 }
-// x3: the products as three fp16 MFMAs on hi + lo halfs (weights from launch_pack_x3) instead of the fp32 MFMA
+// x3: the products as three fp16 MFMAs on hi + lo halfs (weights from launch_pack_x3) instead of the fp32 MFMA.
+// score != null (the last block; w_in_next must be null): ln_f + pooling scores + per-64-token-tile pooling partials follow on the tile.
 void launch_tail32(const float* y, float* h, const void* w_out, const void* w_fc1, const void* w_fc2, const void* w_in_next,
                    const float* b_out, const float* b_fc1, const float* b_fc2, const float* b_in_next, const float* ln2_g,
                    const float* ln2_b, const float* n_g, const float* n_b, float* z, int B, int L, int Lp, float eps, hipStream_t st,
-                   bool x3, const int* p0) {
+                   bool x3, const int* p0, const Tail32Score* score) {
     Tail32Args m{y, h, reinterpret_cast<const f32x4*>(w_out), reinterpret_cast<const f32x4*>(w_fc1), reinterpret_cast<const f32x4*>(w_fc2),
-                 reinterpret_cast<const f32x4*>(w_in_next), b_out, b_fc1, b_fc2, b_in_next, ln2_g, ln2_b, n_g, n_b, z, B, L, Lp,
-                 (L + BM32 - 1) / BM32, eps, p0};
+                 reinterpret_cast<const f32x4*>(score ? score->w1 : w_in_next), b_out, b_fc1, b_fc2, score ? score->b1 : b_in_next, ln2_g, ln2_b,
+                 score ? score->lnf_g : n_g, score ? score->lnf_b : n_b, z, B, L, Lp,
+                 (L + BM32 - 1) / BM32, eps, p0, score ? score->w2 : nullptr, score ? score->b2 : nullptr, score ? score->scores : nullptr,
+                 score ? score->partial : nullptr};
     const size_t lds = (size_t)(2 * BM32 * RS32 + 2 * 8 * BM32) * sizeof(float);
+    static_assert(8 * BM32 + BM32 + 4 * D <= BM32 * RS32, "score stage: P / E / V fit the Hs region");
     const dim3 grid((unsigned)(m.tiles_x * B));
     const dim3 block(512);
     if (x3) {
-        if (w_in_next) launch_lds<tail32_kernel<true, AR_X3>>(grid, block, lds, st, m);
-        else launch_lds<tail32_kernel<false, AR_X3>>(grid, block, lds, st, m);
+        if (score) launch_lds<tail32_kernel<T32_SCORE, AR_X3>>(grid, block, lds, st, m);
+        else if (w_in_next) launch_lds<tail32_kernel<T32_INPROJ, AR_X3>>(grid, block, lds, st, m);
+        else launch_lds<tail32_kernel<T32_NONE, AR_X3>>(grid, block, lds, st, m);
     } else {
-        if (w_in_next) launch_lds<tail32_kernel<true, AR_F32>>(grid, block, lds, st, m);
-        else launch_lds<tail32_kernel<false, AR_F32>>(grid, block, lds, st, m);
+        if (score) launch_lds<tail32_kernel<T32_SCORE, AR_F32>>(grid, block, lds, st, m);
+        else if (w_in_next) launch_lds<tail32_kernel<T32_INPROJ, AR_F32>>(grid, block, lds, st, m);
+        else launch_lds<tail32_kernel<T32_NONE, AR_F32>>(grid, block, lds, st, m);
     }
 }
 

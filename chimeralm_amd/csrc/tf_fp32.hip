@@ -300,7 +300,7 @@ __global__ __launch_bounds__(256, 4) void attention32_kernel(const float* __rest
 // is staged; V^T fragments by transposing LDS reads.  q / k / v arrive as fp32 and are split on their way into registers / LDS.
 constexpr int AX_QT = 128, AX_KT = 64, AX_KRS = 40, AX_VRS = 32;       // halfs: K rows 80 B, V rows 64 B (attention.hip's strides)
 __device__ __forceinline__ int ax_v_row(int k) { return (k & ~12) | ((k & 4) << 1) | ((k & 8) >> 1); }
-__global__ __launch_bounds__(256, 4) void attention_x3_kernel(const float* __restrict__ qkv, float* __restrict__ out, int L) {
+__global__ __launch_bounds__(256, 3) void attention_x3_kernel(const float* __restrict__ qkv, float* __restrict__ out, int L) {
     using f32x4 = float __attribute__((ext_vector_type(4)));
     typedef _Float16 h8 __attribute__((ext_vector_type(8)));
     typedef _Float16 h4 __attribute__((ext_vector_type(4)));

@@ -52,10 +52,11 @@ def test_hot_kernels_have_no_scratch_in_their_loops():
         (r"enc_ffn16_kernelILi[123]E", 0),                        # transformer layer kernel, all three 16-bit modes
         (r"conv3_relu_pool_kernelILi[123]E", 0),
         (r"attention_fwd_kernelILi2ELb[01]E", 0),                 # fp16 attention, one plane and hi + lo planes
-        (r"tail32_kernelILb[01]E", 0),                            # exact fp32, round 4: the fused block tail ...
+        (r"tail32_kernelILi[012]ELi[01]E", 0),                    # exact fp32 / fp16x3, round 4: the fused block tail (round 5: + its score variant) ...
         (r"enc32_kernelILb[01]E", 0),                             # ... and the transformer's encoder layer, CNN stem and attention
         (r"conv32_kernel", 0),
         (r"attention32_kernel", 0),
+        (r"attention_x3_kernel", 0),                              # (round 5: three waves per SIMD instead of four -- 56 B/lane of scratch gone)
     ]
     for pattern, allowed in budget:
         for name, got in _scratch(res, pattern).items():
