@@ -1869,10 +1869,13 @@ void launch_hyena_conv(int prec, const void* z, void* y, const float2* kf, const
     const bool ids = ids8 != nullptr && ztab != nullptr;
     const bool gated = (flags & CONV_GATED) != 0 && !ids;
     const bool lo = prec == PREC_F16C && ylo != nullptr;
-    if (logn == 14 && prec != PREC_F32 && !(flags & CONV_ONESHOT) && !(stamp && !gated) && kf_packed) {
+    if (logn == 14 && !(flags & CONV_ONESHOT) && !(stamp && !gated) && kf_packed) {
         kf = kf_packed;
         const int xcd = !(flags & CONV_NO_XCD);
-        if (prec == PREC_BF16) {
+        if (prec == PREC_F32) {     // round 5: the exact / fp16x3 engine's rows (raw x0 | x1 | v, fp32) through the persistent form too
+            if (ids) launch_conv_pers_inst<float, true>(nullptr, y, kf, tw, ktime, short_w, short_b, B, L, Lp, ids8, ztab, xcd, st);
+            else launch_conv_pers_inst<float, false>(z, y, kf, tw, ktime, short_w, short_b, B, L, Lp, nullptr, nullptr, xcd, st);
+        } else if (prec == PREC_BF16) {
             if (ids) launch_conv_pers_inst<bf16_t, true>(nullptr, y, kf, tw, ktime, short_w, short_b, B, L, Lp, ids8, ztab, xcd, st);
             else if (gated) launch_conv_pers_inst<bf16_t, false, true>(z, y, kf, tw, ktime, short_w, short_b, B, L, Lp, nullptr, nullptr, xcd, st);
             else launch_conv_pers_inst<bf16_t, false>(z, y, kf, tw, ktime, short_w, short_b, B, L, Lp, nullptr, nullptr, xcd, st);

@@ -496,6 +496,27 @@ def test_persistent_convolution_equals_one_workgroup_per_unit(sd, built_lib, mon
     e0.close(), e1.close()
 
 
+@pytest.mark.parametrize("prec,B,L", [("fp32", 5, 8193), ("fp32", 3, 6000), ("fp16x3", 4, 4098)])
+def test_persistent_convolution_of_the_exact_engine(sd, built_lib, monkeypatch, prec, B, L):
+    """Round 5: the exact / fp16x3 engine's fp32 rows (raw x0 | x1 | v; block 0 by token id) go through hyena_conv_pers_kernel as
+    well.  Same transform as hyena_conv_kernel (CLM_DEBUG=conv_oneshot) with x0's short filter evaluated after it: logits agree at
+    fp32-rounding level, and the persistent form stands against the oracle by itself.  Odd batch: a unit with one read."""
+    from chimeralm_amd.engine import Engine
+
+    ids = _ids(B, L, seed=98, pads=3)
+    t = torch.from_numpy(ids).cuda()
+    e0 = Engine("cuda:0", precision=prec, chunk_reads=4)
+    monkeypatch.setenv("CLM_DEBUG", "conv_oneshot")      # read by clm_create
+    e1 = Engine("cuda:0", precision=prec, chunk_reads=4)
+    monkeypatch.delenv("CLM_DEBUG")
+    e0.load_state_dict(sd), e1.load_state_dict(sd)
+    a, b = e0.forward(t).cpu(), e1.forward(t).cpu()
+    assert torch.equal(a, e0.forward(t).cpu())           # deterministic
+    assert (a - b).abs().max() < 2e-5, (a - b).abs().max().item()
+    _check(e0, prec, ids, sd)
+    e0.close(), e1.close()
+
+
 @pytest.mark.parametrize("B,L", [(3, 257), (5, 64), (2, 65), (1, 1), (4, 1000), (3, 8193), (2, 20000), (7, 130)])
 def test_fused_fp32_tail_equals_the_separate_gemm_kernels(sd, built_lib, monkeypatch, B, L):
     """Exact fp32 runs one fused kernel per block tail since round 4 (tail32.hip: out_proj + LN2 + MLP + both residuals + the next
