@@ -14,7 +14,7 @@ CSRC = Path(__file__).resolve().parent / "csrc"
 INCLUDE = Path(__file__).resolve().parent.parent / "include"
 LIB = CSRC / "libchimeralm_hip.so"
 # hipcc's per-kernel resource remarks of the last build (registers, scratch, LDS): tests/test_kernel_resources.py holds the hot
-# kernels to "no scratch" -- spills there are vector-memory traffic inside loops that were tuned to hide it
+# kernels to "no scratch" -- spills there are vector-memory traffic inside loops that were tuned to hide it (HISTORY.md section 4.7)
 RESOURCES = CSRC / "kernel_resources.txt"
 SOURCES = ["clm_api.hip", "gemm.hip", "gemm16.hip", "tail32.hip", "hyena_conv.hip", "head.hip", "pad_prefix.hip", "lone_token.hip", "attention.hip", "tf_model.hip", "tf_fp32.hip", "bam_feeder.cpp", "bam_filter.cpp"]
 HEADERS = ["clm_common.h", "clm_lab.h", "gemm_common.h", "gemm16_common.h", "fft_core.h", "fft_passes.h", "bgzf.h"]

@@ -135,7 +135,7 @@ __device__ __forceinline__ unsigned lo8_pack4(float x0, float x1, float x2, floa
     typedef _Float16 h2 __attribute__((ext_vector_type(2)));
     typedef float f2 __attribute__((ext_vector_type(2)));
     const h2 a = __builtin_convertvector(f2{x0, x1}, h2), b = __builtin_convertvector(f2{x2, x3}, h2);
-    // (elements to scalars FIRST: __builtin_bit_cast straight from a vector element reads element 0 with hipcc 7.2 -- DESIGN.md
+    // (elements to scalars FIRST: __builtin_bit_cast straight from a vector element reads element 0 with hipcc 7.2 -- HISTORY.md
     //  section 4.7; the first version of this function wrote half 0 into every odd slot, which tools/micro/mfma_lo2.cpp caught)
     const _Float16 h0 = a[0], h1 = a[1], h2_ = b[0], h3 = b[1];
     h = u16x4{__builtin_bit_cast(unsigned short, h0), __builtin_bit_cast(unsigned short, h1), __builtin_bit_cast(unsigned short, h2_),
@@ -180,7 +180,7 @@ inline void ensure_lds_attr(const void* kern, size_t lds, std::atomic<unsigned l
 // truncated to e5m2, gathered in registers) into one fp32 accumulator.  The rounding of the packed weights is the one error of the fp16 mode that is coherent across tokens
 // (every token sees the same perturbed matrix, so the attention pooling cannot average it out): tests/error_model.py
 // attributes 1.0e-3 of the fp16 mode's 1.3e-3 logit error to it.  What is left is the fp16 rounding of the activation operands
-// (measured 1.2e-4 .. 9.6e-4 in the logits, DESIGN.md section 2); clm_selfcheck measures it on the loaded weights.
+// (measured 1.2e-4 .. 9.6e-4 in the logits, DESIGN.md section 3); clm_selfcheck measures it on the loaded weights.
 enum Prec { PREC_F32 = 0, PREC_BF16 = 1, PREC_F16 = 2, PREC_F16C = 3 };
 
 struct LayerW {            // device pointers, fp32 unless noted

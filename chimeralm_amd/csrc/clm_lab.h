@@ -4,7 +4,7 @@
 // and the branches it guards are dead code that does not reach the object file.  tools/build_variant.sh NAME -DCLM_LAB -DCLM_EXP_x
 // builds a library in which ONE kind of work is removed (results WRONG by construction, instruction stream otherwise the same);
 // tools/abn.sh alternates it with the product build on one box.  What those builds measured is in profiles/r03_timing_only.txt
-// and DESIGN.md section 4.9.
+// and HISTORY.md section 4.9.
 #pragma once
 
 namespace clm {
@@ -94,6 +94,12 @@ constexpr bool YLO_MAP64 = false;
 constexpr bool NORESID = true;     // the tail kernel loads no residual rows (zeros): what the loads at the tile boundary cost
 #else
 constexpr bool NORESID = false;
+#endif
+// round 5: placement experiments of the next tile's prefetches in the gated in_proj stage (results stay correct)
+#if defined(CLM_LAB) && defined(CLM_EXP_YLATE)
+constexpr bool YLATE = true;       // y pieces + y's lo bytes requested behind the x0 block's last weight set instead of in its hooks
+#else
+constexpr bool YLATE = false;
 #endif
 }  // namespace lab
 }  // namespace clm

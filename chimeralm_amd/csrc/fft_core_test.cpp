@@ -1,7 +1,7 @@
 // Host emulation of the LDS Stockham convolution used by hyena_conv.hip (built with g++ by
 // tests/test_fft_core.py).  Every "thread" of the kernel is run in turn, barriers become loop boundaries,
 // and the result is checked against a direct double-precision causal convolution, including the
-// single-alias correction used when L == N/2 + 1 ("long convolution").
+// single-alias correction used when L == N/2 + 1 (HISTORY.md section 4.6, "long convolution").
 #include <complex>
 #include <cstdio>
 #include <cstdlib>

@@ -177,7 +177,7 @@ __device__ __forceinline__ void zg_fir_inplace(f32x16 (&a)[4], const float4 f, f
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
         // (elements copied to scalars first: __builtin_bit_cast straight from a vector element reads element 0 with hipcc 7.2 --
-        //  DESIGN.md section 4.7; here it made all 32 exchanges of a block fetch four values)
+        //  HISTORY.md section 4.7; here it made all 32 exchanges of a block fetch four values)
         const float s2 = a[i >> 2][4 * (i & 3) + 2], s3 = a[i >> 2][4 * (i & 3) + 3];
         e2[i] = __int_as_float(__builtin_amdgcn_ds_bpermute(paddr, __float_as_int(s2)));
         e3[i] = __int_as_float(__builtin_amdgcn_ds_bpermute(paddr, __float_as_int(s3)));
@@ -483,9 +483,14 @@ __device__ __forceinline__ void inproj_blocks_gated_lo(const f16_t* As, const un
         const int c = wave * 32 + lrow_e;
         auto hook2 = [&](int step) {
             if (step == 4) firq = m.n_fir[c * 3 + q];
-            hook(step);
+            if constexpr (!lab::YLATE) hook(step);
         };
         phase_tm<PREC, K, K, false, false, decltype(hook2), PREC_SAME, true>(As, wp, q, 0, wp, ZG_ORDER[0], 0, wave, lane, bs, accx, hook2, 4, Al);
+        if constexpr (lab::YLATE) {
+            hook(4);
+            hook(5);
+            __builtin_amdgcn_sched_barrier(0);
+        }
         float* hs = halo + ((wave * 3 + q) * 32 + lrow_e) * 2;
         float p2, p3;
         history(q, c, hs, p2, p3);
@@ -587,7 +592,7 @@ struct MlpArgs {
     float eps;
 };
 
-// One workgroup per 128-token tile.  Two variants were measured and rejected (r01 notes in DESIGN.md): a persistent
+// One workgroup per 128-token tile.  Two variants were measured and rejected (r01 notes in HISTORY.md): a persistent
 // loop that prefetches the next tile's rows during the epilogue, and taking the residual as the accumulator's initial
 // value through an LDS half-tile (store-only epilogue): the extra barriers / LDS traffic / register pressure cost more
 // than the 1 KiB/token re-read they save (4.0 ms vs 3.25 ms per 64 reads for this stage).

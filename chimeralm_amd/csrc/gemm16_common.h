@@ -309,7 +309,7 @@ __device__ __forceinline__ void ln_acc_to_tile(f32x16 (&acc2)[4], float* P1, flo
     } else {
     // the two-exchange form: mean first, then the deviations about it.  (ONE exchange -- every lane leaves the sum of its 16 values
     // and their squared deviations about its own mean, combined exactly after Chan et al. -- was built and MEASURED SLOWER in round 3:
-    // 22.76 vs 22.45 ms of tail kernel per step; the statistics cost VALU + LDS instructions, not barriers.  DESIGN.md section 4.9.)
+    // 22.76 vs 22.45 ms of tail kernel per step; the statistics cost VALU + LDS instructions, not barriers.  HISTORY.md section 4.9.)
     // (the two half-waves of a wave hold the same tokens: their partial sums are added through one lane exchange before they go to
     //  the table -- 8 partials per token instead of 16, half the table reads and adds of every thread.  Round 3, timing-only build
     //  of the final kernel: the statistics are 14 % of the tail kernel, profiles/r03_timing_only.txt)

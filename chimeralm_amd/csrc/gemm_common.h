@@ -70,7 +70,7 @@ __device__ __forceinline__ void frag_to_e5m2t(u16x8 af, int& w0, int& w1) {
 
 // ---- round 4: the lo half of an ACTIVATION operand ------------------------------------------------------------------------------
 // With the weights compensated, what is left of the fp16c mode's error is the fp16 rounding of the GEMM activation operands (and of
-// z / y in HBM): token-random, 2^-12 relative per element (tests/error_model.py, DESIGN.md section 2).  The producer of an operand
+// z / y in HBM): token-random, 2^-12 relative per element (tests/error_model.py, DESIGN.md section 3).  The producer of an operand
 // tile (LayerNorm from the accumulators; the convolution for y) has the fp32 value in registers, so it also leaves
 //     lo8 = e5m2((x - fp16(x)) * 2^10 / 0.9155)          one byte per element, in a second tile
 // and the product gets a third term per 64-deep group:  acc += lo8(x) . e5m2_trunc(w_hi)  on the same K = 64 block-scaled MFMA

@@ -1146,7 +1146,7 @@ static void launch_conv_pers_inst(const void* z, void* y, const float2* kf, cons
 // (Round 2 built the 16384-point convolution of 8k reads as two 8192-point problems over the even / odd bins -- hyena_conv_eo_kernel --
 //  and round 3 the same decomposition for 16,384-token segments of long reads -- hyena_conv_seg16_kernel.  Both were correct and both
 //  MEASURED SLOWER than the kernels in this file (8k: 15.4 vs 13.5 ms per batch; 32k: 2.18 vs 1.90 ms per launch at 4.7 instead of
-//  5.8 GB); they were removed in round 4.  The numbers and the reasons are in DESIGN.md section 4.6 / 8 and profiles/r03_seg16.txt;
+//  5.8 GB); they were removed in round 4.  The numbers and the reasons are in HISTORY.md section 4.6 / 8 and profiles/r03_seg16.txt;
 //  the code is in the history at commit 8ca4f7f.)
 
 typedef unsigned v4u32 __attribute__((vector_size(16)));   // the type the buffer builtins take and return

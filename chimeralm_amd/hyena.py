@@ -178,7 +178,7 @@ class HyenaDna(nn.Module):
     `precision` selects the arithmetic of the dense projections -- "fp32" (exact, the reference's), "fp16x3" (every operand as two
     halfs, three fp16 MFMAs per product: fp32-class logits, ~1e-5 from exact, at about twice the exact rate), "fp16c" (fp16
     activations carried with one e5m2 lo byte x in_proj / out_proj / score weights held as fp16 hi + fp8 lo, MLP weights plain fp16:
-    16-bit MFMA rate; 1.3e-4 median / 5.4e-4 max from the fp32 reference over the 32 seeded study batches, DESIGN.md section 2; reads
+    16-bit MFMA rate; 1.3e-4 median / 5.4e-4 max from the fp32 reference over the 32 seeded study batches, DESIGN.md section 3; reads
     below `f16c_min_len` tokens -- 2,048 unless measured lower -- run in the fp16x3 kernels), "fp16" / "bf16" (reduced precision,
     outside the reference's 1e-3 tolerance); `chunk_reads` the number of reads pushed through all layers together.
     `selfcheck` (default: on for "fp16c") -- the reference runs ONE precision, fp32, always (hyena.py:244-256); a 16-bit mode's
@@ -306,7 +306,7 @@ class HyenaDna(nn.Module):
                 # whatever happened in the loop (an engine error included) the handle never stays at "every length in 16 bits":
                 # reads shorter than the shortest sample length that passed (with every longer one) take the fp16x3 kernels; if not
                 # even the longest sample passed, everything up to its length does -- longer reads are judged by the rows of their
-                # own batches (next lines; the error falls with the length, DESIGN.md section 2)
+                # own batches (next lines; the error falls with the length, DESIGN.md section 3)
                 if f16c:
                     rep["f16c_min_len"] = min_ok if min_ok is not None else self._SAMPLE_LENGTHS[0] + 1
                     eng.set_f16c_min_len(rep["f16c_min_len"])
@@ -328,7 +328,7 @@ class HyenaDna(nn.Module):
         worst, measured = self._measure(eng, input_ids, first)
         if not worst <= self.selfcheck_tol and self.precision == "fp16c" and not self._mlp_lo:
             # second level of the mode: fc1 / fc2 on hi + lo weights as well (their rounding shows on SOME weights: DESIGN.md
-            # section 2) -- heard again from the start, samples included, before anybody falls back
+            # section 3) -- heard again from the start, samples included, before anybody falls back
             self._mlp_lo = True
             eng.set_mlp_compensation(True)
             rep["mlp_compensation"] = True

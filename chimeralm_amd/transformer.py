@@ -9,7 +9,7 @@ CPU path.  Engine knobs absent in the reference: `precision` in {"fp32", "fp16x3
 reference's arithmetic; **fp16x3 (the default)** = every operand as two halfs, three fp16 MFMAs per product: 7e-6 .. 2.2e-5 from the
 reference module on the cases it was run on, 2.3x the exact rate, unguarded; fp16c = fp16 activations x weights as fp16 hi + fp8
 lo, the Hyena path's compensated mode: twice fp16x3's rate, but 2e-3 from the reference on those cases -- outside its 1e-3
-tolerance there, so it is opt-in and guarded -- and `selfcheck` / `selfcheck_tol`: before the first batch
+tolerance there, so it is opt-in and guarded (HISTORY.md section 5b) -- and `selfcheck` / `selfcheck_tol`: before the first batch
 after a weight load (and again every `selfcheck_every`-th batch, for a batch more than 1.5x shorter or longer than any checked so
 far, and for the batch after a measurement within 10 % of the threshold) the mode is measured against the exact-fp32 kernels of the
 same engine on seeded reads and on rows of the batch (`clm_tf_selfcheck`); above the threshold the module falls back for good --

@@ -4,7 +4,7 @@ Nothing in `chimeralm_amd/` may import this package.  Only `tests/`,
 `__graft_entry__.smoke()` and the `cpu_baseline` leg of `bench.py` use it, and
 only as the checker / reported baseline -- never as the thing measured or shipped.
 
-Parity status (see DESIGN.md "Oracle"):
+Parity status:
   * head, tokenizer, collator, read-name packing, prediction-file format:
     PINNED against the reference's own importable modules and known-answer
     tests (fixtures under tests/golden/, generator tests/golden/make_golden.py).

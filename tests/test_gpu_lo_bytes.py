@@ -1,4 +1,4 @@
-"""GPU: the activations' lo bytes of fp16c in isolation (round 4) -- tools/micro/mfma_lo2.cpp built against the
+"""GPU: the activations' lo bytes of fp16c in isolation (round 4; HISTORY.md section 4.10) -- tools/micro/mfma_lo2.cpp built against the
 product's own headers (clm_common.h lo8_pack4 / lo8_unpack4, gemm_common.h frag_to_e5m2t / mfma_lo8 / mfma_lo2) and run on the card:
 64-deep products of fp32 operands must come out an order of magnitude closer with the third MFMA term than with the weights' lo
 alone, and fp16(x) + unpack(pack(x)) must be x to ~15 bits.  (This probe caught a real bug: a vector-element bit_cast in lo8_pack4

@@ -1,4 +1,4 @@
-"""GPU (MI355X): the [PAD]-prefix reuse of left-padded batches (csrc/pad_prefix.hip, DESIGN.md section 4.11; VERDICT r04 item 5).
+"""GPU (MI355X): the [PAD]-prefix reuse of left-padded batches (csrc/pad_prefix.hip, DESIGN.md section 5.4; VERDICT r04 item 5).
 
 The reference pads a batch on the left to its longest read and masks nothing (chimeralm/data/tokenizer.py:152-159,
 models/components/hyena.py:244-256); the backbone is causal, so every position inside a read's pad prefix has the same hidden state

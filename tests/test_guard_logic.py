@@ -1,4 +1,4 @@
-"""CPU: the decisions of `HyenaDna`'s self-check (chimeralm_amd/hyena.py, DESIGN.md section 2) with the engine replaced by a stub
+"""CPU: the decisions of `HyenaDna`'s self-check (chimeralm_amd/hyena.py, DESIGN.md section 3) with the engine replaced by a stub
 whose `selfcheck` answers are scripted -- fallback, the measured short-read switch, when a later batch is checked again.  (The
 measurements themselves -- `clm_selfcheck` against the oracle -- are GPU tests: tests/test_gpu_parity.py.)"""
 from __future__ import annotations

@@ -1,6 +1,6 @@
 """Compiler-side regression guard (CPU: hipcc cross-compiles gfx950 without a GPU).
 
-DESIGN.md section 4.7: what cost the hot kernels most in round 2 was not their structure but registers hipcc spilled --
+HISTORY.md section 4.7: what cost the hot kernels most in round 2 was not their structure but registers hipcc spilled --
 scratch loads and stores are vector-memory instructions, `vmcnt` retires in order, so a reload in the middle of a tuned loop
 waits for every weight set / row request issued before it.  `chimeralm_amd.build` keeps hipcc's per-kernel resource remarks of
 the last build in `csrc/kernel_resources.txt`; this test holds the kernels of the headline path to (almost) no scratch."""

@@ -1,5 +1,5 @@
 """Developer study (CPU, not collected by pytest): ONE 16-bit activation tensor of the SequenceCNNTransformer rounded to fp16 at a
-time (fp64 otherwise) -- which rounding moves the logits?  Result: the attention output, 2.2-3.9e-3 alone.
+time (fp64 otherwise) -- which rounding moves the logits?  Result (HISTORY.md section 5b): the attention output, 2.2-3.9e-3 alone.
     python tests/tf_error_rank.py"""
 import math, sys
 import numpy as np, torch, torch.nn.functional as F

@@ -1,4 +1,4 @@
-// Probe for the next lever on the compensated mode's lo half: the lo product as an FP6 MFMA.
+// Probe for the next lever on the compensated mode's lo half (HISTORY.md section 8, round 3): the lo product as an FP6 MFMA.
 //   v_mfma_scale_f32_32x32x64_f8f6f4 with fp6 (e2m3) / bf6 (e3m2) operands: layout, cycles against the fp8 form, and the error of
 //   a . hi (fp16 MFMA) + fp6(a) . fp6(lo) against the exact product; v_cvt_scalef32_pk32_{fp6,bf6}_f16: element order, rounding,
 //   saturation, cycles.

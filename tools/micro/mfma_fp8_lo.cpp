@@ -1,4 +1,4 @@
-// Probe for DESIGN.md section 8's lever: the `lo` half of the compensated fp16 mode (weights w = hi + lo, lo ~ 2^-11 w) as ONE
+// Probe for HISTORY.md section 8's lever: the `lo` half of the compensated fp16 mode (weights w = hi + lo, lo ~ 2^-11 w) as ONE
 // fp8 product on the block-scaled K = 64 MFMA instead of four fp16 MFMAs.
 //   1. operand layout of v_mfma_scale_f32_32x32x64_f8f6f4 with e4m3 operands, checked with exact small-integer data
 //      (assumed: lane l holds row / column l & 31 and the 32 bytes k = 32 (l >> 5) + j of its 8 registers; scale = 2^(byte - 127)
