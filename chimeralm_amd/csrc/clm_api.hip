@@ -148,6 +148,12 @@ struct clm_handle {
         float* scores = nullptr;                    // [L] pooling scores                                   (16-bit fused path)
         float* partial = nullptr;                   // [ceil(L / 128)][POOL_PSTRIDE] pooling partials       (16-bit fused path)
         float* hfin = nullptr;                      // [L][256] the last block's residual rows              (fp32 path; its partials: per 64 tokens)
+        // 16-bit fused path, tables of long reads (S = segments of L > 1): per block the segment spectra of the all-[PAD] read's
+        // gated signal ([256][S][N], the one read's convolution scratch as it stood) and the running per-thread sums of the last
+        // token's dot product -- segments inside the [PAD] prefix of both reads of a pair are not transformed (hyena_conv.hip SegPrefix)
+        int S = 1;
+        float2* gspec[NLAYER] = {};
+        float* dots[NLAYER] = {};
     };
     std::vector<PadTable> pad_tables;
     PadTable* capture = nullptr;                    // inside the forward that fills a table
@@ -155,6 +161,7 @@ struct clm_handle {
     size_t pad_ids_cap = 0;
     float* pad_logits = nullptr;                    // device [2]: that read's logits (unused)
     bool no_pad_skip = false;                       // CLM_DEBUG=no_pad_skip: every tile of every read is computed (A/B runs, tests)
+    bool no_seg_skip = false;                       // CLM_DEBUG=no_seg_skip: ... but every segment of the long-read convolution is transformed
     int last_B = 0, last_L = 0, last_Lp = 0;
     // debug / profiling
     int stop_layer = -1, stop_stage = -1;
@@ -366,8 +373,17 @@ void free_packed(clm_handle* h) {
         if (h->head_t[j]) { (void)hipFree(h->head_t[j]); h->head_t[j] = nullptr; }
 }
 
+void free_pad_table_spectra(clm_handle::PadTable& t) {
+    for (int i = 0; i < NLAYER; ++i) {
+        if (t.gspec[i]) (void)hipFree(t.gspec[i]);
+        if (t.dots[i]) (void)hipFree(t.dots[i]);
+        t.gspec[i] = nullptr; t.dots[i] = nullptr;
+    }
+}
+
 void free_pad_tables(clm_handle* h) {
     for (auto& t : h->pad_tables) {
+        free_pad_table_spectra(t);
         for (int i = 0; i < NLAYER; ++i)
             if (t.z[i]) (void)hipFree(t.z[i]);
         if (t.scores) (void)hipFree(t.scores);
@@ -585,6 +601,7 @@ int ensure_pad_table(clm_handle* h, int prec, bool x3, int L, hipStream_t st, cl
     for (size_t k = 0; k < h->pad_tables.size(); ++k) {      // a shorter table of the same arithmetic is replaced
         auto& t = h->pad_tables[k];
         if (t.prec == prec && t.x3 == x3 && t.mlp_lo == (prec == PREC_F16C && h->mlp_lo)) {
+            free_pad_table_spectra(t);
             for (int i = 0; i < NLAYER; ++i)
                 if (t.z[i]) (void)hipFree(t.z[i]);
             if (t.scores) (void)hipFree(t.scores);
@@ -603,6 +620,13 @@ int ensure_pad_table(clm_handle* h, int prec, bool x3, int L, hipStream_t st, cl
     if (prec == PREC_F32) HIPCHK(h, hipMalloc((void**)&t.hfin, (size_t)LT * D * 4));
     HIPCHK(h, hipMalloc((void**)&t.scores, (size_t)LT * 4));
     HIPCHK(h, hipMalloc((void**)&t.partial, (size_t)((LT + T32_TILE - 1) / T32_TILE) * POOL_PSTRIDE * 4));
+    t.S = conv_segments_for(LT);
+    if (t.S > 1 && prec != PREC_F32 && !h->no_seg_skip)           // (the 16-bit fused path's segmented convolution skips prefix segments)
+        for (int i = 0; i < NLAYER; ++i) {
+            HIPCHK(h, hipMalloc((void**)&t.gspec[i], (size_t)D * t.S * 16384 * sizeof(float2)));
+            HIPCHK(h, hipMalloc((void**)&t.dots[i], (size_t)D * (t.S - 1) * SEG_DOT_THREADS * 4));
+            HIPCHK(h, hipMemsetAsync(t.dots[i], 0, (size_t)D * (t.S - 1) * SEG_DOT_THREADS * 4, st));
+        }
     if ((size_t)t.Lp > h->pad_ids_cap) {
         if (h->pad_ids) HIPCHK(h, hipFree(h->pad_ids));
         h->pad_ids = nullptr; h->pad_ids_cap = 0;
@@ -623,6 +647,7 @@ int ensure_pad_table(clm_handle* h, int prec, bool x3, int L, hipStream_t st, cl
     h->prof = prof;
     h->force_prec = force;
     if (rc) {
+        free_pad_table_spectra(*tp);
         for (int i = 0; i < NLAYER; ++i)
             if (tp->z[i]) (void)hipFree(tp->z[i]);
         if (tp->scores) (void)hipFree(tp->scores);
@@ -726,10 +751,26 @@ int forward_chunk(clm_handle* h, const void* ids, int ids_dtype, int64_t row_str
                 launch_hyena_conv(prec, h->z, h->y, fs->kf[i], fs->tw, fs->ktime[i], lw.short_w, lw.short_b, Bc, L, Lp,
                                   fs->logn, idconv ? h->ids8 : nullptr, idconv ? h->ztab : nullptr, st,
                                   h->conv_flags | ((zgated && i > 0) ? CONV_GATED : 0), fs->kfp[i], ylo);
-            else
+            else {
+                // [PAD]-prefix reuse: segments inside the prefix of both reads of a pair come from the table (SegPrefix).  Reads of
+                // S * 8192 + 1 tokens carry the last token's dot product through the segments: its table sums belong to ONE length
+                SegPrefix pfx;
+                const bool seg_fused = tail16_path && fuse_next && (idconv || (zgated && i > 0));
+                if (h->capture && h->capture->gspec[i]) {
+                    pfx.dots_out = kr ? h->capture->dots[i] : nullptr;
+                    pfx.dots_segs = h->capture->S - 1;
+                } else if (pad_skip && seg_fused && ptab->gspec[i] && (!kr || L == ptab->L)) {
+                    pfx.p0 = h->pad_p0;
+                    pfx.dots_in = ptab->dots[i];
+                    pfx.dots_segs = ptab->S - 1;
+                    launch_prefix_fill_spectra(h->pad_p0, h->gscratch, ptab->gspec[i], Bc, S, ptab->S, st);
+                }
                 launch_hyena_conv_seg(prec, h->z, h->y, fs->kf[i], fs->KS, fs->tw, lw.short_w, lw.short_b, h->gscratch, Bc,
                                       L, Lp, S, kr ? kr->p[i] : nullptr, kr ? kr->stride : 0, idconv ? h->ids8 : nullptr,
-                                      idconv ? h->ztab : nullptr, st, h->conv_flags | ((zgated && i > 0) ? CONV_GATED : 0), ylo);
+                                      idconv ? h->ztab : nullptr, st, h->conv_flags | ((zgated && i > 0) ? CONV_GATED : 0), ylo, pfx);
+                if (h->capture && h->capture->gspec[i])     // (one read = pair 0: [256][S][N] at the head of the scratch)
+                    HIPCHK(h, hipMemcpyAsync(h->capture->gspec[i], h->gscratch, (size_t)D * S * 16384 * sizeof(float2), hipMemcpyDeviceToDevice, st));
+            }
         }
         if (stop_here(h, i, CLM_STAGE_CONV)) return CLM_OK;
         const bool stop_mid = stop_here(h, i, CLM_STAGE_OUTPROJ);
@@ -924,6 +965,7 @@ int clm_create(const clm_config* cfg, int device, clm_handle** out) {
     if (debug_flag("conv_no_xcd")) h->conv_flags |= CONV_NO_XCD;
     h->raw_z = debug_flag("raw_z");                    // the fused in_proj stage writes x0 | x1 | v as before round 3
     h->no_pad_skip = debug_flag("no_pad_skip");        // tiles inside a read's [PAD] prefix are computed like any other
+    h->no_seg_skip = debug_flag("no_seg_skip");        // ... and segments inside it are transformed like any other (pad_prefix.hip, SegPrefix)
     h->cfg = *cfg;
     if (cfg->precision == CLM_PREC_F16X3) {             // an exact-fp32 engine whose fused tails multiply hi + lo halfs
         h->x3 = true;

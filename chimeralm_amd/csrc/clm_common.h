@@ -392,6 +392,16 @@ void launch_spectrum_lanepack(const float2* src, float2* dst, int KS, int j, hip
 void launch_ztab(const float* emb, const float* g, const float* bta, const float* w, const float* bias, float* ztab,
                  float eps, hipStream_t st);
 
+// Round 5, [PAD]-prefix reuse in the segmented convolution (pad_prefix.hip): segments wholly inside the [PAD] prefix of BOTH reads of
+// a pair are not transformed -- launch_prefix_fill_spectra puts the all-[PAD] table's spectra into the pair's scratch first.
+constexpr int SEG_DOT_THREADS = 512;                // threads of hyena_conv_seg_kernel = partial dot products per (channel, segment)
+struct SegPrefix {
+    const int* p0 = nullptr;          // [B] 128-token tiles wholly inside each read's [PAD] prefix; null: every segment is computed
+    const float* dots_in = nullptr;   // [256][dots_segs][SEG_DOT_THREADS]: the table's running per-thread sums of the last token's dot
+                                      // product after each segment (reads of S * 8192 + 1 tokens; needed where p0 is given for them)
+    float* dots_out = nullptr;        // the forward that fills a table: where those sums go (one read)
+    int dots_segs = 0;
+};
 // long reads (L > 8193): partitioned convolution over S segments; kf [256][KS][N] (partition j built with prev_off = (j-1)*SEG_LEN),
 // gscratch [pairs][256][S][N]
 void launch_hyena_conv_seg(int prec, const void* z, void* y, const float2* kf, int KS /*partitions stored per channel >= S*/,
@@ -399,7 +409,10 @@ void launch_hyena_conv_seg(int prec, const void* z, void* y, const float2* kf, i
                            const float* short_b, float2* gscratch, int B, int L, int Lp, int S,
                            const float* krev /*null unless conv_lone_tail(L)*/, int krev_stride,
                            const unsigned char* ids8 /*16-bit modes, block 0: as launch_hyena_conv*/, const float* ztab,
-                           hipStream_t st, int flags = 0, unsigned char* ylo = nullptr /*as launch_hyena_conv*/);
+                           hipStream_t st, int flags = 0, unsigned char* ylo = nullptr /*as launch_hyena_conv*/,
+                           const SegPrefix& pfx = SegPrefix{});
+// table [256][S_T][N] (the scratch of the table's one read) -> segments [0, m_start(pair)) of gscratch [pairs][256][S][N], times 1 + i
+void launch_prefix_fill_spectra(const int* p0, float2* gscratch, const float2* table, int B, int S, int S_T, hipStream_t st);
 
 // head (head.hip)
 void launch_softmax_stats(const float* scores, float* stats /*[B][2] = max, sum*/, int B, int L, hipStream_t st);

@@ -1202,13 +1202,14 @@ __global__ __launch_bounds__(Plan<14>::NT) void hyena_conv_seg_kernel(
     float2* __restrict__ gscratch /*[pairs][256][S][N]*/, int B, int L, int Lp, int S,
     const float* __restrict__ krev /*[256][krev_stride], LONE only*/, int krev_stride,
     const unsigned char* __restrict__ ids8 /*[B][Lp], IDS only*/, const float* __restrict__ ztab /*[16][768]*/, int use_xcd,
-    unsigned char* __restrict__ ylo) {
+    unsigned char* __restrict__ ylo, const SegPrefix pfx) {
     static_assert(!LO || std::is_same<T, f16_t>::value, "lo bytes exist in the compensated fp16 mode only");
     constexpr int LOGN = 14;
     using P = Plan<LOGN>;
     using TL = TwLayout<LOGN>;
     constexpr int N = P::N, NT = P::NT, LAST = P::LAST, HALF = N / 2, CH = HALF / 8 / NT;
     static_assert(HALF == SEG_LEN && CH == 2, "segment = half transform");
+    static_assert(NT == SEG_DOT_THREADS, "one partial dot product per thread in SegPrefix::dots");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float* bre = reinterpret_cast<float*>(smem);             // read A of the pair = real parts
     float* bim = bre + padded_size(N);                       // read B            = imaginary parts
@@ -1230,6 +1231,21 @@ __global__ __launch_bounds__(Plan<14>::NT) void hyena_conv_seg_kernel(
     float2* gs = gscratch + ((size_t)pair * D + c) * S * N;
     const float* kr = LONE ? krev + (size_t)c * krev_stride : nullptr;
     float dotA = 0.f, dotB = 0.f;
+    // Round 5 ([PAD]-prefix reuse, pad_prefix.hip): the segments that lie wholly inside the [PAD] prefix of BOTH reads of the pair
+    // are not transformed -- their spectra are the same in every pair (the all-[PAD] table's, times 1 + i for the two reads packed
+    // as re / im: prefix_fill_spectra_kernel has put them into this unit's scratch), their outputs lie inside tail tiles nobody
+    // computes, and their share of the last token's dot product is the table's per-thread partial sum.  m_start = the segment
+    // that holds the tile BEFORE the pair's first non-prefix tile (the tail kernel computes that tile for its filter history).
+    int m_start = 0;
+    if (pfx.p0 != nullptr && hasB) {
+        const int pa = pfx.p0[bA], pb = pfx.p0[bB], pm = pa < pb ? pa : pb;
+        m_start = pm > 0 ? ((pm - 1) * 128) / SEG_LEN : 0;
+        if (m_start > S - 1) m_start = S - 1;
+    }
+    m_start = __builtin_amdgcn_readfirstlane(m_start);
+    if constexpr (LONE) {
+        if (m_start > 0) dotA = dotB = pfx.dots_in[((size_t)c * pfx.dots_segs + (m_start - 1)) * NT + threadIdx.x];
+    }
 
     float sw[3][3], sb[3];
 #pragma unroll
@@ -1269,9 +1285,9 @@ __global__ __launch_bounds__(Plan<14>::NT) void hyena_conv_seg_kernel(
             }
         }
     };
-    request_g(0, gcur, glcur, tid);
+    request_g(m_start, gcur, glcur, tid);
 #pragma unroll 1
-    for (int m = 0; m < S; ++m) {
+    for (int m = m_start; m < S; ++m) {
         const int seg0 = m * SEG_LEN;
         // Launder the thread index once per segment: otherwise LICM hoists every LDS/global address of all seven
         // passes out of this loop and ~1000 VGPRs spill.
@@ -1413,6 +1429,8 @@ __global__ __launch_bounds__(Plan<14>::NT) void hyena_conv_seg_kernel(
 #pragma unroll
                 for (int e = 0; e < 8; ++e) dotA = fmaf(gA[e], kk[e], dotA), dotB = fmaf(gB[e], kk[e], dotB);
             }
+            // the forward that fills an all-[PAD] table (one read: read A) leaves the running sum after every segment but the last
+            if (pfx.dots_out != nullptr && m + 1 < S) pfx.dots_out[((size_t)c * pfx.dots_segs + m) * NT + ltid] = dotA;
         }
         __syncthreads();                 // (upper half = zero padding: never written, never read -- pass_first_lower)
 
@@ -1665,7 +1683,7 @@ template <typename T, bool LONE, bool IDS, bool GATED = false, bool LO = false>
 static void launch_conv_seg_inst(const void* z, void* y, const float2* kf, int KS, const float2* tw, const float* short_w,
                               const float* short_b, float2* gscratch, int B, int L, int Lp, int S,
                               const float* krev, int krev_stride, const unsigned char* ids8, const float* ztab,
-                              int use_xcd, hipStream_t st, unsigned char* ylo = nullptr) {
+                              int use_xcd, hipStream_t st, unsigned char* ylo = nullptr, const SegPrefix& pfx = SegPrefix{}) {
     using P = Plan<14>;
     constexpr size_t lds = (size_t)2 * padded_size(P::N) * sizeof(float) + 256;   // + the 3x16 id table
     auto kern = hyena_conv_seg_kernel<T, LONE, IDS, GATED, LO>;
@@ -1673,24 +1691,24 @@ static void launch_conv_seg_inst(const void* z, void* y, const float2* kf, int K
     static_assert(D % XCDS == 0, "channels split evenly over the XCDs");
     dim3 grid(((B + 1) / 2) * D), block(P::NT);
     hipLaunchKernelGGL(kern, grid, block, lds, st, reinterpret_cast<const T*>(z), reinterpret_cast<T*>(y), kf, KS, tw,
-                       short_w, short_b, gscratch, B, L, Lp, S, krev, krev_stride, ids8, ztab, use_xcd, ylo);
+                       short_w, short_b, gscratch, B, L, Lp, S, krev, krev_stride, ids8, ztab, use_xcd, ylo, pfx);
 }
 // LO: fp16c (T = f16_t) with a lo plane for y -- the gated rows then carry lo bytes too
 template <typename T, bool LO = false>
 static void launch_conv_seg_t(const void* z, void* y, const float2* kf, int KS, const float2* tw, const float* short_w,
                               const float* short_b, float2* gscratch, int B, int L, int Lp, int S, const float* krev,
                               int krev_stride, const unsigned char* ids8, const float* ztab, int use_xcd, hipStream_t st,
-                              bool gated, unsigned char* ylo = nullptr) {
+                              bool gated, unsigned char* ylo = nullptr, const SegPrefix& pfx = SegPrefix{}) {
 #define CLM_SEG(LONE, IDS)                                                                                               \
-    launch_conv_seg_inst<T, LONE, IDS, false, LO>(z, y, kf, KS, tw, short_w, short_b, gscratch, B, L, Lp, S, krev, krev_stride, ids8, ztab, use_xcd, st, ylo)
+    launch_conv_seg_inst<T, LONE, IDS, false, LO>(z, y, kf, KS, tw, short_w, short_b, gscratch, B, L, Lp, S, krev, krev_stride, ids8, ztab, use_xcd, st, ylo, pfx)
     if constexpr (std::is_same<T, float>::value) {           // fp32 mode never takes the id path
         if (krev) CLM_SEG(true, false);
         else CLM_SEG(false, false);
     } else {
         const bool ids = ids8 != nullptr && ztab != nullptr;
         if (gated && !ids) {
-            if (krev) launch_conv_seg_inst<T, true, false, true, LO>(z, y, kf, KS, tw, short_w, short_b, gscratch, B, L, Lp, S, krev, krev_stride, nullptr, nullptr, use_xcd, st, ylo);
-            else launch_conv_seg_inst<T, false, false, true, LO>(z, y, kf, KS, tw, short_w, short_b, gscratch, B, L, Lp, S, krev, krev_stride, nullptr, nullptr, use_xcd, st, ylo);
+            if (krev) launch_conv_seg_inst<T, true, false, true, LO>(z, y, kf, KS, tw, short_w, short_b, gscratch, B, L, Lp, S, krev, krev_stride, nullptr, nullptr, use_xcd, st, ylo, pfx);
+            else launch_conv_seg_inst<T, false, false, true, LO>(z, y, kf, KS, tw, short_w, short_b, gscratch, B, L, Lp, S, krev, krev_stride, nullptr, nullptr, use_xcd, st, ylo, pfx);
             return;
         }
         if (krev && ids) CLM_SEG(true, true);
@@ -1704,17 +1722,42 @@ static void launch_conv_seg_t(const void* z, void* y, const float2* kf, int KS, 
 void launch_hyena_conv_seg(int prec, const void* z, void* y, const float2* kf, int KS, const float2* tw, const float* short_w,
                            const float* short_b, float2* gscratch, int B, int L, int Lp, int S, const float* krev,
                            int krev_stride, const unsigned char* ids8, const float* ztab, hipStream_t st, int flags,
-                           unsigned char* ylo) {
+                           unsigned char* ylo, const SegPrefix& pfx) {
     const int use_xcd = !(flags & CONV_NO_XCD);
     const bool gated = (flags & CONV_GATED) != 0;
     if (prec == PREC_F16C && ylo)
-        launch_conv_seg_t<f16_t, true>(z, y, kf, KS, tw, short_w, short_b, gscratch, B, L, Lp, S, krev, krev_stride, ids8, ztab, use_xcd, st, gated, ylo);
+        launch_conv_seg_t<f16_t, true>(z, y, kf, KS, tw, short_w, short_b, gscratch, B, L, Lp, S, krev, krev_stride, ids8, ztab, use_xcd, st, gated, ylo, pfx);
     else if (prec == PREC_F32)
-        launch_conv_seg_t<float>(z, y, kf, KS, tw, short_w, short_b, gscratch, B, L, Lp, S, krev, krev_stride, nullptr, nullptr, use_xcd, st, false);
+        launch_conv_seg_t<float>(z, y, kf, KS, tw, short_w, short_b, gscratch, B, L, Lp, S, krev, krev_stride, nullptr, nullptr, use_xcd, st, false, nullptr, pfx);
     else if (prec == PREC_BF16)
-        launch_conv_seg_t<bf16_t>(z, y, kf, KS, tw, short_w, short_b, gscratch, B, L, Lp, S, krev, krev_stride, ids8, ztab, use_xcd, st, gated);
+        launch_conv_seg_t<bf16_t>(z, y, kf, KS, tw, short_w, short_b, gscratch, B, L, Lp, S, krev, krev_stride, ids8, ztab, use_xcd, st, gated, nullptr, pfx);
     else
-        launch_conv_seg_t<f16_t>(z, y, kf, KS, tw, short_w, short_b, gscratch, B, L, Lp, S, krev, krev_stride, ids8, ztab, use_xcd, st, gated);
+        launch_conv_seg_t<f16_t>(z, y, kf, KS, tw, short_w, short_b, gscratch, B, L, Lp, S, krev, krev_stride, ids8, ztab, use_xcd, st, gated, nullptr, pfx);
+}
+
+// Round 5: the spectra of the segments inside the [PAD] prefix of both reads of a pair, from the all-[PAD] table (one read: G) into
+// the pair's scratch as the packed pair's spectrum (1 + i) G -- (re - im, re + im) on the lane-packed quads (re_a, re_b, im_a, im_b).
+__global__ __launch_bounds__(256) void prefix_fill_spectra_kernel(const int* __restrict__ p0, float4* __restrict__ gscratch,
+                                                                  const float4* __restrict__ tab, int B, int S, int S_T) {
+    constexpr int QN = 16384 / 2;                            // quads per segment spectrum
+    const int c = (int)blockIdx.x, pair = (int)blockIdx.y, bA = 2 * pair, bB = bA + 1;
+    if (bB >= B) return;
+    const int pa = p0[bA], pb = p0[bB], pm = pa < pb ? pa : pb;
+    int m_start = pm > 0 ? ((pm - 1) * 128) / SEG_LEN : 0;   // (as in hyena_conv_seg_kernel)
+    if (m_start > S - 1) m_start = S - 1;
+    for (int i = 0; i < m_start; ++i) {
+        const float4* src = tab + ((size_t)c * S_T + i) * QN;
+        float4* dst = gscratch + (((size_t)pair * D + c) * S + i) * QN;
+        for (int q = (int)threadIdx.x; q < QN; q += 256) {
+            const float4 t = src[q];
+            dst[q] = make_float4(t.x - t.z, t.y - t.w, t.x + t.z, t.y + t.w);
+        }
+    }
+}
+void launch_prefix_fill_spectra(const int* p0, float2* gscratch, const float2* table, int B, int S, int S_T, hipStream_t st) {
+    static_assert(Plan<14>::N == 16384, "segment transform size");
+    hipLaunchKernelGGL(prefix_fill_spectra_kernel, dim3(D, (unsigned)((B + 1) / 2)), dim3(256), 0, st, p0, reinterpret_cast<float4*>(gscratch),
+                       reinterpret_cast<const float4*>(table), B, S, S_T);
 }
 
 // ztab[id][n] = in_proj(LN1(embedding[id]))[n] of block 0, fp32: one workgroup per token id

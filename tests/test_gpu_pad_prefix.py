@@ -96,6 +96,45 @@ def test_long_reads_and_a_growing_table(built_lib, sd, monkeypatch, prec):
     skip.close(), full.close()
 
 
+@pytest.mark.parametrize("prec", ["fp16c", "fp16"])
+@pytest.mark.parametrize("L,prefixes", [
+    # 4 segments + the peeled last token (its dot product rides through the segments): a pair that skips three segments, one that
+    # skips one, one with an unpadded read (nothing skipped), an unpaired last read
+    (32769, (30000, 28000, 17000, 9000, 0, 25000, 20000)),
+    # 3 segments, table built for 4: prefixes either side of a segment boundary (8,320 / 8,319: tile 64 is the tile before the first
+    # real one -- its segment is transformed), one pair exactly one tile into the second segment
+    (20000, (19000, 16500, 8320, 8319, 8448, 8400, 12000, 100)),
+])
+def test_prefix_segments_of_long_reads_are_not_transformed(built_lib, sd, monkeypatch, prec, L, prefixes):
+    """Round 5, csrc/hyena_conv.hip SegPrefix: in the segmented convolution of the fused 16-bit path a segment wholly inside the [PAD]
+    prefix of BOTH reads of a pair is not transformed -- its spectrum comes from the all-[PAD] table (times 1 + i for the packed
+    pair), its outputs lie in tail tiles nobody computes, its share of the last token's dot product is the table's partial sum.
+    Against the same engine with every segment transformed (CLM_DEBUG=no_seg_skip), the engine that skips nothing, and the oracle."""
+    from chimeralm_amd.engine import Engine
+
+    ids = _padded_batch(L, prefixes, seed=1300 + L)
+    skip, full = _engines(prec, sd, monkeypatch)
+    monkeypatch.setenv("CLM_DEBUG", "no_seg_skip")
+    noseg = Engine("cuda:0", precision=prec, chunk_reads=8)
+    monkeypatch.delenv("CLM_DEBUG")
+    noseg.load_state_dict(sd)
+    if prec == "fp16c":
+        noseg.set_f16c_min_len(1)
+    t = torch.from_numpy(ids).cuda()
+    a, n, f = skip.forward(t).cpu().numpy(), noseg.forward(t).cpu().numpy(), full.forward(t).cpu().numpy()
+    rows = [0, 2, len(prefixes) - 1]
+    ref = ho.forward(torch.from_numpy(ids[rows].astype(np.int64)), sd).numpy()
+    d1, d2, e = float(np.abs(a - n).max()), float(np.abs(a - f).max()), float(np.abs(a[rows] - ref).max())
+    print(f"{prec} {len(prefixes)} x {L}: |skip - all segments| {d1:.2e}, |skip - full| {d2:.2e}, |skip - oracle| {e:.2e}")
+    assert np.isfinite(a).all() and d1 <= SKIP_VS_FULL[prec] and d2 <= SKIP_VS_FULL[prec] and e <= VS_ORACLE[prec]
+    assert np.array_equal(a, skip.forward(t).cpu().numpy())                      # deterministic
+    # other pair partners: the same reads reversed
+    perm = list(reversed(range(len(prefixes))))
+    a2 = skip.forward(t[perm].contiguous()).cpu().numpy()
+    assert np.abs(a2[np.argsort(perm)] - a).max() <= SKIP_VS_FULL[prec]
+    skip.close(), full.close(), noseg.close()
+
+
 def test_guarded_module_on_a_padded_batch(built_lib, sd):
     """The product path: `HyenaDna(precision="fp16c")` with its guard (both arithmetics of the self-check build their own table) on a
     ragged batch; new weights drop the tables."""
