@@ -101,5 +101,15 @@ constexpr bool YLATE = true;       // y pieces + y's lo bytes requested behind t
 #else
 constexpr bool YLATE = false;
 #endif
+#if defined(CLM_LAB) && defined(CLM_EXP_LN1PASS)
+constexpr bool LN1PASS = true;     // LayerNorm statistics as sum and sum of squares in ONE exchange (var = E[x^2] - mean^2: not the reference's two-pass form)
+#else
+constexpr bool LN1PASS = false;
+#endif
+#if defined(CLM_LAB) && defined(CLM_EXP_AHEAD)
+constexpr int AHEAD = CLM_EXP_AHEAD;   // A fragments requested this many (k-step, row tile) items before their MFMA (product: 4)
+#else
+constexpr int AHEAD = 4;
+#endif
 }  // namespace lab
 }  // namespace clm

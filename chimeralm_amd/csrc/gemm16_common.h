@@ -254,7 +254,7 @@ __device__ __forceinline__ void phase_tm(const typename CT<PREC>::elem* As, cons
         }
         if constexpr (p % (NP / 2) == 0) hook(hook0 + p / (NP / 2));
         __builtin_amdgcn_sched_barrier(0);
-        compute_tm<PREC, ROWS_N, 4, LO2, MT0, NMT>(As, p, lrow, lhalf, bs[p & 1], acc, Al);
+        compute_tm<PREC, ROWS_N, lab::AHEAD, LO2, MT0, NMT>(As, p, lrow, lhalf, bs[p & 1], acc, Al);
         __builtin_amdgcn_sched_barrier(0);
     });
 }
@@ -306,6 +306,25 @@ __device__ __forceinline__ void ln_acc_to_tile(f32x16 (&acc2)[4], float* P1, flo
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) mean[mt] = 0.f, rstd[mt] = 1.f;
         __syncthreads();
+    } else if constexpr (lab::LN1PASS) {
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            float s = 0.f, q = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s += acc2[mt][r], q = fmaf(acc2[mt][r], acc2[mt][r], q);
+            s += __shfl_xor(s, 32, 64);
+            q += __shfl_xor(q, 32, 64);
+            if (lhalf == 0) P1[wave * BM + mt * 32 + lrow] = s, P2[wave * BM + mt * 32 + lrow] = q;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            float s = 0.f, q = 0.f;
+#pragma unroll
+            for (int w = 0; w < 8; ++w) s += P1[w * BM + mt * 32 + lrow], q += P2[w * BM + mt * 32 + lrow];
+            mean[mt] = s * (1.0f / D);
+            rstd[mt] = 1.0f / sqrtf(fmaxf(q * (1.0f / D) - mean[mt] * mean[mt], 0.f) + eps);
+        }
     } else {
     // the two-exchange form: mean first, then the deviations about it.  (ONE exchange -- every lane leaves the sum of its 16 values
     // and their squared deviations about its own mean, combined exactly after Chan et al. -- was built and MEASURED SLOWER in round 3:
