@@ -18,7 +18,7 @@ from collections import defaultdict
 from pathlib import Path
 
 ROOT = Path(__file__).resolve().parent.parent
-STAGE_OF = {"tail16_kernel": "out_proj_ln2_mlp", "mlp16_kernel": "ln2_mlp", "in_proj16_kernel": "ln1_in_proj",
+STAGE_OF = {"tail16_kernel": "out_proj_ln2_mlp", "tail32_kernel": "out_proj_ln2_mlp", "mlp16_kernel": "ln2_mlp", "in_proj16_kernel": "ln1_in_proj",
             "out_proj16_kernel": "out_proj", "hyena_conv_kernel": "short_long_conv", "hyena_conv_seg_kernel": "short_long_conv",
             "hyena_conv_pers_kernel": "short_long_conv",
             "embed_kernel": "embed", "gemm_kernel": "lnf_pool_score", "softmax_stats_kernel": "softmax_pool", "pool_kernel": "softmax_pool",
