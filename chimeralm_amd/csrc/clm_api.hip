@@ -471,7 +471,7 @@ int ensure_filters(clm_handle* h, int L, hipStream_t st, FilterSet** out, const 
                           W(h, p + "implicit_filter.6.weight"), W(h, p + "modulation.deltas"), f.ktime[i], f.Lf, st);
             if (S == 1) {
                 launch_filter_spectrum(f.ktime[i], W(h, p + "bias"), f.kf[i], scratch, f.Lf, logn, 0, f.Lf, -1, st);
-                if (logn == 14 && h->cfg.precision != CLM_PREC_F32) {
+                if (logn == 14) {                            // (round 5: the exact / fp16x3 engine's fp32 rows take the persistent kernel too)
                     HIPCHK(h, hipMalloc((void**)&f.kfp[i], (size_t)D * N * sizeof(float2)));
                     launch_spectrum_lanepack(f.kf[i], f.kfp[i], 1, 0, st);
                 }
@@ -727,7 +727,10 @@ int forward_chunk(clm_handle* h, const void* ids, int ids_dtype, int64_t row_str
                             W(h, "head.attention.2.bias"), h->scores, h->partial, Bc, L, (L + 127) / 128, eps};
     {
         StageTimer t(h, st, CLM_STAGE_EMBED);
-        launch_embed(ids, ids_dtype, row_stride, W(h, "bb.embeddings.word_embeddings.weight"), idpath ? nullptr : h->h,
+        // (exact / fp16x3 engine, one-shot convolution: block 0 reads z from the id table and its tail gathers the residual rows from
+        //  the embedding table -- h is first written by that tail kernel, as in the 16-bit id path)
+        const bool id32 = fused32 && S == 1 && !h->no_idconv;
+        launch_embed(ids, ids_dtype, row_stride, W(h, "bb.embeddings.word_embeddings.weight"), (idpath || id32) ? nullptr : h->h,
                      h->ids8, Bc, L, Lp, st, h->bad_ids);
     }
     if (stop_here(h, -1, CLM_STAGE_EMBED)) return CLM_OK;
@@ -846,7 +849,7 @@ int forward_chunk(clm_handle* h, const void* ids, int ids_dtype, int64_t row_str
             launch_tail32(reinterpret_cast<const float*>(h->y), h->h, lw.t_out, lw.t_fc1, lw.t_fc2, nx ? nx->t_in : nullptr, lw.b_out,
                           lw.b_fc1, lw.b_fc2, nx ? nx->b_in : nullptr, lw.ln2_g, lw.ln2_b, nx ? nx->ln1_g : nullptr,
                           nx ? nx->ln1_b : nullptr, reinterpret_cast<float*>(h->z), Bc, L, Lp, eps, st, x3, pad_skip ? h->pad_p0 : nullptr,
-                          nx ? nullptr : &ts);
+                          nx ? nullptr : &ts, (i == 0 && idconv) ? h->ids8 : nullptr, W(h, "bb.embeddings.word_embeddings.weight"));
             if (h->capture) {
                 if (nx) HIPCHK(h, hipMemcpyAsync(h->capture->z[i + 1], h->z, (size_t)D3 * Lp * 4, hipMemcpyDeviceToDevice, st));
                 else {

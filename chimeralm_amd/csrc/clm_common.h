@@ -212,7 +212,8 @@ void launch_tail32(const float* y, float* h, const void* w_out, const void* w_fc
                    const float* ln2_b, const float* n_g, const float* n_b, float* z, int B, int L, int Lp, float eps, hipStream_t st,
                    bool x3 = false /*three fp16 MFMAs on hi + lo halfs per product, weights from launch_pack_x3*/,
                    const int* p0 = nullptr /*[B]: tiles inside each read's [PAD] prefix, skipped (pad_prefix.hip)*/,
-                   const Tail32Score* score = nullptr);
+                   const Tail32Score* score = nullptr,
+                   const unsigned char* ids8 = nullptr /*block 0: residual rows = embedding rows by token id ([B, Lp])*/, const float* emb = nullptr);
 void launch_pack_x3(const float* w /*[n][k]*/, void* out /*n * k * 4 bytes*/, int n, int k, hipStream_t st);
 void launch_pack_f32t(const float* w /*[n][k]*/, void* out /*n * k floats*/, int n, int k, hipStream_t st);
 // SequenceCNNTransformer, exact fp32 (tail32.hip conv32_kernel): Conv1d(k = 3, padding = 1) + ReLU + MaxPool1d(2); w = three taps

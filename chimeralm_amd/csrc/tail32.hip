@@ -262,6 +262,10 @@ struct Tail32Args {
     const float *att_w2, *att_b2;   // attention.2 weight [256] and bias [1]
     float* scores;            // [B, L] pooling scores
     float* partial;           // [B, tiles_x, POOL_PSTRIDE] per-tile online-softmax pooling partials (64-token tiles here)
+    // block 0 with the id-table convolution: the residual entering the block is the embedding row of the token id -- gathered here,
+    // the embedding kernel's 1 KiB per token never crosses HBM (as in the 16-bit tail kernel)
+    const unsigned char* ids8;   // [B, Lp] or null
+    const float* emb;            // [16, 256]
 };
 
 // NEXT: what follows the block on the tile still in registers -- nothing / the next block's LayerNorm-1 + in_proj / (round 5, the
@@ -317,7 +321,8 @@ __global__ __launch_bounds__(512) void tail32_kernel(Tail32Args m) {
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) {
             const int t = t0 + mt * 32 + lrow, tc = t < L ? t : L - 1;
-            const float* row = m.h + ((size_t)b * L + tc) * D + wave * 32 + 4 * lhalf;
+            const float* row = m.ids8 ? m.emb + (size_t)m.ids8[(size_t)b * Lp + tc] * D + wave * 32 + 4 * lhalf
+                                      : m.h + ((size_t)b * L + tc) * D + wave * 32 + 4 * lhalf;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const float4 hv = *reinterpret_cast<const float4*>(row + 8 * q);
@@ -763,12 +768,12 @@ static void launch_lds(dim3 grid, dim3 block, size_t lds, hipStream_t st, const 
 void launch_tail32(const float* y, float* h, const void* w_out, const void* w_fc1, const void* w_fc2, const void* w_in_next,
                    const float* b_out, const float* b_fc1, const float* b_fc2, const float* b_in_next, const float* ln2_g,
                    const float* ln2_b, const float* n_g, const float* n_b, float* z, int B, int L, int Lp, float eps, hipStream_t st,
-                   bool x3, const int* p0, const Tail32Score* score) {
+                   bool x3, const int* p0, const Tail32Score* score, const unsigned char* ids8, const float* emb) {
     Tail32Args m{y, h, reinterpret_cast<const f32x4*>(w_out), reinterpret_cast<const f32x4*>(w_fc1), reinterpret_cast<const f32x4*>(w_fc2),
                  reinterpret_cast<const f32x4*>(score ? score->w1 : w_in_next), b_out, b_fc1, b_fc2, score ? score->b1 : b_in_next, ln2_g, ln2_b,
                  score ? score->lnf_g : n_g, score ? score->lnf_b : n_b, z, B, L, Lp,
                  (L + BM32 - 1) / BM32, eps, p0, score ? score->w2 : nullptr, score ? score->b2 : nullptr, score ? score->scores : nullptr,
-                 score ? score->partial : nullptr};
+                 score ? score->partial : nullptr, ids8, emb};
     const size_t lds = (size_t)(2 * BM32 * RS32 + 2 * 8 * BM32) * sizeof(float);
     static_assert(8 * BM32 + BM32 + 4 * D <= BM32 * RS32, "score stage: P / E / V fit the Hs region");
     const dim3 grid((unsigned)(m.tiles_x * B));
