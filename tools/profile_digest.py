@@ -35,12 +35,25 @@ def short(name: str) -> str:
 def counters(path_glob):
     acc = defaultdict(lambda: defaultdict(list))
     dur = defaultdict(dict)
+    per = defaultdict(lambda: defaultdict(dict))
     for f in glob.glob(path_glob, recursive=True):
         for r in csv.DictReader(open(f)):
             n = short(r["Kernel_Name"])
             acc[n][r["Counter_Name"]].append(float(r["Counter_Value"]))
             dur[n][r["Dispatch_Id"]] = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
-    return acc, dur
+            per[n][r["Counter_Name"]][r["Dispatch_Id"]] = float(r["Counter_Value"])
+    return acc, dur, per
+
+
+def full_size_mean(values_by_dispatch, dur_by_dispatch):
+    """Mean over the FULL-SIZE dispatches of a kernel in one counter pass: those that ran at least half as long as its longest one.
+    (The guarded product also launches the kernels on 4-read self-check samples; averaged in, they understate the bytes of a
+    256-read launch by the share of small launches -- a share that changes with the number of steps of the pass.)"""
+    if not values_by_dispatch:
+        return None, 0
+    top = max(dur_by_dispatch[i] for i in values_by_dispatch)
+    ids = [i for i in values_by_dispatch if dur_by_dispatch[i] >= 0.5 * top]
+    return sum(values_by_dispatch[i] for i in ids) / len(ids), len(ids)
 
 
 def main(tag):
@@ -56,7 +69,7 @@ def main(tag):
     lines, traffic = [], defaultdict(lambda: {"fetch_kb": None, "write_kb": None})
     busy = {}          # kernel -> (mean SQ_VALU_MFMA_BUSY_CYCLES per dispatch, mean dispatch duration in us of the SAME counter pass)
     for sub in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_inst", "pmc_icache"):
-        acc, dur = counters(str(src / sub / "**" / "*counter_collection.csv"))
+        acc, dur, per = counters(str(src / sub / "**" / "*counter_collection.csv"))
         if not acc:
             continue
         lines.append(f"==== {sub} (counter run: kernels are serialised, durations are for reference only)")
@@ -66,13 +79,15 @@ def main(tag):
                 continue
             lines.append(f"{n:28s} dispatches={len(d):4d} avg_us={sum(d)/len(d):9.1f}")
             for c, v in sorted(acc[n].items()):
-                lines.append(f"    {c:28s} {sum(v)/len(v):18.1f}")
+                fm, nf = full_size_mean(per[n][c], dur[n])
+                fd, _ = full_size_mean(dur[n], dur[n])
+                lines.append(f"    {c:28s} {sum(v)/len(v):18.1f}   full-size launches ({nf:3d}, avg_us {fd:9.1f}): {fm:18.1f}")
                 if c == "FETCH_SIZE":
-                    traffic[n]["fetch_kb"] = sum(v) / len(v)
+                    traffic[n]["fetch_kb"], traffic[n]["fetch_kb_all"] = fm, sum(v) / len(v)
                 if c == "WRITE_SIZE":
-                    traffic[n]["write_kb"] = sum(v) / len(v)
+                    traffic[n]["write_kb"], traffic[n]["write_kb_all"] = fm, sum(v) / len(v)
                 if c == "SQ_VALU_MFMA_BUSY_CYCLES" and sum(v) > 0:
-                    busy[n] = (sum(v) / len(v), sum(d) / len(d))
+                    busy[n] = (fm, fd)
     (dst / f"{tag}_pmc_summary.txt").write_text("\n".join(lines) + "\n")
     out = {}
     for n, t in traffic.items():
@@ -80,10 +95,11 @@ def main(tag):
             continue
         stage = next((s for k, s in sorted(STAGE_OF.items(), key=lambda kv: -len(kv[0])) if k in n), None)   # longest name first
         e = {"kernel": n, "fetch_size_kb": t["fetch_kb"], "write_size_kb": t["write_kb"],
-             "hbm_bytes_per_dispatch": (2.0 * t["fetch_kb"] + t["write_kb"]) * 1024.0}
+             "hbm_bytes_per_dispatch": (2.0 * t["fetch_kb"] + t["write_kb"]) * 1024.0,      # full-size launches only (full_size_mean)
+             "hbm_bytes_per_dispatch_all_launches": (2.0 * t.get("fetch_kb_all", t["fetch_kb"]) + t.get("write_kb_all", t["write_kb"])) * 1024.0}
         if n in busy:
             # MFMA pipe occupancy: busy cycles are summed over the chip's 1,024 SIMDs; both figures are means over the
-            # dispatches of ONE counter pass (the guard's small launches included in both), so their ratio is the kernel's
+            # full-size dispatches of ONE counter pass, so their ratio is the kernel's
             e["mfma_busy_cycles_per_dispatch"], e["pmc_pass_avg_us"] = busy[n]
         if stage and (stage not in out or e["hbm_bytes_per_dispatch"] > out[stage]["hbm_bytes_per_dispatch"]):
             out[stage] = e
