@@ -735,6 +735,13 @@ int forward_chunk(clm_handle* h, const void* ids, int ids_dtype, int64_t row_str
     }
     if (stop_here(h, -1, CLM_STAGE_EMBED)) return CLM_OK;
     if (tail16_path || pad_skip) launch_pad_tiles(h->ids8, Bc, Lp, Lmain, pad_skip ? 1 : 0, h->pad_p0, h->tile_list, st);
+    // does block j's (segmented) convolution leave out the segments inside the [PAD] prefix of both reads of a pair (SegPrefix)?  Block 0
+    // looks z up by token id, the others read the gated hand-over; reads of S * 8192 + 1 tokens need the table's dot-product sums, which
+    // belong to ONE length
+    auto seg_skip_layer = [&](int j) {
+        return pad_skip && S > 1 && tail16_path && fuse_next && !h->capture && (j == 0 ? idpath : zgated) && ptab->gspec[j] != nullptr &&
+               (!kr || L == ptab->L);
+    };
     for (int i = 0; i < NLAYER; ++i) {
         const LayerW& lw = x3 ? h->lwx[i] : (alt32 ? h->lw32[i] : h->lw[i]);
         // block 0 in the 16-bit modes: its in_proj output is a function of the token id alone, the convolution looks it
@@ -758,21 +765,23 @@ int forward_chunk(clm_handle* h, const void* ids, int ids_dtype, int64_t row_str
                 // [PAD]-prefix reuse: segments inside the prefix of both reads of a pair come from the table (SegPrefix).  Reads of
                 // S * 8192 + 1 tokens carry the last token's dot product through the segments: its table sums belong to ONE length
                 SegPrefix pfx;
-                const bool seg_fused = tail16_path && fuse_next && (idconv || (zgated && i > 0));
                 if (h->capture && h->capture->gspec[i]) {
                     pfx.dots_out = kr ? h->capture->dots[i] : nullptr;
                     pfx.dots_segs = h->capture->S - 1;
-                } else if (pad_skip && seg_fused && ptab->gspec[i] && (!kr || L == ptab->L)) {
+                } else if (seg_skip_layer(i)) {
                     pfx.p0 = h->pad_p0;
+                    pfx.tab = ptab->gspec[i];
+                    pfx.tab_segs = ptab->S;
                     pfx.dots_in = ptab->dots[i];
                     pfx.dots_segs = ptab->S - 1;
-                    launch_prefix_fill_spectra(h->pad_p0, h->gscratch, ptab->gspec[i], Bc, S, ptab->S, st);
                 }
                 launch_hyena_conv_seg(prec, h->z, h->y, fs->kf[i], fs->KS, fs->tw, lw.short_w, lw.short_b, h->gscratch, Bc,
                                       L, Lp, S, kr ? kr->p[i] : nullptr, kr ? kr->stride : 0, idconv ? h->ids8 : nullptr,
                                       idconv ? h->ztab : nullptr, st, h->conv_flags | ((zgated && i > 0) ? CONV_GATED : 0), ylo, pfx);
-                if (h->capture && h->capture->gspec[i])     // (one read = pair 0: [256][S][N] at the head of the scratch)
+                if (h->capture && h->capture->gspec[i]) {   // (one read = pair 0: [256][S][N] at the head of the scratch), then pair form
                     HIPCHK(h, hipMemcpyAsync(h->capture->gspec[i], h->gscratch, (size_t)D * S * 16384 * sizeof(float2), hipMemcpyDeviceToDevice, st));
+                    launch_spectra_pair_form(h->capture->gspec[i], S, st);
+                }
             }
         }
         if (stop_here(h, i, CLM_STAGE_CONV)) return CLM_OK;
@@ -834,8 +843,9 @@ int forward_chunk(clm_handle* h, const void* ids, int ids_dtype, int64_t row_str
                     HIPCHK(h, hipMemcpyAsync(h->capture->partial, h->partial, (size_t)((L + 127) / 128) * POOL_PSTRIDE * 4, hipMemcpyDeviceToDevice, st));
                 }
             } else if (pad_skip) {
-                if (next == NEXT_INPROJ)
-                    launch_prefix_fill_z(h->pad_p0, h->z, ptab->z[i + 1], Bc, Lp, ptab->Lp, Lmain, (int)elem_size(prec), nrow16, nlo, st);
+                if (next == NEXT_INPROJ)      // (rows of segments the next convolution will not read are not copied)
+                    launch_prefix_fill_z(h->pad_p0, h->z, ptab->z[i + 1], Bc, Lp, ptab->Lp, Lmain, (int)elem_size(prec), nrow16, nlo, st,
+                                         seg_skip_layer(i + 1) ? S : 0);
                 else
                     launch_prefix_fill_pool(h->pad_p0, h->scores, h->partial, ptab->scores, ptab->partial, Bc, L, (L + 127) / 128, Lmain, st);
             }

@@ -310,7 +310,9 @@ constexpr int PAD_ID = 4;         // [PAD] of the reference's tokenizer (chimera
 void launch_pad_tiles(const unsigned char* ids8, int B, int Lp, int Lmain, int enabled, int* p0, int* tiles, hipStream_t st);
 // rows [0, 128 p0[b]) of every read's z block (nrow16 element rows of `es` bytes + nlo byte rows behind 2 D element rows, as the
 // gated hand-over lays them out) <- the same rows of the all-[PAD] table (one read, row pitch LpT)
-void launch_prefix_fill_z(const int* p0, void* z, const void* table, int B, int Lp, int LpT, int Lmain, int es, int nrow16, int nlo, hipStream_t st);
+void launch_prefix_fill_z(const int* p0, void* z, const void* table, int B, int Lp, int LpT, int Lmain, int es, int nrow16, int nlo, hipStream_t st,
+                          int seg_skip_S = 0 /*> 1: the convolution that reads z skips prefix segments (SegPrefix, S segments): the rows
+                                              of the segments it will not read are not copied either*/);
 // the same for the last block's products: pooling scores [B][L] and per-tile pooling partials [B][ntiles][POOL_PSTRIDE]
 void launch_prefix_fill_pool(const int* p0, float* scores, float* partial, const float* t_scores, const float* t_partial, int B, int L,
                              int ntiles, int Lmain, hipStream_t st, int per128 = 1 /*partials per 128 tokens: 2 for tail32's 64-token tiles*/);
@@ -394,10 +396,12 @@ void launch_ztab(const float* emb, const float* g, const float* bta, const float
                  float eps, hipStream_t st);
 
 // Round 5, [PAD]-prefix reuse in the segmented convolution (pad_prefix.hip): segments wholly inside the [PAD] prefix of BOTH reads of
-// a pair are not transformed -- launch_prefix_fill_spectra puts the all-[PAD] table's spectra into the pair's scratch first.
+// a pair are not transformed -- the partition products read their spectra in the all-[PAD] table (pair form: launch_spectra_pair_form).
 constexpr int SEG_DOT_THREADS = 512;                // threads of hyena_conv_seg_kernel = partial dot products per (channel, segment)
 struct SegPrefix {
     const int* p0 = nullptr;          // [B] 128-token tiles wholly inside each read's [PAD] prefix; null: every segment is computed
+    const float2* tab = nullptr;      // [256][tab_segs][N] the table's segment spectra in pair form (needed where p0 is given)
+    int tab_segs = 0;
     const float* dots_in = nullptr;   // [256][dots_segs][SEG_DOT_THREADS]: the table's running per-thread sums of the last token's dot
                                       // product after each segment (reads of S * 8192 + 1 tokens; needed where p0 is given for them)
     float* dots_out = nullptr;        // the forward that fills a table: where those sums go (one read)
@@ -412,8 +416,8 @@ void launch_hyena_conv_seg(int prec, const void* z, void* y, const float2* kf, i
                            const unsigned char* ids8 /*16-bit modes, block 0: as launch_hyena_conv*/, const float* ztab,
                            hipStream_t st, int flags = 0, unsigned char* ylo = nullptr /*as launch_hyena_conv*/,
                            const SegPrefix& pfx = SegPrefix{});
-// table [256][S_T][N] (the scratch of the table's one read) -> segments [0, m_start(pair)) of gscratch [pairs][256][S][N], times 1 + i
-void launch_prefix_fill_spectra(const int* p0, float2* gscratch, const float2* table, int B, int S, int S_T, hipStream_t st);
+// table [256][S_T][N] (the scratch of the table's one read: G) -> (1 + i) G in place, the spectrum of a PAIR of such reads
+void launch_spectra_pair_form(float2* table, int S_T, hipStream_t st);
 
 // head (head.hip)
 void launch_softmax_stats(const float* scores, float* stats /*[B][2] = max, sum*/, int B, int L, hipStream_t st);

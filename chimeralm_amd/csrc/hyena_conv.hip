@@ -1233,8 +1233,9 @@ __global__ __launch_bounds__(Plan<14>::NT) void hyena_conv_seg_kernel(
     float dotA = 0.f, dotB = 0.f;
     // Round 5 ([PAD]-prefix reuse, pad_prefix.hip): the segments that lie wholly inside the [PAD] prefix of BOTH reads of the pair
     // are not transformed -- their spectra are the same in every pair (the all-[PAD] table's, times 1 + i for the two reads packed
-    // as re / im: prefix_fill_spectra_kernel has put them into this unit's scratch), their outputs lie inside tail tiles nobody
-    // computes, and their share of the last token's dot product is the table's per-thread partial sum.  m_start = the segment
+    // as re / im: pfx.tab holds them in that form and the partition products read them there instead of in this unit's scratch),
+    // their outputs lie inside tail tiles nobody computes, and their share of the last token's dot product is the table's
+    // per-thread partial sum.  m_start = the segment
     // that holds the tile BEFORE the pair's first non-prefix tile (the tail kernel computes that tile for its filter history).
     int m_start = 0;
     if (pfx.p0 != nullptr && hasB) {
@@ -1265,6 +1266,9 @@ __global__ __launch_bounds__(Plan<14>::NT) void hyena_conv_seg_kernel(
     // buffer descriptors of this unit's spectrum scratch and this channel's partition spectra (uniform: blockIdx + arguments)
     const __amdgpu_buffer_rsrc_t g_rs = make_rsrc(gs, (size_t)S * N * sizeof(float2));
     const __amdgpu_buffer_rsrc_t k_rs = make_rsrc(kfc, (size_t)KS * N * sizeof(float2));
+    // (the table's spectra of this channel, pair form; without a table: the scratch again -- never read, m_start is 0 then)
+    const __amdgpu_buffer_rsrc_t t_rs = pfx.tab != nullptr ? make_rsrc(pfx.tab + (size_t)c * pfx.tab_segs * N, (size_t)pfx.tab_segs * N * sizeof(float2))
+                                                            : g_rs;
     // GATED (round 4): the g rows of segment m + 1 are requested before the last inverse pass of segment m and
     // consumed in its phase A -- the HBM round trip that opened every segment (the prefetch that took the 8k kernel from 0.81 to
     // 0.57 ms) -- unconditionally: the last segment re-requests itself (a conditional request makes the waitcnt pass drain to zero)
@@ -1488,7 +1492,7 @@ __global__ __launch_bounds__(Plan<14>::NT) void hyena_conv_seg_kernel(
         auto fetch = [&](Cx2* ga, Cx2* kb, int i, int qtr) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                ga[e] = quad(g_rs, i, 4 * qtr + e);
+                ga[e] = quad(i < m_start ? t_rs : g_rs, i, 4 * qtr + e);      // (uniform select of the descriptor)
                 kb[e] = quad(k_rs, m - i, 4 * qtr + e);
             }
         };
@@ -1735,29 +1739,19 @@ void launch_hyena_conv_seg(int prec, const void* z, void* y, const float2* kf, i
         launch_conv_seg_t<f16_t>(z, y, kf, KS, tw, short_w, short_b, gscratch, B, L, Lp, S, krev, krev_stride, ids8, ztab, use_xcd, st, gated, nullptr, pfx);
 }
 
-// Round 5: the spectra of the segments inside the [PAD] prefix of both reads of a pair, from the all-[PAD] table (one read: G) into
-// the pair's scratch as the packed pair's spectrum (1 + i) G -- (re - im, re + im) on the lane-packed quads (re_a, re_b, im_a, im_b).
-__global__ __launch_bounds__(256) void prefix_fill_spectra_kernel(const int* __restrict__ p0, float4* __restrict__ gscratch,
-                                                                  const float4* __restrict__ tab, int B, int S, int S_T) {
-    constexpr int QN = 16384 / 2;                            // quads per segment spectrum
-    const int c = (int)blockIdx.x, pair = (int)blockIdx.y, bA = 2 * pair, bB = bA + 1;
-    if (bB >= B) return;
-    const int pa = p0[bA], pb = p0[bB], pm = pa < pb ? pa : pb;
-    int m_start = pm > 0 ? ((pm - 1) * 128) / SEG_LEN : 0;   // (as in hyena_conv_seg_kernel)
-    if (m_start > S - 1) m_start = S - 1;
-    for (int i = 0; i < m_start; ++i) {
-        const float4* src = tab + ((size_t)c * S_T + i) * QN;
-        float4* dst = gscratch + (((size_t)pair * D + c) * S + i) * QN;
-        for (int q = (int)threadIdx.x; q < QN; q += 256) {
-            const float4 t = src[q];
-            dst[q] = make_float4(t.x - t.z, t.y - t.w, t.x + t.z, t.y + t.w);
-        }
+// Round 5: the all-[PAD] table's segment spectra (one read: G, the convolution scratch of the forward that filled the table) in the form a
+// PAIR of such reads has -- the two packed as re / im: (1 + i) G = (re - im, re + im) on the lane-packed quads (re_a, re_b, im_a, im_b).
+// In place, once per table; hyena_conv_seg_kernel reads the result where a segment lies inside both reads' [PAD] prefix.
+__global__ __launch_bounds__(256) void spectra_pair_form_kernel(float4* __restrict__ tab, size_t nquads) {
+    for (size_t q = (size_t)blockIdx.x * 256 + threadIdx.x; q < nquads; q += (size_t)gridDim.x * 256) {
+        const float4 t = tab[q];
+        tab[q] = make_float4(t.x - t.z, t.y - t.w, t.x + t.z, t.y + t.w);
     }
 }
-void launch_prefix_fill_spectra(const int* p0, float2* gscratch, const float2* table, int B, int S, int S_T, hipStream_t st) {
+void launch_spectra_pair_form(float2* table, int S_T, hipStream_t st) {
     static_assert(Plan<14>::N == 16384, "segment transform size");
-    hipLaunchKernelGGL(prefix_fill_spectra_kernel, dim3(D, (unsigned)((B + 1) / 2)), dim3(256), 0, st, p0, reinterpret_cast<float4*>(gscratch),
-                       reinterpret_cast<const float4*>(table), B, S, S_T);
+    const size_t nquads = (size_t)D * S_T * (16384 / 2);
+    hipLaunchKernelGGL(spectra_pair_form_kernel, dim3(2048), dim3(256), 0, st, reinterpret_cast<float4*>(table), nquads);
 }
 
 // ztab[id][n] = in_proj(LN1(embedding[id]))[n] of block 0, fp32: one workgroup per token id

@@ -90,16 +90,26 @@ void launch_pad_tiles(const unsigned char* ids8, int B, int Lp, int Lmain, int e
 // multiples of 64; the filled length is a multiple of 128 tokens or ends at Lmain, whose ragged end is copied byte-wise)
 __global__ __launch_bounds__(256) void prefix_fill_z_kernel(const int* __restrict__ p0, unsigned char* __restrict__ z,
                                                             const unsigned char* __restrict__ table, int Lp, int LpT, int Lmain, int es,
-                                                            int nrow16, int nlo) {
+                                                            int nrow16, int nlo, int B, int seg_skip_S) {
     const int b = (int)blockIdx.y, p = p0[b];
     if (p == 0) return;
     const int ntok = 128 * p < Lmain ? 128 * p : Lmain;
+    // the segmented convolution that reads these rows starts at segment m_start of the PAIR (hyena_conv.hip SegPrefix, same formula):
+    // tokens before it are never read
+    int tok0 = 0;
+    if (seg_skip_S > 1 && (b ^ 1) < B) {
+        const int pb = p0[b ^ 1], pm = p < pb ? p : pb;
+        int m_start = pm > 0 ? ((pm - 1) * 128) / SEG_LEN : 0;
+        if (m_start > seg_skip_S - 1) m_start = seg_skip_S - 1;
+        tok0 = m_start * SEG_LEN;
+    }
+    if (tok0 >= ntok) return;
     unsigned char* zb = z + (size_t)b * D3 * Lp * es;
     for (int r = (int)blockIdx.x; r < nrow16 + nlo; r += (int)gridDim.x) {
         const bool lo = r >= nrow16;                       // lo planes: byte rows behind 2 D element rows (clm_common.h TailArgs::zlo)
-        const size_t bytes = (size_t)ntok * (lo ? 1 : es);
-        const unsigned char* src = lo ? table + (size_t)2 * D * LpT * es + (size_t)(r - nrow16) * LpT : table + (size_t)r * LpT * es;
-        unsigned char* dst = lo ? zb + (size_t)2 * D * Lp * es + (size_t)(r - nrow16) * Lp : zb + (size_t)r * Lp * es;
+        const size_t bytes = (size_t)(ntok - tok0) * (lo ? 1 : es), skip = (size_t)tok0 * (lo ? 1 : es);   // (tok0: a multiple of 8,192)
+        const unsigned char* src = (lo ? table + (size_t)2 * D * LpT * es + (size_t)(r - nrow16) * LpT : table + (size_t)r * LpT * es) + skip;
+        unsigned char* dst = (lo ? zb + (size_t)2 * D * Lp * es + (size_t)(r - nrow16) * Lp : zb + (size_t)r * Lp * es) + skip;
         const size_t n16 = bytes / 16;
         for (size_t i = threadIdx.x; i < n16; i += 256) reinterpret_cast<uint4*>(dst)[i] = reinterpret_cast<const uint4*>(src)[i];
         for (size_t i = n16 * 16 + threadIdx.x; i < bytes; i += 256) dst[i] = src[i];
@@ -107,9 +117,9 @@ __global__ __launch_bounds__(256) void prefix_fill_z_kernel(const int* __restric
 }
 
 void launch_prefix_fill_z(const int* p0, void* z, const void* table, int B, int Lp, int LpT, int Lmain, int es, int nrow16, int nlo,
-                          hipStream_t st) {
+                          hipStream_t st, int seg_skip_S) {
     hipLaunchKernelGGL(prefix_fill_z_kernel, dim3(32, (unsigned)B), dim3(256), 0, st, p0, reinterpret_cast<unsigned char*>(z),
-                       reinterpret_cast<const unsigned char*>(table), Lp, LpT, Lmain, es, nrow16, nlo);
+                       reinterpret_cast<const unsigned char*>(table), Lp, LpT, Lmain, es, nrow16, nlo, B, seg_skip_S);
 }
 
 __global__ __launch_bounds__(256) void prefix_fill_pool_kernel(const int* __restrict__ p0, float* __restrict__ scores, float* __restrict__ partial,
