@@ -416,7 +416,7 @@ int ensure_workspace(clm_handle* h, int Bc, int L, hipStream_t st) {
     need[WS_IDS8] = nb * Lp;
     need[WS_EDGE_READ] = nb * D3 * sizeof(float2);
     need[WS_YLO] = h->cfg.precision == PREC_F16C ? nb * D * Lp : 0;
-    need[WS_P0] = nb * sizeof(int);
+    need[WS_P0] = 3 * nb * sizeof(int);                     // p0 | pair order | pair partner (pad_prefix.hip)
     need[WS_TILES] = (1 + nb * ((nl + 127) / 128)) * sizeof(int);
     if (conv_segments_for(L) > 1) need[WS_GSCRATCH] = ((nb + 1) / 2) * D * (size_t)conv_segments_for(L) * 16384 * sizeof(float2);
     bool grow = false;
@@ -738,6 +738,10 @@ int forward_chunk(clm_handle* h, const void* ids, int ids_dtype, int64_t row_str
     // does block j's (segmented) convolution leave out the segments inside the [PAD] prefix of both reads of a pair (SegPrefix)?  Block 0
     // looks z up by token id, the others read the gated hand-over; reads of S * 8192 + 1 tokens need the table's dot-product sums, which
     // belong to ONE length
+    // (with it the pairs of those convolutions are formed by descending prefix: perm / partner live behind p0)
+    int* const pair_perm = h->pad_p0 + Bc;
+    int* const pair_partner = h->pad_p0 + 2 * Bc;
+    if (pad_skip && S > 1) launch_pair_order(h->pad_p0, Bc, pair_perm, pair_partner, st);
     auto seg_skip_layer = [&](int j) {
         return pad_skip && S > 1 && tail16_path && fuse_next && !h->capture && (j == 0 ? idpath : zgated) && ptab->gspec[j] != nullptr &&
                (!kr || L == ptab->L);
@@ -770,6 +774,7 @@ int forward_chunk(clm_handle* h, const void* ids, int ids_dtype, int64_t row_str
                     pfx.dots_segs = h->capture->S - 1;
                 } else if (seg_skip_layer(i)) {
                     pfx.p0 = h->pad_p0;
+                    pfx.perm = pair_perm;
                     pfx.tab = ptab->gspec[i];
                     pfx.tab_segs = ptab->S;
                     pfx.dots_in = ptab->dots[i];
@@ -845,7 +850,7 @@ int forward_chunk(clm_handle* h, const void* ids, int ids_dtype, int64_t row_str
             } else if (pad_skip) {
                 if (next == NEXT_INPROJ)      // (rows of segments the next convolution will not read are not copied)
                     launch_prefix_fill_z(h->pad_p0, h->z, ptab->z[i + 1], Bc, Lp, ptab->Lp, Lmain, (int)elem_size(prec), nrow16, nlo, st,
-                                         seg_skip_layer(i + 1) ? S : 0);
+                                         seg_skip_layer(i + 1) ? S : 0, pair_partner);
                 else
                     launch_prefix_fill_pool(h->pad_p0, h->scores, h->partial, ptab->scores, ptab->partial, Bc, L, (L + 127) / 128, Lmain, st);
             }

@@ -312,7 +312,11 @@ void launch_pad_tiles(const unsigned char* ids8, int B, int Lp, int Lmain, int e
 // gated hand-over lays them out) <- the same rows of the all-[PAD] table (one read, row pitch LpT)
 void launch_prefix_fill_z(const int* p0, void* z, const void* table, int B, int Lp, int LpT, int Lmain, int es, int nrow16, int nlo, hipStream_t st,
                           int seg_skip_S = 0 /*> 1: the convolution that reads z skips prefix segments (SegPrefix, S segments): the rows
-                                              of the segments it will not read are not copied either*/);
+                                              of the segments it will not read are not copied either*/,
+                          const int* partner = nullptr /*[B] the other read of each read's pair (-1: none); null: b ^ 1*/);
+// pairs of the segmented convolution by descending [PAD] prefix (stable): perm[r] = the read of rank r, partner[b] = the other read of
+// b's pair or -1
+void launch_pair_order(const int* p0, int B, int* perm, int* partner, hipStream_t st);
 // the same for the last block's products: pooling scores [B][L] and per-tile pooling partials [B][ntiles][POOL_PSTRIDE]
 void launch_prefix_fill_pool(const int* p0, float* scores, float* partial, const float* t_scores, const float* t_partial, int B, int L,
                              int ntiles, int Lmain, hipStream_t st, int per128 = 1 /*partials per 128 tokens: 2 for tail32's 64-token tiles*/);
@@ -402,6 +406,7 @@ struct SegPrefix {
     const int* p0 = nullptr;          // [B] 128-token tiles wholly inside each read's [PAD] prefix; null: every segment is computed
     const float2* tab = nullptr;      // [256][tab_segs][N] the table's segment spectra in pair form (needed where p0 is given)
     int tab_segs = 0;
+    const int* perm = nullptr;        // [B] or null: read perm[2 k] and perm[2 k + 1] form pair k (launch_pair_order: by descending prefix)
     const float* dots_in = nullptr;   // [256][dots_segs][SEG_DOT_THREADS]: the table's running per-thread sums of the last token's dot
                                       // product after each segment (reads of S * 8192 + 1 tokens; needed where p0 is given for them)
     float* dots_out = nullptr;        // the forward that fills a table: where those sums go (one read)

@@ -1219,8 +1219,11 @@ __global__ __launch_bounds__(Plan<14>::NT) void hyena_conv_seg_kernel(
     // (S x 128 KB, read (S+1)S/2 times per unit) are served by that XCD's L2 instead of being fetched by all eight
     const int pairs = (B + 1) / 2, xcd = blockIdx.x % XCDS, slot = blockIdx.x / XCDS;
     const int c = use_xcd ? XCDS * (slot / pairs) + xcd : (int)blockIdx.x / pairs, pair = use_xcd ? slot % pairs : (int)blockIdx.x % pairs;
-    const int bA = 2 * pair, bB = 2 * pair + 1;
-    const bool hasB = bB < B;
+    // the two reads of the pair: batch order, or (pfx.perm, round 5) the order of descending [PAD] prefix -- reads with long prefixes
+    // share a pair, and a pair skips the segments inside BOTH prefixes
+    const bool hasB = 2 * pair + 1 < B;
+    const int bA = pfx.perm ? pfx.perm[2 * pair] : 2 * pair;
+    const int bB = hasB ? (pfx.perm ? pfx.perm[2 * pair + 1] : 2 * pair + 1) : bA;
     const T* zA = z + (size_t)bA * D3 * Lp;
     const T* zB = z + (size_t)(hasB ? bB : bA) * D3 * Lp;
     T* yA = y + ((size_t)bA * D + c) * Lp;

@@ -90,15 +90,16 @@ void launch_pad_tiles(const unsigned char* ids8, int B, int Lp, int Lmain, int e
 // multiples of 64; the filled length is a multiple of 128 tokens or ends at Lmain, whose ragged end is copied byte-wise)
 __global__ __launch_bounds__(256) void prefix_fill_z_kernel(const int* __restrict__ p0, unsigned char* __restrict__ z,
                                                             const unsigned char* __restrict__ table, int Lp, int LpT, int Lmain, int es,
-                                                            int nrow16, int nlo, int B, int seg_skip_S) {
+                                                            int nrow16, int nlo, int B, int seg_skip_S, const int* __restrict__ partner) {
     const int b = (int)blockIdx.y, p = p0[b];
     if (p == 0) return;
     const int ntok = 128 * p < Lmain ? 128 * p : Lmain;
     // the segmented convolution that reads these rows starts at segment m_start of the PAIR (hyena_conv.hip SegPrefix, same formula):
     // tokens before it are never read
     int tok0 = 0;
-    if (seg_skip_S > 1 && (b ^ 1) < B) {
-        const int pb = p0[b ^ 1], pm = p < pb ? p : pb;
+    const int other = partner ? partner[b] : ((b ^ 1) < B ? (b ^ 1) : -1);
+    if (seg_skip_S > 1 && other >= 0) {
+        const int pb = p0[other], pm = p < pb ? p : pb;
         int m_start = pm > 0 ? ((pm - 1) * 128) / SEG_LEN : 0;
         if (m_start > seg_skip_S - 1) m_start = seg_skip_S - 1;
         tok0 = m_start * SEG_LEN;
@@ -117,9 +118,29 @@ __global__ __launch_bounds__(256) void prefix_fill_z_kernel(const int* __restric
 }
 
 void launch_prefix_fill_z(const int* p0, void* z, const void* table, int B, int Lp, int LpT, int Lmain, int es, int nrow16, int nlo,
-                          hipStream_t st, int seg_skip_S) {
+                          hipStream_t st, int seg_skip_S, const int* partner) {
     hipLaunchKernelGGL(prefix_fill_z_kernel, dim3(32, (unsigned)B), dim3(256), 0, st, p0, reinterpret_cast<unsigned char*>(z),
-                       reinterpret_cast<const unsigned char*>(table), Lp, LpT, Lmain, es, nrow16, nlo, B, seg_skip_S);
+                       reinterpret_cast<const unsigned char*>(table), Lp, LpT, Lmain, es, nrow16, nlo, B, seg_skip_S, partner);
+}
+
+// Pairs of the segmented convolution by descending prefix length (stable: equal prefixes keep batch order, so a batch without pads
+// keeps its pairs): rank by counting -- B is a chunk's reads (12 ... 256, at most 4,096), one workgroup.
+__global__ __launch_bounds__(256) void pair_order_kernel(const int* __restrict__ p0, int B, int* __restrict__ perm, int* __restrict__ partner) {
+    for (int b = (int)threadIdx.x; b < B; b += 256) {
+        const int p = p0[b];
+        int rank = 0;
+        for (int j = 0; j < B; ++j) {
+            const int q = p0[j];
+            rank += (q > p || (q == p && j < b)) ? 1 : 0;
+        }
+        perm[rank] = b;
+    }
+    __threadfence_block();                                 // (one workgroup; perm is in global memory: the writes before the barrier)
+    __syncthreads();
+    for (int r = (int)threadIdx.x; r < B; r += 256) partner[perm[r]] = (r ^ 1) < B ? perm[r ^ 1] : -1;
+}
+void launch_pair_order(const int* p0, int B, int* perm, int* partner, hipStream_t st) {
+    hipLaunchKernelGGL(pair_order_kernel, dim3(1), dim3(256), 0, st, p0, B, perm, partner);
 }
 
 __global__ __launch_bounds__(256) void prefix_fill_pool_kernel(const int* __restrict__ p0, float* __restrict__ scores, float* __restrict__ partial,
