@@ -226,6 +226,7 @@ class HyenaDna(nn.Module):
         self._checked_min_len: int | None = None          # shortest / longest batch MEASURED in the mode since the last weight
         self._checked_max_len: int | None = None          # load, and the batches that went by since the last check
         self._batches_since_check = 0
+        self._reads_since_check = 0
         self._recheck_next = False                        # the last measurement was kept within 10 % of the threshold
         self._mlp_lo = False                              # fp16c: the guard's second level is on (fc1 / fc2 on hi + lo weights)
 
@@ -252,6 +253,7 @@ class HyenaDna(nn.Module):
             self._heard = self._recheck_next = False
             self._checked_min_len = self._checked_max_len = None
             self._batches_since_check = 0
+            self._reads_since_check = 0
             self.selfcheck_report = {}
         return self._engine
 
@@ -343,6 +345,7 @@ class HyenaDna(nn.Module):
             self._checked_min_len = L if self._checked_min_len is None else min(L, self._checked_min_len)
             self._checked_max_len = max(L, self._checked_max_len or 0)
         self._batches_since_check = 0
+        self._reads_since_check = 0
         # kept, but within 10 % of the threshold: the spread from batch to batch at fixed weights is 2-3x (profiles/r04_fp16c_margin.txt),
         # so the NEXT batch is measured too instead of the 16th from now
         self._recheck_next = measured and 0.9 * self.selfcheck_tol < worst <= self.selfcheck_tol
@@ -362,13 +365,20 @@ class HyenaDna(nn.Module):
             warnings.warn(msg, RuntimeWarning, stacklevel=3)
         rep.setdefault("fallback", False)
 
-    def guard_due(self, n_tokens: int) -> bool:
+    # The periodic re-check is meant to cost ~1 % of the work between two checks: two passes over 4 reads, one of them in exact fp32
+    # (~19 read-equivalents).  At the bench's batch of 256 that is every 16th batch; at the reference's default batch of 12 sixteen
+    # batches are 192 reads and the same rule costs 10 % -- so a periodic check also waits for this many READS since the last one
+    # (round 5; 86 batches of 12).  The other triggers (first batch, length range, a measurement near the threshold) do not wait.
+    selfcheck_min_reads = 1024
+
+    def guard_due(self, n_tokens: int, n_reads: int | None = None) -> bool:
         """Is a self-check due for a batch of `n_tokens`-token reads?  The first batch since a weight load (the seeded samples); then,
         for batches that run in the mode (fp16c: not those below the length switch -- they take the fp16x3 kernels, which are not on
         trial): the first such batch, a batch whose length leaves the range already measured by more than a factor 1.5 in EITHER
         direction (the mode's error is neither monotone in the length nor the same from batch to batch:
         profiles/r03_fp16c_margin.txt), the batch after a measurement within 10 % of the threshold, and every `selfcheck_every`-th
-        batch (default 16: two passes over 4 reads, under 1 % of the time between two checks).  Counts the batch."""
+        batch (default 16) once `selfcheck_min_reads` reads went by as well (`n_reads` unknown: not waited for) -- two passes over
+        4 reads, ~1 % of the work between two checks.  Counts the batch."""
         if not self.selfcheck or self.precision == "fp32" or self.selfcheck_report.get("fallback"):
             return False
         if not self._heard:
@@ -378,15 +388,19 @@ class HyenaDna(nn.Module):
         if self._checked_min_len is None:
             return True
         self._batches_since_check += 1
+        self._reads_since_check += int(n_reads) if n_reads is not None else self.selfcheck_min_reads
         return (self._recheck_next or 3 * n_tokens < 2 * self._checked_min_len or 2 * n_tokens > 3 * self._checked_max_len
-                or (self.selfcheck_every > 0 and self._batches_since_check >= self.selfcheck_every))
+                or (self.selfcheck_every > 0 and self._batches_since_check >= self.selfcheck_every
+                    and self._reads_since_check >= self.selfcheck_min_reads))
 
-    def guard(self, eng: Engine, input_ids, n_tokens: int | None = None) -> None:
+    def guard(self, eng: Engine, input_ids, n_tokens: int | None = None, n_reads: int | None = None) -> None:
         """Self-check of the 16-bit mode where one is due (`guard_due`).  `forward` calls it; loops that drive the engine directly
         (predict.run_predict_native) call it with a CALLABLE that returns the batch's ids on the device, so that nothing is
         copied for the batches -- almost all -- on which no check is due."""
         L = int(n_tokens if n_tokens is not None else input_ids.shape[1])
-        if self.guard_due(L):
+        if n_reads is None and not callable(input_ids):
+            n_reads = int(input_ids.shape[0])
+        if self.guard_due(L, n_reads):
             self._selfcheck(eng, input_ids() if callable(input_ids) else input_ids)
 
     def forward(self, input_ids: torch.Tensor, input_quals: torch.Tensor | None = None) -> torch.Tensor:

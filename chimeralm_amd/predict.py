@@ -174,7 +174,7 @@ def run_predict_native(model, feeder, writer, device: torch.device, *, rank: int
             # the 16-bit mode against the exact-fp32 kernels on this batch's first reads, where a self-check is due (HyenaDna.guard)
             # (a callable: the host copy + H2D of the sampled rows happens only on the few batches a check is due for)
             model.net.guard(eng, lambda c=cur: torch.from_numpy(c.ids[: c.n_reads, : c.n_tokens][
-                model.net._sample_rows(c.n_reads, model.net._BATCH_ROWS)].copy()).to(device), n_tokens=cur.n_tokens)
+                model.net._sample_rows(c.n_reads, model.net._BATCH_ROWS)].copy()).to(device), n_tokens=cur.n_tokens, n_reads=cur.n_reads)
             logits = eng.forward_staged(staged, cur.n_reads)
             eng.stage_wait(staged)                            # the copy has left the slot ...
             feeder.release(cur)                               # ... which goes back to the decoder

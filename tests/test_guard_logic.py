@@ -77,6 +77,7 @@ def test_all_samples_pass_lowers_the_switch_to_the_shortest_sample():
 
 def test_periodic_recheck_and_rows_spread_over_the_batch():
     net = lm.ChimeraLM.new(precision="fp16c", selfcheck_every=3).net
+    net.selfcheck_min_reads = 0                                                    # (the periodic rule by batches alone: next test for the reads)
     eng = StubEngine({4097: 2e-4, 2048: 3e-4, 1024: 7e-4})
     seen = []
     eng_selfcheck = eng.selfcheck
@@ -95,6 +96,23 @@ def test_periodic_recheck_and_rows_spread_over_the_batch():
     with pytest.warns(RuntimeWarning, match="falling back to fp16x3"):
         net.guard(eng, ids)
     assert eng.fallback == 1 and net.selfcheck_report["fallback"] is True and net.selfcheck_report["fallback_precision"] == "fp16x3"
+
+
+def test_periodic_recheck_waits_for_reads_as_well_as_batches():
+    """Round 5: at the reference's default batch of 12, sixteen batches are 192 reads and a check (two passes over 4 reads, one in exact
+    fp32) would cost 10 % of them -- a periodic check is due after `selfcheck_every` batches AND `selfcheck_min_reads` reads."""
+    net = lm.ChimeraLM.new(precision="fp16c", selfcheck_every=2).net
+    net.selfcheck_min_reads = 30
+    eng = StubEngine({4097: 2e-4, 2048: 3e-4, 1024: 7e-4})
+    ids = _ids(12, 3000)
+    net.guard(eng, ids)
+    assert net.selfcheck_report["checks"] == 1
+    net.guard(eng, ids), net.guard(eng, ids)                                       # two batches, 24 reads: not yet
+    assert net.selfcheck_report["checks"] == 1
+    net.guard(eng, ids)                                                            # 36 reads
+    assert net.selfcheck_report["checks"] == 2
+    net.guard(eng, lambda: ids, n_tokens=3000), net.guard(eng, lambda: ids, n_tokens=3000)   # batch size unknown: batches alone decide
+    assert net.selfcheck_report["checks"] == 3
 
 
 def test_lowering_the_switch_below_its_default_needs_a_margin_of_two():
@@ -230,7 +248,7 @@ def test_second_level_is_heard_before_the_fallback():
     assert eng2.mlp_lo is True and eng2.fallback == 1 and net2.selfcheck_report["fallback"] is True
     net3 = _net()                                                                  # a LATER batch drifts: escalate then, not fall back
     eng3 = StubEngine({4097: 2e-4, 2048: 3e-4, 1024: 7e-4}, level2=({4097: 1e-4, 2048: 1e-4, 1024: 1e-4, 512: 1e-4, 256: 1e-4}, 1e-4))
-    net3.selfcheck_every = 2
+    net3.selfcheck_every, net3.selfcheck_min_reads = 2, 0
     net3.guard(eng3, _ids(4, 5000))
     assert eng3.mlp_lo is False
     eng3.batch_err = 9e-4
