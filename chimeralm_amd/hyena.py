@@ -188,7 +188,8 @@ class HyenaDna(nn.Module):
     one) becomes the length below which reads take the fp16x3 kernels inside the mode (`clm_set_short_read_len`; 4,098 if not even
     the longest sample passes).  "Passes" = within `selfcheck_tol` (5e-4, half the tolerance) down to the unmeasured default of 2,048
     tokens and within HALF of it below: one seeded sample places the switch, so lowering it wants a margin of 2 -- and four reads
-    spread over that batch.  Later: four reads of every `selfcheck_every`-th batch (16), of any batch more than 1.5x shorter or
+    spread over that batch.  Later: four reads of every `selfcheck_every`-th batch (16; and not before `selfcheck_min_reads` =
+    1,024 reads went by, so that small batches do not pay 10 % for it), of any batch more than 1.5x shorter or
     longer than every batch measured so far, and of the batch that follows a measurement within 10 % of the threshold.  A sample,
     not a bound: batches in between are not measured.  A BATCH above the threshold moves fp16c to its second level -- its MLP
     products run on plain fp16 weights (fast; enough on most weights) and then on hi + lo weights like the other projections
