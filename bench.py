@@ -170,7 +170,7 @@ def bench_transformer(a):
         enc = 12 * L3 * 2 * 256 * (768 + 256 + 2 * 1024)
         att = 12 * 2 * 2 * L3 * L3 * 256
         flops = (conv + enc + att) * a.batch * a.steps / elapsed / 1e12
-        res = {"metric": "reads/sec, SequenceCNNTransformer, 8k-bp reads batch=256", "value": a.batch * a.steps / elapsed,
+        res = {"metric": f"reads/sec, SequenceCNNTransformer, {a.bases}-bp reads batch={a.batch}", "value": a.batch * a.steps / elapsed,
                "unit": "reads/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": elapsed / a.steps * 1e3,
                "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": a.precision,
                "data": "synthetic reads (seeded), seeded random-init weights of the configured architecture",
