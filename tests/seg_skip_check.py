@@ -1,7 +1,7 @@
 """Developer check (GPU): segment skipping of the long-read convolution on shapes the test suite does not hold -- odd chunks, L just past the
-one-shot kernel, a length whose dot-product table does not apply, prefixes at every segment boundary.  python tools/dev/seg_skip_check.py"""
+one-shot kernel, a length whose dot-product table does not apply, prefixes at every segment boundary.  python tests/seg_skip_check.py"""
 import os, sys, numpy as np, torch
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 from oracle import hyena_oracle as ho
 from chimeralm_amd.engine import Engine
 sd = ho.make_state_dict(0, head_scale=3.0)
